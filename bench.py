@@ -1,0 +1,195 @@
+#!/usr/bin/env python
+"""bench.py -- throughput of the ELFI hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 50 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Headline line (one JSON object on stdout, rank 0): BASELINE.json's metric
+"ABC distances/sec" on configs[1] -- a synthetic Gaussian summary matrix of 10^6
+samples x 32 summaries per GPU, euclidean distance to the observed summaries
+(elfi.Distance('euclidean'), elfi/model/elfi_model.py:1037).  A step is one pass of
+the distance path over the rank's batch, inputs already resident in HBM.  Weak
+scaling: every rank owns an independent batch (independent ABC batches,
+elfi/methods/parameter_inference.py:283-292); the only exchange is one RCCL gather of
+the final distance shard to rank 0 inside the timed region.
+
+The same line carries
+  "roofline"      HBM roofline of the distance kernel (HIP events on the library's stream)
+  "cpu_baseline"  the oracle (column_stack + SciPy cdist, what the reference executes)
+                  timed on this box's host cores for the same batch shape
+  "bolfi"         BASELINE.json's second metric, BOLFI iters/sec (GP fit + acquisition,
+                  n=4096, d=10) with its own MFMA-fp64 roofline (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "oracle")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 measured)
+FP64_MFMA_PEAK_TFLOPS = 78.6  # AMD public spec, FP64 matrix (not in the local guide)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--n", type=int, default=10 ** 6, help="samples per GPU per step")
+    ap.add_argument("--m", type=int, default=32, help="summaries per sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-bolfi", action="store_true")
+    ap.add_argument("--bolfi-iters", type=int, default=5)
+    return ap.parse_args()
+
+
+def cpu_baseline_distance(n, m, budget_s=12.0):
+    """Reference path on the host: 32 separate summary columns -> np.column_stack -> cdist
+    (elfi/model/utils.py:37-52).  Single thread (SciPy's cdist is not threaded)."""
+    import numpy as np
+    import distance_oracle as O
+    rs = np.random.RandomState(0)
+    cols = [rs.randn(n) for _ in range(m)]
+    obs = tuple(np.random.RandomState(1).randn(1, m)[:, j] for j in range(m))
+    op = O.make_distance('euclidean')
+    op(*cols, observed=obs)  # warm-up
+    best, reps, t_end = float("inf"), 0, time.perf_counter() + budget_s
+    while time.perf_counter() < t_end or reps < 2:
+        t0 = time.perf_counter()
+        op(*cols, observed=obs)
+        best = min(best, time.perf_counter() - t0)
+        reps += 1
+    X = np.column_stack(cols)
+    t0 = time.perf_counter()
+    O.cdist_rows(X, np.array(obs).reshape(1, -1), 'euclidean')
+    kern = time.perf_counter() - t0
+    return dict(value=n / best, unit="distances/s", cores=1, kind="port",
+                sample="%d x %d batch through oracle distance_as_discrepancy (np.column_stack + "
+                       "scipy cdist), best of %d; cdist alone %.0f Mdist/s" % (n, m, reps, n / kern / 1e6))
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import elfi_amd
+    from elfi_amd import _lib
+    ctx = elfi_amd.Context(local_rank)
+    # one explicit (non-null) stream shared by torch/RCCL and the library, so the gather is
+    # ordered after the last kernel without a host sync
+    stream = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(stream)
+    ctx.set_stream(stream.cuda_stream)
+
+    n, m = args.n, args.m
+    # Synthetic Gaussian simulator outputs: N(0,1) summaries,
+    # one independent batch per rank (seeded by rank), observed row from a fixed seed.
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+    X = torch.randn(n, m, dtype=torch.float64, device=dev, generator=gen)
+    y = torch.from_numpy(np.random.RandomState(1).randn(1, m)).to(dev)
+    out = torch.empty(n, dtype=torch.float64, device=dev)
+    gathered = [torch.empty(n, dtype=torch.float64, device=dev) for _ in range(world)] \
+        if (world > 1 and rank == 0) else None
+
+    def step():
+        ctx.call("elfihip_dist_rows_dev", 0, X.data_ptr(), n, m, m, y.data_ptr(), None,
+                 2.0, out.data_ptr())
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:  # warm the gather path too
+        dist.gather(out, gathered, dst=0)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if world > 1:
+        dist.gather(out, gathered, dst=0)  # the one exchange: final distance shards -> rank 0
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # Kernel-only timing for the roofline: HIP events on the SAME stream the kernel runs on.
+    torch.cuda.synchronize(dev)
+    ctx.timer_start()
+    for _ in range(args.steps):
+        step()
+    kernel_ms = ctx.timer_stop() / args.steps
+    alg_bytes = (8.0 * m + 8.0) * n          # 8m + 8 bytes per distance
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+
+    # parity guard on what was just timed (checker only)
+    if rank == 0:
+        import distance_oracle as O
+        idx = np.arange(0, n, max(1, n // 4096))[:4096]
+        ref = O.cdist_rows(X[idx].cpu().numpy(), y.cpu().numpy(), 'euclidean')
+        assert np.array_equal(out[idx].cpu().numpy(), ref), "bench output differs from the oracle"
+
+    result = None
+    if rank == 0:
+        value = world * n * args.steps / elapsed
+        result = {
+            "metric": "ABC distances/sec", "value": value, "unit": "distances/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "configs[1]: synthetic Gaussian summaries, %d samples x %d summaries per "
+                                   "GPU per step, elfi.Distance('euclidean'), inputs resident in HBM" % (n, m),
+                       "samples_per_gpu": n, "summaries": m, "layout": "row-major (n,m) f64",
+                       "exchange": "one RCCL gather of the final distance shard per job" if world > 1 else "none"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "dist_rows_kernel<euclidean>", "kernel_ms": kernel_ms,
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "frac_of_measured_copy_peak_6290": achieved / 6290.0},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline_distance(n, m)
+            result["cpu_baseline"]["host_cores_available"] = os.cpu_count()
+        if world == 1 and not args.no_bolfi:
+            try:
+                from elfi_amd import bolfi_bench
+            except ImportError:
+                bolfi_bench = None
+            if bolfi_bench is not None:
+                result["bolfi"] = bolfi_bench.run(ctx, iters=args.bolfi_iters,
+                                                  with_cpu=not args.no_cpu_baseline)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

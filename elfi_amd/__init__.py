@@ -1,0 +1,19 @@
+"""elfi_amd -- the MI355X (gfx950) hot path for ELFI (elfi-dev/elfi).
+
+One data-parallel path, built from scratch in HIP behind ELFI's own operation and
+surrogate-model interfaces:
+
+  * batched summary -> distance evaluation (elfi.Distance / elfi.AdaptiveDistance
+    operations; the reference delegates to scipy.spatial.distance.cdist), and
+  * the BOLFI Gaussian-process surrogate loop (the `target_model=` object of
+    elfi.BOLFI; the reference delegates to GPy).
+
+Everything else (graph compilation, samplers, storage, plotting ...) stays reference
+ELFI.  The compute lives in libelfihip.so (C ABI: include/elfihip.h); this package is
+the thin host-side mirror of the reference interfaces.  See DESIGN.md / INTEGRATION.md.
+"""
+from ._lib import LIB_PATH, Context, ElfiHipError, default_context, device_count, load_library  # noqa: F401
+from .distance import (AdaptiveDistanceState, HipDiscrepancy, HipDistance, cdist_cols,  # noqa: F401
+                       cdist_rows, nested_weighted_euclidean, welford_update)
+
+__version__ = "0.1.0"

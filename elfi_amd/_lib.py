@@ -1,0 +1,210 @@
+"""ctypes binding of libelfihip.so (the C ABI declared in include/elfihip.h).
+
+The product path has no CPU fallback: if the shared library is missing or a GPU entry
+point fails, the error is raised to the caller.  Mapping of status codes to Python
+exceptions follows the reference's error conventions:
+shape/argument errors -> ValueError (what scipy.cdist raises and
+elfi/model/utils.py:42-49 re-raises), non-PD Cholesky -> numpy.linalg.LinAlgError
+(what GPy raises and elfi/methods/bo/gpy_regression.py:320-323 catches), HIP failures
+-> RuntimeError.
+"""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libelfihip.so")
+
+OK, ERR_ARG, ERR_HIP, ERR_NOT_PD, ERR_STATE, ERR_NOMEM = range(6)
+
+METRICS = {
+    "euclidean": 0,
+    "sqeuclidean": 1,
+    "cityblock": 2,
+    "chebyshev": 3,
+    "minkowski": 4,
+    "seuclidean": 5,
+    "mahalanobis": 6,
+}
+
+c_double_p = C.POINTER(C.c_double)
+c_void_pp = C.POINTER(C.c_void_p)
+
+# name -> (restype, argtypes).  tests/test_abi.py checks this table against the header.
+PROTOTYPES = {
+    "elfihip_version": (C.c_int, []),
+    "elfihip_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "elfihip_ctx_create": (C.c_int, [C.c_int, c_void_pp]),
+    "elfihip_ctx_destroy": (C.c_int, [C.c_void_p]),
+    "elfihip_last_error": (C.c_char_p, [C.c_void_p]),
+    "elfihip_ctx_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "elfihip_ctx_synchronize": (C.c_int, [C.c_void_p]),
+    "elfihip_device_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                      C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                      C.POINTER(C.c_int64), C.c_char_p, C.c_int]),
+    "elfihip_timer_start": (C.c_int, [C.c_void_p]),
+    "elfihip_timer_stop": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "elfihip_dist_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_int64,
+                                    C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]),
+    "elfihip_dist_rows_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int,
+                                        C.c_int64, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]),
+    "elfihip_dist_cols": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_int64,
+                                    C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]),
+    "elfihip_dist_cols_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int,
+                                        C.c_int64, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]),
+    "elfihip_dist_multiw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int64,
+                                      C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "elfihip_dist_multiw_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int64,
+                                          C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "elfihip_welford_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int64,
+                                         C.POINTER(C.c_int64), C.c_void_p, C.c_void_p]),
+    "elfihip_welford_update_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int64,
+                                             C.c_void_p]),
+}
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+class ElfiHipError(RuntimeError):
+    """HIP runtime / device failure inside libelfihip.so."""
+
+
+def load_library():
+    """dlopen libelfihip.so (once per process) and attach the prototypes.
+
+    If torch is already imported its bundled HIP runtime (same soname,
+    libamdhip64.so.7) is the one the dynamic loader binds to, so device pointers and
+    streams can be shared with torch; otherwise /opt/rocm's runtime is used.
+    """
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "libelfihip.so is not built ({}). Run `python -c 'import __graft_entry__ as g; "
+                "g.build()'` or `make -C elfi_amd/csrc`; there is no CPU fallback.".format(LIB_PATH))
+        try:
+            import torch  # noqa: F401  (binds torch's HIP runtime first when available)
+        except Exception:  # pragma: no cover - torch is optional for the C ABI itself
+            pass
+        lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        for name, (restype, argtypes) in PROTOTYPES.items():
+            fn = getattr(lib, name)
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = lib
+        return _lib
+
+
+def _raise(lib, ctx, rc):
+    msg = lib.elfihip_last_error(ctx)
+    msg = msg.decode("utf-8", "replace") if msg else "status %d" % rc
+    if rc == ERR_ARG:
+        raise ValueError(msg)
+    if rc == ERR_NOT_PD:
+        raise np.linalg.LinAlgError(msg)
+    if rc == ERR_NOMEM:
+        raise MemoryError(msg)
+    raise ElfiHipError(msg)
+
+
+def check(ctx, rc):
+    if rc != OK:
+        _raise(load_library(), ctx, rc)
+
+
+def ptr(a):
+    """Address of a numpy array's data (None -> NULL)."""
+    if a is None:
+        return None
+    return a.ctypes.data
+
+
+class Context:
+    """One GPU + one HIP stream.  Created lazily per process (never before a fork).
+
+    Mirrors the per-process laziness the reference's picklable operations need
+    (elfi/clients/multiprocessing.py:50 pickles operations into pool workers).
+    """
+
+    def __init__(self, device=-1):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.elfihip_ctx_create(int(device), C.byref(h))
+        if rc != OK:
+            _raise(self.lib, None, rc)
+        self.handle = h
+        self.pid = os.getpid()
+
+    def close(self):
+        if getattr(self, "handle", None) is not None and self.pid == os.getpid():
+            self.lib.elfihip_ctx_destroy(self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def call(self, name, *args):
+        rc = getattr(self.lib, name)(self.handle, *args)
+        if rc != OK:
+            _raise(self.lib, self.handle, rc)
+
+    def synchronize(self):
+        self.call("elfihip_ctx_synchronize")
+
+    def set_stream(self, stream_handle):
+        self.call("elfihip_ctx_set_stream", C.c_void_p(stream_handle or 0))
+
+    def device_info(self):
+        cu, clk, mclk, bus = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        mem = C.c_int64()
+        name = C.create_string_buffer(256)
+        self.call("elfihip_device_info", C.byref(cu), C.byref(clk), C.byref(mclk), C.byref(bus),
+                  C.byref(mem), name, 256)
+        return dict(cu_count=cu.value, clock_khz=clk.value, mem_clock_khz=mclk.value,
+                    mem_bus_bits=bus.value, total_mem=mem.value, name=name.value.decode())
+
+    def timer_start(self):
+        self.call("elfihip_timer_start")
+
+    def timer_stop(self):
+        ms = C.c_float()
+        self.call("elfihip_timer_stop", C.byref(ms))
+        return ms.value
+
+
+_ctx_by_device = {}
+_ctx_lock = threading.Lock()
+
+
+def default_context(device=-1):
+    """Process-local context for `device` (-1: current HIP device, or $ELFI_AMD_DEVICE)."""
+    if device < 0:
+        env = os.environ.get("ELFI_AMD_DEVICE")
+        if env is not None:
+            device = int(env)
+    key = (os.getpid(), device)
+    ctx = _ctx_by_device.get(key)
+    if ctx is None:
+        with _ctx_lock:
+            ctx = _ctx_by_device.get(key)
+            if ctx is None:
+                ctx = Context(device)
+                _ctx_by_device[key] = ctx
+    return ctx
+
+
+def device_count():
+    lib = load_library()
+    n = C.c_int()
+    rc = lib.elfihip_device_count(C.byref(n))
+    return n.value if rc == OK else 0

@@ -1,0 +1,124 @@
+// Shared internals of libelfihip.so: context object, error plumbing, device workspace.
+// Nothing here is part of the ABI (see include/elfihip.h for that).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/elfihip.h"
+
+namespace elfihip {
+
+// Grow-only device buffer owned by a context (host entry points stage through these).
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) {
+      hipError_t e = hipFree(p);
+      p = nullptr;
+      cap = 0;
+      if (e != hipSuccess) return e;
+    }
+    // round up so a slowly growing batch does not realloc every call
+    size_t want = bytes + bytes / 4 + 4096;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+      p = nullptr;
+      return e;
+    }
+    cap = want;
+    return hipSuccess;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <class T>
+  T* as() const {
+    return reinterpret_cast<T*>(p);
+  }
+};
+
+}  // namespace elfihip
+
+struct elfihip_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;  // own_stream or an adopted one
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int cu_count = 0;
+  std::string err;
+  // staging buffers for the host entry points
+  elfihip::DevBuf in, out, par, scratch;
+};
+
+namespace elfihip {
+
+extern thread_local std::string g_err;  // context-less errors
+
+inline int fail(elfihip_ctx* ctx, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (ctx)
+    ctx->err = buf;
+  else
+    g_err = buf;
+  return code;
+}
+
+#define ELFIHIP_CHECK_HIP(ctx, expr)                                                          \
+  do {                                                                                        \
+    hipError_t e__ = (expr);                                                                  \
+    if (e__ != hipSuccess)                                                                    \
+      return ::elfihip::fail((ctx), ELFIHIP_ERR_HIP, "%s failed: %s (%s:%d)", #expr,          \
+                             hipGetErrorString(e__), __FILE__, __LINE__);                     \
+  } while (0)
+
+#define ELFIHIP_REQUIRE(ctx, cond, ...)                                          \
+  do {                                                                           \
+    if (!(cond)) return ::elfihip::fail((ctx), ELFIHIP_ERR_ARG, __VA_ARGS__);    \
+  } while (0)
+
+#define ELFIHIP_TRY(expr)            \
+  do {                               \
+    int rc__ = (expr);               \
+    if (rc__ != ELFIHIP_OK) return rc__; \
+  } while (0)
+
+// RAII device guard: entry points run on the context's device and restore the caller's.
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = true;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) {
+      ok = false;
+      return;
+    }
+    if (prev != dev && hipSetDevice(dev) != hipSuccess) ok = false;
+  }
+  ~DeviceGuard() {
+    int cur = -1;
+    if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+  }
+};
+
+inline int launch_status(elfihip_ctx* ctx, const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess)
+    return fail(ctx, ELFIHIP_ERR_HIP, "launch of %s failed: %s", what, hipGetErrorString(e));
+  return ELFIHIP_OK;
+}
+
+}  // namespace elfihip

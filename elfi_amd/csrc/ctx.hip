@@ -1,0 +1,130 @@
+// Context lifecycle, error text, stream adoption and event timing for libelfihip.so.
+#include "common.hpp"
+
+namespace elfihip {
+thread_local std::string g_err;
+}
+
+using namespace elfihip;
+
+extern "C" {
+
+int elfihip_version(void) { return ELFIHIP_VERSION; }
+
+int elfihip_device_count(int* count) {
+  if (!count) return fail(nullptr, ELFIHIP_ERR_ARG, "count is NULL");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    *count = 0;
+    return fail(nullptr, ELFIHIP_ERR_HIP, "hipGetDeviceCount failed: %s", hipGetErrorString(e));
+  }
+  *count = n;
+  return ELFIHIP_OK;
+}
+
+int elfihip_ctx_create(int device, elfihip_ctx** out) {
+  if (!out) return fail(nullptr, ELFIHIP_ERR_ARG, "ctx out-pointer is NULL");
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n == 0)
+    return fail(nullptr, ELFIHIP_ERR_HIP, "no HIP device available (%s)",
+                e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+  if (device < 0) {
+    e = hipGetDevice(&device);
+    if (e != hipSuccess)
+      return fail(nullptr, ELFIHIP_ERR_HIP, "hipGetDevice failed: %s", hipGetErrorString(e));
+  }
+  if (device >= n) return fail(nullptr, ELFIHIP_ERR_ARG, "device %d out of range (have %d)", device, n);
+
+  elfihip_ctx* ctx = new elfihip_ctx();
+  ctx->device = device;
+  DeviceGuard g(device);
+  if (!g.ok) {
+    delete ctx;
+    return fail(nullptr, ELFIHIP_ERR_HIP, "cannot select device %d", device);
+  }
+  hipDeviceProp_t prop;
+  e = hipGetDeviceProperties(&prop, device);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
+  if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
+  if (e != hipSuccess) {
+    int rc = fail(nullptr, ELFIHIP_ERR_HIP, "context setup failed: %s", hipGetErrorString(e));
+    delete ctx;
+    return rc;
+  }
+  ctx->cu_count = prop.multiProcessorCount;
+  ctx->stream = ctx->own_stream;
+  *out = ctx;
+  return ELFIHIP_OK;
+}
+
+int elfihip_ctx_destroy(elfihip_ctx* ctx) {
+  if (!ctx) return ELFIHIP_OK;
+  {
+    DeviceGuard g(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    ctx->in.release();
+    ctx->out.release();
+    ctx->par.release();
+    ctx->scratch.release();
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+  }
+  delete ctx;
+  return ELFIHIP_OK;
+}
+
+const char* elfihip_last_error(const elfihip_ctx* ctx) {
+  return ctx ? ctx->err.c_str() : g_err.c_str();
+}
+
+int elfihip_ctx_set_stream(elfihip_ctx* ctx, void* hip_stream) {
+  if (!ctx) return fail(nullptr, ELFIHIP_ERR_ARG, "ctx is NULL");
+  ctx->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+  return ELFIHIP_OK;
+}
+
+int elfihip_ctx_synchronize(elfihip_ctx* ctx) {
+  if (!ctx) return fail(nullptr, ELFIHIP_ERR_ARG, "ctx is NULL");
+  DeviceGuard g(ctx->device);
+  ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ELFIHIP_OK;
+}
+
+int elfihip_device_info(elfihip_ctx* ctx, int* cu_count, int* clock_khz, int* mem_clock_khz,
+                        int* mem_bus_bits, int64_t* total_mem, char* name, int name_len) {
+  if (!ctx) return fail(nullptr, ELFIHIP_ERR_ARG, "ctx is NULL");
+  hipDeviceProp_t prop;
+  ELFIHIP_CHECK_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+  if (cu_count) *cu_count = prop.multiProcessorCount;
+  if (clock_khz) *clock_khz = prop.clockRate;
+  if (mem_clock_khz) *mem_clock_khz = prop.memoryClockRate;
+  if (mem_bus_bits) *mem_bus_bits = prop.memoryBusWidth;
+  if (total_mem) *total_mem = (int64_t)prop.totalGlobalMem;
+  if (name && name_len > 0) {
+    snprintf(name, (size_t)name_len, "%s (%s)", prop.name, prop.gcnArchName);
+  }
+  return ELFIHIP_OK;
+}
+
+int elfihip_timer_start(elfihip_ctx* ctx) {
+  if (!ctx) return fail(nullptr, ELFIHIP_ERR_ARG, "ctx is NULL");
+  DeviceGuard g(ctx->device);
+  ELFIHIP_CHECK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  return ELFIHIP_OK;
+}
+
+int elfihip_timer_stop(elfihip_ctx* ctx, float* elapsed_ms) {
+  if (!ctx || !elapsed_ms) return fail(ctx, ELFIHIP_ERR_ARG, "NULL argument");
+  DeviceGuard g(ctx->device);
+  ELFIHIP_CHECK_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  ELFIHIP_CHECK_HIP(ctx, hipEventSynchronize(ctx->ev1));
+  ELFIHIP_CHECK_HIP(ctx, hipEventElapsedTime(elapsed_ms, ctx->ev0, ctx->ev1));
+  return ELFIHIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,682 @@
+// Batched row-vs-observed distances for gfx950 (MI355X).
+//
+// Replaces the scipy.spatial.distance.cdist(X (n,m), Y (1,m), ...) call that
+// elfi.Distance / AdaptiveDistance make once per batch
+// (elfi/model/elfi_model.py:1037,1084 via elfi/model/utils.py:37-52).
+//
+// These kernels are HBM-bound: 8*m bytes in and 8 bytes out per distance, 2-3 flops
+// per byte.  Design:
+//   * row-major input (the np.column_stack layout): a workgroup streams a tile of
+//     R = blockDim rows as ONE contiguous span with 16-byte loads per lane (fully
+//     coalesced), drops it into LDS with an odd row pitch (m|1 doubles, so a
+//     column walk by 64 lanes is bank-conflict free for ds_read_b64), and then lane r
+//     sums row r left to right.  The LDS transpose is what lets every lane own a
+//     whole row, so the accumulation order is exactly SciPy's (sequential over j) and
+//     the result is bit-identical to cdist for the +,*,abs,max metrics.
+//   * column-major input (ELFI's separate summary arrays, before column_stack): lane
+//     i walks column j at row i -- coalesced by construction, no LDS needed.
+//   * very wide rows (m >= 300): one wavefront per row with a shuffle tree (order
+//     differs from SciPy by a few ulp; documented tolerance).
+// FMA contraction is off in this file: a fused d*d+s would round differently from the
+// reference's separate multiply and add.
+#include "common.hpp"
+
+#pragma clang fp contract(off)
+
+namespace elfihip {
+
+constexpr int kMaxTileM = 299;  // widest row the LDS-tile kernel takes (64 rows * 301 * 8 B < 160 KiB)
+constexpr int kMaxK = 64;
+
+struct FastDiv {
+  uint32_t mul, d;
+};
+static FastDiv make_fastdiv(uint32_t d) {
+  FastDiv f;
+  f.d = d;
+  uint64_t q = (1ull << 32) / d;
+  f.mul = q > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)q;
+  return f;
+}
+__device__ __forceinline__ uint32_t fastdiv(uint32_t x, FastDiv f) {
+  // floor(2^32/d) under-estimates by at most one; a single fix-up makes it exact.
+  uint32_t q = __umulhi(x, f.mul);
+  if (x - q * f.d >= f.d) ++q;
+  return q;
+}
+
+// ---- per-metric term / finish --------------------------------------------------
+template <int METRIC, bool W>
+struct Op {
+  __device__ static __forceinline__ double init() { return 0.0; }
+  __device__ static __forceinline__ double step(double s, double x, double y, double a, double p) {
+    double d = x - y;
+    if constexpr (METRIC == ELFIHIP_EUCLIDEAN) {
+      double t = d * d;
+      if constexpr (W) t = a * t;  // SciPy: w * (d*d)
+      return s + t;
+    } else if constexpr (METRIC == ELFIHIP_SQEUCLIDEAN) {
+      if constexpr (W) return s + (a * d) * d;  // SciPy associates the other way here
+      return s + d * d;
+    } else if constexpr (METRIC == ELFIHIP_CITYBLOCK) {
+      double t = fabs(d);
+      if constexpr (W) t = a * t;
+      return s + t;
+    } else if constexpr (METRIC == ELFIHIP_CHEBYSHEV) {
+      double t = fabs(d);
+      if constexpr (W) t = (a == 0.0) ? 0.0 : t;  // SciPy: zero-weight columns are ignored
+      return t > s ? t : s;
+    } else if constexpr (METRIC == ELFIHIP_MINKOWSKI) {
+      double t = pow(fabs(d), p);
+      if constexpr (W) t = a * t;
+      return s + t;
+    } else {  // ELFIHIP_SEUCLIDEAN, a = V_j
+      return s + (d * d) / a;
+    }
+  }
+  __device__ static __forceinline__ double combine(double a, double b) {
+    if constexpr (METRIC == ELFIHIP_CHEBYSHEV)
+      return a > b ? a : b;
+    else
+      return a + b;
+  }
+  __device__ static __forceinline__ double finish(double s, double inv_p) {
+    if constexpr (METRIC == ELFIHIP_EUCLIDEAN || METRIC == ELFIHIP_SEUCLIDEAN)
+      return sqrt(s);
+    else if constexpr (METRIC == ELFIHIP_MINKOWSKI)
+      return pow(s, inv_p);
+    else
+      return s;
+  }
+};
+
+struct RowArgs {
+  const double* X;
+  int64_t n;
+  int64_t ldx;
+  const double* y;
+  const double* aux;
+  double* out;
+  double p, inv_p;
+  int m, mp;      // mp = m | 1: LDS row pitch in doubles
+  int K;          // multi-weight: number of weight rows in aux
+  int vec2;       // 16-byte loads are legal (m, ldx even; X 16-byte aligned)
+  FastDiv div_h;  // by m/2 (vec2) or m
+};
+
+// Stream one tile of `rows` rows starting at row0 into LDS (pitch mp).
+template <int U>
+__device__ __forceinline__ void load_tile(const RowArgs& A, double* tile, int64_t row0, int rows) {
+  const int T = blockDim.x, tid = threadIdx.x;
+  const double* __restrict__ X = A.X + row0 * A.ldx;
+  if (A.vec2) {
+    const uint32_t h = (uint32_t)A.m >> 1;
+    const uint32_t npairs = (uint32_t)rows * h;
+    for (uint32_t base = 0; base < npairs; base += (uint32_t)(T * U)) {
+      double2 v[U];
+      uint32_t r[U], jj[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        uint32_t idx = base + (uint32_t)(u * T + tid);
+        bool ok = idx < npairs;
+        uint32_t q = fastdiv(ok ? idx : 0u, A.div_h);
+        r[u] = q;
+        jj[u] = (ok ? idx : 0u) - q * h;
+        if (ok)
+          v[u] = *reinterpret_cast<const double2*>(X + (int64_t)q * A.ldx + 2 * jj[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        uint32_t idx = base + (uint32_t)(u * T + tid);
+        if (idx < npairs) {
+          double* dst = tile + r[u] * (uint32_t)A.mp + 2 * jj[u];
+          dst[0] = v[u].x;
+          dst[1] = v[u].y;
+        }
+      }
+    }
+  } else {
+    const uint32_t m = (uint32_t)A.m;
+    const uint32_t nel = (uint32_t)rows * m;
+    for (uint32_t base = 0; base < nel; base += (uint32_t)(T * U)) {
+      double v[U];
+      uint32_t r[U], j[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        uint32_t idx = base + (uint32_t)(u * T + tid);
+        bool ok = idx < nel;
+        uint32_t q = fastdiv(ok ? idx : 0u, A.div_h);
+        r[u] = q;
+        j[u] = (ok ? idx : 0u) - q * m;
+        if (ok) v[u] = X[(int64_t)q * A.ldx + j[u]];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        uint32_t idx = base + (uint32_t)(u * T + tid);
+        if (idx < nel) tile[r[u] * (uint32_t)A.mp + j[u]] = v[u];
+      }
+    }
+  }
+}
+
+// One distance per row, SciPy accumulation order.
+template <int METRIC, bool W, int U>
+__global__ void dist_rows_kernel(RowArgs A) {
+  extern __shared__ __align__(16) double lds[];
+  const int T = blockDim.x, tid = threadIdx.x, m = A.m;
+  double* tile = lds;
+  double* ys = tile + (size_t)T * A.mp;
+  double* as = ys + m;
+  for (int j = tid; j < m; j += T) {
+    ys[j] = A.y[j];
+    if constexpr (W) as[j] = A.aux[j];
+  }
+  const int64_t ntiles = (A.n + T - 1) / T;
+  for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int64_t row0 = t * T;
+    const int rows = (int)((A.n - row0) < T ? (A.n - row0) : T);
+    __syncthreads();  // tile free (previous readers done); ys/as visible on the first trip
+    load_tile<U>(A, tile, row0, rows);
+    __syncthreads();
+    if (tid < rows) {
+      const double* row = tile + (size_t)tid * A.mp;
+      double s = Op<METRIC, W>::init();
+#pragma unroll 4
+      for (int j = 0; j < m; ++j) s = Op<METRIC, W>::step(s, row[j], ys[j], W ? as[j] : 1.0, A.p);
+      A.out[row0 + tid] = Op<METRIC, W>::finish(s, A.inv_p);
+    }
+  }
+}
+
+// Mahalanobis: sqrt(d' VI d); VI (m*m, row-major) is read through the scalar/L1 path.
+template <int U>
+__global__ void dist_rows_mahalanobis_kernel(RowArgs A) {
+  extern __shared__ __align__(16) double lds[];
+  const int T = blockDim.x, tid = threadIdx.x, m = A.m;
+  double* tile = lds;
+  double* ys = tile + (size_t)T * A.mp;
+  for (int j = tid; j < m; j += T) ys[j] = A.y[j];
+  const double* __restrict__ VI = A.aux;
+  const int64_t ntiles = (A.n + T - 1) / T;
+  for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int64_t row0 = t * T;
+    const int rows = (int)((A.n - row0) < T ? (A.n - row0) : T);
+    __syncthreads();
+    load_tile<U>(A, tile, row0, rows);
+    __syncthreads();
+    if (tid < rows) {
+      double* row = tile + (size_t)tid * A.mp;
+      for (int j = 0; j < m; ++j) row[j] = row[j] - ys[j];  // own row only: no hazard
+      double s = 0.0;
+      for (int i = 0; i < m; ++i) {
+        double ti = 0.0;
+        const double* vi = VI + (size_t)i * m;
+        for (int k = 0; k < m; ++k) ti += row[k] * vi[k];
+        s += row[i] * ti;
+      }
+      A.out[row0 + tid] = sqrt(s);
+    }
+  }
+}
+
+// K weighted euclidean distances per row (AdaptiveDistance.nested_distance); out (n,K).
+template <int U>
+__global__ void dist_multiw_kernel(RowArgs A) {
+  extern __shared__ __align__(16) double lds[];
+  const int T = blockDim.x, tid = threadIdx.x, m = A.m, K = A.K;
+  double* tile = lds;
+  double* ys = tile + (size_t)T * A.mp;
+  double* ws = ys + m;  // (K, m)
+  for (int j = tid; j < m; j += T) ys[j] = A.y[j];
+  for (int j = tid; j < K * m; j += T) ws[j] = A.aux[j];
+  const int64_t ntiles = (A.n + T - 1) / T;
+  for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int64_t row0 = t * T;
+    const int rows = (int)((A.n - row0) < T ? (A.n - row0) : T);
+    __syncthreads();
+    load_tile<U>(A, tile, row0, rows);
+    __syncthreads();
+    if (tid < rows) {
+      double* row = tile + (size_t)tid * A.mp;
+      for (int j = 0; j < m; ++j) {  // (x-y)^2 once, reused by every weight vector
+        double d = row[j] - ys[j];
+        row[j] = d * d;
+      }
+      for (int k = 0; k < K; ++k) {
+        const double* w = ws + (size_t)k * m;
+        double s = 0.0;
+#pragma unroll 4
+        for (int j = 0; j < m; ++j) s = s + w[j] * row[j];
+        A.out[(row0 + tid) * K + k] = sqrt(s);
+      }
+    }
+  }
+}
+
+// Column-major input: lane i reads C[j*ldc + i]; two rows per lane when aligned.
+struct ColArgs {
+  const double* C;
+  int64_t n, ldc;
+  const double* y;
+  const double* aux;
+  double* out;
+  double p, inv_p;
+  int m;
+  int vec2;
+};
+
+template <int METRIC, bool W>
+__global__ void dist_cols_kernel(ColArgs A) {
+  extern __shared__ __align__(16) double lds[];
+  const int m = A.m;
+  double* ys = lds;
+  double* as = ys + m;
+  for (int j = threadIdx.x; j < m; j += blockDim.x) {
+    ys[j] = A.y[j];
+    if constexpr (W) as[j] = A.aux[j];
+  }
+  __syncthreads();
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (A.vec2) {
+    const int64_t npair = A.n >> 1;
+    for (int64_t i2 = gid; i2 < npair; i2 += stride) {
+      double s0 = Op<METRIC, W>::init(), s1 = s0;
+      const double* __restrict__ c = A.C + 2 * i2;
+      int j = 0;
+      for (; j + 8 <= m; j += 8) {
+        double2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const double2*>(c + (int64_t)(j + u) * A.ldc);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          s0 = Op<METRIC, W>::step(s0, v[u].x, ys[j + u], W ? as[j + u] : 1.0, A.p);
+          s1 = Op<METRIC, W>::step(s1, v[u].y, ys[j + u], W ? as[j + u] : 1.0, A.p);
+        }
+      }
+      for (; j < m; ++j) {
+        double2 v = *reinterpret_cast<const double2*>(c + (int64_t)j * A.ldc);
+        s0 = Op<METRIC, W>::step(s0, v.x, ys[j], W ? as[j] : 1.0, A.p);
+        s1 = Op<METRIC, W>::step(s1, v.y, ys[j], W ? as[j] : 1.0, A.p);
+      }
+      double2 o;
+      o.x = Op<METRIC, W>::finish(s0, A.inv_p);
+      o.y = Op<METRIC, W>::finish(s1, A.inv_p);
+      *reinterpret_cast<double2*>(A.out + 2 * i2) = o;
+    }
+    if ((A.n & 1) && gid == 0) {  // odd tail row
+      const int64_t i = A.n - 1;
+      double s = Op<METRIC, W>::init();
+      for (int j = 0; j < m; ++j)
+        s = Op<METRIC, W>::step(s, A.C[(int64_t)j * A.ldc + i], ys[j], W ? as[j] : 1.0, A.p);
+      A.out[i] = Op<METRIC, W>::finish(s, A.inv_p);
+    }
+  } else {
+    for (int64_t i = gid; i < A.n; i += stride) {
+      double s = Op<METRIC, W>::init();
+      const double* __restrict__ c = A.C + i;
+      int j = 0;
+      for (; j + 8 <= m; j += 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = c[(int64_t)(j + u) * A.ldc];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s = Op<METRIC, W>::step(s, v[u], ys[j + u], W ? as[j + u] : 1.0, A.p);
+      }
+      for (; j < m; ++j) s = Op<METRIC, W>::step(s, c[(int64_t)j * A.ldc], ys[j], W ? as[j] : 1.0, A.p);
+      A.out[i] = Op<METRIC, W>::finish(s, A.inv_p);
+    }
+  }
+}
+
+// Very wide rows: one wavefront per row, lanes stride over the columns, butterfly combine.
+template <int METRIC, bool W>
+__global__ void dist_rows_wide_kernel(RowArgs A) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t r = wave; r < A.n; r += nwaves) {
+    const double* __restrict__ x = A.X + r * A.ldx;
+    double s = Op<METRIC, W>::init();
+    for (int j = lane; j < A.m; j += 64) s = Op<METRIC, W>::step(s, x[j], A.y[j], W ? A.aux[j] : 1.0, A.p);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s = Op<METRIC, W>::combine(s, __shfl_xor(s, off, 64));
+    if (lane == 0) A.out[r] = Op<METRIC, W>::finish(s, A.inv_p);
+  }
+}
+
+// ---- host-side launch logic ------------------------------------------------------
+static int pick_block(int m, size_t extra_doubles, size_t* lds_bytes) {
+  const int mp = m | 1;
+  const int cand[3] = {256, 128, 64};
+  for (int c = 0; c < 3; ++c) {
+    size_t b = ((size_t)cand[c] * mp + extra_doubles) * sizeof(double);
+    if (b <= 41 * 1024 || cand[c] == 64) {
+      *lds_bytes = b;
+      return cand[c];
+    }
+  }
+  return 64;
+}
+
+static int grid_for(const elfihip_ctx* ctx, int64_t ntiles, size_t lds_bytes, int T) {
+  int per_cu = (int)((160 * 1024) / (lds_bytes ? lds_bytes : 1));
+  int by_waves = 32 / (T / 64);
+  if (per_cu > by_waves) per_cu = by_waves;
+  if (per_cu > 8) per_cu = 8;
+  if (per_cu < 1) per_cu = 1;
+  int64_t g = (int64_t)ctx->cu_count * per_cu;
+  if (g > ntiles) g = ntiles;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+template <class KernelT>
+static int set_lds(elfihip_ctx* ctx, KernelT k, size_t lds) {
+  if (lds > 64 * 1024)
+    ELFIHIP_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  return ELFIHIP_OK;
+}
+
+template <int METRIC, bool W>
+static int launch_rows(elfihip_ctx* ctx, RowArgs A) {
+  if (A.m > kMaxTileM) {
+    int64_t rows_per_block = 4;
+    int64_t g = (A.n + rows_per_block - 1) / rows_per_block;
+    int64_t cap = (int64_t)ctx->cu_count * 8;
+    if (g > cap) g = cap;
+    hipLaunchKernelGGL((dist_rows_wide_kernel<METRIC, W>), dim3((unsigned)g), dim3(256), 0, ctx->stream, A);
+    return launch_status(ctx, "dist_rows_wide_kernel");
+  }
+  size_t lds;
+  const int T = pick_block(A.m, 2 * (size_t)A.m, &lds);
+  const int64_t ntiles = (A.n + T - 1) / T;
+  const int g = grid_for(ctx, ntiles, lds, T);
+  if (T == 64) {
+    ELFIHIP_TRY(set_lds(ctx, dist_rows_kernel<METRIC, W, 16>, lds));
+    hipLaunchKernelGGL((dist_rows_kernel<METRIC, W, 16>), dim3(g), dim3(T), lds, ctx->stream, A);
+  } else {
+    hipLaunchKernelGGL((dist_rows_kernel<METRIC, W, 8>), dim3(g), dim3(T), lds, ctx->stream, A);
+  }
+  return launch_status(ctx, "dist_rows_kernel");
+}
+
+template <int METRIC, bool W>
+static int launch_cols(elfihip_ctx* ctx, ColArgs A) {
+  const int T = 256;
+  int64_t work = A.vec2 ? ((A.n + 1) >> 1) : A.n;
+  int64_t g = (work + T - 1) / T;
+  int64_t cap = (int64_t)ctx->cu_count * 8;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  size_t lds = 2 * (size_t)A.m * sizeof(double);
+  hipLaunchKernelGGL((dist_cols_kernel<METRIC, W>), dim3((unsigned)g), dim3(T), lds, ctx->stream, A);
+  return launch_status(ctx, "dist_cols_kernel");
+}
+
+// SciPy folds minkowski p=1 / p=2 / p=inf into cityblock / euclidean / chebyshev.
+static int canonical_metric(elfihip_ctx* ctx, int metric, double p, const double* aux, int* out_metric) {
+  switch (metric) {
+    case ELFIHIP_EUCLIDEAN:
+    case ELFIHIP_SQEUCLIDEAN:
+    case ELFIHIP_CITYBLOCK:
+    case ELFIHIP_CHEBYSHEV:
+      *out_metric = metric;
+      return ELFIHIP_OK;
+    case ELFIHIP_MINKOWSKI:
+      if (!(p > 0.0)) return fail(ctx, ELFIHIP_ERR_ARG, "minkowski needs p > 0 (got %g)", p);
+      if (p == 1.0)
+        *out_metric = ELFIHIP_CITYBLOCK;
+      else if (p == 2.0)
+        *out_metric = ELFIHIP_EUCLIDEAN;
+      else if (p > 1.7e308)
+        *out_metric = ELFIHIP_CHEBYSHEV;
+      else
+        *out_metric = ELFIHIP_MINKOWSKI;
+      return ELFIHIP_OK;
+    case ELFIHIP_SEUCLIDEAN:
+      if (!aux) return fail(ctx, ELFIHIP_ERR_ARG, "seuclidean needs V");
+      *out_metric = metric;
+      return ELFIHIP_OK;
+    case ELFIHIP_MAHALANOBIS:
+      if (!aux) return fail(ctx, ELFIHIP_ERR_ARG, "mahalanobis needs VI");
+      *out_metric = metric;
+      return ELFIHIP_OK;
+    default:
+      return fail(ctx, ELFIHIP_ERR_ARG, "unknown metric id %d", metric);
+  }
+}
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+static RowArgs make_row_args(const double* dX, int64_t n, int m, int64_t ldx, const double* dy,
+                             const double* daux, double p, double* dout) {
+  RowArgs A;
+  A.X = dX;
+  A.n = n;
+  A.ldx = ldx;
+  A.y = dy;
+  A.aux = daux;
+  A.out = dout;
+  A.p = p;
+  A.inv_p = p != 0.0 ? 1.0 / p : 0.0;
+  A.m = m;
+  A.mp = m | 1;
+  A.K = 0;
+  A.vec2 = (m % 2 == 0) && (ldx % 2 == 0) && aligned16(dX);
+  A.div_h = make_fastdiv((uint32_t)(A.vec2 ? m / 2 : m));
+  return A;
+}
+
+static int dist_rows_dev_impl(elfihip_ctx* ctx, int metric, const double* dX, int64_t n, int m,
+                              int64_t ldx, const double* dy, const double* daux, double p, double* dout) {
+  ELFIHIP_REQUIRE(ctx, n >= 0 && m >= 1, "bad shape n=%lld m=%d", (long long)n, m);
+  ELFIHIP_REQUIRE(ctx, ldx >= m, "ldx (%lld) < m (%d)", (long long)ldx, m);
+  ELFIHIP_REQUIRE(ctx, n == 0 || (dX && dy && dout), "NULL data pointer");
+  int cm;
+  ELFIHIP_TRY(canonical_metric(ctx, metric, p, daux, &cm));
+  if (n == 0) return ELFIHIP_OK;
+  RowArgs A = make_row_args(dX, n, m, ldx, dy, daux, p, dout);
+  const bool w = daux != nullptr;
+  if (cm == ELFIHIP_MAHALANOBIS) {
+    ELFIHIP_REQUIRE(ctx, m <= kMaxTileM, "mahalanobis supports m <= %d", kMaxTileM);
+    size_t lds;
+    const int T = pick_block(m, (size_t)m, &lds);
+    const int g = grid_for(ctx, (n + T - 1) / T, lds, T);
+    ELFIHIP_TRY(set_lds(ctx, dist_rows_mahalanobis_kernel<8>, lds));
+    hipLaunchKernelGGL((dist_rows_mahalanobis_kernel<8>), dim3(g), dim3(T), lds, ctx->stream, A);
+    return launch_status(ctx, "dist_rows_mahalanobis_kernel");
+  }
+#define ELFIHIP_DISPATCH_ROWS(M)                                                  \
+  case M:                                                                         \
+    return w ? launch_rows<M, true>(ctx, A) : launch_rows<M, false>(ctx, A);
+  switch (cm) {
+    ELFIHIP_DISPATCH_ROWS(ELFIHIP_EUCLIDEAN)
+    ELFIHIP_DISPATCH_ROWS(ELFIHIP_SQEUCLIDEAN)
+    ELFIHIP_DISPATCH_ROWS(ELFIHIP_CITYBLOCK)
+    ELFIHIP_DISPATCH_ROWS(ELFIHIP_CHEBYSHEV)
+    ELFIHIP_DISPATCH_ROWS(ELFIHIP_MINKOWSKI)
+    case ELFIHIP_SEUCLIDEAN:
+      return launch_rows<ELFIHIP_SEUCLIDEAN, true>(ctx, A);
+  }
+#undef ELFIHIP_DISPATCH_ROWS
+  return fail(ctx, ELFIHIP_ERR_ARG, "unhandled metric %d", cm);
+}
+
+static int dist_cols_dev_impl(elfihip_ctx* ctx, int metric, const double* dC, int64_t n, int m,
+                              int64_t ldc, const double* dy, const double* daux, double p, double* dout) {
+  ELFIHIP_REQUIRE(ctx, n >= 0 && m >= 1, "bad shape n=%lld m=%d", (long long)n, m);
+  ELFIHIP_REQUIRE(ctx, ldc >= n, "ldc (%lld) < n (%lld)", (long long)ldc, (long long)n);
+  ELFIHIP_REQUIRE(ctx, n == 0 || (dC && dy && dout), "NULL data pointer");
+  ELFIHIP_REQUIRE(ctx, metric != ELFIHIP_MAHALANOBIS, "mahalanobis needs the row-major entry point");
+  int cm;
+  ELFIHIP_TRY(canonical_metric(ctx, metric, p, daux, &cm));
+  if (n == 0) return ELFIHIP_OK;
+  ColArgs A;
+  A.C = dC;
+  A.n = n;
+  A.ldc = ldc;
+  A.y = dy;
+  A.aux = daux;
+  A.out = dout;
+  A.p = p;
+  A.inv_p = p != 0.0 ? 1.0 / p : 0.0;
+  A.m = m;
+  A.vec2 = (ldc % 2 == 0) && aligned16(dC) && aligned16(dout);
+  const bool w = daux != nullptr;
+#define ELFIHIP_DISPATCH_COLS(M)                                                  \
+  case M:                                                                         \
+    return w ? launch_cols<M, true>(ctx, A) : launch_cols<M, false>(ctx, A);
+  switch (cm) {
+    ELFIHIP_DISPATCH_COLS(ELFIHIP_EUCLIDEAN)
+    ELFIHIP_DISPATCH_COLS(ELFIHIP_SQEUCLIDEAN)
+    ELFIHIP_DISPATCH_COLS(ELFIHIP_CITYBLOCK)
+    ELFIHIP_DISPATCH_COLS(ELFIHIP_CHEBYSHEV)
+    ELFIHIP_DISPATCH_COLS(ELFIHIP_MINKOWSKI)
+    case ELFIHIP_SEUCLIDEAN:
+      return launch_cols<ELFIHIP_SEUCLIDEAN, true>(ctx, A);
+  }
+#undef ELFIHIP_DISPATCH_COLS
+  return fail(ctx, ELFIHIP_ERR_ARG, "unhandled metric %d", cm);
+}
+
+static int dist_multiw_dev_impl(elfihip_ctx* ctx, const double* dX, int64_t n, int m, int64_t ldx,
+                                const double* dy, const double* dW, int K, double* dout) {
+  ELFIHIP_REQUIRE(ctx, n >= 0 && m >= 1, "bad shape n=%lld m=%d", (long long)n, m);
+  ELFIHIP_REQUIRE(ctx, K >= 1 && K <= kMaxK, "K=%d outside [1,%d]", K, kMaxK);
+  ELFIHIP_REQUIRE(ctx, ldx >= m, "ldx (%lld) < m (%d)", (long long)ldx, m);
+  ELFIHIP_REQUIRE(ctx, n == 0 || (dX && dy && dW && dout), "NULL data pointer");
+  if (n == 0) return ELFIHIP_OK;
+  RowArgs A = make_row_args(dX, n, m, ldx, dy, dW, 2.0, dout);
+  A.K = K;
+  size_t lds;
+  int T = pick_block(m, (size_t)m + (size_t)K * m, &lds);
+  ELFIHIP_REQUIRE(ctx, lds <= 160 * 1024, "m=%d with K=%d weight vectors does not fit LDS", m, K);
+  const int g = grid_for(ctx, (n + T - 1) / T, lds, T);
+  ELFIHIP_TRY(set_lds(ctx, dist_multiw_kernel<8>, lds));
+  hipLaunchKernelGGL((dist_multiw_kernel<8>), dim3(g), dim3(T), lds, ctx->stream, A);
+  return launch_status(ctx, "dist_multiw_kernel");
+}
+
+static size_t aux_len(int metric, int m) {
+  return metric == ELFIHIP_MAHALANOBIS ? (size_t)m * m : (size_t)m;
+}
+
+}  // namespace elfihip
+
+using namespace elfihip;
+
+extern "C" {
+
+int elfihip_dist_rows_dev(elfihip_ctx* ctx, int metric, const double* dX, int64_t n, int m, int64_t ldx,
+                          const double* dy, const double* daux, double p, double* dout) {
+  if (!ctx) return fail(nullptr, ELFIHIP_ERR_ARG, "ctx is NULL");
+  DeviceGuard g(ctx->device);
+  return dist_rows_dev_impl(ctx, metric, dX, n, m, ldx, dy, daux, p, dout);
+}
+
+int elfihip_dist_cols_dev(elfihip_ctx* ctx, int metric, const double* dC, int64_t n, int m, int64_t ldc,
+                          const double* dy, const double* daux, double p, double* dout) {
+  if (!ctx) return fail(nullptr, ELFIHIP_ERR_ARG, "ctx is NULL");
+  DeviceGuard g(ctx->device);
+  return dist_cols_dev_impl(ctx, metric, dC, n, m, ldc, dy, daux, p, dout);
+}
+
+int elfihip_dist_multiw_dev(elfihip_ctx* ctx, const double* dX, int64_t n, int m, int64_t ldx,
+                            const double* dy, const double* dW, int K, double* dout) {
+  if (!ctx) return fail(nullptr, ELFIHIP_ERR_ARG, "ctx is NULL");
+  DeviceGuard g(ctx->device);
+  return dist_multiw_dev_impl(ctx, dX, n, m, ldx, dy, dW, K, dout);
+}
+
+// ---- host-pointer entry points: stage, launch, copy back, synchronise ---------------
+static int stage_params(elfihip_ctx* ctx, const double* y, const double* aux, int m, size_t naux,
+                        double** dy, double** daux) {
+  ELFIHIP_CHECK_HIP(ctx, ctx->par.reserve(((size_t)m + naux) * sizeof(double)));
+  *dy = ctx->par.as<double>();
+  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(*dy, y, (size_t)m * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  *daux = nullptr;
+  if (aux) {
+    *daux = *dy + m;
+    ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(*daux, aux, naux * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  }
+  return ELFIHIP_OK;
+}
+
+static int stage_rows(elfihip_ctx* ctx, const double* X, int64_t n, int m, int64_t ldx, double** dX) {
+  ELFIHIP_CHECK_HIP(ctx, ctx->in.reserve((size_t)n * m * sizeof(double)));
+  *dX = ctx->in.as<double>();
+  if (n == 0) return ELFIHIP_OK;
+  if (ldx == m)
+    ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(*dX, X, (size_t)n * m * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  else
+    ELFIHIP_CHECK_HIP(ctx, hipMemcpy2DAsync(*dX, (size_t)m * sizeof(double), X, (size_t)ldx * sizeof(double),
+                                            (size_t)m * sizeof(double), (size_t)n, hipMemcpyHostToDevice,
+                                            ctx->stream));
+  return ELFIHIP_OK;
+}
+
+int elfihip_dist_rows(elfihip_ctx* ctx, int metric, const double* X, int64_t n, int m, int64_t ldx,
+                      const double* y, const double* aux, double p, double* out) {
+  if (!ctx) return fail(nullptr, ELFIHIP_ERR_ARG, "ctx is NULL");
+  ELFIHIP_REQUIRE(ctx, n >= 0 && m >= 1 && ldx >= m, "bad shape n=%lld m=%d ldx=%lld", (long long)n, m,
+                  (long long)ldx);
+  ELFIHIP_REQUIRE(ctx, y && (n == 0 || (X && out)), "NULL data pointer");
+  DeviceGuard g(ctx->device);
+  double *dX, *dy, *daux;
+  ELFIHIP_TRY(stage_params(ctx, y, aux, m, aux ? aux_len(metric, m) : 0, &dy, &daux));
+  ELFIHIP_TRY(stage_rows(ctx, X, n, m, ldx, &dX));
+  ELFIHIP_CHECK_HIP(ctx, ctx->out.reserve((size_t)(n ? n : 1) * sizeof(double)));
+  ELFIHIP_TRY(dist_rows_dev_impl(ctx, metric, dX, n, m, m, dy, daux, p, ctx->out.as<double>()));
+  if (n)
+    ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(out, ctx->out.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ELFIHIP_OK;
+}
+
+int elfihip_dist_cols(elfihip_ctx* ctx, int metric, const double* const* cols, int m, int64_t n,
+                      const double* y, const double* aux, double p, double* out) {
+  if (!ctx) return fail(nullptr, ELFIHIP_ERR_ARG, "ctx is NULL");
+  ELFIHIP_REQUIRE(ctx, n >= 0 && m >= 1, "bad shape n=%lld m=%d", (long long)n, m);
+  ELFIHIP_REQUIRE(ctx, y && cols && (n == 0 || out), "NULL data pointer");
+  ELFIHIP_REQUIRE(ctx, metric != ELFIHIP_MAHALANOBIS, "mahalanobis needs the row-major entry point");
+  DeviceGuard g(ctx->device);
+  double *dy, *daux;
+  ELFIHIP_TRY(stage_params(ctx, y, aux, m, aux ? (size_t)m : 0, &dy, &daux));
+  const int64_t ldc = (n + 1) & ~(int64_t)1;  // even pitch keeps every column 16-byte aligned
+  ELFIHIP_CHECK_HIP(ctx, ctx->in.reserve((size_t)(ldc ? ldc : 2) * m * sizeof(double)));
+  double* dC = ctx->in.as<double>();
+  for (int j = 0; j < m && n; ++j) {
+    ELFIHIP_REQUIRE(ctx, cols[j] != nullptr, "column %d is NULL", j);
+    ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(dC + (size_t)j * ldc, cols[j], (size_t)n * sizeof(double),
+                                          hipMemcpyHostToDevice, ctx->stream));
+  }
+  ELFIHIP_CHECK_HIP(ctx, ctx->out.reserve((size_t)(ldc ? ldc : 2) * sizeof(double)));
+  ELFIHIP_TRY(dist_cols_dev_impl(ctx, metric, dC, n, m, ldc ? ldc : 2, dy, daux, p, ctx->out.as<double>()));
+  if (n)
+    ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(out, ctx->out.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ELFIHIP_OK;
+}
+
+int elfihip_dist_multiw(elfihip_ctx* ctx, const double* X, int64_t n, int m, int64_t ldx, const double* y,
+                        const double* W, int K, double* out) {
+  if (!ctx) return fail(nullptr, ELFIHIP_ERR_ARG, "ctx is NULL");
+  ELFIHIP_REQUIRE(ctx, n >= 0 && m >= 1 && ldx >= m, "bad shape n=%lld m=%d ldx=%lld", (long long)n, m,
+                  (long long)ldx);
+  ELFIHIP_REQUIRE(ctx, K >= 1 && K <= kMaxK, "K=%d outside [1,%d]", K, kMaxK);
+  ELFIHIP_REQUIRE(ctx, y && W && (n == 0 || (X && out)), "NULL data pointer");
+  DeviceGuard g(ctx->device);
+  double *dX, *dy, *dW;
+  ELFIHIP_TRY(stage_params(ctx, y, W, m, (size_t)K * m, &dy, &dW));
+  ELFIHIP_TRY(stage_rows(ctx, X, n, m, ldx, &dX));
+  ELFIHIP_CHECK_HIP(ctx, ctx->out.reserve((size_t)(n ? n : 1) * K * sizeof(double)));
+  ELFIHIP_TRY(dist_multiw_dev_impl(ctx, dX, n, m, m, dy, dW, K, ctx->out.as<double>()));
+  if (n)
+    ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(out, ctx->out.p, (size_t)n * K * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ELFIHIP_OK;
+}
+
+}  // extern "C"

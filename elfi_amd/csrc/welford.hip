@@ -1,0 +1,180 @@
+// Running column mean / sum of squared deviations for AdaptiveDistance on gfx950.
+//
+// Replaces AdaptiveDistance.add_data (elfi/model/elfi_model.py:1104-1125):
+//     N += b; d1 = x - mean; mean += sum(d1, axis=0)/N; d2 = x - mean; M2 += sum(d1*d2, axis=0)
+// The update needs the NEW mean before the second sum, so it is two streaming passes
+// over the batch (the second one is served from L2 / Infinity Cache for ordinary batch
+// sizes).  Both passes are HBM-bound column reductions: 8*m bytes per row.
+//
+// Determinism: lane t always owns column t % m, rows are assigned to (block, row-group)
+// in a fixed pattern, and partial sums are combined in a fixed order (row-groups inside
+// a workgroup, then workgroups by index) -- no atomics, so repeated runs and different
+// grid schedules of the same launch shape give identical bits.
+#include "common.hpp"
+
+#pragma clang fp contract(off)
+
+namespace elfihip {
+
+struct WelfordArgs {
+  const double* X;
+  int64_t n, ldx;
+  int m;
+  int rpi;           // row-groups per workgroup iteration (blockDim / m, at least 1)
+  const double* mean_old;  // state + 1
+  const double* mean_new;  // scratch (pass 2)
+  double* partial;   // (gridDim, m)
+};
+
+// PASS 1: sum_rows (x - mean_old).  PASS 2: sum_rows (x - mean_old) * (x - mean_new).
+template <int PASS>
+__global__ void welford_partial_kernel(WelfordArgs A) {
+  extern __shared__ __align__(16) double red[];  // blockDim doubles
+  const int T = blockDim.x, tid = threadIdx.x, m = A.m;
+  const int cstride = m <= T ? m : T;
+  const int rg = m <= T ? tid / m : 0;
+  const int c0 = m <= T ? tid - rg * m : tid;
+  const bool active = rg < A.rpi;
+  const int64_t rstride = (int64_t)gridDim.x * A.rpi;
+  for (int c = c0; c < m; c += cstride) {
+    double acc = 0.0;
+    if (active) {
+      const double mo = A.mean_old[c];
+      const double mn = PASS == 2 ? A.mean_new[c] : 0.0;
+      const double* __restrict__ col = A.X + c;
+      int64_t r = (int64_t)blockIdx.x * A.rpi + rg;
+      for (; r + 7 * rstride < A.n; r += 8 * rstride) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = col[(r + u * rstride) * A.ldx];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          double d1 = v[u] - mo;
+          if constexpr (PASS == 1)
+            acc += d1;
+          else
+            acc += d1 * (v[u] - mn);
+        }
+      }
+      for (; r < A.n; r += rstride) {
+        double x = col[r * A.ldx];
+        double d1 = x - mo;
+        if constexpr (PASS == 1)
+          acc += d1;
+        else
+          acc += d1 * (x - mn);
+      }
+    }
+    if (m <= T) {  // every lane makes exactly one trip of the column loop here
+      red[tid] = acc;
+      __syncthreads();
+      if (tid < m) {
+        double s = red[tid];
+        for (int g = 1; g < A.rpi; ++g) s += red[g * m + tid];
+        A.partial[(size_t)blockIdx.x * m + tid] = s;
+      }
+    } else {
+      A.partial[(size_t)blockIdx.x * m + c] = acc;
+    }
+  }
+}
+
+// state = [N, mean (m), M2 (m)].  PASS 1 writes mean_new to scratch; PASS 2 commits.
+template <int PASS>
+__global__ void welford_finish_kernel(const double* partial, int nblocks, int m, double nrows,
+                                      double* state, double* mean_new) {
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < m; c += gridDim.x * blockDim.x) {
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * m + c];
+    if constexpr (PASS == 1) {
+      const double N = state[0] + nrows;
+      mean_new[c] = state[1 + c] + s / N;
+    } else {
+      state[1 + m + c] += s;
+      state[1 + c] = mean_new[c];
+    }
+  }
+  if constexpr (PASS == 2) {
+    // one writer for the count, after every reader of state[0] in pass 1 has long finished
+    if (blockIdx.x == 0 && threadIdx.x == 0) state[0] += nrows;
+  }
+}
+
+static int welford_dev_impl(elfihip_ctx* ctx, const double* dX, int64_t n, int m, int64_t ldx, double* dstate) {
+  ELFIHIP_REQUIRE(ctx, n >= 0 && m >= 1 && ldx >= m, "bad shape n=%lld m=%d ldx=%lld", (long long)n, m,
+                  (long long)ldx);
+  ELFIHIP_REQUIRE(ctx, dstate && (n == 0 || dX), "NULL data pointer");
+  if (n == 0) return ELFIHIP_OK;
+  const int T = 256;
+  WelfordArgs A;
+  A.X = dX;
+  A.n = n;
+  A.ldx = ldx;
+  A.m = m;
+  A.rpi = m <= T ? T / m : 1;
+  int64_t groups = (n + A.rpi - 1) / A.rpi;
+  int64_t g = (int64_t)ctx->cu_count * 8;
+  if (g > groups) g = groups;
+  if (g < 1) g = 1;
+  ELFIHIP_CHECK_HIP(ctx, ctx->scratch.reserve(((size_t)g * m + m) * sizeof(double)));
+  A.partial = ctx->scratch.as<double>();
+  double* mean_new = A.partial + (size_t)g * m;
+  A.mean_old = dstate + 1;
+  A.mean_new = mean_new;
+  const int fb = (m + 255) / 256;
+  hipLaunchKernelGGL((welford_partial_kernel<1>), dim3((unsigned)g), dim3(T), T * sizeof(double), ctx->stream, A);
+  hipLaunchKernelGGL((welford_finish_kernel<1>), dim3(fb), dim3(256), 0, ctx->stream, A.partial, (int)g, m,
+                     (double)n, dstate, mean_new);
+  hipLaunchKernelGGL((welford_partial_kernel<2>), dim3((unsigned)g), dim3(T), T * sizeof(double), ctx->stream, A);
+  hipLaunchKernelGGL((welford_finish_kernel<2>), dim3(fb), dim3(256), 0, ctx->stream, A.partial, (int)g, m,
+                     (double)n, dstate, mean_new);
+  return launch_status(ctx, "welford kernels");
+}
+
+}  // namespace elfihip
+
+using namespace elfihip;
+
+extern "C" {
+
+int elfihip_welford_update_dev(elfihip_ctx* ctx, const double* dX, int64_t n, int m, int64_t ldx,
+                               double* dstate) {
+  if (!ctx) return fail(nullptr, ELFIHIP_ERR_ARG, "ctx is NULL");
+  DeviceGuard g(ctx->device);
+  return welford_dev_impl(ctx, dX, n, m, ldx, dstate);
+}
+
+int elfihip_welford_update(elfihip_ctx* ctx, const double* X, int64_t n, int m, int64_t ldx, int64_t* count,
+                           double* mean, double* M2) {
+  if (!ctx) return fail(nullptr, ELFIHIP_ERR_ARG, "ctx is NULL");
+  ELFIHIP_REQUIRE(ctx, n >= 0 && m >= 1 && ldx >= m, "bad shape n=%lld m=%d ldx=%lld", (long long)n, m,
+                  (long long)ldx);
+  ELFIHIP_REQUIRE(ctx, count && mean && M2 && (n == 0 || X), "NULL data pointer");
+  if (n == 0) return ELFIHIP_OK;
+  DeviceGuard g(ctx->device);
+  const size_t ns = 1 + 2 * (size_t)m;
+  std::vector<double> st(ns);
+  st[0] = (double)*count;
+  memcpy(&st[1], mean, (size_t)m * sizeof(double));
+  memcpy(&st[1 + m], M2, (size_t)m * sizeof(double));
+  ELFIHIP_CHECK_HIP(ctx, ctx->par.reserve(ns * sizeof(double)));
+  double* dstate = ctx->par.as<double>();
+  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(dstate, st.data(), ns * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  ELFIHIP_CHECK_HIP(ctx, ctx->in.reserve((size_t)n * m * sizeof(double)));
+  double* dX = ctx->in.as<double>();
+  if (ldx == m)
+    ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(dX, X, (size_t)n * m * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  else
+    ELFIHIP_CHECK_HIP(ctx, hipMemcpy2DAsync(dX, (size_t)m * sizeof(double), X, (size_t)ldx * sizeof(double),
+                                            (size_t)m * sizeof(double), (size_t)n, hipMemcpyHostToDevice,
+                                            ctx->stream));
+  ELFIHIP_TRY(welford_dev_impl(ctx, dX, n, m, m, dstate));
+  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(st.data(), dstate, ns * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *count += n;
+  memcpy(mean, &st[1], (size_t)m * sizeof(double));
+  memcpy(M2, &st[1 + m], (size_t)m * sizeof(double));
+  return ELFIHIP_OK;
+}
+
+}  // extern "C"

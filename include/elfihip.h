@@ -1,0 +1,132 @@
+/*
+ * elfihip.h -- C ABI of libelfihip.so: the MI355X (gfx950) hot path for ELFI.
+ *
+ * Drop-in boundary.  Every entry point replaces one piece of
+ * arithmetic that reference ELFI (v0.8.7, /root/reference) delegates to SciPy / GPy /
+ * NumPy on the host.  The reference site each function stands in for is cited next
+ * to its declaration as `elfi/<file>:<lines>`.
+ *
+ * Conventions
+ *  - plain C types only: pointers, sizes, doubles.  No torch / numpy types.
+ *  - every function returns an int status (ELFIHIP_OK == 0); the text of the last
+ *    failure on a context is available from elfihip_last_error().
+ *  - "host" entry points take HOST pointers; the library stages through device
+ *    buffers it owns and never keeps a caller pointer after it returns.
+ *  - "_dev" twins take DEVICE pointers (every pointer argument, including the small
+ *    y / w vectors), enqueue on the context's stream and return without
+ *    synchronising; results are ordered with later work on the same stream.
+ *  - a context is bound to one GPU and one HIP stream; it is not thread-safe, but
+ *    distinct contexts may be used from distinct threads.
+ *  - all floating point is IEEE binary64; row sums are accumulated in the same
+ *    left-to-right order SciPy's cdist uses, with FMA contraction disabled, so the
+ *    euclidean / cityblock / chebyshev families reproduce cdist bit for bit.
+ */
+#ifndef ELFIHIP_H
+#define ELFIHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ELFIHIP_VERSION 100 /* 0.1.0 */
+
+/* status codes */
+enum {
+  ELFIHIP_OK = 0,
+  ELFIHIP_ERR_ARG = 1,      /* bad argument / shape -> ValueError on the Python side   */
+  ELFIHIP_ERR_HIP = 2,      /* HIP runtime failure  -> RuntimeError                      */
+  ELFIHIP_ERR_NOT_PD = 3,   /* Cholesky met a non-positive pivot -> np.linalg.LinAlgError */
+  ELFIHIP_ERR_STATE = 4,    /* call made in the wrong state (e.g. predict before factor) */
+  ELFIHIP_ERR_NOMEM = 5
+};
+
+/* metrics of scipy.spatial.distance.cdist that elfi.Distance accepts by name
+ * (elfi/model/elfi_model.py:1020-1037). */
+enum {
+  ELFIHIP_EUCLIDEAN = 0,   /* sqrt(sum w_j (x_j-y_j)^2)            */
+  ELFIHIP_SQEUCLIDEAN = 1, /* sum w_j (x_j-y_j)^2                  */
+  ELFIHIP_CITYBLOCK = 2,   /* sum w_j |x_j-y_j|                    */
+  ELFIHIP_CHEBYSHEV = 3,   /* max_j |x_j-y_j|   (w ignored unless 0: SciPy drops w_j==0 columns) */
+  ELFIHIP_MINKOWSKI = 4,   /* (sum w_j |x_j-y_j|^p)^(1/p)          */
+  ELFIHIP_SEUCLIDEAN = 5,  /* sqrt(sum (x_j-y_j)^2 / V_j), aux = V */
+  ELFIHIP_MAHALANOBIS = 6  /* sqrt(d' VI d), aux = VI (m x m row-major) */
+};
+
+typedef struct elfihip_ctx elfihip_ctx;
+typedef struct elfihip_gp elfihip_gp;
+
+/* ------------------------------------------------------------------ context */
+int elfihip_version(void);
+int elfihip_device_count(int* count);
+/* device < 0: use the current HIP device. */
+int elfihip_ctx_create(int device, elfihip_ctx** ctx);
+int elfihip_ctx_destroy(elfihip_ctx* ctx);
+/* Text of the last error on ctx (or the last context-less error if ctx == NULL). */
+const char* elfihip_last_error(const elfihip_ctx* ctx);
+/* Adopt an externally owned hipStream_t (e.g. torch's current stream); NULL restores
+ * the context's own stream. */
+int elfihip_ctx_set_stream(elfihip_ctx* ctx, void* hip_stream);
+int elfihip_ctx_synchronize(elfihip_ctx* ctx);
+/* Device properties the roofline needs: CU count, clock (kHz), memory clock (kHz),
+ * bus width (bits), total global memory (bytes).  Any pointer may be NULL. */
+int elfihip_device_info(elfihip_ctx* ctx, int* cu_count, int* clock_khz, int* mem_clock_khz,
+                        int* mem_bus_bits, int64_t* total_mem, char* name, int name_len);
+
+/* Kernel timing with HIP events on the context's stream (bench.py's roofline leg). */
+int elfihip_timer_start(elfihip_ctx* ctx);
+int elfihip_timer_stop(elfihip_ctx* ctx, float* elapsed_ms); /* synchronises on the stop event */
+
+/* ----------------------------------------------------------------- distance
+ * Replaces scipy.spatial.distance.cdist(X (n,m), Y (1,m), metric, p=, w=, V=, VI=)
+ * as called from distance_as_discrepancy (elfi/model/utils.py:37-52) through
+ * elfi.Distance (elfi/model/elfi_model.py:1037) and AdaptiveDistance (:1084).
+ * out has n doubles -- the (n,1)->(n,) squeeze of utils.py:50-51 is built in.
+ *
+ * aux: w (m) for EUCLIDEAN/SQEUCLIDEAN/CITYBLOCK/MINKOWSKI/CHEBYSHEV (NULL = unweighted),
+ *      V (m) for SEUCLIDEAN, VI (m*m, row-major) for MAHALANOBIS.  p only for MINKOWSKI.
+ */
+
+/* X row-major (n, m) with leading dimension ldx >= m (doubles). */
+int elfihip_dist_rows(elfihip_ctx* ctx, int metric, const double* X, int64_t n, int m, int64_t ldx,
+                      const double* y, const double* aux, double p, double* out);
+int elfihip_dist_rows_dev(elfihip_ctx* ctx, int metric, const double* dX, int64_t n, int m,
+                          int64_t ldx, const double* dy, const double* daux, double p,
+                          double* dout);
+
+/* m separately stored summary columns of length n each (structure of arrays): the
+ * form ELFI hands to distance_as_discrepancy BEFORE np.column_stack
+ * (elfi/model/utils.py:39) -- lets the caller skip that host-side copy. */
+int elfihip_dist_cols(elfihip_ctx* ctx, int metric, const double* const* cols, int m, int64_t n,
+                      const double* y, const double* aux, double p, double* out);
+/* Column-major device matrix: column j starts at dC + j*ldc, ldc >= n. */
+int elfihip_dist_cols_dev(elfihip_ctx* ctx, int metric, const double* dC, int64_t n, int m,
+                          int64_t ldc, const double* dy, const double* daux, double p,
+                          double* dout);
+
+/* AdaptiveDistance.nested_distance (elfi/model/elfi_model.py:1135-1151): K weighted
+ * euclidean distances of the same rows in one pass.  W is (K, m) row-major holding the
+ * cdist weights (i.e. (1/scale)^2, elfi_model.py:1132); the unweighted first function
+ * (w=None, :1089) is passed as a row of ones, which is bit-identical.  out is (n, K)
+ * row-major, as np.column_stack of the K cdist results. */
+int elfihip_dist_multiw(elfihip_ctx* ctx, const double* X, int64_t n, int m, int64_t ldx,
+                        const double* y, const double* W, int K, double* out);
+int elfihip_dist_multiw_dev(elfihip_ctx* ctx, const double* dX, int64_t n, int m, int64_t ldx,
+                            const double* dy, const double* dW, int K, double* dout);
+
+/* AdaptiveDistance.add_data (elfi/model/elfi_model.py:1104-1125): one batched
+ * Welford/Chan update of the running column statistics with the rows of X (n, m):
+ *   N += n; d1 = x - mean; mean += sum(d1)/N; d2 = x - mean; M2 += sum(d1*d2).
+ * Host form: count/mean/M2 are host scalars/vectors updated in place.
+ * Device form: dstate is a device vector of 1 + 2m doubles [N, mean (m), M2 (m)]
+ * updated in place on the context's stream (no host round trip). */
+int elfihip_welford_update(elfihip_ctx* ctx, const double* X, int64_t n, int m, int64_t ldx,
+                           int64_t* count, double* mean, double* M2);
+int elfihip_welford_update_dev(elfihip_ctx* ctx, const double* dX, int64_t n, int m, int64_t ldx,
+                               double* dstate);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ELFIHIP_H */

@@ -1,0 +1,223 @@
+"""TEST INFRASTRUCTURE ONLY -- regenerates tests/golden/*.npz by running REAL reference ELFI.
+
+Run in the build container (needs /root/reference; the GPU box never runs this):
+
+    python oracle/make_golden.py            # all fixtures
+    python oracle/make_golden.py ma2 adaptive metrics
+
+Fixtures (inputs + the reference's outputs on them):
+
+  ma2_tutorial.npz   docs/usage/tutorial.rst:28-29,95-100,290-323,360,386,396 -- the
+                     documented run Rejection(d, batch_size=10000, seed=20170530)
+                     .sample(1000, quantile=0.01) -> threshold 0.116859716394976.
+                     Holds every batch's summaries S1, S2 (inputs of the Distance
+                     operation), the distances the reference computed, the observed
+                     summaries, and the final threshold / sample means.
+  adaptive_ex1.npz   docs/usage/adaptive_distance.rst:43-214 (weights [0.06940134, 0.0097677])
+  adaptive_ex2.npz   docs/usage/adaptive_distance.rst:231-378 (seven weight vectors)
+                     -- full call trace of the AdaptiveDistance node (add_data /
+                     update_distance / nested_distance) recorded from the reference run.
+  metrics.npz        cdist through elfi.Distance's own partial(...) for every metric /
+                     keyword form the node accepts, on seeded random summaries.
+
+Outputs larger than a few hundred rows are stored as a leading slice plus a SHA-256 of
+the full float64 byte string (the GPU kernels are bit-exact on these metrics, so the
+parity tests compare digests as well as the slices).
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+import scipy.stats as ss
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_shim  # noqa: E402
+
+GOLDEN = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a, dtype=np.float64).tobytes()).hexdigest()
+
+
+class Tap:
+    """Record every call of a node operation (args, kwargs, result)."""
+
+    def __init__(self, op, log):
+        self.op, self.log = op, log
+
+    def __call__(self, *a, **k):
+        out = self.op(*a, **k)
+        self.log.append((a, k, out))
+        return out
+
+
+def make_ma2(elfi):
+    from elfi.examples.ma2 import MA2, autocov
+    from elfi.examples.ma2 import CustomPrior1 as CustomPrior_t1, CustomPrior2 as CustomPrior_t2
+    seed = 20170530
+    np.random.seed(seed)
+    y_obs = MA2(0.6, 0.2)
+    m = elfi.new_model()
+    t1 = elfi.Prior(CustomPrior_t1, 2, model=m, name='t1')
+    t2 = elfi.Prior(CustomPrior_t2, t1, 1, name='t2')
+    Y = elfi.Simulator(MA2, t1, t2, observed=y_obs, name='MA2')
+    S1 = elfi.Summary(autocov, Y, name='S1')
+    S2 = elfi.Summary(autocov, Y, 2, name='S2')
+    d = elfi.Distance('euclidean', S1, S2, name='d')
+    log = []
+    d.state['attr_dict']['_operation'] = Tap(d.state['attr_dict']['_operation'], log)
+    rej = elfi.Rejection(d, batch_size=10000, seed=seed, output_names=['S1', 'S2'])
+    res = rej.sample(1000, quantile=0.01)
+    assert repr(float(res.threshold)) == '0.116859716394976', repr(res.threshold)
+    # first logged call is on the observed data?  no: observed summaries are computed by the
+    # compiler and handed in through `observed=`; every logged call is one batch.
+    S1b = np.stack([c[0][0] for c in log])
+    S2b = np.stack([c[0][1] for c in log])
+    dist = np.stack([c[2] for c in log])
+    obs = log[0][1]['observed']
+    np.savez_compressed(
+        os.path.join(GOLDEN, 'ma2_tutorial.npz'),
+        S1=S1b, S2=S2b, d0=dist[0], d_sha=np.array(sha(dist)), observed=np.concatenate([np.atleast_2d(o) for o in obs], axis=1),
+        y_obs=y_obs, threshold=np.float64(res.threshold),
+        mean_t1=np.float64(res.sample_means['t1']), mean_t2=np.float64(res.sample_means['t2']),
+        n_sim=np.int64(res.n_sim))
+    print('ma2_tutorial: batches', S1b.shape, 'threshold', repr(float(res.threshold)))
+
+
+def _trace_adaptive(elfi, simulator, prior, observed, batch_size, seed, calls, tag):
+    """Run AdaptiveDistanceSMC on the real reference with a recording AdaptiveDistance."""
+    events = []
+
+    class RecAdaptiveDistance(elfi.AdaptiveDistance):
+        def add_data(self, *data):
+            events.append(('add_data', np.column_stack(data).copy()))
+            return super().add_data(*data)
+
+        def update_distance(self):
+            super().update_distance()
+            events.append(('update_distance', self.state['w'][-1].copy()))
+
+        def nested_distance(self, u, v):
+            out = super().nested_distance(u, v)
+            events.append(('nested_distance', u.copy(), v.copy(), out.copy()))
+            return out
+
+    m = elfi.new_model()
+    theta = elfi.Prior(*prior, model=m, name='theta')
+    sim = elfi.Simulator(simulator, theta, observed=observed, name='sim')
+    d = RecAdaptiveDistance(sim, name='d')
+    ada = elfi.AdaptiveDistanceSMC(d, batch_size=batch_size, seed=seed)
+    results = [ada.sample(*c[0], **c[1]) for c in calls]
+    out = {}
+    kinds = []
+    for i, ev in enumerate(events):
+        kinds.append(ev[0])
+        if ev[0] == 'add_data':
+            out['e%d_data' % i] = ev[1]
+        elif ev[0] == 'update_distance':
+            out['e%d_w' % i] = ev[1]
+        else:
+            out['e%d_u' % i] = ev[1]
+            out['e%d_v' % i] = ev[2]
+            out['e%d_head' % i] = ev[3][:64]
+            out['e%d_sha' % i] = np.array(sha(ev[3]))
+            out['e%d_shape' % i] = np.array(ev[3].shape)
+    out['kinds'] = np.array(kinds)
+    last = results[-1]
+    out['final_w'] = np.array(last.adaptive_distance_w)
+    out['threshold'] = np.float64(last.threshold)
+    out['n_sim'] = np.int64(last.n_sim)
+    out['mean_theta'] = np.float64(last.sample_means['theta'])
+    np.savez_compressed(os.path.join(GOLDEN, tag + '.npz'), **out)
+    print(tag, 'events', len(events), 'w', out['final_w'].round(8).tolist(), 'thr', float(last.threshold))
+    return last
+
+
+def make_adaptive(elfi):
+    def simulator1(mu, batch_size=1, random_state=None):
+        mu = np.asarray(mu).reshape((-1, 1))
+        o1 = ss.norm.rvs(loc=mu, scale=1, random_state=random_state).reshape((-1, 1))
+        o2 = ss.norm.rvs(loc=mu, scale=100, random_state=random_state).reshape((-1, 1))
+        return np.hstack((o1, o2))
+
+    r1 = _trace_adaptive(elfi, simulator1, (ss.uniform, 0, 50), np.array([20, 20])[None, :],
+                         10000, 123, [((100, 1), dict(quantile=0.01))], 'adaptive_ex1')
+    assert np.allclose(r1.adaptive_distance_w[0], [0.06940134, 0.0097677], rtol=0, atol=5e-9)
+
+    def simulator2(mu, batch_size=1, random_state=None):
+        mu = np.asarray(mu).reshape((-1, 1))
+        o1 = ss.norm.rvs(loc=mu, scale=0.1, random_state=random_state).reshape((-1, 1))
+        o2 = ss.norm.rvs(loc=1, scale=1, size=batch_size, random_state=random_state).reshape((-1, 1))
+        return np.hstack((o1, o2))
+
+    r2 = _trace_adaptive(elfi, simulator2, (ss.norm, 0, 100), np.array([0, 0])[None, :],
+                         2000, 123, [((1000, 5), {}), ((1000, 2), {})], 'adaptive_ex2')
+    doc = np.array([[0.01023228, 1.00584519], [0.00921258, 0.99287166], [0.01201937, 0.99365522],
+                    [0.02217631, 0.98925365], [0.04355987, 1.00076738], [0.07863284, 0.9971017],
+                    [0.13892778, 1.00929049]])
+    assert np.allclose(np.array(r2.adaptive_distance_w), doc, rtol=0, atol=5e-9)
+
+
+def make_metrics(elfi):
+    """Every metric / keyword form through the partial() elfi.Distance itself builds."""
+    rs = np.random.RandomState(20240917)
+    out = {}
+    cases = []
+    for m in (1, 2, 3, 32, 33, 64, 100):
+        n = 389 if m < 64 else 131
+        X = rs.randn(n, m) * rs.uniform(0.1, 10, m)
+        y = rs.randn(1, m)
+        w = rs.uniform(0.5, 2.0, m)
+        w0 = w.copy()
+        w0[::3] = 0.0
+        A = rs.randn(m, m)
+        VI = A @ A.T + m * np.eye(m)
+        out['X_%d' % m], out['y_%d' % m], out['w_%d' % m] = X, y, w
+        out['w0_%d' % m], out['VI_%d' % m] = w0, VI
+        forms = [('euclidean', {}), ('euclidean', dict(w=w)), ('sqeuclidean', {}),
+                 ('sqeuclidean', dict(w=w)), ('cityblock', {}), ('cityblock', dict(w=w)),
+                 ('chebyshev', {}), ('chebyshev', dict(w=w0)), ('minkowski', dict(p=1)),
+                 ('minkowski', dict(p=2)), ('minkowski', dict(p=3)), ('minkowski', dict(p=2.5, w=w)),
+                 ('minkowski', dict(p=np.inf)), ('seuclidean', dict(V=w)),
+                 ('mahalanobis', dict(VI=VI))]
+        for k, (metric, kw) in enumerate(forms):
+            mdl = elfi.new_model()
+            c0 = elfi.Constant(0, model=mdl, name='c0')
+            S = elfi.Summary(lambda x: x, c0, observed=y, model=mdl, name='S')
+            node = elfi.Distance(metric, S, model=mdl, name='d', **dict(kw))
+            op = node.state['attr_dict']['_operation']  # partial(distance_as_discrepancy, partial(cdist, ...))
+            res = op(X, observed=(y,))
+            key = 'd_%d_%d' % (m, k)
+            out[key] = res
+            cases.append('%d|%d|%s|%s' % (m, k, metric, ','.join(
+                '%s=%s' % (a, ('w0' if (a == 'w' and metric == 'chebyshev') else a)
+                           if a in ('w', 'V', 'VI') else repr(float(b))) for a, b in kw.items())))
+    out['cases'] = np.array(cases)
+    np.savez_compressed(os.path.join(GOLDEN, 'metrics.npz'), **out)
+    print('metrics:', len(cases), 'cases')
+
+
+def main(argv):
+    os.makedirs(GOLDEN, exist_ok=True)
+    elfi = ref_shim.install()
+    which = set(argv) or {'ma2', 'adaptive', 'metrics', 'gp'}
+    if 'ma2' in which:
+        make_ma2(elfi)
+    if 'adaptive' in which:
+        make_adaptive(elfi)
+    if 'metrics' in which:
+        make_metrics(elfi)
+    if 'gp' in which:
+        try:
+            import make_golden_gp
+        except ImportError:
+            print('gp fixtures: generator not present yet')
+        else:
+            make_golden_gp.main(elfi, GOLDEN)
+
+
+if __name__ == '__main__':
+    main(sys.argv[1:])

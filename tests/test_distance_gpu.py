@@ -1,0 +1,269 @@
+"""Parity of the HIP distance path (through the C ABI) with the oracle and the reference's
+golden fixtures.  Runs on an MI355X (`-m gpu`).
+
+Tolerances (stated per SURVEY.md section 8c):
+  * euclidean(+w), sqeuclidean(+w), cityblock(+w), chebyshev(+w0), minkowski p in {1,2,inf}:
+    BIT-EXACT against SciPy's cdist (same left-to-right accumulation, no FMA).
+  * minkowski general p (device pow vs libm pow), seuclidean, mahalanobis (SciPy's
+    operation order is not reproducible from outside): relative 1e-14.
+  * Welford column statistics (different but fixed summation order): relative 1e-12.
+"""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import distance_oracle as O
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+EXACT = {'euclidean', 'sqeuclidean', 'cityblock', 'chebyshev'}
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a, dtype=np.float64).tobytes()).hexdigest()
+
+
+def _parse_case(g, case):
+    m, k, metric, kws = case.split('|')
+    m = int(m)
+    kw = {}
+    for item in filter(None, kws.split(',')):
+        a, b = item.split('=')
+        if b in ('w', 'w0', 'V', 'VI'):
+            kw[a] = g['%s_%d' % ({'V': 'w'}.get(b, b), m)]
+        else:
+            kw[a] = float(b)
+    return m, int(k), metric, kw
+
+
+def _is_exact(metric, kw):
+    return metric in EXACT or (metric == 'minkowski' and kw.get('p') in (1.0, 2.0, np.inf))
+
+
+def _check(got, ref, exact, what):
+    assert got.shape == ref.shape, what
+    if exact:
+        assert np.array_equal(got, ref), '%s: max rel %g' % (
+            what, np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1e-300)))
+    else:
+        np.testing.assert_allclose(got, ref, rtol=1e-14, atol=0, err_msg=what)
+
+
+def test_native_library_is_loaded(hip_ctx):
+    import elfi_amd
+    info = hip_ctx.device_info()
+    assert 'gfx950' in info['name'], info
+    assert info['cu_count'] == 256
+    with open('/proc/self/maps') as f:
+        assert 'libelfihip.so' in f.read()
+
+
+def test_golden_metrics_rows(hip_ctx):
+    """Every metric / keyword form elfi.Distance accepts, vs the reference's own outputs."""
+    import elfi_amd
+    g = np.load(os.path.join(GOLDEN, 'metrics.npz'))
+    for case in g['cases']:
+        m, k, metric, kw = _parse_case(g, str(case))
+        X, y, ref = g['X_%d' % m], g['y_%d' % m], g['d_%d_%d' % (m, k)]
+        got = elfi_amd.cdist_rows(X, y, metric, **kw)
+        _check(got, ref, _is_exact(metric, kw), str(case))
+        # the operation interface: op(*summaries, observed=...) with one 2-d summary
+        op = elfi_amd.HipDiscrepancy(metric, **kw)
+        _check(op(X, observed=(y,)), ref, _is_exact(metric, kw), 'op ' + str(case))
+
+
+def test_golden_metrics_cols(hip_ctx):
+    """Same fixtures through the structure-of-arrays path (separate summary columns)."""
+    import elfi_amd
+    g = np.load(os.path.join(GOLDEN, 'metrics.npz'))
+    for case in g['cases']:
+        m, k, metric, kw = _parse_case(g, str(case))
+        if metric == 'mahalanobis':
+            continue
+        X, y, ref = g['X_%d' % m], g['y_%d' % m], g['d_%d_%d' % (m, k)]
+        cols = [np.ascontiguousarray(X[:, j]) for j in range(m)]
+        op = elfi_amd.HipDiscrepancy(metric, **kw)
+        got = op(*cols, observed=tuple(y[:, j] for j in range(m)))
+        _check(got, ref, _is_exact(metric, kw), 'cols ' + str(case))
+
+
+def test_ma2_tutorial_known_answer(hip_ctx):
+    """docs/usage/tutorial.rst:360-396: threshold 0.116859716394976 from GPU distances."""
+    import elfi_amd
+    g = np.load(os.path.join(GOLDEN, 'ma2_tutorial.npz'))
+    op = elfi_amd.HipDiscrepancy('euclidean')
+    obs = (g['observed'][:, 0], g['observed'][:, 1])
+    d = np.stack([op(g['S1'][b], g['S2'][b], observed=obs) for b in range(g['S1'].shape[0])])
+    assert np.array_equal(d[0], g['d0'])
+    assert sha(d) == str(g['d_sha'])
+    thr = np.sort(d.reshape(-1))[999]
+    assert repr(float(thr)) == '0.116859716394976'
+    # and the elfi.Distance(callable) form on the stacked matrix
+    fn = elfi_amd.HipDistance('euclidean')
+    X = np.column_stack((g['S1'][0], g['S2'][0]))
+    assert np.array_equal(fn(X, g['observed']), g['d0'])
+
+
+@pytest.mark.parametrize('tag', ['adaptive_ex1', 'adaptive_ex2'])
+def test_adaptive_trace_replay(hip_ctx, tag):
+    """Replay the AdaptiveDistance call trace recorded from the real reference run
+    (docs/usage/adaptive_distance.rst examples 1 and 2) through the GPU state machine."""
+    import elfi_amd
+    g = np.load(os.path.join(GOLDEN, tag + '.npz'))
+    a = elfi_amd.AdaptiveDistanceState()
+    ref = O.AdaptiveDistanceOracle()
+    ws = []
+    for i, kind in enumerate(g['kinds']):
+        if kind == 'add_data':
+            a.add_data(g['e%d_data' % i])
+            ref.add_data(g['e%d_data' % i])
+            np.testing.assert_allclose(a.state['scale'], ref.scale, rtol=1e-12)
+            assert a.state['store'][0] == ref.store[0]
+        elif kind == 'update_distance':
+            a.update_distance()
+            ref.update_distance()
+            np.testing.assert_allclose(a.state['w'][-1], g['e%d_w' % i], rtol=1e-12)
+            ws.append(a.state['w'][-1])
+            # keep the replay on the reference's exact weights so later distance checks are bit-exact
+            a.state['w'][-1] = g['e%d_w' % i].copy()
+        else:
+            out = a.nested_distance(g['e%d_u' % i], g['e%d_v' % i])
+            assert tuple(g['e%d_shape' % i]) == out.shape
+            assert np.array_equal(out[:64], g['e%d_head' % i])
+            assert sha(out) == str(g['e%d_sha' % i])
+    np.testing.assert_allclose(np.array(ws), g['final_w'], rtol=1e-12)
+
+
+@pytest.mark.parametrize('n', [0, 1, 2, 63, 64, 65, 255, 257, 1000, 4099])
+@pytest.mark.parametrize('m', [1, 2, 5, 32, 64, 100])
+def test_shapes_vs_oracle(hip_ctx, n, m):
+    """Empty, ragged and tile-boundary sizes; weighted and unweighted."""
+    import elfi_amd
+    rs = np.random.RandomState(1000 * m + n)
+    X, y, w = rs.randn(n, m), rs.randn(1, m), rs.uniform(0.1, 3, m)
+    for metric, kw in [('euclidean', {}), ('euclidean', dict(w=w)), ('cityblock', dict(w=w)),
+                       ('chebyshev', {})]:
+        got = elfi_amd.cdist_rows(X, y, metric, **kw)
+        assert np.array_equal(got, O.cdist_rows(X, y, metric, **kw)), (metric, n, m)
+        if n:
+            cols = [np.ascontiguousarray(X[:, j]) for j in range(m)]
+            got = elfi_amd.cdist_cols(cols, y, metric, **kw)
+            assert np.array_equal(got, O.cdist_rows(X, y, metric, **kw)), ('cols', metric, n, m)
+
+
+def test_strided_rows_and_dtypes(hip_ctx):
+    import elfi_amd
+    rs = np.random.RandomState(5)
+    big = rs.randn(777, 40)
+    X = big[:, 3:20]                       # row pitch 40, odd width 17, unaligned start
+    y = rs.randn(1, 17)
+    assert np.array_equal(elfi_amd.cdist_rows(X, y), O.cdist_rows(X, y, 'euclidean'))
+    X32 = rs.randn(300, 6).astype(np.float32)   # cdist casts to float64
+    assert np.array_equal(elfi_amd.cdist_rows(X32, y[:, :6]), O.cdist_rows(X32, y[:, :6], 'euclidean'))
+    Xi = rs.randint(-5, 5, (100, 3))
+    assert np.array_equal(elfi_amd.cdist_rows(Xi, y[:, :3]), O.cdist_rows(Xi, y[:, :3], 'euclidean'))
+
+
+def test_wide_rows_fallback(hip_ctx):
+    import elfi_amd
+    rs = np.random.RandomState(6)
+    X, y = rs.randn(257, 700), rs.randn(1, 700)
+    np.testing.assert_allclose(elfi_amd.cdist_rows(X, y), O.cdist_rows(X, y, 'euclidean'), rtol=1e-14)
+    np.testing.assert_allclose(elfi_amd.cdist_rows(X, y, 'chebyshev'), O.cdist_rows(X, y, 'chebyshev'),
+                               rtol=0)
+
+
+def test_error_behaviour(hip_ctx):
+    """Same exception classes as the reference path (ValueError from cdist / utils.py:42-49)."""
+    import elfi_amd
+    X, y = np.zeros((4, 3)), np.zeros((1, 2))
+    with pytest.raises(ValueError):
+        elfi_amd.cdist_rows(X, y)
+    with pytest.raises(ValueError):
+        elfi_amd.cdist_rows(np.zeros((2, 2, 2)), np.zeros((1, 2)))
+    with pytest.raises(ValueError):
+        elfi_amd.HipDistance('seuclidean')
+    with pytest.raises(ValueError):
+        elfi_amd.HipDistance('nonsense')
+    with pytest.raises(ValueError):
+        elfi_amd.cdist_rows(np.zeros((4, 2)), y, 'minkowski', p=-1)
+    op = elfi_amd.HipDiscrepancy('euclidean')
+    with pytest.raises(ValueError):
+        op(np.zeros((4, 2, 2)), observed=(np.zeros((1, 2)),))
+
+
+def test_full_size_properties(hip_ctx):
+    """BASELINE config 2 size (10^6 x 32): size-independent properties, no CPU pass needed
+    for the bulk -- a seeded 2^16-row sample is checked bit-exactly against cdist."""
+    import elfi_amd
+    rs = np.random.RandomState(0)
+    n, m = 10 ** 6, 32
+    X = rs.randn(n, m)
+    y = np.random.RandomState(1).randn(1, m)
+    w = 1 / np.random.RandomState(2).uniform(.5, 2, m) ** 2
+    d = elfi_amd.cdist_rows(X, y)
+    dw = elfi_amd.cdist_rows(X, y, w=w)
+    d2 = elfi_amd.cdist_rows(X, y, 'sqeuclidean')
+    idx = rs.choice(n, 1 << 16, replace=False)
+    assert np.array_equal(d[idx], O.cdist_rows(X[idx], y, 'euclidean'))
+    assert np.array_equal(dw[idx], O.cdist_rows(X[idx], y, 'euclidean', w=w))
+    assert np.array_equal(np.sqrt(d2), d)                      # euclid == sqrt(sqeuclid), exactly
+    # permutation equivariance: distances of permuted rows are the permuted distances
+    perm = rs.permutation(n)
+    assert np.array_equal(elfi_amd.cdist_rows(X[perm], y), d[perm])
+    # scaling: dist(c*X, c*y) == c*dist for a power of two (exact in binary floating point)
+    assert np.array_equal(elfi_amd.cdist_rows(4.0 * X, 4.0 * y), 4.0 * d)
+    # a row equal to the observation has distance exactly 0; weights of zero drop columns
+    X[123] = y[0]
+    assert elfi_amd.cdist_rows(X[100:200], y)[23] == 0.0
+    # SoA path agrees with AoS path bit for bit
+    cols = [np.ascontiguousarray(X[:, j]) for j in range(m)]
+    assert np.array_equal(elfi_amd.cdist_cols(cols, y), elfi_amd.cdist_rows(X, y))
+
+
+def test_welford_reference_unit_test(hip_ctx):
+    """tests/unit/test_elfi_model.py:186-253 restated on the GPU state machine."""
+    import elfi_amd
+    rs = np.random.RandomState(1)
+    a = elfi_amd.AdaptiveDistanceState()
+    d1, d2, d3 = rs.randn(10, 3) * [1, 10, 100], rs.randn(10, 3) * [1, 10, 100], rs.randn(1, 3)
+    for d in (d1, d2, d3):
+        a.add_data(d)
+    allrows = np.vstack((d1, d2, d3))
+    assert np.allclose(a.state['scale'], np.std(allrows, axis=0))
+    a.update_distance()
+    assert np.allclose(a.state['w'][1], 1 / np.std(allrows, axis=0))
+    obs = rs.randn(1, 3)
+    nd = a.nested_distance(d1, obs)
+    assert nd.shape == (10, 2)
+    assert np.allclose(nd[:, 0], np.sqrt(np.sum((d1 - obs) ** 2, axis=1)))
+    assert np.allclose(nd[:, 1], np.sqrt(np.sum(((d1 - obs) / a.state['scale']) ** 2, axis=1)))
+
+
+@pytest.mark.parametrize('n,m', [(1, 1), (7, 3), (10000, 2), (100003, 64), (5000, 300)])
+def test_welford_vs_oracle(hip_ctx, n, m):
+    import elfi_amd
+    rs = np.random.RandomState(n + m)
+    ref = O.AdaptiveDistanceOracle()
+    cnt, mean, M2 = 0, np.zeros(m), np.zeros(m)
+    for b in range(3):
+        X = rs.randn(n, m) * rs.uniform(0.1, 100, m) + rs.uniform(-1000, 1000, m)
+        ref.add_data(X)
+        cnt, mean, M2 = elfi_amd.welford_update(X, cnt, mean, M2)
+        assert cnt == ref.store[0]
+        np.testing.assert_allclose(mean, ref.store[1], rtol=1e-12)
+        np.testing.assert_allclose(M2, ref.store[2], rtol=1e-11)
+
+
+def test_determinism(hip_ctx):
+    import elfi_amd
+    rs = np.random.RandomState(9)
+    X, y = rs.randn(200000, 33), rs.randn(1, 33)
+    a, b = elfi_amd.cdist_rows(X, y, 'minkowski', p=3), elfi_amd.cdist_rows(X, y, 'minkowski', p=3)
+    assert np.array_equal(a, b)
+    c1 = elfi_amd.welford_update(X, 0, np.zeros(33), np.zeros(33))
+    c2 = elfi_amd.welford_update(X, 0, np.zeros(33), np.zeros(33))
+    assert np.array_equal(c1[1], c2[1]) and np.array_equal(c1[2], c2[2])
