@@ -62,6 +62,19 @@ PROTOTYPES = {
                                          C.POINTER(C.c_int64), C.c_void_p, C.c_void_p]),
     "elfihip_welford_update_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int64,
                                              C.c_void_p]),
+    "elfihip_gp_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, c_void_pp]),
+    "elfihip_gp_free": (C.c_int, [C.c_void_p]),
+    "elfihip_gp_set_hyper": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double]),
+    "elfihip_gp_set_data": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
+    "elfihip_gp_append": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
+    "elfihip_gp_factorize": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "elfihip_gp_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                  C.POINTER(C.c_int)]),
+    "elfihip_gp_get": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "elfihip_gp_predict": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
+    "elfihip_gp_predict_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p]),
+    "elfihip_gp_lcb": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_void_p, C.c_void_p]),
 }
 
 _lib = None

@@ -1,0 +1,36 @@
+// Internal definition of the GP object behind the elfihip_gp_* entry points.
+#pragma once
+
+#include "common.hpp"
+
+namespace elfihip {
+constexpr int NB = 128;          // block size of the factorisation (one MFMA GEMM tile)
+constexpr double GP_JITTER = 1e-8;  // [GPy-upstream] ExactGaussianInference: Ky = K + (noise + 1e-8) I
+inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+}  // namespace elfihip
+
+struct elfihip_gp {
+  elfihip_ctx* ctx = nullptr;
+  int d = 0, dp = 0;          // input dimension, padded to a multiple of 4 (MFMA k-step)
+  int64_t cap = 0;            // capacity in evidence points (multiple of NB)
+  int64_t n = 0, np = 0;      // current evidence count, padded to a multiple of NB
+  int64_t lda = 0;            // row pitch (doubles) of A and WT
+  double var = 1, ls = 1, bias = 0, noise = 1;
+  bool factored = false, has_kinv = false;
+  double logdet = 0, yKy = 0;
+
+  // device memory
+  double* X = nullptr;      // (cap, dp) evidence inputs, zero padded
+  double* x2 = nullptr;     // (cap)     |x_i|^2
+  double* y = nullptr;      // (cap)
+  double* A = nullptr;      // (cap + NB, lda): K -> L (lower); row block [np, np+NB) carries y -> z = L^-1 y
+  double* WT = nullptr;     // (cap, lda): L^-T (upper triangular, strictly-lower part kept zero)
+  double* Kinv = nullptr;   // (cap, lda): K^-1 (lower tiles), only for the hyper-parameter gradient
+  double* W11 = nullptr;    // (NB, NB) inverse of the diagonal block being eliminated (lower)
+  double* alpha = nullptr;  // (cap) K^-1 y
+  double* red = nullptr;    // small reduction scratch
+  int* info = nullptr;      // device: 1-based index of the first non-positive pivot, 0 if none
+  // prediction workspace (grown on demand)
+  elfihip::DevBuf ws;
+  int64_t ws_S = 0;
+};

@@ -1,0 +1,405 @@
+// GP posterior mean / variance / gradients and the LCB acquisition at many points at once.
+//
+// Replaces GPyRegression.predict / predictive_gradients
+// (elfi/methods/bo/gpy_regression.py:98-147,179-223; closed forms :127-140,:206-218) and
+// LCBSC.evaluate / evaluate_gradient (elfi/methods/bo/acquisition.py:262-301).  The reference
+// evaluates ONE point per call (three O(n^2) products with the dense K^-1 each, see
+// SURVEY.md 3.3); here S points are evaluated together in groups of 16 columns:
+//
+//   kr[s][i] = s_f exp(-|x_s - X_i|^2 / 2 l^2)                       (S x n, VALU + exp)
+//   mu_s     = sum_i (kr + s_b) alpha_i
+//   v        = L^-1 (kr + s_b)^T        v[i][s] = sum_{k<=i} WT[k][i] kb[s][k]   (n x 16, MFMA f64)
+//   var_s    = s_f + s_b - sum_i v[i][s]^2
+//   u        = L^-T v = K^-1 kb^T       u[i][s] = sum_{k>=i} WT[i][k] v[k][s]    (n x 16, MFMA f64)
+//   dmu_s    = sum_i alpha_i dk_si,   dvar_s = -2 sum_i u[i][s] dk_si,
+//              dk_si = -(kr[s][i] / l^2) (x_s - X_i)                  (RBF part only, as GPy)
+//
+// The two triangular products stream L^-T once each (8 n^2 / 2 bytes): HBM/L3-bound for 16
+// columns, so they are split over (row block, k chunk) pairs to fill the chip and reduced
+// in a fixed order (deterministic).  WT's strictly-lower part is zero, so no masking.
+#include "gp.hpp"
+#include "mfma_f64.hpp"
+
+namespace elfihip {
+
+constexpr int PC = 16;    // columns (query points) per pass
+constexpr int KCH = 2;    // 128-blocks of k per workgroup
+constexpr int SLAB = 32;  // k-slab staged per step
+
+struct PredictWs {
+  double *xs, *xs2, *kr, *part, *v, *u, *mu_part, *var_part, *g_part, *out;
+  int nblk_k;   // blocks of the kstar kernel along i
+  int nkc;      // k chunks
+  int ngc;      // i chunks of the gradient kernel
+};
+
+// ---- kr[s][i], partial mu ----------------------------------------------------------
+__global__ __launch_bounds__(256) void kstar_kernel(const double* X, const double* x2, const double* alpha,
+                                                    const double* xs, const double* xs2, double* kr, double* mu_part,
+                                                    int64_t n, int64_t np, int dp, double var,
+                                                    double neg_half_inv_ls2, double bias) {
+  __shared__ double red[256];
+  const int s = blockIdx.y;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  double contrib = 0.0;
+  if (i < np) {
+    double k = 0.0;
+    if (i < n) {
+      double dot = 0.0;
+      for (int c = 0; c < dp; ++c) dot += xs[s * dp + c] * X[i * dp + c];
+      double r2 = (xs2[s] + x2[i]) + (-2.0 * dot);
+      r2 = r2 > 0.0 ? r2 : 0.0;
+      k = var * exp(r2 * neg_half_inv_ls2);
+      contrib = (k + bias) * alpha[i];
+    }
+    kr[(int64_t)s * np + i] = k;
+  }
+  red[threadIdx.x] = contrib;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) mu_part[s * gridDim.x + blockIdx.x] = red[0];
+}
+
+// ---- triangular skinny products on the matrix cores ------------------------------------
+// TRANS = true :  out[i][s] += sum_k WT[k][i] * (kr[s][k] + bias [k < n])      (v = L^-1 kb)
+// TRANS = false:  out[i][s] += sum_k WT[i][k] * vin[k][s]                        (u = L^-T v)
+// Workgroup (ib, kc): rows i in block ib, k in blocks [kc*KCH, kc*KCH+KCH) clipped to the
+// triangle.  Writes part[kc][i][s] (zeros if the chunk is outside the triangle).
+struct TriArgs {
+  const double* WT;
+  const double* kr;    // TRANS
+  const double* vin;   // !TRANS
+  double* part;
+  int64_t lda, n, np;
+  int nb, nkc;
+  double bias;
+};
+
+template <bool TRANS>
+__global__ __launch_bounds__(256) void tri_apply_kernel(TriArgs T) {
+  // LDS: W slab + B slab.  TRANS: W as [k][i] pitch 144, B = kb as [s][k] pitch 34.
+  //      !TRANS: W as [i][k] pitch 34, B = v as [k][s] pitch 16.
+  extern __shared__ __align__(16) double sm[];
+  constexpr int WP = TRANS ? 144 : 34;
+  double* Ws = sm;
+  double* Bs = sm + (TRANS ? SLAB * 144 : 128 * 34);
+  const int ib = blockIdx.x, kc = blockIdx.y;
+  const int t = threadIdx.x, l = t & 63, w = t >> 6;
+  int kb0 = kc * KCH, kb1 = kb0 + KCH;  // k-block range of this chunk
+  if (TRANS) {
+    if (kb1 > ib + 1) kb1 = ib + 1;     // k <= i
+  } else {
+    if (kb0 < ib) kb0 = ib;             // k >= i
+    if (kb1 > T.nb) kb1 = T.nb;
+  }
+  if (kb0 >= kb1) return;  // chunk lies outside the triangle (the reduction never reads it)
+  v4d acc[2];
+  acc[0] = (v4d){0, 0, 0, 0};
+  acc[1] = (v4d){0, 0, 0, 0};
+  const int64_t i0 = (int64_t)ib * NB;
+  for (int64_t k0 = (int64_t)kb0 * NB; k0 < (int64_t)kb1 * NB; k0 += SLAB) {
+    __syncthreads();
+    if (TRANS) {
+      // WT rows k0..k0+31, columns i0..i0+127: each row 1 KiB, one wave-instruction per row
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        const int kr_ = (t >> 6) + 4 * p, ip = t & 63;
+        const double2 x = *reinterpret_cast<const double2*>(T.WT + (k0 + kr_) * T.lda + i0 + 2 * ip);
+        *reinterpret_cast<double2*>(Ws + kr_ * 144 + 2 * ip) = x;
+      }
+      // kb slab [16 s][32 k]
+      for (int e = t; e < PC * SLAB; e += 256) {
+        const int s = e >> 5, kk = e & 31;
+        const int64_t k = k0 + kk;
+        Bs[s * 34 + kk] = (k < T.n) ? (T.kr[(int64_t)s * T.np + k] + T.bias) : 0.0;
+      }
+    } else {
+      // WT rows i0..i0+127, columns k0..k0+31: 256 B per row = 16 lanes
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        const int ir = (t >> 4) + 16 * p, kp = t & 15;
+        const double2 x = *reinterpret_cast<const double2*>(T.WT + (i0 + ir) * T.lda + k0 + 2 * kp);
+        *reinterpret_cast<double2*>(Ws + ir * 34 + 2 * kp) = x;
+      }
+      for (int e = t; e < SLAB * PC; e += 256) Bs[e] = T.vin[k0 * PC + e];  // [k][s], contiguous
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < SLAB / 4; ++ks) {
+      const int kq = 4 * ks + (l >> 4);
+      const double b = TRANS ? Bs[(l & 15) * 34 + kq] : Bs[kq * PC + (l & 15)];
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const int i = (2 * w + m) * 16 + (l & 15);
+        const double a = TRANS ? Ws[kq * WP + i] : Ws[i * WP + kq];
+        acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[m], 0, 0, 0);
+      }
+    }
+  }
+  double* out = T.part + ((int64_t)kc * T.np + i0) * PC;
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = (2 * w + m) * 16 + (l >> 4) + 4 * r;
+      out[row * PC + (l & 15)] = acc[m][r];
+    }
+}
+
+// v[i][s] = sum_kc part[kc][i][s] (fixed order); optional per-block partials of sum_i v^2.
+__global__ __launch_bounds__(256) void tri_reduce_kernel(const double* part, double* out, double* sq_part,
+                                                         int64_t np, int nkc, int kc_lo_is_row, int want_sq) {
+  __shared__ double red[256];
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;  // element (i, s), 16 rows per block
+  double v = 0.0;
+  if (e < np * PC) {
+    const int64_t i = e / PC;
+    const int ib = (int)(i / NB);
+    // chunks that can be non-zero: TRANS (kc_lo_is_row == 0): kc*KCH <= ib ; else kc*KCH+KCH > ib
+    const int lo = kc_lo_is_row ? ib / KCH : 0;
+    const int hi = kc_lo_is_row ? nkc : ib / KCH + 1;
+    for (int kc = lo; kc < hi; ++kc) v += part[(int64_t)kc * np * PC + e];
+    out[e] = v;
+  }
+  if (want_sq) {
+    red[threadIdx.x] = v * v;
+    __syncthreads();
+    // columns are e % 16: reduce the 16 rows of this block per column, fixed order
+    if (threadIdx.x < PC) {
+      double s = 0.0;
+      for (int r = 0; r < 16; ++r) s += red[r * PC + threadIdx.x];
+      sq_part[(int64_t)blockIdx.x * PC + threadIdx.x] = s;
+    }
+  }
+}
+
+// ---- gradients ---------------------------------------------------------------------
+// g_part[s][chunk][0..dp) = sum_i alpha_i kr_si (x_s - X_i),  [dp..2dp) = sum_i u_is kr_si (x_s - X_i)
+__global__ __launch_bounds__(256) void grad_kernel(const double* X, const double* alpha, const double* xs,
+                                                   const double* kr, const double* u, double* g_part, int64_t n,
+                                                   int64_t np, int dp, int rows_per_block) {
+  __shared__ double red[256];
+  const int s = blockIdx.y;
+  const int64_t ibeg = (int64_t)blockIdx.x * rows_per_block;
+  int64_t iend = ibeg + rows_per_block;
+  if (iend > n) iend = n;
+  double* outp = g_part + ((int64_t)s * gridDim.x + blockIdx.x) * 2 * dp;
+  for (int a0 = 0; a0 < dp; a0 += 4) {
+    double g1[4] = {0, 0, 0, 0}, g2[4] = {0, 0, 0, 0};
+    for (int64_t i = ibeg + threadIdx.x; i < iend; i += 256) {
+      const double k = kr[(int64_t)s * np + i];
+      const double c1 = alpha[i] * k, c2 = u[i * PC + s] * k;
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const double diff = xs[s * dp + a0 + a] - X[i * dp + a0 + a];
+        g1[a] += c1 * diff;
+        g2[a] += c2 * diff;
+      }
+    }
+    // wave butterfly, then the 4 wave partials in fixed order
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+      double v = a < 4 ? g1[a] : g2[a - 4];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+      if ((threadIdx.x & 63) == 0) red[(threadIdx.x >> 6) * 8 + a] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+      const int a = threadIdx.x;
+      const double v = ((red[a] + red[8 + a]) + red[16 + a]) + red[24 + a];
+      outp[(a < 4 ? 0 : dp) + a0 + (a & 3)] = v;
+    }
+    __syncthreads();
+  }
+}
+
+// ---- final assembly: mu, var, dmu, dvar, LCB value and gradient ---------------------------
+// out layout per pass: mu[16] var[16] val[16] dmu[16*dp] dvar[16*dp] grad[16*dp]
+__global__ void finish_kernel(const double* mu_part, int nblk_k, const double* var_part, int nblk_v,
+                              const double* g_part, int ngc, double* out, int dp, int S, double prior_var,
+                              double noise_add, double inv_ls2, double beta, int with_grad) {
+  const int s = threadIdx.x;
+  if (s >= PC) return;
+  double* mu = out;
+  double* var = out + PC;
+  double* val = out + 2 * PC;
+  double* dmu = out + 3 * PC;
+  double* dvar = dmu + PC * dp;
+  double* grad = dvar + PC * dp;
+  if (s >= S) {
+    mu[s] = 0;
+    var[s] = 0;
+    val[s] = 0;
+    return;
+  }
+  double m = 0.0;
+  for (int b = 0; b < nblk_k; ++b) m += mu_part[s * nblk_k + b];
+  double q = 0.0;
+  for (int b = 0; b < nblk_v; ++b) q += var_part[(int64_t)b * PC + s];
+  double v = prior_var - q;
+  v = v > 1e-15 ? v : 1e-15;  // [GPy-upstream] predict clips the variance at 1e-15
+  mu[s] = m;
+  var[s] = v + noise_add;
+  val[s] = m - sqrt(beta * v);
+  if (with_grad) {
+    const double sc = sqrt(beta / v);
+    for (int a = 0; a < dp; ++a) {
+      double g1 = 0.0, g2 = 0.0;
+      for (int c = 0; c < ngc; ++c) {
+        g1 += g_part[((int64_t)s * ngc + c) * 2 * dp + a];
+        g2 += g_part[((int64_t)s * ngc + c) * 2 * dp + dp + a];
+      }
+      const double dm = -inv_ls2 * g1;
+      const double dv = 2.0 * inv_ls2 * g2;  // -2 * sum u_i dk_i, dk_i = -(k/l^2)(x - X_i)
+      dmu[s * dp + a] = dm;
+      dvar[s * dp + a] = dv;
+      grad[s * dp + a] = dm - 0.5 * dv * sc;
+    }
+  }
+}
+
+static int ensure_ws(elfihip_gp* gp, PredictWs* W) {
+  elfihip_ctx* ctx = gp->ctx;
+  const int64_t np = gp->np;
+  const int nb = (int)(np / NB);
+  W->nblk_k = (int)((np + 255) / 256);
+  W->nkc = (nb + KCH - 1) / KCH;
+  const int rows_per_block = 1024;
+  W->ngc = (int)((gp->n + rows_per_block - 1) / rows_per_block);
+  size_t off = 0;
+  auto take = [&](size_t doubles) {
+    size_t o = off;
+    off += (doubles + 15) & ~(size_t)15;
+    return o;
+  };
+  const size_t o_xs = take((size_t)PC * gp->dp), o_xs2 = take(PC), o_kr = take((size_t)PC * np),
+               o_part = take((size_t)W->nkc * np * PC), o_v = take((size_t)np * PC), o_u = take((size_t)np * PC),
+               o_mu = take((size_t)PC * W->nblk_k), o_var = take((size_t)(np * PC / 256 + 1) * PC),
+               o_g = take((size_t)PC * W->ngc * 2 * gp->dp), o_out = take((size_t)3 * PC + 3 * PC * gp->dp);
+  ELFIHIP_CHECK_HIP(ctx, gp->ws.reserve(off * sizeof(double)));
+  double* base = gp->ws.as<double>();
+  W->xs = base + o_xs;
+  W->xs2 = base + o_xs2;
+  W->kr = base + o_kr;
+  W->part = base + o_part;
+  W->v = base + o_v;
+  W->u = base + o_u;
+  W->mu_part = base + o_mu;
+  W->var_part = base + o_var;
+  W->g_part = base + o_g;
+  W->out = base + o_out;
+  return ELFIHIP_OK;
+}
+
+// mode: 0 = mean/var only, 1 = + gradients (and LCB)
+static int predict_impl(elfihip_gp* gp, const double* Xs, int64_t S, int mode, int noiseless, double beta,
+                        double* mu, double* var, double* dmu, double* dvar, double* val, double* grad) {
+  elfihip_ctx* ctx = gp->ctx;
+  ELFIHIP_REQUIRE(ctx, S >= 0, "negative S");
+  if (S == 0) return ELFIHIP_OK;
+  ELFIHIP_REQUIRE(ctx, Xs, "Xs is NULL");
+  if (!gp->factored)
+    return fail(ctx, ELFIHIP_ERR_STATE, "GP is not factorised (call elfihip_gp_factorize after changing data)");
+  hipStream_t st = ctx->stream;
+  PredictWs W;
+  ELFIHIP_TRY(ensure_ws(gp, &W));
+  const int dp = gp->dp, d = gp->d;
+  const int64_t np = gp->np;
+  const int nb = (int)(np / NB);
+  const double inv_ls2 = 1.0 / (gp->ls * gp->ls);
+  static thread_local std::vector<double> hx, hout;
+  hx.assign((size_t)PC * dp + PC, 0.0);
+  hout.resize((size_t)3 * PC + 3 * PC * dp);
+  const size_t lds_t = (SLAB * 144 + PC * 34) * sizeof(double);
+  const size_t lds_n = (128 * 34 + SLAB * PC) * sizeof(double);
+  for (int64_t s0 = 0; s0 < S; s0 += PC) {
+    const int sc = (int)((S - s0) < PC ? (S - s0) : PC);
+    std::fill(hx.begin(), hx.end(), 0.0);
+    for (int s = 0; s < sc; ++s) {
+      double q = 0.0;
+      for (int c = 0; c < d; ++c) {
+        const double x = Xs[(s0 + s) * d + c];
+        hx[(size_t)s * dp + c] = x;
+        q += x * x;
+      }
+      hx[(size_t)PC * dp + s] = q;
+    }
+    ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(W.xs, hx.data(), (size_t)PC * dp * sizeof(double),
+                                          hipMemcpyHostToDevice, st));
+    ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(W.xs2, hx.data() + (size_t)PC * dp, PC * sizeof(double),
+                                          hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(kstar_kernel, dim3(W.nblk_k, PC), dim3(256), 0, st, gp->X, gp->x2, gp->alpha, W.xs, W.xs2,
+                       W.kr, W.mu_part, gp->n, np, dp, gp->var, -0.5 * inv_ls2, gp->bias);
+    TriArgs T;
+    T.WT = gp->WT;
+    T.kr = W.kr;
+    T.vin = nullptr;
+    T.part = W.part;
+    T.lda = gp->lda;
+    T.n = gp->n;
+    T.np = np;
+    T.nb = nb;
+    T.nkc = W.nkc;
+    T.bias = gp->bias;
+    hipLaunchKernelGGL((tri_apply_kernel<true>), dim3(nb, W.nkc), dim3(256), lds_t, st, T);
+    const int rblocks = (int)(np * PC / 256);
+    hipLaunchKernelGGL(tri_reduce_kernel, dim3(rblocks), dim3(256), 0, st, W.part, W.v, W.var_part, np, W.nkc, 0, 1);
+    if (mode == 1) {
+      T.vin = W.v;
+      hipLaunchKernelGGL((tri_apply_kernel<false>), dim3(nb, W.nkc), dim3(256), lds_n, st, T);
+      hipLaunchKernelGGL(tri_reduce_kernel, dim3(rblocks), dim3(256), 0, st, W.part, W.u, (double*)nullptr, np,
+                         W.nkc, 1, 0);
+      hipLaunchKernelGGL(grad_kernel, dim3(W.ngc, PC), dim3(256), 0, st, gp->X, gp->alpha, W.xs, W.kr, W.u, W.g_part,
+                         gp->n, np, dp, 1024);
+    }
+    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(64), 0, st, W.mu_part, W.nblk_k, W.var_part, rblocks, W.g_part,
+                       W.ngc, W.out, dp, sc, gp->var + gp->bias, noiseless ? 0.0 : gp->noise, inv_ls2, beta, mode);
+    ELFIHIP_TRY(launch_status(ctx, "predict kernels"));
+    ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(hout.data(), W.out, hout.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(st));
+    const double* o = hout.data();
+    for (int s = 0; s < sc; ++s) {
+      if (mu) mu[s0 + s] = o[s];
+      if (var) var[s0 + s] = o[PC + s];
+      if (val) val[s0 + s] = o[2 * PC + s];
+      for (int c = 0; c < d; ++c) {
+        if (dmu) dmu[(s0 + s) * d + c] = o[3 * PC + s * dp + c];
+        if (dvar) dvar[(s0 + s) * d + c] = o[3 * PC + PC * dp + s * dp + c];
+        if (grad) grad[(s0 + s) * d + c] = o[3 * PC + 2 * PC * dp + s * dp + c];
+      }
+    }
+  }
+  return ELFIHIP_OK;
+}
+
+}  // namespace elfihip
+
+using namespace elfihip;
+
+extern "C" {
+
+int elfihip_gp_predict(elfihip_gp* gp, const double* Xs, int64_t S, int noiseless, double* mu, double* var) {
+  if (!gp) return fail(nullptr, ELFIHIP_ERR_ARG, "gp is NULL");
+  DeviceGuard g(gp->ctx->device);
+  return predict_impl(gp, Xs, S, 0, noiseless, 0.0, mu, var, nullptr, nullptr, nullptr, nullptr);
+}
+
+int elfihip_gp_predict_grad(elfihip_gp* gp, const double* Xs, int64_t S, double* mu, double* var, double* dmu,
+                            double* dvar) {
+  if (!gp) return fail(nullptr, ELFIHIP_ERR_ARG, "gp is NULL");
+  DeviceGuard g(gp->ctx->device);
+  return predict_impl(gp, Xs, S, 1, 1, 0.0, mu, var, dmu, dvar, nullptr, nullptr);
+}
+
+int elfihip_gp_lcb(elfihip_gp* gp, const double* Xs, int64_t S, double beta, double* val, double* grad) {
+  if (!gp) return fail(nullptr, ELFIHIP_ERR_ARG, "gp is NULL");
+  ELFIHIP_REQUIRE(gp->ctx, beta >= 0, "beta must be non-negative");
+  DeviceGuard g(gp->ctx->device);
+  return predict_impl(gp, Xs, S, grad ? 1 : 0, 1, beta, nullptr, nullptr, nullptr, nullptr, val, grad);
+}
+
+}  // extern "C"

@@ -1,0 +1,402 @@
+"""GP surrogate for elfi.BOLFI on the GPU: drop-in for GPyRegression.
+
+`HipGPRegression` has the duck-type ELFI's Bayesian-optimisation code expects from
+`target_model` (reference elfi v0.8.7):
+
+    elfi/methods/bo/gpy_regression.py:15-364   GPyRegression (the class mirrored here)
+    elfi/methods/inference/bolfi.py:35,86-87    BayesianOptimization(target_model=...)
+    elfi/methods/bo/acquisition.py:37-41        what acquisition rules call on the model
+
+Same constructor arguments, attributes (parameter_names, input_dim, bounds, n_evidence,
+X, Y, noise, instance, is_sampling) and methods (predict, predict_mean,
+predictive_gradients, predictive_gradient_mean, update, optimize, copy), same default
+kernel / prior heuristics (gpy_regression.py:242-280).  The arithmetic GPy performs in the
+reference (Gram matrix, Cholesky, K^-1, predict, gradients) runs in libelfihip.so through
+the C ABI of include/elfihip.h; nothing here falls back to the CPU.
+
+Use:  elfi.BOLFI(model, target_model=HipGPRegression(parameter_names, bounds=bounds), ...)
+"""
+import copy
+import ctypes as C
+import logging
+
+import numpy as np
+
+from . import _lib
+
+logger = logging.getLogger(__name__)
+
+
+class GPHandle:
+    """Owner of one elfihip_gp (device-resident evidence, factor and alpha)."""
+
+    def __init__(self, d, capacity, ctx=None):
+        self.ctx = ctx or _lib.default_context()
+        self.lib = self.ctx.lib
+        self.d = int(d)
+        h = C.c_void_p()
+        self._check(self.lib.elfihip_gp_create(self.ctx.handle, self.d, int(capacity), C.byref(h)))
+        self.h = h
+        n, cap, dd = C.c_int64(), C.c_int64(), C.c_int()
+        self._check(self.lib.elfihip_gp_size(self.h, C.byref(n), C.byref(cap), C.byref(dd)))
+        self.capacity = cap.value
+        self.n = 0
+
+    def _check(self, rc):
+        if rc != _lib.OK:
+            _lib._raise(self.lib, self.ctx.handle, rc)
+
+    def close(self):
+        if getattr(self, 'h', None) is not None:
+            self.lib.elfihip_gp_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_hyper(self, var, ls, bias, noise):
+        self._check(self.lib.elfihip_gp_set_hyper(self.h, float(var), float(ls), float(bias), float(noise)))
+
+    def set_data(self, X, y):
+        X = np.ascontiguousarray(X, dtype=np.float64).reshape(-1, self.d)
+        y = np.ascontiguousarray(y, dtype=np.float64).reshape(-1)
+        self._check(self.lib.elfihip_gp_set_data(self.h, _lib.ptr(X), _lib.ptr(y), X.shape[0]))
+        self.n = X.shape[0]
+
+    def append(self, X, y):
+        X = np.ascontiguousarray(X, dtype=np.float64).reshape(-1, self.d)
+        y = np.ascontiguousarray(y, dtype=np.float64).reshape(-1)
+        self._check(self.lib.elfihip_gp_append(self.h, _lib.ptr(X), _lib.ptr(y), X.shape[0]))
+        self.n += X.shape[0]
+
+    def factorize(self):
+        lz = C.c_double()
+        self._check(self.lib.elfihip_gp_factorize(self.h, C.byref(lz)))
+        return lz.value
+
+    def get(self, which):
+        n, d = self.n, self.d
+        shape = {0: (n, n), 1: (n, n), 2: (n, 1), 3: (n, d), 4: (n, 1), 5: (n, n)}[which]
+        out = np.empty(shape, dtype=np.float64)
+        self._check(self.lib.elfihip_gp_get(self.h, which, _lib.ptr(out)))
+        return out
+
+    def _xs(self, x):
+        return np.ascontiguousarray(x, dtype=np.float64).reshape(-1, self.d)
+
+    def predict(self, x, noiseless=False):
+        x = self._xs(x)
+        S = x.shape[0]
+        mu, var = np.empty((S, 1)), np.empty((S, 1))
+        self._check(self.lib.elfihip_gp_predict(self.h, _lib.ptr(x), S, int(bool(noiseless)),
+                                                _lib.ptr(mu), _lib.ptr(var)))
+        return mu, var
+
+    def predict_grad(self, x):
+        x = self._xs(x)
+        S = x.shape[0]
+        mu, var = np.empty((S, 1)), np.empty((S, 1))
+        dmu, dvar = np.empty((S, self.d)), np.empty((S, self.d))
+        self._check(self.lib.elfihip_gp_predict_grad(self.h, _lib.ptr(x), S, _lib.ptr(mu), _lib.ptr(var),
+                                                     _lib.ptr(dmu), _lib.ptr(dvar)))
+        return mu, var, dmu, dvar
+
+    def lcb(self, x, beta, with_grad=True):
+        x = self._xs(x)
+        S = x.shape[0]
+        val = np.empty((S, 1))
+        grad = np.empty((S, self.d)) if with_grad else None
+        self._check(self.lib.elfihip_gp_lcb(self.h, _lib.ptr(x), S, float(beta), _lib.ptr(val), _lib.ptr(grad)))
+        return val, grad
+
+
+# ---- the small part of the GPy object graph that ELFI code touches ---------------------------
+class _Param:
+    """Stands in for a paramz Param: float(p), p[0], p.values."""
+
+    def __init__(self, value):
+        self.values = np.array([float(value)])
+
+    def __float__(self):
+        return float(self.values[0])
+
+    def __getitem__(self, i):
+        return self.values[i]
+
+    def __repr__(self):
+        return repr(self.values)
+
+
+class _Part:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+class _GPShim:
+    """`target_model._gp` / `.instance` for code that reaches into GPy
+    (tests/unit/test_bo.py:41 reads _gp.X; acquisition.py:754 calls _gp.kern.K;
+    posteriors.py:296 reads _gp.param_array)."""
+
+    def __init__(self, model):
+        self._m = model
+
+    @property
+    def X(self):
+        return self._m._X
+
+    @property
+    def Y(self):
+        return self._m._Y
+
+    @property
+    def num_data(self):
+        return self._m._X.shape[0]
+
+    @property
+    def kern(self):
+        m = self._m
+
+        def K(X, X2=None):
+            X = np.asarray(X, dtype=float)
+            X2 = X if X2 is None else np.asarray(X2, dtype=float)
+            r2 = np.sum(X**2, 1)[:, None] + np.sum(X2**2, 1)[None, :] - 2. * X.dot(X2.T)
+            return m._hyper['var'] * np.exp(-0.5 * np.clip(r2, 0, np.inf) / m._hyper['ls']**2) + m._hyper['bias']
+
+        return _Part(K=K, rbf=_Part(variance=_Param(m._hyper['var']), lengthscale=_Param(m._hyper['ls'])),
+                     bias=_Part(variance=_Param(m._hyper['bias']),
+                                K=lambda X, X2=None: np.full((len(X), len(X if X2 is None else X2)),
+                                                             m._hyper['bias'])))
+
+    @property
+    def Gaussian_noise(self):
+        return _Part(variance=_Param(self._m._hyper['noise']))
+
+    likelihood = Gaussian_noise
+
+    @property
+    def param_array(self):
+        h = self._m._hyper
+        return np.array([h['var'], h['ls'], h['bias'], h['noise']])
+
+    @property
+    def posterior(self):
+        m = self._m
+        L = m._handle.get(0)
+        Linv_T = m._handle.get(1)
+        return _Part(woodbury_vector=m._handle.get(2), woodbury_chol=L, woodbury_inv=Linv_T @ Linv_T.T)
+
+    def log_likelihood(self):
+        return self._m._log_marginal
+
+    def __str__(self):
+        h = self._m._hyper
+        return ("HipGPRegression  n=%d  log-marginal=%.6g\n  rbf.variance %.6g\n  rbf.lengthscale %.6g\n"
+                "  bias.variance %.6g\n  Gaussian_noise.variance %.6g" %
+                (self.num_data, self._m._log_marginal, h['var'], h['ls'], h['bias'], h['noise']))
+
+
+class HipGPRegression:
+    """Gaussian-process regression on the GPU with the interface of GPyRegression
+    (elfi/methods/bo/gpy_regression.py:15-364)."""
+
+    def __init__(self, parameter_names=None, bounds=None, optimizer="scg", max_opt_iters=50, gp=None,
+                 device=-1, **gp_params):
+        if parameter_names is None:
+            input_dim = 1
+        elif isinstance(parameter_names, (list, tuple)):
+            input_dim = len(parameter_names)
+        else:
+            raise ValueError("Keyword `parameter_names` must be a list of strings")
+
+        if bounds is None:
+            logger.warning('Parameter bounds not specified. Using [0,1] for each parameter.')
+            bounds = [(0, 1)] * input_dim
+        elif len(bounds) != input_dim:
+            raise ValueError('Length of `bounds` ({}) does not match the length of `parameter_names` ({}).'
+                             .format(len(bounds), input_dim))
+        elif isinstance(bounds, dict):
+            if len(bounds) == 1:  # might be the case parameter_names=None
+                bounds = [bounds[n] for n in bounds.keys()]
+            else:
+                bounds = [bounds[n] for n in parameter_names]
+        else:
+            raise ValueError("Keyword `bounds` must be a dictionary "
+                             "`{'parameter_name': (lower, upper), ... }`")
+        if gp_params.get('kernel') is not None or gp_params.get('mean_function') is not None:
+            raise NotImplementedError('HipGPRegression implements the default RBF+Bias kernel with a zero '
+                                      'mean function (gpy_regression.py:260-280); custom GPy kernels / mean '
+                                      'functions need the reference GPyRegression')
+        self.parameter_names = parameter_names
+        self.input_dim = input_dim
+        self.bounds = bounds
+        self.gp_params = gp_params
+        self.optimizer = optimizer
+        self.max_opt_iters = max_opt_iters
+        self.device = device
+        self._gp = gp
+        self._rbf_is_cached = False
+        self.is_sampling = False
+        self._kernel_is_default = True
+        self._handle = None
+        self._X = None
+        self._Y = None
+        self._hyper = None
+        self._priors = None
+        self._log_marginal = None
+
+    # -- representation -----------------------------------------------------------------
+    def __str__(self):
+        return str(self._gp)
+
+    __repr__ = __str__
+
+    # -- prediction -----------------------------------------------------------------------
+    def predict(self, x, noiseless=False):
+        """GP (mean, var) at x, each (n, 1).  gpy_regression.py:98-147."""
+        x = np.asanyarray(x).reshape((-1, self.input_dim))
+        if self._gp is None:
+            return np.zeros((x.shape[0], 1)), np.ones((x.shape[0], 1))
+        if self.is_sampling and self._kernel_is_default:
+            # the reference's sampling-phase closed form always includes the noise (:139)
+            self._rbf_is_cached = True
+            return self._handle.predict(x, noiseless=False)
+        self._rbf_is_cached = False
+        return self._handle.predict(x, noiseless=noiseless)
+
+    def predict_mean(self, x):
+        return self.predict(x)[0]
+
+    def predictive_gradients(self, x):
+        """(grad_mean, grad_var) at x, each (n, input_dim).  gpy_regression.py:179-223."""
+        x = np.asanyarray(x).reshape((-1, self.input_dim))
+        if self._gp is None:
+            return np.zeros((x.shape[0], self.input_dim)), np.zeros((x.shape[0], self.input_dim))
+        _, _, dmu, dvar = self._handle.predict_grad(x)
+        return dmu, dvar
+
+    def predictive_gradient_mean(self, x):
+        return self.predictive_gradients(x)[0]
+
+    # -- batched LCB used by elfi_amd.acquisition (one device pass for all start points) -------
+    def lcb(self, x, beta, with_grad=True):
+        x = np.asanyarray(x).reshape((-1, self.input_dim))
+        return self._handle.lcb(x, beta, with_grad)
+
+    # -- fitting --------------------------------------------------------------------------
+    def _default_hyper(self, y):
+        # gpy_regression.py:255,260-264
+        length_scale = (np.max(self.bounds) - np.min(self.bounds)) / 3.
+        kernel_var = (np.max(y) / 3.)**2.
+        bias_var = kernel_var / 4.
+        noise_var = self.gp_params.get('noise_var') or np.max(y)**2. / 100.
+        return dict(var=float(kernel_var), ls=float(length_scale), bias=float(bias_var), noise=float(noise_var))
+
+    def _init_gp(self, x, y):
+        self._kernel_is_default = self.gp_params.get('noise_var') is None
+        self._hyper = self._default_hyper(y)
+        h = self._hyper
+        # Gamma priors from_EV(E, V=E): a = E, b = 1 (gpy_regression.py:270-278) on ls, var, bias
+        self._priors = {k: (h[k] ** 2 / h[k], h[k] / h[k]) for k in ('var', 'ls', 'bias')}
+        self._X = np.empty((0, self.input_dim))
+        self._Y = np.empty((0, 1))
+        self._gp = _GPShim(self)
+        self._append_and_fit(x, y)
+
+    def _ensure_capacity(self, n):
+        if self._handle is not None and n <= self._handle.capacity:
+            return False
+        cap = max(512, int(2 ** np.ceil(np.log2(max(n, 1)))))
+        old = self._handle
+        self._handle = GPHandle(self.input_dim, cap, ctx=_lib.default_context(self.device))
+        if old is not None:
+            old.close()
+        return True
+
+    def _append_and_fit(self, x, y):
+        n_old = self._X.shape[0]
+        self._X = np.r_[self._X, x]
+        self._Y = np.r_[self._Y, y]
+        if self._ensure_capacity(self._X.shape[0]) or n_old != self._handle.n:
+            self._handle.set_data(self._X, self._Y)
+        else:
+            self._handle.append(x, y)
+        self._refit()
+
+    def _refit(self):
+        h = self._hyper
+        self._handle.set_hyper(h['var'], h['ls'], h['bias'], h['noise'])
+        self._log_marginal = self._handle.factorize()
+
+    def update(self, x, y, optimize=False):
+        """Add evidence and rebuild the GP (gpy_regression.py:286-315)."""
+        x = np.asarray(x, dtype=np.float64).reshape((-1, self.input_dim))
+        y = np.asarray(y, dtype=np.float64).reshape((-1, 1))
+        if self._gp is None:
+            self._init_gp(x, y)
+        else:
+            self._append_and_fit(x, y)
+        if optimize:
+            self.optimize()
+
+    def optimize(self):
+        """Optimise the hyper-parameters (gpy_regression.py:317-323)."""
+        logger.debug("Optimizing GP hyperparameters")
+        from .hyperopt import optimize_hyperparameters
+        try:
+            optimize_hyperparameters(self, max_iters=self.max_opt_iters)
+        except np.linalg.LinAlgError:
+            logger.warning("Numerical error in GP optimization. Stopping optimization")
+
+    # -- attributes -------------------------------------------------------------------------
+    @property
+    def n_evidence(self):
+        return 0 if self._gp is None else self._X.shape[0]
+
+    @property
+    def X(self):
+        return self._gp.X
+
+    @property
+    def Y(self):
+        return self._gp.Y
+
+    @property
+    def noise(self):
+        return self._hyper['noise']
+
+    @property
+    def instance(self):
+        return self._gp
+
+    def copy(self):
+        """Independent copy (own device state), as GPyRegression.copy (gpy_regression.py:352-364)."""
+        kopy = copy.copy(self)
+        kopy.gp_params = dict(self.gp_params)
+        if self._gp is not None:
+            kopy._hyper = dict(self._hyper)
+            kopy._priors = dict(self._priors)
+            kopy._X = self._X.copy()
+            kopy._Y = self._Y.copy()
+            kopy._gp = _GPShim(kopy)
+            kopy._handle = None
+            kopy._ensure_capacity(kopy._X.shape[0])
+            kopy._handle.set_data(kopy._X, kopy._Y)
+            kopy._refit()
+        return kopy
+
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        st['_handle'] = None  # device state is rebuilt on first use after unpickling
+        st['_gp'] = None if self._gp is None else True
+        return st
+
+    def __setstate__(self, st):
+        self.__dict__.update(st)
+        if self._gp:
+            self._gp = _GPShim(self)
+            self._ensure_capacity(self._X.shape[0])
+            self._handle.set_data(self._X, self._Y)
+            self._refit()

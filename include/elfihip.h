@@ -126,6 +126,44 @@ int elfihip_welford_update(elfihip_ctx* ctx, const double* X, int64_t n, int m, 
 int elfihip_welford_update_dev(elfihip_ctx* ctx, const double* dX, int64_t n, int m, int64_t ldx,
                                double* dstate);
 
+/* ------------------------------------------------------------------- GP surrogate
+ * Replaces the GPy model behind elfi.methods.bo.gpy_regression.GPyRegression
+ * (elfi/methods/bo/gpy_regression.py:15-364): kernel RBF(variance, lengthscale) + Bias
+ * (:260-280), Gaussian noise, exact inference.  One elfihip_gp holds the evidence
+ * (X (n,d), y (n)) and, after elfihip_gp_factorize, L = chol(K + (noise + 1e-8) I),
+ * L^-T and alpha = K^-1 y in device memory.  Host pointers in, host pointers out.
+ */
+/* capacity: the largest n this GP will hold (rounded up to a multiple of 128). */
+int elfihip_gp_create(elfihip_ctx* ctx, int d, int64_t capacity, elfihip_gp** gp);
+int elfihip_gp_free(elfihip_gp* gp);
+/* kern.rbf.variance, kern.rbf.lengthscale, kern.bias.variance, Gaussian_noise.variance
+ * (gpy_regression.py:151-155). */
+int elfihip_gp_set_hyper(elfihip_gp* gp, double rbf_variance, double lengthscale, double bias_variance,
+                         double noise_variance);
+/* Replace / extend the evidence (GPyRegression.update, gpy_regression.py:286-315: np.r_[X_old, x]). */
+int elfihip_gp_set_data(elfihip_gp* gp, const double* X, const double* y, int64_t n);
+int elfihip_gp_append(elfihip_gp* gp, const double* X_new, const double* y_new, int64_t k);
+/* Gram matrix + Cholesky + L^-T + alpha (what GPy's ExactGaussianInference does when
+ * gpy_regression.py:283-284 / :311-312 construct GPRegression).  log_marginal may be NULL.
+ * ELFIHIP_ERR_NOT_PD if a pivot is not positive (GPy would raise LinAlgError). */
+int elfihip_gp_factorize(elfihip_gp* gp, double* log_marginal);
+int elfihip_gp_size(const elfihip_gp* gp, int64_t* n, int64_t* capacity, int* d);
+/* Copy state to the host: 0 = L (n*n lower), 1 = L^-T (n*n upper), 2 = alpha (n),
+ * 3 = X (n*d), 4 = y (n), 5 = K^-1 (n*n, after elfihip_gp_nlml_grad). */
+int elfihip_gp_get(elfihip_gp* gp, int which, double* out);
+
+/* GPyRegression.predict(x, noiseless) (gpy_regression.py:98-147; closed form :127-140):
+ * mu_s = k_s^T alpha,  var_s = clip(s_f + s_b - k_s^T K^-1 k_s, 1e-15) (+ noise unless noiseless).
+ * Xs is (S, d) row-major; mu, var get S doubles each. */
+int elfihip_gp_predict(elfihip_gp* gp, const double* Xs, int64_t S, int noiseless, double* mu, double* var);
+/* GPyRegression.predictive_gradients(x) (gpy_regression.py:179-223; closed form :206-218):
+ * dmu (S,d), dvar (S,d).  mu/var (noiseless) are returned too when non-NULL. */
+int elfihip_gp_predict_grad(elfihip_gp* gp, const double* Xs, int64_t S, double* mu, double* var,
+                            double* dmu, double* dvar);
+/* LCBSC.evaluate / evaluate_gradient (elfi/methods/bo/acquisition.py:262-301) for S points at
+ * once: val_s = mu - sqrt(beta var),  grad_s = dmu - 0.5 dvar sqrt(beta / var)  (noiseless). */
+int elfihip_gp_lcb(elfihip_gp* gp, const double* Xs, int64_t S, double beta, double* val, double* grad);
+
 #ifdef __cplusplus
 }
 #endif

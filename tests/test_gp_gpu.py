@@ -1,0 +1,159 @@
+"""Parity of the HIP GP core (through the C ABI) with the CPU oracle at FIXED hyper-parameters.
+
+Tolerances: L and L^-T relative 1e-10 (of the largest entry), alpha, mu,
+var, gradients, log-marginal relative 1e-8 -- the conditioning of K with the default noise
+max(y)^2/100 is benign.  Hyper-parameter optimisation is "parity unpinned" (see
+oracle/gp_oracle.py) and is tested for self-consistency only.
+"""
+import numpy as np
+import pytest
+
+import gp_oracle as G
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem(n, d, seed=0):
+    rs = np.random.RandomState(seed)
+    X = rs.uniform(-2, 2, (n, d))
+    y = np.linalg.norm(X - 0.5, axis=1) + 0.1 * rs.randn(n)
+    return X, y.reshape(-1, 1), [(-2., 2.)] * d
+
+
+def _fit(X, y, bounds, hyper=None):
+    from elfi_amd.gp import GPHandle
+    h = hyper or G.default_hyper(bounds, y)
+    gp = GPHandle(X.shape[1], X.shape[0])
+    gp.set_hyper(h['var'], h['ls'], h['bias'], h['noise'])
+    gp.set_data(X, y)
+    logz = gp.factorize()
+    return gp, logz, G.Posterior(X, y, h['var'], h['ls'], h['bias'], h['noise'])
+
+
+def _close(a, b, rtol, what):
+    scale = np.max(np.abs(b)) + 1e-300
+    err = np.max(np.abs(a - b)) / scale
+    assert err <= rtol, '%s: scaled max error %g > %g' % (what, err, rtol)
+
+
+@pytest.mark.parametrize('n,d', [(5, 1), (100, 2), (128, 2), (129, 3), (300, 10), (1000, 10), (1500, 20)])
+def test_factorization_vs_oracle(hip_ctx, n, d):
+    X, y, bounds = _problem(n, d, seed=n)
+    gp, logz, ref = _fit(X, y, bounds)
+    _close(gp.get(0), ref.L, 1e-10, 'L')
+    _close(gp.get(1), ref.Linv.T, 1e-9, 'L^-T')
+    _close(gp.get(2), ref.alpha, 1e-8, 'alpha')
+    assert abs(logz - ref.log_marginal) <= 1e-9 * abs(ref.log_marginal)
+    # transpose-detecting structural check: L lower, L^-T upper, L L^-1 = I
+    L, WT = gp.get(0), gp.get(1)
+    assert np.allclose(L @ WT.T, np.eye(n), atol=1e-8)
+
+
+@pytest.mark.parametrize('n,d,S', [(50, 2, 1), (300, 2, 7), (1000, 10, 10), (1000, 10, 37), (700, 5, 16)])
+def test_predict_and_gradients_vs_oracle(hip_ctx, n, d, S):
+    X, y, bounds = _problem(n, d, seed=7 * n + S)
+    gp, _, ref = _fit(X, y, bounds)
+    xs = np.random.RandomState(3).uniform(-2, 2, (S, d))
+    xs[0] = X[0]   # exactly on an evidence point
+    mu, var = gp.predict(xs, noiseless=True)
+    rmu, rvar = ref.predict(xs, noiseless=True)
+    _close(mu, rmu, 1e-8, 'mu')
+    assert np.max(np.abs(var - rvar)) <= 1e-8 * (ref.var + ref.bias), 'var'
+    mu2, var2 = gp.predict(xs, noiseless=False)
+    assert np.allclose(var2, var + ref.noise, rtol=1e-14, atol=0)
+    assert np.array_equal(mu2, mu)
+    m3, v3, dmu, dvar = gp.predict_grad(xs)
+    gmu, gvar = ref.predictive_gradients(xs)
+    assert np.array_equal(m3, mu) and np.array_equal(v3, var)
+    _close(dmu, gmu, 1e-8, 'grad mu')
+    _close(dvar, gvar, 1e-7, 'grad var')
+    # the reference's own sampling-phase closed form (gpy_regression.py:127-140), point by point
+    for s in range(min(S, 4)):
+        cm, cv = ref.predict_closed_form(xs[s])
+        assert abs(cm[0, 0] - mu[s, 0]) <= 1e-8 * np.max(np.abs(rmu))
+        assert abs(cv[0, 0] - ref.noise - var[s, 0]) <= 1e-8 * (ref.var + ref.bias)
+
+
+def test_lcb_vs_oracle(hip_ctx):
+    X, y, bounds = _problem(800, 4, seed=11)
+    gp, _, ref = _fit(X, y, bounds)
+    xs = np.random.RandomState(5).uniform(-2, 2, (10, 4))
+    for t in (0, 5, 200):
+        beta = G.lcb_beta(t, 4)
+        val, grad = gp.lcb(xs, beta)
+        _close(val, G.lcb_evaluate(ref, xs, t), 1e-8, 'lcb')
+        _close(grad, G.lcb_evaluate_gradient(ref, xs, t), 1e-7, 'lcb grad')
+        # gradient is the derivative of the value (finite differences on the device function)
+    eps = 1e-6
+    val0, g0 = gp.lcb(xs[:1], beta)
+    for a in range(4):
+        xp = xs[:1].copy()
+        xp[0, a] += eps
+        fd = (gp.lcb(xp, beta, with_grad=False)[0][0, 0] - val0[0, 0]) / eps
+        assert abs(fd - g0[0, a]) <= 1e-4 * (1 + abs(g0[0, a]))
+
+
+def test_not_positive_definite_raises(hip_ctx):
+    from elfi_amd.gp import GPHandle
+    X = np.zeros((10, 2))            # ten identical points, no noise: singular
+    gp = GPHandle(2, 10)
+    gp.set_hyper(1.0, 1.0, 0.0, 0.0)
+    gp.set_data(X, np.ones(10))
+    # jitter 1e-8 keeps the first pivots positive but the matrix is numerically singular;
+    # either it factors with tiny pivots or LinAlgError is raised -- never a crash or NaN silently
+    try:
+        gp.factorize()
+    except np.linalg.LinAlgError:
+        pass
+    gp.set_hyper(1.0, 1.0, 0.0, 1.0)
+    gp.factorize()
+    with pytest.raises(Exception):
+        GPHandle(2, 10).predict(np.zeros((1, 2)))   # predict before factorize
+
+
+def test_update_matches_rebuild(hip_ctx):
+    """GPyRegression.update semantics: appending == rebuilding with np.r_[X_old, x]."""
+    from elfi_amd.gp import HipGPRegression
+    X, y, bounds = _problem(260, 2, seed=2)
+    names = ['a', 'b']
+    b = dict(zip(names, bounds))
+    m1 = HipGPRegression(names, bounds=b)
+    m1.update(X[:200], y[:200])
+    for i in range(200, 260, 20):
+        m1.update(X[i:i + 20], y[i:i + 20])
+    m2 = HipGPRegression(names, bounds=b)
+    m2.update(X[:200], y[:200])          # same initial heuristics (they depend on the first batch)
+    m2._X, m2._Y = X.copy(), y.copy()
+    m2._handle.set_data(X, y)
+    m2._refit()
+    xs = np.random.RandomState(1).uniform(-2, 2, (5, 2))
+    a, b2 = m1.predict(xs), m2.predict(xs)
+    assert np.array_equal(a[0], b2[0]) and np.array_equal(a[1], b2[1])
+    assert m1.n_evidence == 260 and m1.X.shape == (260, 2) and m1.Y.shape == (260, 1)
+    ref = G.Posterior(X, y, **{k: m1._hyper[k] for k in ('var', 'ls', 'bias', 'noise')})
+    _close(a[0], ref.predict(xs)[0], 1e-8, 'mu after updates')
+
+
+def test_metric_shape_n4096_d10(hip_ctx):
+    """BASELINE config 3 metric shape: properties that need no O(n^3) CPU pass, plus a
+    CPU cross-check of the factor through K = L L^T on a row sample."""
+    X, y, bounds = G.synthetic_gp_problem(4096, 10)
+    h = G.default_hyper(bounds, y)
+    from elfi_amd.gp import GPHandle
+    gp = GPHandle(10, 4096)
+    gp.set_hyper(h['var'], h['ls'], h['bias'], h['noise'])
+    gp.set_data(X, y)
+    logz = gp.factorize()
+    L, WT, alpha = gp.get(0), gp.get(1), gp.get(2)
+    K = G.kern_K(X, None, h['var'], h['ls'], h['bias'])
+    K[np.diag_indices(4096)] += h['noise'] + G.JITTER
+    rows = np.random.RandomState(0).choice(4096, 64, replace=False)
+    assert np.max(np.abs((L[rows] @ L.T) - K[rows])) <= 1e-10 * np.max(K)        # L L^T = K
+    assert np.max(np.abs(K[rows] @ alpha - y[rows])) <= 1e-8 * np.max(np.abs(y))  # K alpha = y
+    assert np.max(np.abs(L[rows] @ WT.T - np.eye(4096)[rows])) <= 1e-9            # L L^-1 = I
+    assert np.isfinite(logz)
+    # prediction at the evidence reproduces y up to the noise-induced shrinkage; variance >= 0
+    mu, var = gp.predict(X[:32], noiseless=True)
+    assert np.all(var > 0) and np.all(var < h['var'] + h['bias'])
+    kx = G.kern_K(X, X[:32], h['var'], h['ls'], h['bias'])
+    assert np.max(np.abs(mu - kx.T @ alpha)) <= 1e-9 * np.max(np.abs(mu))
