@@ -55,6 +55,9 @@ struct elfihip_ctx {
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;  // own_stream or an adopted one
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // look-ahead machinery of the GP factorisation (created on first use)
+  hipStream_t hi_stream = nullptr;
+  hipEvent_t ev_a = nullptr, ev_b = nullptr;
   int cu_count = 0;
   std::string err;
   // staging buffers for the host entry points
@@ -113,6 +116,8 @@ struct DeviceGuard {
     if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
   }
 };
+
+int ctx_aux(elfihip_ctx* ctx);  // ctx.hip: lazily creates hi_stream / ev_a / ev_b
 
 inline int launch_status(elfihip_ctx* ctx, const char* what) {
   hipError_t e = hipGetLastError();

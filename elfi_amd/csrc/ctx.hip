@@ -3,7 +3,17 @@
 
 namespace elfihip {
 thread_local std::string g_err;
+
+int ctx_aux(elfihip_ctx* ctx) {
+  if (ctx->hi_stream) return ELFIHIP_OK;
+  int lo = 0, hi = 0;
+  ELFIHIP_CHECK_HIP(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));
+  ELFIHIP_CHECK_HIP(ctx, hipStreamCreateWithPriority(&ctx->hi_stream, hipStreamNonBlocking, hi));
+  ELFIHIP_CHECK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_a, hipEventDisableTiming));
+  ELFIHIP_CHECK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_b, hipEventDisableTiming));
+  return ELFIHIP_OK;
 }
+}  // namespace elfihip
 
 using namespace elfihip;
 
@@ -72,6 +82,9 @@ int elfihip_ctx_destroy(elfihip_ctx* ctx) {
     ctx->scratch.release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->ev_a) (void)hipEventDestroy(ctx->ev_a);
+    if (ctx->ev_b) (void)hipEventDestroy(ctx->ev_b);
+    if (ctx->hi_stream) (void)hipStreamDestroy(ctx->hi_stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   }
   delete ctx;

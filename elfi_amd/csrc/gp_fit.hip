@@ -140,79 +140,115 @@ __device__ __forceinline__ void sqrt_rsqrt(double p, double& s, double& y) {
 }
 
 constexpr int SP = 129;   // pitch of the 128x128 working block S in LDS
-constexpr int PP = 18;    // pitch of the 16-wide panel copy
-constexpr int POTF2_LDS_DOUBLES = NB * SP + NB + 16 + 16 * 17 + 144 * PP;
+constexpr int PP = 18;    // pitch of the 16-wide panel copy / the tile inverse
+constexpr int POTF2_LDS_DOUBLES = NB * SP + NB + 16 * PP + 144 * PP;
+
+// Lower-triangular 16x16 tile held ENTIRELY in one lane's registers (every lane of the wave
+// computes the same thing): the serial pivot chain then needs no cross-lane traffic at all.
+struct Tile16 {
+  double a[136];  // packed lower triangle, row-major: (i, c) at i*(i+1)/2 + c
+  __device__ __forceinline__ double& at(int i, int c) { return a[i * (i + 1) / 2 + c]; }
+};
 
 // S holds two triangles at once: entries (i, c <= i) are the block of Ky being turned into
 // L11; entries (r, c > r) are the rows of the appended identity being turned into L11^-T
 // (its diagonal lives in bd[]).  Eliminating 16 columns at a time:
-//   phase 1  one wave factors the 16x16 diagonal tile in registers (row per lane, pivots and
-//            multipliers broadcast with v_readlane) -- this is the serial pivot chain;
-//   phase 2  every other row (112-c0 rows below + c0+16 identity rows above = 128 rows)
-//            forward-substitutes its 16 panel entries against that tile;
-//   phase 3  rank-16 update of everything to the right of the panel.
+//   phase 1  wave 0 factors the 16x16 diagonal tile T = L L^T and inverts L, all in registers;
+//   phase 2  the other 128 rows (112-c0 below + c0+16 identity rows above) get their panel
+//            entries multiplied by L^-T on the matrix cores (X = P W^T, W = L^-1);
+//   phase 3  rank-16 update of everything right of the panel, 16x16 MFMA tiles.
 __global__ __launch_bounds__(256) void potf2_aug_kernel(double* Akk, int64_t lda, double* Wkk, int64_t ldw,
-                                                        double* W11, int* info, int kblock) {
+                                                        double* W11, int* info, int kblock, int skip) {
   extern __shared__ __align__(16) double sm[];
   double* S = sm;
   double* bd = S + NB * SP;
-  double* rinvs = bd + NB;
-  double* Lt = rinvs + 16;   // 16 x 17
-  double* P2 = Lt + 16 * 17; // 144 x PP
-  const int tid = threadIdx.x;
+  double* Wt = bd + NB;        // 16 x PP : inverse of the current tile, Wt[i][c] = (L^-1)[i][c]
+  double* P2 = Wt + 16 * PP;   // 144 x PP: dense copy of the panel entries of the 128 other rows
+  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
+  long long tc[6] = {0, 0, 0, 0, 0, 0};
+  const long long t_begin = clock64(), r_begin = wall_clock64();
 
-  for (int e = tid; e < NB * NB; e += 256) {
-    const int i = e >> 7, c = e & 127;
-    S[i * SP + c] = (c <= i) ? Akk[(int64_t)i * lda + c] : 0.0;
+  // block load, lower triangle only (plus the diagonal pair): 16-byte loads, 8 in flight
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    double2 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e2 = tid + 256 * (8 * g + u);
+      const int i = e2 >> 6, c = 2 * (e2 & 63);
+      v[u] = make_double2(0.0, 0.0);
+      if (c <= i) v[u] = *reinterpret_cast<const double2*>(Akk + (int64_t)i * lda + c);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e2 = tid + 256 * (8 * g + u);
+      const int i = e2 >> 6, c = 2 * (e2 & 63);
+      S[i * SP + c] = (c <= i) ? v[u].x : 0.0;
+      S[i * SP + c + 1] = (c + 1 <= i) ? v[u].y : 0.0;
+    }
   }
   if (tid < NB) bd[tid] = 1.0;
   __syncthreads();
+  int bad = 0;
 
   for (int p = 0; p < NB / 16; ++p) {
     const int c0 = 16 * p;
-    // ---- phase 1: 16x16 tile, wave 0, lane i < 16 owns row c0 + i
-    if (tid < 64) {
-      const int li = tid & 15;
-      double a[16];
+    const int ntop = NB - 16 - c0;  // rows below the tile
+    long long t0 = clock64();
+    // ---- phase 1 (wave 0): tile Cholesky + inverse, lane-redundant, straight-line
+    if (w == 0 && !(skip & 1)) {
+      Tile16 T;
 #pragma unroll
-      for (int c = 0; c < 16; ++c) a[c] = (c <= li) ? S[(c0 + li) * SP + c0 + c] : 0.0;
+      for (int i = 0; i < 16; ++i)
+#pragma unroll
+        for (int c = 0; c <= i; ++c) T.at(i, c) = S[(c0 + i) * SP + c0 + c];  // broadcast reads
       double rinv[16];
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
-        const double pj = readlane_f64(a[j], j);
+        const double pj = T.at(j, j);
         double sj, yj;
-        if (pj > 0.0) {
-          sqrt_rsqrt(pj, sj, yj);
-        } else {  // not positive definite (or NaN): record, keep going with zeros
-          sj = 0.0;
-          yj = 0.0;
-          if (tid == 0) atomicCAS(info, 0, kblock * NB + c0 + j + 1);
-        }
+        sqrt_rsqrt(pj, sj, yj);
+        const bool ok = pj > 0.0;
+        if (!ok && bad == 0) bad = kblock * NB + c0 + j + 1;
+        sj = ok ? sj : 0.0;
+        yj = ok ? yj : 0.0;
         rinv[j] = yj;
-        a[j] = (li == j) ? sj : a[j] * yj;
+        T.at(j, j) = sj;
 #pragma unroll
-        for (int c = j + 1; c < 16; ++c) {
-          const double lcj = readlane_f64(a[j], c);
-          a[c] = fma(-a[j], lcj, a[c]);
-        }
+        for (int i = j + 1; i < 16; ++i) T.at(i, j) *= yj;
+#pragma unroll
+        for (int c = j + 1; c < 16; ++c)
+#pragma unroll
+          for (int i = c; i < 16; ++i) T.at(i, c) = fma(-T.at(i, j), T.at(c, j), T.at(i, c));
       }
-      if (tid < 16) {
+      // column (l & 15) of W = L^-1 by forward substitution on a unit vector: lanes work in parallel
+      const int wc = l & 15;
+      double wv[16];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {
-          const double v = (c <= li) ? a[c] : 0.0;
-          Lt[li * 17 + c] = v;
-          if (c <= li) S[(c0 + li) * SP + c0 + c] = v;
-        }
-        rinvs[li] = rinv[li];
+      for (int i = 0; i < 16; ++i) {
+        double acc = (i == wc) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < i; ++k) acc = fma(-T.at(i, k), wv[k], acc);
+        wv[i] = acc * rinv[i];   // entries above the diagonal (i < wc) come out exactly 0
+      }
+      if (l < 16) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) Wt[i * PP + wc] = wv[i];
+      }
+      if (l == 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+#pragma unroll
+          for (int c = 0; c <= i; ++c) S[(c0 + i) * SP + c0 + c] = T.at(i, c);
       }
     }
-    __syncthreads();
-    // ---- phase 2: forward substitution of the other 128 rows' panel entries
-    const int ntop = NB - 16 - c0;  // rows below the tile
-    if (tid < NB) {
-      const bool top = tid < ntop;
-      const int row = top ? (c0 + 16 + tid) : (tid - ntop);  // S row index (bottom: identity row r)
-      double x[16];
+    tc[0] += clock64() - t0;
+    t0 = clock64();
+    // ---- phase 2a: dense copy of the other 128 rows' panel entries (identity rows unmasked here)
+    const bool top = tid < ntop;
+    const int row = top ? (c0 + 16 + tid) : (tid - ntop);  // S row (bottom: identity row r)
+    if (tid < NB && !(skip & 2)) {
+      double x[16];  // all loads first, then all stores: LDS reads are not serialised behind the writes
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
         const int col = c0 + c;
@@ -222,50 +258,134 @@ __global__ __launch_bounds__(256) void potf2_aug_kernel(double* Akk, int64_t lda
           x[c] = col > row ? S[row * SP + col] : (col == row ? bd[row] : 0.0);
       }
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        x[j] *= rinvs[j];
+      for (int c = 0; c < 16; c += 2) *reinterpret_cast<double2*>(P2 + tid * PP + c) = make_double2(x[c], x[c + 1]);
+    }
+    __syncthreads();
+    tc[1] += clock64() - t0;
+    t0 = clock64();
+    // ---- phase 2b: X = P W^T on the matrix cores, two 16-row tiles per wave, in place
+    if (!(skip & 2)) {
+      double av[2][4], bv[4];
 #pragma unroll
-        for (int c = j + 1; c < 16; ++c) x[c] = fma(-x[j], Lt[c * 17 + j], x[c]);
+      for (int kk = 0; kk < 4; ++kk) {
+        bv[kk] = Wt[(l & 15) * PP + 4 * kk + (l >> 4)];  // B[k][c] = W[c][k]
+#pragma unroll
+        for (int m = 0; m < 2; ++m) av[m][kk] = P2[((2 * w + m) * 16 + (l & 15)) * PP + 4 * kk + (l >> 4)];
+      }
+      v4d x[2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        x[m] = (v4d){0, 0, 0, 0};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) x[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m][kk], bv[kk], x[m], 0, 0, 0);
+      }
+      // each wave owns its two row tiles: reads above are complete (registers) before these writes
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) P2[((2 * w + m) * 16 + (l >> 4) + 4 * r) * PP + (l & 15)] = x[m][r];
+    }
+    __syncthreads();
+    tc[2] += clock64() - t0;
+    t0 = clock64();
+    // ---- phase 2c: solved panel entries back into S / bd (columns of the panel only)
+    if (tid < NB && !(skip & 2)) {
+      double x[16];
+#pragma unroll
+      for (int c = 0; c < 16; c += 2) {
+        const double2 v = *reinterpret_cast<const double2*>(P2 + tid * PP + c);
+        x[c] = v.x;
+        x[c + 1] = v.y;
       }
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
         const int col = c0 + c;
-        P2[tid * PP + c] = x[c];
         if (top || col > row)
           S[row * SP + col] = x[c];
         else if (col == row)
           bd[row] = x[c];
       }
     }
-    __syncthreads();
-    // ---- phase 3: rank-16 update to the right of the panel
-    const int nq = NB - 16 - c0;  // remaining columns
-    if (nq > 0) {
-      const int xr = tid & 127, half = tid >> 7;
-      const bool top = xr < ntop;
-      const int row = top ? (c0 + 16 + xr) : (xr - ntop);
-      double a[16];
+    tc[3] += clock64() - t0;
+    t0 = clock64();
+    // ---- phase 3: rank-16 update right of the panel, one 16x16 MFMA tile at a time per wave.
+    // Cholesky rows: tiles (a >= b) of the ntop x ntop lower triangle; identity rows: (rt <= p, b).
+    const int Tn = ntop / 16;
+    const int ntiles = Tn * (Tn + 1) / 2 + (p + 1) * Tn;
+    if (!(skip & 4)) {
+      for (int t = w; t < ntiles; t += 4) {
+        int prow, pcol, srow, diag = 0;
+        if (t < Tn * (Tn + 1) / 2) {
+          int a = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+          while (a * (a + 1) / 2 > t) --a;
+          while ((a + 1) * (a + 2) / 2 <= t) ++a;
+          const int b2 = t - a * (a + 1) / 2;
+          prow = 16 * a;
+          pcol = 16 * b2;
+          srow = c0 + 16 + 16 * a;
+          diag = (a == b2);
+        } else {
+          const int u = t - Tn * (Tn + 1) / 2;
+          const int rt = u / Tn;
+          pcol = 16 * (u - rt * Tn);
+          prow = ntop + 16 * rt;
+          srow = 16 * rt;
+        }
+        const int scol = c0 + 16 + pcol;
+        v4d c;
 #pragma unroll
-      for (int c = 0; c < 16; ++c) a[c] = P2[xr * PP + c];
-      const int qmax = top ? (xr + 1) : nq;  // lower triangle only for the Cholesky rows
-      for (int q = half; q < qmax; q += 2) {
-        const double* bq = P2 + q * PP;  // L[c0+16+q][panel]
-        double acc = 0.0;
+        for (int r = 0; r < 4; ++r) c[r] = S[(srow + (l >> 4) + 4 * r) * SP + scol + (l & 15)];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) acc = fma(a[c], bq[c], acc);
-        S[row * SP + c0 + 16 + q] -= acc;
+        for (int kk = 0; kk < 4; ++kk) {
+          const double a_ = -P2[(prow + (l & 15)) * PP + 4 * kk + (l >> 4)];
+          const double b_ = P2[(pcol + (l & 15)) * PP + 4 * kk + (l >> 4)];
+          c = __builtin_amdgcn_mfma_f64_16x16x4f64(a_, b_, c, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int rr = (l >> 4) + 4 * r, cc = l & 15;
+          if (!diag || cc <= rr) S[(srow + rr) * SP + scol + cc] = c[r];
+        }
       }
     }
     __syncthreads();
+    tc[4] += clock64() - t0;
   }
+  if (bad != 0 && tid == 0) atomicCAS(info, 0, bad);
+  const long long t_mid = clock64();
 
-  // ---- write out: L11 (lower), L11^-T into WT's diagonal block (upper, zero below), W11 = L11^-1
-  for (int e = tid; e < NB * NB; e += 256) {
-    const int i = e >> 7, c = e & 127;
-    if (c <= i) Akk[(int64_t)i * lda + c] = S[i * SP + c];
-    Wkk[(int64_t)i * ldw + c] = c > i ? S[i * SP + c] : (c == i ? bd[i] : 0.0);
-    // W11[i][c] = L11^-1[i][c] = (L11^-T)[c][i]
-    W11[i * NB + c] = c < i ? S[c * SP + i] : (c == i ? bd[i] : 0.0);
+  // ---- write out: L11 (lower), L11^-T into WT's diagonal block (upper incl. diagonal), W11 = L11^-1
+  // (lower incl. diagonal).  The other triangles of those two targets are zero from allocation and
+  // are never written by anyone, so they are not rewritten here.
+#pragma unroll 4
+  for (int it = 0; it < 32; ++it) {
+    const int e2 = tid + 256 * it;
+    const int i = e2 >> 6, c = 2 * (e2 & 63);
+    const double s0 = S[i * SP + c], s1 = S[i * SP + c + 1];
+    if (c + 1 <= i) {
+      *reinterpret_cast<double2*>(Akk + (int64_t)i * lda + c) = make_double2(s0, s1);
+    } else if (c <= i) {
+      Akk[(int64_t)i * lda + c] = s0;
+    }
+    if (c + 1 >= i) {  // pair touches the upper triangle (diagonal included)
+      double2 wv;
+      wv.x = c > i ? s0 : (c == i ? bd[i] : 0.0);
+      wv.y = c + 1 > i ? s1 : (c + 1 == i ? bd[i] : 0.0);
+      *reinterpret_cast<double2*>(Wkk + (int64_t)i * ldw + c) = wv;
+    }
+    if (c <= i) {  // W11[i][c] = L11^-1[i][c] = (L11^-T)[c][i]
+      double2 q;
+      q.x = c < i ? S[c * SP + i] : bd[i];
+      q.y = c + 1 < i ? S[(c + 1) * SP + i] : (c + 1 == i ? bd[i] : 0.0);
+      *reinterpret_cast<double2*>(W11 + i * NB + c) = q;
+    }
+  }
+  if ((skip & 8) && tid == 0) {  // developer probe: cycle counts (shader clock) and 100 MHz wall ticks
+    double* dbg = W11 + NB * NB;
+    for (int q = 0; q < 5; ++q) dbg[q] = (double)tc[q];
+    dbg[5] = (double)(t_mid - t_begin);
+    dbg[6] = (double)(clock64() - t_begin);
+    dbg[7] = (double)(wall_clock64() - r_begin);
   }
 }
 
@@ -288,12 +408,14 @@ __device__ __forceinline__ double* panel_block(const PanelArgs& P, int idx) {
 }
 
 __global__ __launch_bounds__(256) void trsm_gemm_kernel(PanelArgs P) {
+  // 4 workgroups per 128-row block, 32 rows each: a workgroup reads only the rows it
+  // overwrites, so the in-place update is race free, and 4*nb workgroups fill the chip.
   extern __shared__ __align__(16) double lds[];
-  double* Pb = panel_block(P, blockIdx.x);
-  GemmAcc acc;
+  double* Pb = panel_block(P, blockIdx.x >> 2) + (int64_t)(blockIdx.x & 3) * 32 * P.lda;
+  GemmAcc32 acc;
   acc.zero();
-  gemm_tile_nt(acc, Pb, P.lda, P.W11, NB, 0, NB, lds, false);
-  acc_foreach(acc, [&](int row, int col, double v) { Pb[(int64_t)row * P.lda + col] = v; });
+  gemm_tile32_nt(acc, Pb, P.lda, P.W11, NB, 0, NB, lds);
+  acc32_foreach(acc, [&](int row, int col, double v) { Pb[(int64_t)row * P.lda + col] = v; });
 }
 
 // --------------------------------------------------------------- trailing update on the matrix cores
@@ -301,45 +423,105 @@ __global__ __launch_bounds__(256) void trsm_gemm_kernel(PanelArgs P) {
 //   [0, tA)            Cholesky rows: (i, c), k < c <= i < nb      C -= P_i P_c^T   (SYRK)
 //   [tA, tA+m)         y block:       (y, c)                        C -= P_y P_c^T
 //   [tA+m, ...)        L^-T rows:     (r, c), r <= k                C  = beta C - P_r P_c^T, beta = 0 for r == k
-__global__ __launch_bounds__(256) void trailing_update_kernel(PanelArgs P) {
+//
+// Look-ahead split: `single` = 1 updates only block column c0 = k+1 (what the next diagonal
+// block and panel solve need); `single` = 0 updates block columns >= c0 (c0 = k+2 for the bulk
+// launch that overlaps the next panel factorisation on another stream, c0 = k+1 for all).
+__global__ __launch_bounds__(256) void trailing_update_kernel(PanelArgs P, int c0, int single) {
   extern __shared__ __align__(16) double lds[];
-  const int m = P.nb - 1 - P.k;
-  const int tA = m * (m + 1) / 2;
   int idx = blockIdx.x;
   const double* Ap;
   double* C;
   int cblk;
   bool same = false, beta0 = false;
-  if (idx < tA) {
-    int i = (int)((sqrtf(8.0f * (float)idx + 1.0f) - 1.0f) * 0.5f);
-    while (i * (i + 1) / 2 > idx) --i;
-    while ((i + 1) * (i + 2) / 2 <= idx) ++i;
-    const int c = idx - i * (i + 1) / 2;
-    const int ib = P.k + 1 + i;
-    cblk = P.k + 1 + c;
-    Ap = P.A + ((int64_t)ib * NB) * P.lda + (int64_t)P.k * NB;
-    C = P.A + ((int64_t)ib * NB) * P.lda + (int64_t)cblk * NB;
-    same = (i == c);
-  } else if (idx < tA + m) {
-    cblk = P.k + 1 + (idx - tA);
-    Ap = P.A + ((int64_t)P.nb * NB) * P.lda + (int64_t)P.k * NB;
-    C = P.A + ((int64_t)P.nb * NB) * P.lda + (int64_t)cblk * NB;
+  if (single) {
+    cblk = c0;
+    const int mrows = P.nb - c0;  // Cholesky row blocks c0..nb-1
+    if (idx < mrows) {
+      const int ib = c0 + idx;
+      Ap = P.A + ((int64_t)ib * NB) * P.lda + (int64_t)P.k * NB;
+      C = P.A + ((int64_t)ib * NB) * P.lda + (int64_t)cblk * NB;
+      same = (idx == 0);
+    } else if (idx == mrows) {
+      Ap = P.A + ((int64_t)P.nb * NB) * P.lda + (int64_t)P.k * NB;
+      C = P.A + ((int64_t)P.nb * NB) * P.lda + (int64_t)cblk * NB;
+    } else {
+      const int r = idx - mrows - 1;
+      Ap = P.WT + ((int64_t)r * NB) * P.lda + (int64_t)P.k * NB;
+      C = P.WT + ((int64_t)r * NB) * P.lda + (int64_t)cblk * NB;
+      beta0 = (r == P.k);
+    }
   } else {
-    idx -= tA + m;
-    const int r = idx / m;
-    cblk = P.k + 1 + (idx - r * m);
-    Ap = P.WT + ((int64_t)r * NB) * P.lda + (int64_t)P.k * NB;
-    C = P.WT + ((int64_t)r * NB) * P.lda + (int64_t)cblk * NB;
-    beta0 = (r == P.k);
+    const int m = P.nb - c0;
+    const int tA = m * (m + 1) / 2;
+    if (idx < tA) {
+      int i = (int)((sqrtf(8.0f * (float)idx + 1.0f) - 1.0f) * 0.5f);
+      while (i * (i + 1) / 2 > idx) --i;
+      while ((i + 1) * (i + 2) / 2 <= idx) ++i;
+      const int c = idx - i * (i + 1) / 2;
+      const int ib = c0 + i;
+      cblk = c0 + c;
+      Ap = P.A + ((int64_t)ib * NB) * P.lda + (int64_t)P.k * NB;
+      C = P.A + ((int64_t)ib * NB) * P.lda + (int64_t)cblk * NB;
+      same = (i == c);
+    } else if (idx < tA + m) {
+      cblk = c0 + (idx - tA);
+      Ap = P.A + ((int64_t)P.nb * NB) * P.lda + (int64_t)P.k * NB;
+      C = P.A + ((int64_t)P.nb * NB) * P.lda + (int64_t)cblk * NB;
+    } else {
+      idx -= tA + m;
+      const int r = idx / m;
+      cblk = c0 + (idx - r * m);
+      Ap = P.WT + ((int64_t)r * NB) * P.lda + (int64_t)P.k * NB;
+      C = P.WT + ((int64_t)r * NB) * P.lda + (int64_t)cblk * NB;
+      beta0 = (r == P.k);
+    }
   }
   const double* Bp = P.A + ((int64_t)cblk * NB) * P.lda + (int64_t)P.k * NB;
   GemmAcc acc;
   acc.zero();
-  gemm_tile_nt(acc, Ap, P.lda, Bp, P.lda, 0, NB, lds, same);
+  if (same)
+    gemm_tile_nt<true>(acc, Ap, P.lda, Bp, P.lda, 0, NB, lds);
+  else
+    gemm_tile_nt<false>(acc, Ap, P.lda, Bp, P.lda, 0, NB, lds);
   if (beta0)
     acc_foreach(acc, [&](int row, int col, double v) { C[(int64_t)row * P.lda + col] = -v; });
   else
     acc_foreach(acc, [&](int row, int col, double v) { C[(int64_t)row * P.lda + col] -= v; });
+}
+
+// Same update for ONE block column (the look-ahead column k+1) with 32-row workgroups: four
+// times the workgroups at a quarter of the latency -- this launch sits on the critical path.
+__global__ __launch_bounds__(256) void trailing_update_col_kernel(PanelArgs P, int cblk) {
+  extern __shared__ __align__(16) double lds[];
+  const int rb = blockIdx.x >> 2, sub = blockIdx.x & 3;
+  const int mrows = P.nb - cblk;
+  const double* Ap;
+  double* C;
+  bool beta0 = false;
+  if (rb < mrows) {
+    const int ib = cblk + rb;
+    Ap = P.A + ((int64_t)ib * NB) * P.lda + (int64_t)P.k * NB;
+    C = P.A + ((int64_t)ib * NB) * P.lda + (int64_t)cblk * NB;
+  } else if (rb == mrows) {
+    Ap = P.A + ((int64_t)P.nb * NB) * P.lda + (int64_t)P.k * NB;
+    C = P.A + ((int64_t)P.nb * NB) * P.lda + (int64_t)cblk * NB;
+  } else {
+    const int r = rb - mrows - 1;
+    Ap = P.WT + ((int64_t)r * NB) * P.lda + (int64_t)P.k * NB;
+    C = P.WT + ((int64_t)r * NB) * P.lda + (int64_t)cblk * NB;
+    beta0 = (r == P.k);
+  }
+  Ap += (int64_t)sub * 32 * P.lda;
+  C += (int64_t)sub * 32 * P.lda;
+  const double* Bp = P.A + ((int64_t)cblk * NB) * P.lda + (int64_t)P.k * NB;
+  GemmAcc32 acc;
+  acc.zero();
+  gemm_tile32_nt(acc, Ap, P.lda, Bp, P.lda, 0, NB, lds);
+  if (beta0)
+    acc32_foreach(acc, [&](int row, int col, double v) { C[(int64_t)row * P.lda + col] = -v; });
+  else
+    acc32_foreach(acc, [&](int row, int col, double v) { C[(int64_t)row * P.lda + col] -= v; });
 }
 
 // --------------------------------------------------------------- alpha, logdet, y^T K^-1 y
@@ -428,20 +610,40 @@ int gp_factorize_impl(elfihip_gp* gp) {
   P.W11 = gp->W11;
   P.lda = gp->lda;
   P.nb = nb;
+  // Two streams: `hi` carries the critical path  potf2(k) -> trsm(k) -> update of block column
+  // k+1,  `st` carries the bulk of the trailing update (block columns >= k+2), which overlaps the
+  // next panel factorisation.  Hazards: the column-(k+1) update must follow the previous bulk
+  // update (same tiles), the bulk update must follow trsm(k) (reads its panels).
+  ELFIHIP_TRY(ctx_aux(ctx));
+  hipStream_t hi = ctx->hi_stream;
+  ELFIHIP_CHECK_HIP(ctx, hipEventRecord(ctx->ev_b, st));  // 'previous bulk update' of step -1
+  ELFIHIP_CHECK_HIP(ctx, hipEventRecord(ctx->ev_a, st));
+  ELFIHIP_CHECK_HIP(ctx, hipStreamWaitEvent(hi, ctx->ev_a, 0));
   for (int k = 0; k < nb; ++k) {
     P.k = k;
     double* Akk = gp->A + ((int64_t)k * NB) * gp->lda + (int64_t)k * NB;
     double* Wkk = gp->WT + ((int64_t)k * NB) * gp->lda + (int64_t)k * NB;
-    hipLaunchKernelGGL(potf2_aug_kernel, dim3(1), dim3(256), potf2_lds, st, Akk, gp->lda, Wkk, gp->lda, gp->W11,
-                       gp->info, k);
+    hipLaunchKernelGGL(potf2_aug_kernel, dim3(1), dim3(256), potf2_lds, hi, Akk, gp->lda, Wkk, gp->lda, gp->W11,
+                       gp->info, k, 0);
     const int nrows = (nb - 1 - k) + 1 + k;  // below + y block + L^-T rows above
-    hipLaunchKernelGGL(trsm_gemm_kernel, dim3(nrows), dim3(256), gemm_lds, st, P);
+    hipLaunchKernelGGL(trsm_gemm_kernel, dim3(4 * nrows), dim3(256), GEMM32_LDS_DOUBLES * sizeof(double), hi, P);
     const int m = nb - 1 - k;
     if (m > 0) {
-      const int tiles = m * (m + 1) / 2 + m + (k + 1) * m;
-      hipLaunchKernelGGL(trailing_update_kernel, dim3(tiles), dim3(256), gemm_lds, st, P);
+      ELFIHIP_CHECK_HIP(ctx, hipEventRecord(ctx->ev_a, hi));       // trsm(k) done
+      ELFIHIP_CHECK_HIP(ctx, hipStreamWaitEvent(hi, ctx->ev_b, 0));  // previous bulk update done
+      hipLaunchKernelGGL(trailing_update_col_kernel, dim3(4 * (m + 1 + (k + 1))), dim3(256),
+                         GEMM32_LDS_DOUBLES * sizeof(double), hi, P, k + 1);
+      if (m > 1) {
+        const int mc = m - 1;
+        const int tiles = mc * (mc + 1) / 2 + mc + (k + 1) * mc;
+        ELFIHIP_CHECK_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_a, 0));
+        hipLaunchKernelGGL(trailing_update_kernel, dim3(tiles), dim3(256), gemm_lds, st, P, k + 2, 0);
+        ELFIHIP_CHECK_HIP(ctx, hipEventRecord(ctx->ev_b, st));
+      }
     }
   }
+  ELFIHIP_CHECK_HIP(ctx, hipEventRecord(ctx->ev_a, hi));
+  ELFIHIP_CHECK_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_a, 0));
   ELFIHIP_TRY(launch_status(ctx, "cholesky sweep"));
   const double* z = gp->A + np * gp->lda;  // row np of A: z = L^-1 y
   hipLaunchKernelGGL(alpha_kernel, dim3((unsigned)((np * 64 + 255) / 256)), dim3(256), 0, st, gp->WT, z, gp->alpha,
@@ -494,7 +696,7 @@ int elfihip_gp_create(elfihip_ctx* ctx, int d, int64_t capacity, elfihip_gp** ou
   alloc(&gp->y, (size_t)gp->cap * sizeof(double));
   alloc(&gp->A, (size_t)(gp->cap + NB) * mat);
   alloc(&gp->WT, (size_t)gp->cap * mat);
-  alloc(&gp->W11, (size_t)NB * NB * sizeof(double));
+  alloc(&gp->W11, ((size_t)NB * NB + 64) * sizeof(double));
   alloc(&gp->alpha, (size_t)gp->cap * sizeof(double));
   alloc(&gp->red, 64 * sizeof(double));
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&gp->info), sizeof(int));
@@ -580,6 +782,29 @@ int elfihip_gp_factorize(elfihip_gp* gp, double* log_marginal) {
   ELFIHIP_TRY(gp_factorize_impl(gp));
   if (log_marginal)
     *log_marginal = 0.5 * (-(double)gp->n * 1.8378770664093453 /* log(2 pi) */ - gp->logdet - gp->yKy);
+  return ELFIHIP_OK;
+}
+
+// Developer probe: time `reps` launches of the diagonal-block kernel with phases masked out.
+int elfihip_debug_potf2(elfihip_gp* gp, int skip, int reps, float* ms) {
+  elfihip_ctx* ctx = gp->ctx;
+  DeviceGuard g(ctx->device);
+  const size_t potf2_lds = POTF2_LDS_DOUBLES * sizeof(double);
+  ELFIHIP_TRY(enable_lds(ctx, potf2_aug_kernel, potf2_lds));
+  ELFIHIP_CHECK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  for (int r = 0; r < reps; ++r)
+    hipLaunchKernelGGL(potf2_aug_kernel, dim3(1), dim3(256), potf2_lds, ctx->stream, gp->A, gp->lda, gp->WT, gp->lda,
+                       gp->W11, gp->info, 0, skip);
+  ELFIHIP_CHECK_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  ELFIHIP_CHECK_HIP(ctx, hipEventSynchronize(ctx->ev1));
+  ELFIHIP_CHECK_HIP(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+  *ms /= (float)reps;
+  if (skip & 8) {
+    double dbg[8];
+    ELFIHIP_CHECK_HIP(ctx, hipMemcpy(dbg, gp->W11 + NB * NB, sizeof dbg, hipMemcpyDeviceToHost));
+    fprintf(stderr, "potf2 cycles: p1 %.0f p2a %.0f p2b %.0f p2c %.0f p3 %.0f | loop-end %.0f total %.0f | wall100MHz %.0f\n",
+            dbg[0], dbg[1], dbg[2], dbg[3], dbg[4], dbg[5], dbg[6], dbg[7]);
+  }
   return ELFIHIP_OK;
 }
 

@@ -219,11 +219,21 @@ __global__ __launch_bounds__(256) void grad_kernel(const double* X, const double
 
 // ---- final assembly: mu, var, dmu, dvar, LCB value and gradient ---------------------------
 // out layout per pass: mu[16] var[16] val[16] dmu[16*dp] dvar[16*dp] grad[16*dp]
-__global__ void finish_kernel(const double* mu_part, int nblk_k, const double* var_part, int nblk_v,
-                              const double* g_part, int ngc, double* out, int dp, int S, double prior_var,
-                              double noise_add, double inv_ls2, double beta, int with_grad) {
-  const int s = threadIdx.x;
-  if (s >= PC) return;
+__global__ __launch_bounds__(256) void finish_kernel(const double* mu_part, int nblk_k, const double* var_part,
+                                                     int nblk_v, const double* g_part, int ngc, double* out, int dp,
+                                                     int S, double prior_var, double noise_add, double inv_ls2,
+                                                     double beta, int with_grad) {
+  // 16 groups of 16 lanes: lane (s, j) sums the partial blocks b = j, j+16, ... of column s;
+  // the 16 group sums are then added in a fixed order.
+  __shared__ double red_m[16][PC], red_q[16][PC];
+  const int s = threadIdx.x & 15, j = threadIdx.x >> 4;
+  double m = 0.0, q = 0.0;
+  for (int b = j; b < nblk_k; b += 16) m += mu_part[s * nblk_k + b];
+  for (int b = j; b < nblk_v; b += 16) q += var_part[(int64_t)b * PC + s];
+  red_m[j][s] = m;
+  red_q[j][s] = q;
+  __syncthreads();
+  if (j != 0) return;
   double* mu = out;
   double* var = out + PC;
   double* val = out + 2 * PC;
@@ -236,10 +246,12 @@ __global__ void finish_kernel(const double* mu_part, int nblk_k, const double* v
     val[s] = 0;
     return;
   }
-  double m = 0.0;
-  for (int b = 0; b < nblk_k; ++b) m += mu_part[s * nblk_k + b];
-  double q = 0.0;
-  for (int b = 0; b < nblk_v; ++b) q += var_part[(int64_t)b * PC + s];
+  m = 0.0;
+  q = 0.0;
+  for (int g = 0; g < 16; ++g) {
+    m += red_m[g][s];
+    q += red_q[g][s];
+  }
   double v = prior_var - q;
   v = v > 1e-15 ? v : 1e-15;  // [GPy-upstream] predict clips the variance at 1e-15
   mu[s] = m;
@@ -356,7 +368,7 @@ static int predict_impl(elfihip_gp* gp, const double* Xs, int64_t S, int mode, i
       hipLaunchKernelGGL(grad_kernel, dim3(W.ngc, PC), dim3(256), 0, st, gp->X, gp->alpha, W.xs, W.kr, W.u, W.g_part,
                          gp->n, np, dp, 1024);
     }
-    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(64), 0, st, W.mu_part, W.nblk_k, W.var_part, rblocks, W.g_part,
+    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(256), 0, st, W.mu_part, W.nblk_k, W.var_part, rblocks, W.g_part,
                        W.ngc, W.out, dp, sc, gp->var + gp->bias, noiseless ? 0.0 : gp->noise, inv_ls2, beta, mode);
     ELFIHIP_TRY(launch_status(ctx, "predict kernels"));
     ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(hout.data(), W.out, hout.size() * sizeof(double), hipMemcpyDeviceToHost, st));

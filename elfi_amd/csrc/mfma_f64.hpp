@@ -42,26 +42,6 @@ struct GemmAcc {
   }
 };
 
-// Global -> register stage of one 128 x 16 operand tile (rows r0.., k-columns k0..k0+15).
-// Thread t loads rows (t >> 3) + 32 p, k-pair (t & 7): 8 lanes cover one 128-byte row.
-struct StageRegs {
-  double2 v[4];
-};
-
-__device__ __forceinline__ void stage_load(StageRegs& s, const double* __restrict__ P, int64_t ld, int k0) {
-  const int t = threadIdx.x;
-  const double* src = P + (int64_t)(t >> 3) * ld + k0 + 2 * (t & 7);
-#pragma unroll
-  for (int p = 0; p < 4; ++p) s.v[p] = *reinterpret_cast<const double2*>(src + (int64_t)(32 * p) * ld);
-}
-
-__device__ __forceinline__ void stage_store(const StageRegs& s, double* tile) {
-  const int t = threadIdx.x;
-  double* dst = tile + (t >> 3) * GLP + 2 * (t & 7);
-#pragma unroll
-  for (int p = 0; p < 4; ++p) *reinterpret_cast<double2*>(dst + 32 * p * GLP) = s.v[p];
-}
-
 // Multiply the staged k-tile: 16 ds_read_b128 and 64 MFMAs per wave.
 __device__ __forceinline__ void mma_ktile(GemmAcc& acc, const double* As, const double* Bs) {
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -86,26 +66,56 @@ __device__ __forceinline__ void mma_ktile(GemmAcc& acc, const double* As, const 
   }
 }
 
-// acc += A(128 x K) * B(128 x K)^T for k in [kbeg, kend), both multiples of 16.
-// `lds` holds GEMM_LDS_DOUBLES doubles.  same_ab: B tile is the A tile (diagonal SYRK tile).
+// acc += A(128 x K) * B(128 x K)^T for k in [kbeg, kend), both multiples of 16, kbeg < kend.
+// `lds` holds GEMM_LDS_DOUBLES doubles.  SAME: the B tile is the A tile (diagonal SYRK tile).
+template <bool SAME>
 __device__ __forceinline__ void gemm_tile_nt(GemmAcc& acc, const double* __restrict__ A, int64_t lda,
                                              const double* __restrict__ B, int64_t ldb, int kbeg, int kend,
-                                             double* lds, bool same_ab) {
+                                             double* lds) {
   double* As = lds;
-  double* Bs = same_ab ? lds : lds + GT * GLP;
-  StageRegs ra, rb;
-  if (kbeg < kend) {
-    stage_load(ra, A, lda, kbeg);
-    if (!same_ab) stage_load(rb, B, ldb, kbeg);
+  double* Bs = SAME ? lds : lds + GT * GLP;
+  const int t = threadIdx.x;
+  const double* pa = A + (int64_t)(t >> 3) * lda + 2 * (t & 7) + kbeg;
+  const double* pb = B + (int64_t)(t >> 3) * ldb + 2 * (t & 7) + kbeg;
+  double* da = As + (t >> 3) * GLP + 2 * (t & 7);
+  double* db = Bs + (t >> 3) * GLP + 2 * (t & 7);
+  double2 a0, a1, a2, a3, b0, b1, b2, b3;
+  a0 = *reinterpret_cast<const double2*>(pa);
+  a1 = *reinterpret_cast<const double2*>(pa + 32 * lda);
+  a2 = *reinterpret_cast<const double2*>(pa + 64 * lda);
+  a3 = *reinterpret_cast<const double2*>(pa + 96 * lda);
+  if (!SAME) {
+    b0 = *reinterpret_cast<const double2*>(pb);
+    b1 = *reinterpret_cast<const double2*>(pb + 32 * ldb);
+    b2 = *reinterpret_cast<const double2*>(pb + 64 * ldb);
+    b3 = *reinterpret_cast<const double2*>(pb + 96 * ldb);
   }
   for (int k0 = kbeg; k0 < kend; k0 += GK) {
     __syncthreads();  // previous tile fully consumed
-    stage_store(ra, As);
-    if (!same_ab) stage_store(rb, Bs);
+    *reinterpret_cast<double2*>(da) = a0;
+    *reinterpret_cast<double2*>(da + 32 * GLP) = a1;
+    *reinterpret_cast<double2*>(da + 64 * GLP) = a2;
+    *reinterpret_cast<double2*>(da + 96 * GLP) = a3;
+    if (!SAME) {
+      *reinterpret_cast<double2*>(db) = b0;
+      *reinterpret_cast<double2*>(db + 32 * GLP) = b1;
+      *reinterpret_cast<double2*>(db + 64 * GLP) = b2;
+      *reinterpret_cast<double2*>(db + 96 * GLP) = b3;
+    }
     __syncthreads();
-    if (k0 + GK < kend) {
-      stage_load(ra, A, lda, k0 + GK);
-      if (!same_ab) stage_load(rb, B, ldb, k0 + GK);
+    if (k0 + GK < kend) {  // prefetch the next k-tile; it lands while the MFMAs below run
+      pa += GK;
+      a0 = *reinterpret_cast<const double2*>(pa);
+      a1 = *reinterpret_cast<const double2*>(pa + 32 * lda);
+      a2 = *reinterpret_cast<const double2*>(pa + 64 * lda);
+      a3 = *reinterpret_cast<const double2*>(pa + 96 * lda);
+      if (!SAME) {
+        pb += GK;
+        b0 = *reinterpret_cast<const double2*>(pb);
+        b1 = *reinterpret_cast<const double2*>(pb + 32 * ldb);
+        b2 = *reinterpret_cast<const double2*>(pb + 64 * ldb);
+        b3 = *reinterpret_cast<const double2*>(pb + 96 * ldb);
+      }
     }
     mma_ktile(acc, As, Bs);
   }
@@ -126,6 +136,87 @@ __device__ __forceinline__ void acc_foreach(const GemmAcc& acc, F f) {
         const int col = wc * 64 + j * 16 + (l & 15);
         f(row, col, acc.c[i][j][r]);
       }
+}
+
+
+// ---- skinny variant: 32 x 128 output tile (panel solve: many workgroups, short latency) ----
+// 4 waves side by side, each 32 rows x 32 columns = 2 x 2 MFMA tiles.
+struct GemmAcc32 {
+  v4d c[2][2];
+  __device__ __forceinline__ void zero() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) c[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+  }
+};
+
+constexpr int GEMM32_LDS_DOUBLES = (32 + GT) * GLP;
+
+// acc += A(32 x K) * B(128 x K)^T, k in [kbeg, kend).
+__device__ __forceinline__ void gemm_tile32_nt(GemmAcc32& acc, const double* __restrict__ A, int64_t lda,
+                                               const double* __restrict__ B, int64_t ldb, int kbeg, int kend,
+                                               double* lds) {
+  double* As = lds;
+  double* Bs = lds + 32 * GLP;
+  const int t = threadIdx.x, l = t & 63, w = t >> 6;
+  const double* pa = A + (int64_t)(t >> 3) * lda + 2 * (t & 7) + kbeg;
+  const double* pb = B + (int64_t)(t >> 3) * ldb + 2 * (t & 7) + kbeg;
+  double* da = As + (t >> 3) * GLP + 2 * (t & 7);
+  double* db = Bs + (t >> 3) * GLP + 2 * (t & 7);
+  double2 a0, b0, b1, b2, b3;
+  a0 = *reinterpret_cast<const double2*>(pa);
+  b0 = *reinterpret_cast<const double2*>(pb);
+  b1 = *reinterpret_cast<const double2*>(pb + 32 * ldb);
+  b2 = *reinterpret_cast<const double2*>(pb + 64 * ldb);
+  b3 = *reinterpret_cast<const double2*>(pb + 96 * ldb);
+  const double* fa = As + (l & 15) * GLP + 2 * (l >> 4);
+  const double* fb = Bs + (w * 32 + (l & 15)) * GLP + 2 * (l >> 4);
+  for (int k0 = kbeg; k0 < kend; k0 += GK) {
+    __syncthreads();
+    *reinterpret_cast<double2*>(da) = a0;
+    *reinterpret_cast<double2*>(db) = b0;
+    *reinterpret_cast<double2*>(db + 32 * GLP) = b1;
+    *reinterpret_cast<double2*>(db + 64 * GLP) = b2;
+    *reinterpret_cast<double2*>(db + 96 * GLP) = b3;
+    __syncthreads();
+    if (k0 + GK < kend) {
+      pa += GK;
+      pb += GK;
+      a0 = *reinterpret_cast<const double2*>(pa);
+      b0 = *reinterpret_cast<const double2*>(pb);
+      b1 = *reinterpret_cast<const double2*>(pb + 32 * ldb);
+      b2 = *reinterpret_cast<const double2*>(pb + 64 * ldb);
+      b3 = *reinterpret_cast<const double2*>(pb + 96 * ldb);
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      double2 a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        a[i] = *reinterpret_cast<const double2*>(fa + i * 16 * GLP + 8 * h);
+        b[i] = *reinterpret_cast<const double2*>(fb + i * 16 * GLP + 8 * h);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc.c[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].x, b[j].x, acc.c[i][j], 0, 0, 0);
+          acc.c[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].y, b[j].y, acc.c[i][j], 0, 0, 0);
+        }
+    }
+  }
+}
+
+template <class F>
+__device__ __forceinline__ void acc32_foreach(const GemmAcc32& acc, F f) {
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) f(i * 16 + (l >> 4) + 4 * r, w * 32 + j * 16 + (l & 15), acc.c[i][j][r]);
 }
 
 }  // namespace elfihip
