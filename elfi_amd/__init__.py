@@ -16,4 +16,7 @@ from ._lib import LIB_PATH, Context, ElfiHipError, default_context, device_count
 from .distance import (AdaptiveDistanceState, HipDiscrepancy, HipDistance, cdist_cols,  # noqa: F401
                        cdist_rows, nested_weighted_euclidean, welford_update)
 
+from .gp import GPHandle, HipGPRegression  # noqa: F401
+from .lcb_acquisition import HipLCBSC  # noqa: F401
+
 __version__ = "0.1.0"

@@ -68,6 +68,8 @@ PROTOTYPES = {
     "elfihip_gp_set_data": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
     "elfihip_gp_append": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
     "elfihip_gp_factorize": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "elfihip_gp_nlml_grad": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_void_p]),
+    "elfihip_gp_form_kinv": (C.c_int, [C.c_void_p]),
     "elfihip_gp_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                   C.POINTER(C.c_int)]),
     "elfihip_gp_get": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
@@ -75,6 +77,8 @@ PROTOTYPES = {
     "elfihip_gp_predict_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p]),
     "elfihip_gp_lcb": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_void_p, C.c_void_p]),
+    "elfihip_gp_lcb_minimize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_double,
+                                          C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
 }
 
 _lib = None

@@ -1,0 +1,88 @@
+"""BASELINE.json's first metric: BOLFI iterations per second (GP fit + acquisition, n=4096, d=10).
+
+Workload (SURVEY.md section 8d "G-1"):
+    X = RandomState(0).uniform(-2, 2, (4096, 10)),  y = |X - 0.5|_2 + 0.1 RandomState(1).randn(4096)
+    hyper-parameters fixed at the heuristic values of gpy_regression.py:255,260-264
+    LCBSC, exploration_rate = 10, S = 10 start points, L-BFGS run to convergence (maxiter 1000)
+One iteration is what elfi.BOLFI does per acquired point with batch_size = 1
+(elfi/methods/inference/bolfi.py:201-254): `target_model.update(x, y)` -- append one evidence
+point and REBUILD the whole GP, as GPyRegression.update does (gpy_regression.py:304-312) --
+followed by `acquisition_method.acquire(1, t)`.  It is driven through the same two objects a
+user hands to elfi.BOLFI (HipGPRegression, HipLCBSC), so Python and ctypes overhead are inside
+the timed region.
+
+Flop model per iteration (FMA = 2 flops): Gram 2 n^2 d; factorisation n^3/3
+(Cholesky) + n^3/3 (L^-T, which replaces GPy's dpotri + the per-point triangular solves);
+acquisition E point-evaluations of value+gradient at 2 n^2 + 6 n d + 4 n each.  Reported against
+the FP64 matrix peak (78.6 TFLOP/s) in two ways: `achieved_exec` counts the flops actually
+executed (both n^3/3 terms), `achieved_model` SURVEY's reference count (n^3/3 only).
+"""
+import time
+
+import numpy as np
+
+FP64_MFMA_PEAK_TFLOPS = 78.6
+
+
+def problem(n, d):
+    X = np.random.RandomState(0).uniform(-2, 2, (n, d))
+    y = np.linalg.norm(X - 0.5, axis=1) + 0.1 * np.random.RandomState(1).randn(n)
+    return X, y.reshape(-1, 1), [(-2., 2.)] * d
+
+
+def heuristic_hyper(bounds, y):
+    ls = (np.max(bounds) - np.min(bounds)) / 3.
+    var = (np.max(y) / 3.) ** 2
+    return dict(var=float(var), ls=float(ls), bias=float(var / 4.), noise=float(np.max(y) ** 2 / 100.))
+
+
+def run(n=4096, d=10, S=10, iters=5, warm=2):
+    from .gp import HipGPRegression
+    from .lcb_acquisition import HipLCBSC
+    X, y, bounds = problem(n, d)
+    names = ['t%d' % i for i in range(d)]
+    n0 = n - (iters + warm)
+    gp = HipGPRegression(names, bounds=dict(zip(names, bounds)))
+    gp.update(X[:n0], y[:n0])
+    gp._hyper = heuristic_hyper(bounds, y)
+    gp._refit()
+    acq = HipLCBSC(gp, n_inits=S, exploration_rate=10, seed=2)
+    t_fit, t_acq, evals, steps = [], [], [], []
+    x_next = None
+    for i in range(warm + iters):
+        k = n0 + i
+        xi = X[k:k + 1] if x_next is None else x_next
+        yi = np.linalg.norm(xi - 0.5, axis=1).reshape(1, 1)   # the synthetic discrepancy at the acquired point
+        t0 = time.perf_counter()
+        gp.update(xi, yi)
+        t1 = time.perf_counter()
+        x_next = acq.acquire(1, t=k)
+        t2 = time.perf_counter()
+        if i >= warm:
+            t_fit.append(t1 - t0)
+            t_acq.append(t2 - t1)
+            evals.append(acq.last_opt['n_eval'])
+            steps.append(int(np.max(acq.last_opt['iters'])))
+    fit, ac = float(np.mean(t_fit)), float(np.mean(t_acq))
+    it_s = 1.0 / (fit + ac)
+    E = float(np.mean(evals))
+    fl_gram = 2.0 * n * n * d
+    fl_chol = n ** 3 / 3.0
+    fl_eval = E * (2.0 * n * n + 6.0 * n * d + 4.0 * n)
+    exec_flops = fl_gram + 2 * fl_chol + fl_eval
+    model_flops = fl_gram + fl_chol + fl_eval
+    out = {
+        "metric": "BOLFI iters/sec (GP fit+acq, n=%d d=%d)" % (n, d), "value": it_s, "unit": "iters/s",
+        "mode": "refactor (full GP rebuild per update, as GPyRegression.update)",
+        "ms_fit": 1e3 * fit, "ms_acquire": 1e3 * ac, "starts": S,
+        "point_evaluations_per_acquire": E, "max_lbfgs_iterations": int(np.max(steps)),
+        "flops_per_iter_executed": exec_flops, "flops_per_iter_model": model_flops,
+        "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": FP64_MFMA_PEAK_TFLOPS,
+                     "achieved": exec_flops * it_s / 1e12, "frac": exec_flops * it_s / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                     "achieved_model": model_flops * it_s / 1e12,
+                     "fit_only_achieved": (fl_gram + 2 * fl_chol) / fit / 1e12,
+                     "fit_only_frac": (fl_gram + 2 * fl_chol) / fit / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                     "note": "acquisition phase (S=%d columns) is HBM/L2-bound, not MFMA-bound "
+                             "(SURVEY.md 8d roofline caveat)" % S},
+    }
+    return out

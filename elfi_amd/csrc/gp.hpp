@@ -34,3 +34,10 @@ struct elfihip_gp {
   elfihip::DevBuf ws;
   int64_t ws_S = 0;
 };
+
+namespace elfihip {
+// gp_predict.hip: mean / variance / gradients / LCB for S host points (one stream sync per call).
+// mode 0 = values only, 1 = + gradients.  Any output pointer may be NULL.
+int predict_impl(elfihip_gp* gp, const double* Xs, int64_t S, int mode, int noiseless, double beta, double* mu,
+                 double* var, double* dmu, double* dvar, double* val, double* grad);
+}  // namespace elfihip

@@ -1,0 +1,224 @@
+// Gradient of the GP log marginal likelihood w.r.t. the four hyper-parameters, on gfx950.
+//
+// Replaces what GPy computes on every objective evaluation of GPyRegression.optimize()
+// (elfi/methods/bo/gpy_regression.py:317-323 -> GPy model.optimize, [GPy-upstream]
+// ExactGaussianInference + kern.update_gradients_full):
+//     K^-1   = L^-T L^-1                      (GPy: dpotri)
+//     dL/dK  = 0.5 (alpha alpha^T - K^-1)
+//     d logZ / d s_f = sum(dL/dK * K_rbf) / s_f
+//     d logZ / d l   = sum(dL/dK * K_rbf * r^2) / l^3
+//     d logZ / d s_b = sum(dL/dK)
+//     d logZ / d s_n = trace(dL/dK)
+// The factorisation already holds L^-T (upper triangular, gp_fit.hip), so K^-1 is one SYRK on
+// the matrix cores: tile (I, J), I >= J, is sum_{k >= I} WT[I][k] WT[J][k]^T.  The four
+// contractions are fused into that SYRK's epilogue -- K_rbf and r^2 are recomputed from X for
+// the tile (a d-long dot product per entry, noise next to the n/2-long one just finished), so
+// K^-1 is never written to memory unless the caller asks for it (GPy's `woodbury_inv`).
+// Flops: n^3/3 on v_mfma_f64_16x16x4_f64; HBM: WT read once per tile row pair through L2/MALL.
+#include "gp.hpp"
+#include "mfma_f64.hpp"
+
+namespace elfihip {
+
+struct HyperArgs {
+  const double* WT;
+  const double* X;
+  const double* x2;
+  const double* alpha;
+  double* Kinv;   // optional (cap, lda) output, lower tiles
+  double* part;   // (ntiles, 4) per-tile partial sums
+  int64_t lda, n, np;
+  int dp, x_in_lds;
+  double var, neg_half_inv_ls2;
+};
+
+__global__ __launch_bounds__(256) void kinv_grad_kernel(HyperArgs H) {
+  extern __shared__ __align__(16) double lds[];
+  // decode (ti >= tj) from the linear index; ti ascending = longest k-range first
+  const int64_t b = blockIdx.x;
+  int64_t ti = (int64_t)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
+  while (ti * (ti + 1) / 2 > b) --ti;
+  while ((ti + 1) * (ti + 2) / 2 <= b) ++ti;
+  const int64_t tj = b - ti * (ti + 1) / 2;
+  const int64_t i0 = ti * NB, j0 = tj * NB;
+  GemmAcc acc;
+  acc.zero();
+  const double* Ai = H.WT + i0 * H.lda;
+  const double* Bj = H.WT + j0 * H.lda;
+  if (ti == tj)
+    gemm_tile_nt<true>(acc, Ai, H.lda, Bj, H.lda, (int)i0, (int)H.np, lds);
+  else
+    gemm_tile_nt<false>(acc, Ai, H.lda, Bj, H.lda, (int)i0, (int)H.np, lds);
+  if (H.Kinv) {
+    double* C = H.Kinv + i0 * H.lda + j0;
+    acc_foreach(acc, [&](int row, int col, double v) { C[(int64_t)row * H.lda + col] = v; });
+  }
+  // ---- epilogue: the four contractions of dL/dK with the kernel derivatives
+  __syncthreads();  // GEMM staging area is free
+  const int dp = H.dp;
+  const double* xi_base;
+  const double* xj_base;
+  int pitch;
+  if (H.x_in_lds) {
+    pitch = dp + 1;
+    double* Xi = lds;
+    double* Xj = lds + NB * pitch;
+    for (int e = threadIdx.x; e < NB * dp; e += 256) {
+      const int r = e / dp, c = e - r * dp;
+      Xi[r * pitch + c] = H.X[(i0 + r) * dp + c];
+      Xj[r * pitch + c] = H.X[(j0 + r) * dp + c];
+    }
+    __syncthreads();
+    xi_base = Xi;
+    xj_base = Xj;
+  } else {
+    pitch = dp;
+    xi_base = H.X + i0 * dp;
+    xj_base = H.X + j0 * dp;
+  }
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int wr = w >> 1, wc = w & 1;
+  double s_var = 0.0, s_ls = 0.0, s_bias = 0.0, s_noise = 0.0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = wr * 64 + i * 16 + (l >> 4) + 4 * r;
+      const int64_t gi = i0 + row;
+      const double* xi = xi_base + row * pitch;
+      double dot[4] = {0.0, 0.0, 0.0, 0.0};
+      for (int c = 0; c < dp; ++c) {
+        const double a = xi[c];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dot[j] = fma(a, xj_base[(wc * 64 + j * 16 + (l & 15)) * pitch + c], dot[j]);
+      }
+      const double ai = gi < H.n ? H.alpha[gi] : 0.0;
+      const double x2i = H.x2[gi];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int col = wc * 64 + j * 16 + (l & 15);
+        const int64_t gj = j0 + col;
+        if (gi < H.n && gj <= gi) {
+          double r2 = (x2i + H.x2[gj]) + (-2.0 * dot[j]);
+          r2 = r2 > 0.0 ? r2 : 0.0;
+          if (gi == gj) r2 = 0.0;
+          const double krbf = H.var * exp(r2 * H.neg_half_inv_ls2);
+          const double D = 0.5 * (ai * H.alpha[gj] - acc.c[i][j][r]);
+          const double wt = gi == gj ? 1.0 : 2.0;  // the strict upper triangle mirrors the lower
+          s_var += wt * D * krbf;
+          s_ls += wt * D * krbf * r2;
+          s_bias += wt * D;
+          if (gi == gj) s_noise += D;
+        }
+      }
+    }
+  // fixed-order workgroup reduction: butterfly inside the wave, then the four waves in order
+  __syncthreads();
+  double v[4] = {s_var, s_ls, s_bias, s_noise};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v[q] += __shfl_xor(v[q], off, 64);
+    if (l == 0) lds[w * 4 + q] = v[q];
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    const int q = threadIdx.x;
+    H.part[b * 4 + q] = ((lds[q] + lds[4 + q]) + lds[8 + q]) + lds[12 + q];
+  }
+}
+
+// red[2..5] = sum over tiles of part[t][0..3], fixed order.
+__global__ __launch_bounds__(256) void hyper_reduce_kernel(const double* part, int64_t ntiles, double* red) {
+  __shared__ double s[256][4];
+  double a[4] = {0, 0, 0, 0};
+  for (int64_t t = threadIdx.x; t < ntiles; t += 256)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a[q] += part[t * 4 + q];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) s[threadIdx.x][q] = a[q];
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) s[threadIdx.x][q] += s[threadIdx.x + off][q];
+    __syncthreads();
+  }
+  if (threadIdx.x < 4) red[2 + threadIdx.x] = s[0][threadIdx.x];
+}
+
+static int hyper_grad_impl(elfihip_gp* gp, bool store_kinv, double* grad) {
+  elfihip_ctx* ctx = gp->ctx;
+  if (!gp->factored)
+    return fail(ctx, ELFIHIP_ERR_STATE, "GP is not factorised (call elfihip_gp_factorize first)");
+  hipStream_t st = ctx->stream;
+  const int64_t np = gp->np;
+  const int64_t nt = np / NB;
+  const int64_t ntiles = nt * (nt + 1) / 2;
+  if (store_kinv && !gp->Kinv) {
+    const size_t bytes = (size_t)gp->cap * gp->lda * sizeof(double);
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&gp->Kinv), bytes);
+    if (e != hipSuccess)
+      return fail(ctx, e == hipErrorOutOfMemory ? ELFIHIP_ERR_NOMEM : ELFIHIP_ERR_HIP, "K^-1 allocation failed: %s",
+                  hipGetErrorString(e));
+    ELFIHIP_CHECK_HIP(ctx, hipMemsetAsync(gp->Kinv, 0, bytes, st));
+  }
+  ELFIHIP_CHECK_HIP(ctx, gp->ws.reserve((size_t)ntiles * 4 * sizeof(double)));
+  HyperArgs H;
+  H.WT = gp->WT;
+  H.X = gp->X;
+  H.x2 = gp->x2;
+  H.alpha = gp->alpha;
+  H.Kinv = store_kinv ? gp->Kinv : nullptr;
+  H.part = gp->ws.as<double>();
+  H.lda = gp->lda;
+  H.n = gp->n;
+  H.np = np;
+  H.dp = gp->dp;
+  H.var = gp->var;
+  H.neg_half_inv_ls2 = -0.5 / (gp->ls * gp->ls);
+  size_t lds = GEMM_LDS_DOUBLES * sizeof(double);
+  const size_t xlds = 2 * (size_t)NB * (gp->dp + 1) * sizeof(double);
+  H.x_in_lds = xlds <= 96 * 1024;
+  if (H.x_in_lds && xlds > lds) lds = xlds;
+  ELFIHIP_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kinv_grad_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kinv_grad_kernel, dim3((unsigned)ntiles), dim3(256), lds, st, H);
+  hipLaunchKernelGGL(hyper_reduce_kernel, dim3(1), dim3(256), 0, st, H.part, ntiles, gp->red);
+  ELFIHIP_TRY(launch_status(ctx, "kinv_grad_kernel"));
+  double s[4];
+  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(s, gp->red + 2, sizeof s, hipMemcpyDeviceToHost, st));
+  ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(st));
+  if (store_kinv) gp->has_kinv = true;
+  if (grad) {
+    grad[0] = s[0] / gp->var;
+    grad[1] = s[1] / (gp->ls * gp->ls * gp->ls);
+    grad[2] = s[2];
+    grad[3] = s[3];
+  }
+  return ELFIHIP_OK;
+}
+
+}  // namespace elfihip
+
+using namespace elfihip;
+
+extern "C" {
+
+int elfihip_gp_nlml_grad(elfihip_gp* gp, double* log_marginal, double* grad) {
+  if (!gp) return fail(nullptr, ELFIHIP_ERR_ARG, "gp is NULL");
+  ELFIHIP_REQUIRE(gp->ctx, grad != nullptr, "grad is NULL");
+  DeviceGuard g(gp->ctx->device);
+  ELFIHIP_TRY(hyper_grad_impl(gp, false, grad));
+  if (log_marginal)
+    *log_marginal = 0.5 * (-(double)gp->n * 1.8378770664093453 /* log(2 pi) */ - gp->logdet - gp->yKy);
+  return ELFIHIP_OK;
+}
+
+int elfihip_gp_form_kinv(elfihip_gp* gp) {
+  if (!gp) return fail(nullptr, ELFIHIP_ERR_ARG, "gp is NULL");
+  DeviceGuard g(gp->ctx->device);
+  return hyper_grad_impl(gp, true, nullptr);
+}
+
+}  // extern "C"

@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256) void finish_kernel(const double* mu_part, int 
   }
 }
 
-static int ensure_ws(elfihip_gp* gp, PredictWs* W) {
+static int ensure_ws(elfihip_gp* gp, PredictWs* W, int64_t npass) {
   elfihip_ctx* ctx = gp->ctx;
   const int64_t np = gp->np;
   const int nb = (int)(np / NB);
@@ -288,10 +288,11 @@ static int ensure_ws(elfihip_gp* gp, PredictWs* W) {
     off += (doubles + 15) & ~(size_t)15;
     return o;
   };
-  const size_t o_xs = take((size_t)PC * gp->dp), o_xs2 = take(PC), o_kr = take((size_t)PC * np),
+  const size_t o_xs = take((size_t)npass * PC * gp->dp), o_xs2 = take((size_t)npass * PC), o_kr = take((size_t)PC * np),
                o_part = take((size_t)W->nkc * np * PC), o_v = take((size_t)np * PC), o_u = take((size_t)np * PC),
                o_mu = take((size_t)PC * W->nblk_k), o_var = take((size_t)(np * PC / 256 + 1) * PC),
-               o_g = take((size_t)PC * W->ngc * 2 * gp->dp), o_out = take((size_t)3 * PC + 3 * PC * gp->dp);
+               o_g = take((size_t)PC * W->ngc * 2 * gp->dp),
+               o_out = take((size_t)npass * (3 * PC + 3 * PC * gp->dp));
   ELFIHIP_CHECK_HIP(ctx, gp->ws.reserve(off * sizeof(double)));
   double* base = gp->ws.as<double>();
   W->xs = base + o_xs;
@@ -308,7 +309,7 @@ static int ensure_ws(elfihip_gp* gp, PredictWs* W) {
 }
 
 // mode: 0 = mean/var only, 1 = + gradients (and LCB)
-static int predict_impl(elfihip_gp* gp, const double* Xs, int64_t S, int mode, int noiseless, double beta,
+int predict_impl(elfihip_gp* gp, const double* Xs, int64_t S, int mode, int noiseless, double beta,
                         double* mu, double* var, double* dmu, double* dvar, double* val, double* grad) {
   elfihip_ctx* ctx = gp->ctx;
   ELFIHIP_REQUIRE(ctx, S >= 0, "negative S");
@@ -318,33 +319,40 @@ static int predict_impl(elfihip_gp* gp, const double* Xs, int64_t S, int mode, i
     return fail(ctx, ELFIHIP_ERR_STATE, "GP is not factorised (call elfihip_gp_factorize after changing data)");
   hipStream_t st = ctx->stream;
   PredictWs W;
-  ELFIHIP_TRY(ensure_ws(gp, &W));
+  const int64_t npass = (S + PC - 1) / PC;
+  ELFIHIP_TRY(ensure_ws(gp, &W, npass));
   const int dp = gp->dp, d = gp->d;
   const int64_t np = gp->np;
   const int nb = (int)(np / NB);
   const double inv_ls2 = 1.0 / (gp->ls * gp->ls);
+  // All S points go up in one copy, every pass runs back to back on the stream (the per-pass
+  // scratch is reused in stream order), all results come down in one copy: one host sync per call.
+  const size_t outsz = (size_t)3 * PC + 3 * PC * dp;
   static thread_local std::vector<double> hx, hout;
-  hx.assign((size_t)PC * dp + PC, 0.0);
-  hout.resize((size_t)3 * PC + 3 * PC * dp);
+  hx.assign((size_t)npass * PC * dp + (size_t)npass * PC, 0.0);
+  hout.resize((size_t)npass * outsz);
+  double* hx2 = hx.data() + (size_t)npass * PC * dp;
+  for (int64_t s = 0; s < S; ++s) {
+    double q = 0.0;
+    for (int c = 0; c < d; ++c) {
+      const double x = Xs[s * d + c];
+      hx[(size_t)s * dp + c] = x;
+      q += x * x;
+    }
+    hx2[s] = q;
+  }
+  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(W.xs, hx.data(), (size_t)npass * PC * dp * sizeof(double),
+                                        hipMemcpyHostToDevice, st));
+  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(W.xs2, hx2, (size_t)npass * PC * sizeof(double), hipMemcpyHostToDevice, st));
   const size_t lds_t = (SLAB * 144 + PC * 34) * sizeof(double);
   const size_t lds_n = (128 * 34 + SLAB * PC) * sizeof(double);
-  for (int64_t s0 = 0; s0 < S; s0 += PC) {
+  for (int64_t pass = 0; pass < npass; ++pass) {
+    const int64_t s0 = pass * PC;
     const int sc = (int)((S - s0) < PC ? (S - s0) : PC);
-    std::fill(hx.begin(), hx.end(), 0.0);
-    for (int s = 0; s < sc; ++s) {
-      double q = 0.0;
-      for (int c = 0; c < d; ++c) {
-        const double x = Xs[(s0 + s) * d + c];
-        hx[(size_t)s * dp + c] = x;
-        q += x * x;
-      }
-      hx[(size_t)PC * dp + s] = q;
-    }
-    ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(W.xs, hx.data(), (size_t)PC * dp * sizeof(double),
-                                          hipMemcpyHostToDevice, st));
-    ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(W.xs2, hx.data() + (size_t)PC * dp, PC * sizeof(double),
-                                          hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(kstar_kernel, dim3(W.nblk_k, PC), dim3(256), 0, st, gp->X, gp->x2, gp->alpha, W.xs, W.xs2,
+    const double* xs = W.xs + (size_t)pass * PC * dp;
+    const double* xs2 = W.xs2 + (size_t)pass * PC;
+    double* out = W.out + (size_t)pass * outsz;
+    hipLaunchKernelGGL(kstar_kernel, dim3(W.nblk_k, PC), dim3(256), 0, st, gp->X, gp->x2, gp->alpha, xs, xs2,
                        W.kr, W.mu_part, gp->n, np, dp, gp->var, -0.5 * inv_ls2, gp->bias);
     TriArgs T;
     T.WT = gp->WT;
@@ -365,24 +373,25 @@ static int predict_impl(elfihip_gp* gp, const double* Xs, int64_t S, int mode, i
       hipLaunchKernelGGL((tri_apply_kernel<false>), dim3(nb, W.nkc), dim3(256), lds_n, st, T);
       hipLaunchKernelGGL(tri_reduce_kernel, dim3(rblocks), dim3(256), 0, st, W.part, W.u, (double*)nullptr, np,
                          W.nkc, 1, 0);
-      hipLaunchKernelGGL(grad_kernel, dim3(W.ngc, PC), dim3(256), 0, st, gp->X, gp->alpha, W.xs, W.kr, W.u, W.g_part,
+      hipLaunchKernelGGL(grad_kernel, dim3(W.ngc, PC), dim3(256), 0, st, gp->X, gp->alpha, xs, W.kr, W.u, W.g_part,
                          gp->n, np, dp, 1024);
     }
     hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(256), 0, st, W.mu_part, W.nblk_k, W.var_part, rblocks, W.g_part,
-                       W.ngc, W.out, dp, sc, gp->var + gp->bias, noiseless ? 0.0 : gp->noise, inv_ls2, beta, mode);
-    ELFIHIP_TRY(launch_status(ctx, "predict kernels"));
-    ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(hout.data(), W.out, hout.size() * sizeof(double), hipMemcpyDeviceToHost, st));
-    ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(st));
-    const double* o = hout.data();
-    for (int s = 0; s < sc; ++s) {
-      if (mu) mu[s0 + s] = o[s];
-      if (var) var[s0 + s] = o[PC + s];
-      if (val) val[s0 + s] = o[2 * PC + s];
-      for (int c = 0; c < d; ++c) {
-        if (dmu) dmu[(s0 + s) * d + c] = o[3 * PC + s * dp + c];
-        if (dvar) dvar[(s0 + s) * d + c] = o[3 * PC + PC * dp + s * dp + c];
-        if (grad) grad[(s0 + s) * d + c] = o[3 * PC + 2 * PC * dp + s * dp + c];
-      }
+                       W.ngc, out, dp, sc, gp->var + gp->bias, noiseless ? 0.0 : gp->noise, inv_ls2, beta, mode);
+  }
+  ELFIHIP_TRY(launch_status(ctx, "predict kernels"));
+  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(hout.data(), W.out, hout.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+  ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(st));
+  for (int64_t s = 0; s < S; ++s) {
+    const double* o = hout.data() + (size_t)(s / PC) * outsz;
+    const int q = (int)(s % PC);
+    if (mu) mu[s] = o[q];
+    if (var) var[s] = o[PC + q];
+    if (val) val[s] = o[2 * PC + q];
+    for (int c = 0; c < d; ++c) {
+      if (dmu) dmu[s * d + c] = o[3 * PC + q * dp + c];
+      if (dvar) dvar[s * d + c] = o[3 * PC + PC * dp + q * dp + c];
+      if (grad) grad[s * d + c] = o[3 * PC + 2 * PC * dp + q * dp + c];
     }
   }
   return ELFIHIP_OK;

@@ -112,6 +112,33 @@ class GPHandle:
         self._check(self.lib.elfihip_gp_lcb(self.h, _lib.ptr(x), S, float(beta), _lib.ptr(val), _lib.ptr(grad)))
         return val, grad
 
+    def nlml_grad(self):
+        """(log marginal likelihood, d logZ / d (var, ls, bias, noise)) at the current factorisation."""
+        lz = C.c_double()
+        g = np.empty(4)
+        self._check(self.lib.elfihip_gp_nlml_grad(self.h, C.byref(lz), _lib.ptr(g)))
+        return lz.value, g
+
+    def form_kinv(self):
+        self._check(self.lib.elfihip_gp_form_kinv(self.h))
+
+    def lcb_minimize(self, starts, bounds, beta, maxiter=1000):
+        """Lock-step multi-start minimisation of the LCB; returns (x (S,d), f (S,), iters (S,), n_eval)."""
+        starts = self._xs(starts)
+        S = starts.shape[0]
+        lo = np.ascontiguousarray([b[0] for b in bounds], dtype=np.float64)
+        hi = np.ascontiguousarray([b[1] for b in bounds], dtype=np.float64)
+        if lo.shape[0] != self.d:
+            raise ValueError('bounds must have one (lower, upper) pair per input dimension')
+        x = np.empty((S, self.d))
+        f = np.empty(S)
+        it = np.empty(S, dtype=np.int32)
+        ne = C.c_int64()
+        self._check(self.lib.elfihip_gp_lcb_minimize(self.h, _lib.ptr(starts), S, _lib.ptr(lo), _lib.ptr(hi),
+                                                     float(beta), int(maxiter), _lib.ptr(x), _lib.ptr(f),
+                                                     _lib.ptr(it), C.byref(ne)))
+        return x, f, it, ne.value
+
 
 # ---- the small part of the GPy object graph that ELFI code touches ---------------------------
 class _Param:
@@ -184,9 +211,9 @@ class _GPShim:
     @property
     def posterior(self):
         m = self._m
-        L = m._handle.get(0)
-        Linv_T = m._handle.get(1)
-        return _Part(woodbury_vector=m._handle.get(2), woodbury_chol=L, woodbury_inv=Linv_T @ Linv_T.T)
+        m._handle.form_kinv()
+        return _Part(woodbury_vector=m._handle.get(2), woodbury_chol=m._handle.get(0),
+                     woodbury_inv=m._handle.get(5))
 
     def log_likelihood(self):
         return self._m._log_marginal
@@ -286,20 +313,26 @@ class HipGPRegression:
         return self._handle.lcb(x, beta, with_grad)
 
     # -- fitting --------------------------------------------------------------------------
-    def _default_hyper(self, y):
-        # gpy_regression.py:255,260-264
+    def _prior_expectations(self, y):
+        # heuristics of gpy_regression.py:260-264: they parametrise the Gamma PRIORS only
         length_scale = (np.max(self.bounds) - np.min(self.bounds)) / 3.
         kernel_var = (np.max(y) / 3.)**2.
         bias_var = kernel_var / 4.
+        return dict(var=float(kernel_var), ls=float(length_scale), bias=float(bias_var))
+
+    def _default_hyper(self, y):
+        # gpy_regression.py:267,275 construct GPy.kern.RBF(input_dim) / GPy.kern.Bias(input_dim) with
+        # GPy's own defaults (variance 1, lengthscale 1 [GPy-upstream]); set_prior does not move the
+        # values.  Only the noise gets a data-driven start (:255).
         noise_var = self.gp_params.get('noise_var') or np.max(y)**2. / 100.
-        return dict(var=float(kernel_var), ls=float(length_scale), bias=float(bias_var), noise=float(noise_var))
+        return dict(var=1.0, ls=1.0, bias=1.0, noise=float(noise_var))
 
     def _init_gp(self, x, y):
         self._kernel_is_default = self.gp_params.get('noise_var') is None
         self._hyper = self._default_hyper(y)
-        h = self._hyper
-        # Gamma priors from_EV(E, V=E): a = E, b = 1 (gpy_regression.py:270-278) on ls, var, bias
-        self._priors = {k: (h[k] ** 2 / h[k], h[k] / h[k]) for k in ('var', 'ls', 'bias')}
+        # Gamma priors from_EV(E, V=E) -> shape a = E^2/V = E, rate b = E/V = 1
+        # (gpy_regression.py:270-278) on lengthscale, rbf variance and bias variance; none on the noise
+        self._priors = {k: (E, 1.0) for k, E in self._prior_expectations(y).items()}
         self._X = np.empty((0, self.input_dim))
         self._Y = np.empty((0, 1))
         self._gp = _GPShim(self)

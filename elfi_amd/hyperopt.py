@@ -1,0 +1,224 @@
+"""Hyper-parameter optimisation of the GP surrogate: what GPyRegression.optimize() does.
+
+Reference: elfi/methods/bo/gpy_regression.py:317-323 calls
+`self._gp.optimize(self.optimizer, max_iters=self.max_opt_iters)` with optimizer="scg",
+max_opt_iters=50 (:30-31).  The arithmetic is third-party ([GPy-upstream] GPy.core.Model /
+paramz, not vendored in the reference, not installed here); its published algorithm is
+restated:
+
+  * parameters theta = (rbf.variance, rbf.lengthscale, bias.variance, Gaussian_noise.variance),
+    each constrained positive through paramz's Logexp transform theta = log(1 + exp(phi));
+    the optimiser works on phi.
+  * objective(phi) = -[ log Z(theta) + sum_priored ( ln Gamma(theta_i; a_i, b_i)
+                        + ln(1 - exp(-theta_i)) ) ]
+    -- the log marginal likelihood, the Gamma priors set in gpy_regression.py:270-278 (rbf
+    variance, lengthscale, bias variance; none on the noise) and, for parameters that carry a
+    prior, the log-Jacobian of the Logexp transform (paramz Parameterized.log_prior).
+  * gradient w.r.t. phi = -(d log Z/d theta + d log prior/d theta [+ 1/(exp(theta)-1)]) *
+    (1 - exp(-theta)).
+  * optimiser: Moller's scaled conjugate gradient as paramz ships it (sigma0 = 1e-7, second-order
+    information from one extra gradient per successful step, trust parameter beta in
+    [1e-15, 1e15], x/f/g tolerances 1e-6 / 1e-6 / 1e-5, `max_iters` iterations).
+
+Every objective / gradient evaluation is a full refit on the GPU through the C ABI
+(elfihip_gp_set_hyper + elfihip_gp_factorize + elfihip_gp_nlml_grad: Gram matrix, Cholesky,
+L^-T, and the K^-1 SYRK with the four kernel-derivative contractions fused into its epilogue);
+this module only holds the four-dimensional optimiser state.  "Parity unpinned": no reference
+test or fixture fixes the optimum; tests compare against the CPU oracle's
+restatement of the same algorithm and check descent / stationarity.
+"""
+import numpy as np
+from scipy.special import gammaln
+
+_LIM_VAL = 36.0
+_LOG_LIM_VAL = np.log(np.finfo(np.float64).max)
+NAMES = ('var', 'ls', 'bias', 'noise')
+
+
+def logexp(phi):
+    """paramz Logexp.f: theta = log(1 + exp(phi)), linear above 36."""
+    phi = np.asarray(phi, dtype=np.float64)
+    return np.where(phi > _LIM_VAL, phi, np.log1p(np.exp(np.clip(phi, -_LOG_LIM_VAL, _LIM_VAL))))
+
+
+def logexp_inv(theta):
+    """paramz Logexp.finv."""
+    theta = np.asarray(theta, dtype=np.float64)
+    return np.where(theta > _LIM_VAL, theta, np.log(np.expm1(theta)))
+
+
+def logexp_gradfactor(theta):
+    """d theta / d phi expressed in theta (paramz Logexp.gradfactor)."""
+    return np.where(theta > _LIM_VAL, 1., -np.expm1(-theta))
+
+
+def gamma_lnpdf(x, a, b):
+    return a * np.log(b) - gammaln(a) + (a - 1.) * np.log(x) - b * x
+
+
+class MarginalObjective:
+    """objective(phi) and its gradient, evaluated by refitting the device GP."""
+
+    allowed_failures = 10  # paramz Model._allowed_failures
+
+    def __init__(self, model):
+        self.model = model          # HipGPRegression
+        self.handle = model._handle
+        self.priors = model._priors or {}
+        self._phi = None
+        self._logz = None
+        self._fail_count = 0
+        self._last_grad = np.zeros(4)
+        self.n_fits = 0
+
+    def _fit(self, phi):
+        phi = np.asarray(phi, dtype=np.float64)
+        if self._phi is not None and np.array_equal(phi, self._phi):
+            return
+        theta = logexp(phi)
+        self._phi = None
+        self.handle.set_hyper(*theta)
+        self._logz = self.handle.factorize()   # LinAlgError when K is not positive definite
+        self._phi = phi.copy()
+        self.n_fits += 1
+
+    def _prior_terms(self, theta):
+        lp, dlp = 0.0, np.zeros(4)
+        for i, name in enumerate(NAMES):
+            if name in self.priors:
+                a, b = self.priors[name]
+                t = theta[i]
+                lp += gamma_lnpdf(t, a, b) + (np.log(np.expm1(t)) - t if t <= _LIM_VAL else 0.0)
+                dlp[i] = (a - 1.) / t - b + 1. / np.expm1(t)
+        return lp, dlp
+
+    def f(self, phi):
+        try:
+            self._fit(phi)
+            self._fail_count = 0
+        except (np.linalg.LinAlgError, ZeroDivisionError, ValueError):
+            if self._fail_count >= self.allowed_failures:
+                raise
+            self._fail_count += 1
+            return np.inf
+        lp, _ = self._prior_terms(logexp(phi))
+        return -(self._logz + lp)
+
+    def grad(self, phi):
+        try:
+            self._fit(phi)
+            _, g = self.handle.nlml_grad()
+            self._fail_count = 0
+        except (np.linalg.LinAlgError, ZeroDivisionError, ValueError):
+            if self._fail_count >= self.allowed_failures:
+                raise
+            self._fail_count += 1
+            return np.clip(self._last_grad, -1e10, 1e10)
+        theta = logexp(phi)
+        _, dlp = self._prior_terms(theta)
+        self._last_grad = -(g + dlp) * logexp_gradfactor(theta)
+        return self._last_grad
+
+
+def scg(f, gradf, x, maxiters=50, xtol=1e-6, ftol=1e-6, gtol=1e-5):
+    """Scaled conjugate gradients (Moller 1993) with the constants paramz uses.
+
+    Returns (x, objective trace, function evaluations, status)."""
+    sigma0 = 1.0e-7
+    x = np.array(x, dtype=np.float64)
+    fold = f(x)
+    function_eval = 1
+    fnow = fold
+    gradnew = gradf(x)
+    function_eval += 1
+    current_grad = np.dot(gradnew, gradnew)
+    gradold = gradnew.copy()
+    d = -gradnew
+    success = True
+    nsuccess = 0
+    beta, betamin, betamax = 1.0, 1.0e-15, 1.0e15
+    status = "maxiter exceeded"
+    flog = [fold]
+    iteration = 0
+    mu = kappa = theta = 0.0
+    while iteration < maxiters:
+        if success:
+            mu = np.dot(d, gradnew)
+            if mu >= 0:
+                d = -gradnew
+                mu = np.dot(d, gradnew)
+            kappa = np.dot(d, d)
+            if kappa <= 0 or not np.isfinite(kappa):
+                status = "zero search direction"
+                break
+            sigma = sigma0 / np.sqrt(kappa)
+            gplus = gradf(x + sigma * d)
+            function_eval += 1
+            theta = np.dot(d, (gplus - gradnew)) / sigma
+        delta = theta + beta * kappa
+        if delta <= 0:
+            delta = beta * kappa
+            beta = beta - theta / kappa
+        alpha = -mu / delta
+        xnew = x + alpha * d
+        fnew = f(xnew)
+        function_eval += 1
+        Delta = 2. * (fnew - fold) / (alpha * mu)
+        if Delta >= 0:
+            success = True
+            nsuccess += 1
+            x = xnew
+            fnow = fnew
+        else:
+            success = False
+            fnow = fold
+        flog.append(fnow)
+        iteration += 1
+        if success:
+            if np.abs(fnew - fold) < ftol:
+                status = "converged - relative reduction in objective"
+                break
+            if np.max(np.abs(alpha * d)) < xtol:
+                status = "converged - relative stepsize"
+                break
+            gradold = gradnew
+            gradnew = gradf(x)
+            function_eval += 1
+            current_grad = np.dot(gradnew, gradnew)
+            fold = fnew
+            if current_grad <= gtol:
+                status = "converged - relative reduction in gradient"
+                break
+        if Delta < 0.25:
+            beta = min(4.0 * beta, betamax)
+        if Delta > 0.75:
+            beta = max(0.25 * beta, betamin)
+        if nsuccess == x.size:
+            d = -gradnew
+            beta = 1.
+            nsuccess = 0
+        elif success:
+            Gamma = np.dot(gradold - gradnew, gradnew) / mu
+            d = Gamma * d - gradnew
+    return x, flog, function_eval, status
+
+
+def optimize_hyperparameters(model, max_iters=50):
+    """MAP hyper-parameters for `model` (a fitted HipGPRegression); refits it at the optimum."""
+    if model.optimizer != 'scg':
+        raise NotImplementedError("optimizer %r: only 'scg' (the reference's default, "
+                                  "gpy_regression.py:30) is implemented" % (model.optimizer,))
+    h0 = dict(model._hyper)
+    obj = MarginalObjective(model)
+    phi0 = logexp_inv(np.array([h0[k] for k in NAMES]))
+    try:
+        phi, flog, nfev, status = scg(obj.f, obj.grad, phi0, maxiters=max_iters)
+    except np.linalg.LinAlgError:
+        model._hyper = h0
+        model._refit()
+        raise
+    theta = logexp(phi)
+    model._hyper = dict(zip(NAMES, (float(t) for t in theta)))
+    model._refit()
+    model._opt_info = dict(status=status, objective=flog, n_fits=obj.n_fits, n_eval=nfev)
+    return model._opt_info

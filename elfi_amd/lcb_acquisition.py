@@ -1,0 +1,150 @@
+"""LCBSC acquisition for elfi.BOLFI with the multi-start optimisation batched on the GPU.
+
+Mirrors (reference elfi v0.8.7):
+    AcquisitionBase.__init__ / acquire / _add_noise   elfi/methods/bo/acquisition.py:24-191
+    LCBSC._beta / evaluate / evaluate_gradient        elfi/methods/bo/acquisition.py:226-301
+    minimize (start points, arg-min, final clip)      elfi/methods/bo/utils.py:40-111
+
+Use:  elfi.BOLFI(model, target_model=gp, acquisition_method=HipLCBSC(gp, prior=ModelPrior(model),
+                 noise_var=..., exploration_rate=10, seed=...), ...)      (bolfi.py:36,103-107)
+
+What changes against the reference is WHERE the work happens, not what is computed: the
+reference minimises the acquisition from each of the `n_inits` start points one after the other
+with scipy's L-BFGS-B, paying one single-point GP prediction per evaluation; here
+`elfihip_gp_lcb_minimize` advances every start in lock-step, one batched device evaluation per
+step (include/elfihip.h).  The random-number consumption is the reference's (start points
+first, then the truncated-normal jitter), so a seeded run draws the same start points and the
+same jitter.
+"""
+import logging
+
+import numpy as np
+import scipy.stats as ss
+
+logger = logging.getLogger(__name__)
+
+
+class HipLCBSC:
+    """Lower Confidence Bound Selection Criterion (GP-LCB of Srinivas et al.), interface of
+    elfi.methods.bo.acquisition.LCBSC."""
+
+    def __init__(self, model, prior=None, n_inits=10, max_opt_iters=1000, noise_var=None,
+                 exploration_rate=10, seed=None, constraints=None, delta=None, additive_cost=None):
+        if constraints is not None or additive_cost is not None:
+            raise NotImplementedError('constraints / additive_cost need the reference LCBSC (SLSQP / '
+                                      'user callbacks on the host); it accepts HipGPRegression as model')
+        if delta is not None:
+            if delta <= 0 or delta >= 1:
+                logger.warning('Parameter delta should be in the interval (0,1)')
+            exploration_rate = 1 / delta
+        self.model = model
+        self.prior = prior
+        self.n_inits = int(n_inits)
+        self.max_opt_iters = int(max_opt_iters)
+        self.constraints = None
+        self.additive_cost = None
+        self.noise_var = None if noise_var is None else self._noise_spec(noise_var)
+        self.exploration_rate = exploration_rate
+        self.random_state = np.random if seed is None else np.random.RandomState(seed)
+        self.seed = 0 if seed is None else seed
+        self.name = 'lcbsc'
+        self.label_fn = 'Confidence Bound'
+        self.last_opt = None   # diagnostics of the latest acquire(): per-start optima, iterations
+
+    # -- argument handling, same accepted forms and error texts as acquisition.py:75-109
+    def _noise_spec(self, noise_var):
+        """Validate `noise_var`; return a scalar or a per-parameter list in parameter_names order."""
+        number = (int, float)
+        if isinstance(noise_var, number):
+            if noise_var < 0:
+                raise ValueError("Acquisition noise should be non-negative int or float.")
+            return noise_var
+        if not isinstance(noise_var, dict):
+            raise ValueError("Either acquisition noise is a float or it is a dictionary of floats "
+                             "defining variance for each parameter dimension.")
+        names = self.model.parameter_names
+        if set(noise_var) != set(names):
+            raise ValueError("Acquisition noise dictionary should contain all parameters.")
+        values = [noise_var[k] for k in names]
+        if not all(isinstance(v, number) for v in values):
+            raise ValueError("Acquisition noise dictionary values should all be int or float.")
+        if min(values) < 0:
+            raise ValueError("Acquisition noises values should all be non-negative int or float.")
+        return values
+
+    @property
+    def delta(self):
+        return 1 / self.exploration_rate
+
+    def _beta(self, t):
+        t += 1   # start from 0
+        d = self.model.input_dim
+        return 2 * np.log(t**(2 * d + 2) * np.pi**2 / (3 * self.delta))
+
+    # -- point-wise interface (plots, tests, other optimisers): acquisition.py:262-301
+    def evaluate(self, x, t=None):
+        mean, var = self.model.predict(x, noiseless=True)
+        return mean - np.sqrt(self._beta(t) * var)
+
+    def evaluate_gradient(self, x, t=None):
+        mean, var = self.model.predict(x, noiseless=True)
+        grad_mean, grad_var = self.model.predictive_gradients(x)
+        return grad_mean - 0.5 * grad_var * np.sqrt(self._beta(t) / var)
+
+    # -- start points exactly as minimize() draws them: utils.py:72-88
+    def _start_points(self):
+        bounds = self.model.bounds
+        ndim = len(bounds)
+        n = self.n_inits
+        start_points = np.empty((n, ndim))
+        if self.prior is None:
+            random_state = self.random_state or np.random
+            for i in range(ndim):
+                start_points[:, i] = random_state.uniform(*bounds[i], n)
+        else:
+            start_points = self.prior.rvs(n, random_state=self.random_state)
+            if len(start_points.shape) == 1:
+                start_points = start_points[:, None]
+            for i in range(ndim):
+                start_points[:, i] = np.clip(start_points[:, i], *bounds[i])
+        return start_points
+
+    def minimize(self, t=None, start_points=None):
+        """All starts in lock-step on the device; returns (xhat, value) like utils.minimize."""
+        if start_points is None:
+            start_points = self._start_points()
+        bounds = self.model.bounds
+        if getattr(self.model, '_handle', None) is None or self.model.n_evidence == 0:
+            # no evidence yet: the reference's GP predicts (0, 1) everywhere, every start is a minimum
+            self.last_opt = None
+            return np.array(start_points[0], dtype=float), float(-np.sqrt(self._beta(t)))
+        locs, vals, iters, n_eval = self.model._handle.lcb_minimize(start_points, bounds, self._beta(t),
+                                                                   maxiter=self.max_opt_iters)
+        ind_min = np.argmin(vals)
+        xhat = locs[ind_min].copy()
+        for i in range(len(bounds)):
+            xhat[i] = np.clip(xhat[i], *bounds[i])
+        self.last_opt = dict(starts=start_points, locs=locs, vals=vals, iters=iters, n_eval=n_eval,
+                             ind_min=int(ind_min))
+        return xhat, float(vals[ind_min])
+
+    def acquire(self, n, t=None):
+        """Next batch of acquisition points, (n, input_dim).  acquisition.py:129-172."""
+        logger.debug('Acquiring the next batch of %d values', n)
+        xhat, _ = self.minimize(t)
+        x = np.tile(xhat, (n, 1))
+        return self._add_noise(x)
+
+    def _add_noise(self, x):
+        """Truncated-normal jitter inside the bounds, one draw call per dimension in index order
+        (the reference's random-number consumption, acquisition.py:174-191)."""
+        if self.noise_var is None:
+            return x
+        std = np.sqrt(np.broadcast_to(np.asarray(self.noise_var, dtype=float), (self.model.input_dim,)))
+        for i, (lo, hi) in enumerate(self.model.bounds):
+            if std[i] == 0:
+                continue
+            centre = x[:, i]
+            x[:, i] = ss.truncnorm.rvs((lo - centre) / std[i], (hi - centre) / std[i], loc=centre,
+                                       scale=std[i], size=len(x), random_state=self.random_state)
+        return x

@@ -147,9 +147,18 @@ int elfihip_gp_append(elfihip_gp* gp, const double* X_new, const double* y_new, 
  * gpy_regression.py:283-284 / :311-312 construct GPRegression).  log_marginal may be NULL.
  * ELFIHIP_ERR_NOT_PD if a pivot is not positive (GPy would raise LinAlgError). */
 int elfihip_gp_factorize(elfihip_gp* gp, double* log_marginal);
+/* What GPy evaluates once per objective call of GPyRegression.optimize() (gpy_regression.py:317-323
+ * -> [GPy-upstream] ExactGaussianInference + kern.update_gradients_full): the log marginal
+ * likelihood and its gradient w.r.t. (rbf.variance, rbf.lengthscale, bias.variance,
+ * Gaussian_noise.variance), grad[4], from dL/dK = 0.5 (alpha alpha^T - K^-1).  Priors and the
+ * positivity transform are host-side scalars (elfi_amd/hyperopt.py).  Needs a factorised GP. */
+int elfihip_gp_nlml_grad(elfihip_gp* gp, double* log_marginal, double* grad);
+/* Materialise K^-1 (GPy's posterior.woodbury_inv, read by gpy_regression.py:158) for
+ * elfihip_gp_get(gp, 5, ...).  Not needed by predict / gradients / nlml_grad. */
+int elfihip_gp_form_kinv(elfihip_gp* gp);
 int elfihip_gp_size(const elfihip_gp* gp, int64_t* n, int64_t* capacity, int* d);
 /* Copy state to the host: 0 = L (n*n lower), 1 = L^-T (n*n upper), 2 = alpha (n),
- * 3 = X (n*d), 4 = y (n), 5 = K^-1 (n*n, after elfihip_gp_nlml_grad). */
+ * 3 = X (n*d), 4 = y (n), 5 = K^-1 (n*n, after elfihip_gp_form_kinv). */
 int elfihip_gp_get(elfihip_gp* gp, int which, double* out);
 
 /* GPyRegression.predict(x, noiseless) (gpy_regression.py:98-147; closed form :127-140):
@@ -163,6 +172,18 @@ int elfihip_gp_predict_grad(elfihip_gp* gp, const double* Xs, int64_t S, double*
 /* LCBSC.evaluate / evaluate_gradient (elfi/methods/bo/acquisition.py:262-301) for S points at
  * once: val_s = mu - sqrt(beta var),  grad_s = dmu - 0.5 dvar sqrt(beta / var)  (noiseless). */
 int elfihip_gp_lcb(elfihip_gp* gp, const double* Xs, int64_t S, double beta, double* val, double* grad);
+
+/* The inner optimisation of AcquisitionBase.acquire (elfi/methods/bo/acquisition.py:146-163 ->
+ * minimize(), elfi/methods/bo/utils.py:40-111) for the LCBSC rule: minimise
+ * a(x) = mu(x) - sqrt(beta var(x)) inside the box [lower, upper] from S start points (S, d).
+ * The reference runs scipy L-BFGS-B from each start in turn, one GP prediction per evaluation;
+ * here all starts advance in lock-step with ONE batched device evaluation per step
+ * (bound-projected L-BFGS, memory 10, scipy's default tolerances; see csrc/gp_acq.hip).
+ * x_out (S,d) and f_out (S) receive every start's end point / value (the caller takes the
+ * arg-min, utils.py:105-109); iters_out (S) and n_eval_out (total point evaluations) may be NULL. */
+int elfihip_gp_lcb_minimize(elfihip_gp* gp, const double* starts, int64_t S, const double* lower,
+                            const double* upper, double beta, int maxiter, double* x_out, double* f_out,
+                            int* iters_out, int64_t* n_eval_out);
 
 #ifdef __cplusplus
 }

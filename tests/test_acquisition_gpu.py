@@ -1,0 +1,82 @@
+"""GPU: the lock-step multi-start LCB minimiser and HipLCBSC.acquire vs the reference recipe.
+
+The reference minimises from each start with scipy's L-BFGS-B (elfi/methods/bo/utils.py:97-103).
+The device path is a different bound-projected L-BFGS (csrc/gp_acq.hip), so iterates are not
+comparable; what must agree:
+  * every end point is a stationary point of the box-constrained problem (projected gradient
+    <= 1e-4 on the ORACLE's gradient) with a value not above its start's;
+  * the best value over the starts is within 1e-6 (relative to the value scale) of, or below,
+    the best value scipy finds from the same starts on the CPU oracle;
+  * identical seeds give identical acquisitions (determinism).
+"""
+import numpy as np
+import pytest
+
+import gp_oracle as G
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(n, d, seed):
+    from elfi_amd import HipGPRegression
+    X, y, bounds = G.synthetic_gp_problem(n, d, seed=seed)
+    names = ['p%d' % i for i in range(d)]
+    m = HipGPRegression(names, bounds=dict(zip(names, bounds)))
+    m.update(X, y)
+    ref = G.Posterior(X, y, **m._hyper)
+    return m, ref, bounds
+
+
+@pytest.mark.parametrize('n,d,S,t', [(150, 1, 5, 0), (300, 2, 10, 3), (600, 5, 10, 40), (500, 3, 37, 7)])
+def test_lockstep_minimiser_vs_scipy_on_the_oracle(hip_ctx, n, d, S, t):
+    m, ref, bounds = _setup(n, d, seed=n + S)
+    beta = G.lcb_beta(t, d)
+    starts = np.random.RandomState(S).uniform(-2, 2, (S, d))
+    locs, vals, iters, n_eval = m._handle.lcb_minimize(starts, bounds, beta, maxiter=1000)
+    f0 = G.lcb_evaluate(ref, starts, t)[:, 0]
+    scale = np.max(np.abs(f0)) + 1.0
+    lo, hi = np.array(bounds).T
+    assert np.all(locs >= lo) and np.all(locs <= hi)
+    assert np.all(vals <= f0 + 1e-9 * scale)
+    np.testing.assert_allclose(vals, G.lcb_evaluate(ref, locs, t)[:, 0], rtol=0, atol=1e-8 * scale)
+    g = G.lcb_evaluate_gradient(ref, locs, t)
+    pg = locs - np.clip(locs - g, lo, hi)
+    assert np.max(np.abs(pg)) <= 1e-3, 'end points must be stationary in the box'
+    fun = lambda x: float(G.lcb_evaluate(ref, x, t)[0, 0])
+    grad = lambda x: G.lcb_evaluate_gradient(ref, x, t)[0]
+    xs, fs = G.minimize_multistart(fun, grad, bounds, starts)
+    assert vals.min() <= fs + 1e-6 * scale, (vals.min(), fs)
+    assert n_eval >= S and np.all(iters <= 1000)
+
+
+def test_acquire_end_to_end_and_determinism(hip_ctx):
+    from elfi_amd import HipLCBSC
+    m, ref, bounds = _setup(400, 2, seed=1)
+    a1 = HipLCBSC(m, n_inits=10, noise_var=0.1, exploration_rate=10, seed=7)
+    a2 = HipLCBSC(m, n_inits=10, noise_var=0.1, exploration_rate=10, seed=7)
+    x1, x2 = a1.acquire(3, t=5), a2.acquire(3, t=5)
+    assert x1.shape == (3, 2) and np.array_equal(x1, x2)
+    lo, hi = np.array(bounds).T
+    assert np.all(x1 >= lo) and np.all(x1 <= hi)
+    info = a1.last_opt
+    assert info['locs'].shape == (10, 2) and info['ind_min'] == int(np.argmin(info['vals']))
+    # the point-wise interface agrees with the oracle's LCBSC (acquisition.py:262-301)
+    xs = info['locs']
+    np.testing.assert_allclose(a1.evaluate(xs, 5), G.lcb_evaluate(ref, xs, 5), rtol=1e-8)
+    np.testing.assert_allclose(a1.evaluate_gradient(xs, 5), G.lcb_evaluate_gradient(ref, xs, 5), rtol=1e-6,
+                               atol=1e-8)
+
+
+def test_minimiser_edge_cases(hip_ctx):
+    m, ref, bounds = _setup(100, 2, seed=3)
+    beta = G.lcb_beta(0, 2)
+    # maxiter = 0: returns the (clipped) starts and their values
+    starts = np.array([[5.0, -7.0], [0.1, 0.2]])
+    locs, vals, iters, n_eval = m._handle.lcb_minimize(starts, bounds, beta, maxiter=0)
+    assert np.array_equal(locs, np.clip(starts, -2, 2)) and np.all(iters == 0) and n_eval == 2
+    # degenerate box: nothing to optimise
+    b0 = [(0.5, 0.5), (-1.0, 1.0)]
+    locs, vals, iters, _ = m._handle.lcb_minimize(starts, b0, beta)
+    assert np.all(locs[:, 0] == 0.5)
+    with pytest.raises(ValueError):
+        m._handle.lcb_minimize(starts, [(1.0, -1.0), (0, 1)], beta)

@@ -1,0 +1,109 @@
+"""GPU: log-marginal gradient, K^-1 and the hyper-parameter MAP fit vs the CPU oracle.
+
+Tolerances: gradient of log Z w.r.t. (var, ls, bias, noise) relative 1e-7 of the largest
+component (sums of n^2 terms with cancellation between alpha alpha^T and K^-1); K^-1 relative
+1e-8.  The optimiser is "parity unpinned" (oracle/gp_hyper_oracle.py): the GPU run and the CPU
+restatement start from the same point and must reach the same MAP objective within 1e-5
+relative and hyper-parameters within 1 %; SCG amplifies last-digit gradient differences through
+its one-sided curvature estimate (sigma = 1e-7), so trajectories are not compared point by point.
+"""
+import numpy as np
+import pytest
+
+import gp_hyper_oracle as HO
+import gp_oracle as G
+
+pytestmark = pytest.mark.gpu
+
+
+def _fit(n, d, seed, hyper=None):
+    from elfi_amd.gp import GPHandle
+    X, y, bounds = G.synthetic_gp_problem(n, d, seed=seed)
+    h = hyper or G.default_hyper(bounds, y)
+    gp = GPHandle(d, n)
+    gp.set_hyper(h['var'], h['ls'], h['bias'], h['noise'])
+    gp.set_data(X, y)
+    logz = gp.factorize()
+    return gp, logz, G.Posterior(X, y, h['var'], h['ls'], h['bias'], h['noise']), (X, y, bounds)
+
+
+@pytest.mark.parametrize('n,d', [(7, 1), (100, 2), (128, 3), (257, 2), (700, 10), (1300, 20), (400, 70)])
+def test_log_marginal_gradient_vs_oracle(hip_ctx, n, d):
+    gp, logz, ref, _ = _fit(n, d, seed=n + d)
+    lz, g = gp.nlml_grad()
+    assert lz == logz
+    assert abs(lz - ref.log_marginal) <= 1e-9 * abs(ref.log_marginal)
+    rg = ref.log_marginal_grad()
+    assert np.max(np.abs(g - rg)) <= 1e-7 * np.max(np.abs(rg)), (g, rg)
+
+
+def test_gradient_with_other_hyperparameters(hip_ctx):
+    h = dict(var=1.0, ls=1.0, bias=1.0, noise=0.05)   # the reference's initial kernel values
+    gp, logz, ref, _ = _fit(500, 4, seed=3, hyper=h)
+    _, g = gp.nlml_grad()
+    rg = ref.log_marginal_grad()
+    assert np.max(np.abs(g - rg)) <= 1e-7 * np.max(np.abs(rg))
+    # the gradient is the derivative of what factorize() returns
+    eps = 1e-5
+    for i, k in enumerate(('var', 'ls', 'bias', 'noise')):
+        hp, hm = dict(h), dict(h)
+        hp[k] += eps
+        hm[k] -= eps
+        gp.set_hyper(hp['var'], hp['ls'], hp['bias'], hp['noise'])
+        fp = gp.factorize()
+        gp.set_hyper(hm['var'], hm['ls'], hm['bias'], hm['noise'])
+        fm = gp.factorize()
+        fd = (fp - fm) / (2 * eps)
+        assert abs(fd - g[i]) <= 1e-5 * (1 + abs(g[i])), (k, fd, g[i])
+
+
+def test_kinv_vs_oracle(hip_ctx):
+    gp, _, ref, _ = _fit(300, 3, seed=9)
+    gp.form_kinv()
+    Ki = gp.get(5)
+    assert np.max(np.abs(Ki - ref.Kinv)) <= 1e-8 * np.max(np.abs(ref.Kinv))
+    assert np.array_equal(Ki, Ki.T)
+
+
+def test_optimize_vs_oracle(hip_ctx):
+    from elfi_amd import HipGPRegression
+    from elfi_amd import hyperopt as H
+    X, y, bounds = G.synthetic_gp_problem(200, 2, seed=5)
+    names = ['t1', 't2']
+    m = HipGPRegression(names, bounds=dict(zip(names, bounds)))
+    m.update(X, y)
+    assert m._hyper == G.initial_hyper(y)
+    pri = G.default_priors(bounds, y)
+    assert {k: tuple(v) for k, v in m._priors.items()} == {k: (pytest.approx(v[0]), pytest.approx(v[1]))
+                                                          for k, v in pri.items()}
+    obj = H.MarginalObjective(m)
+    ref_obj = HO.MapObjective(X, y, pri)
+    phi0 = H.logexp_inv(np.array([m._hyper[k] for k in H.NAMES]))
+    f0, g0 = obj.f(phi0), obj.grad(phi0)
+    assert abs(f0 - ref_obj.value(phi0)) <= 1e-9 * abs(f0)
+    assert np.max(np.abs(g0 - ref_obj.gradient(phi0))) <= 1e-7 * np.max(np.abs(g0))
+    m.optimize()
+    info = m._opt_info
+    href, iref = HO.optimize(X, y, G.initial_hyper(y), pri, max_iters=50)
+    f_gpu, f_cpu = info['objective'][-1], iref['objective'][-1]
+    assert f_gpu < f0 - 1.0, 'optimisation must improve the MAP objective'
+    assert abs(f_gpu - f_cpu) <= 1e-5 * abs(f_cpu), (f_gpu, f_cpu)
+    for k in H.NAMES:
+        assert abs(m._hyper[k] - href[k]) <= 1e-2 * href[k], (k, m._hyper[k], href[k])
+    # the model is refitted at the optimum
+    ref = G.Posterior(X, y, **m._hyper)
+    xs = np.random.RandomState(0).uniform(-2, 2, (5, 2))
+    np.testing.assert_allclose(m.predict(xs)[0], ref.predict(xs)[0], rtol=1e-7)
+    assert m.noise == m._hyper['noise']
+    assert 'rbf.lengthscale' in str(m)
+
+
+def test_update_with_optimize_flag(hip_ctx):
+    from elfi_amd import HipGPRegression
+    X, y, bounds = G.synthetic_gp_problem(120, 2, seed=8)
+    m = HipGPRegression(['a', 'b'], bounds={'a': bounds[0], 'b': bounds[1]}, max_opt_iters=10)
+    m.update(X[:100], y[:100], optimize=True)
+    h1 = dict(m._hyper)
+    assert h1 != G.initial_hyper(y[:100])
+    m.update(X[100:], y[100:])          # no optimisation: hyper-parameters carried over (:306-310)
+    assert m._hyper == h1 and m.n_evidence == 120

@@ -1,0 +1,157 @@
+"""Host-side logic that needs no GPU: the hyper-parameter optimiser state machine, the Logexp
+transform, the LCBSC argument handling and random-number consumption.
+
+The SCG restatements in elfi_amd/hyperopt.py (product) and oracle/gp_hyper_oracle.py (checker)
+are written independently; on analytic objectives they must walk the same trajectory.
+"""
+import pickle
+
+import numpy as np
+import pytest
+
+import gp_hyper_oracle as HO
+import gp_oracle as G
+from elfi_amd import hyperopt as H
+
+
+def _rosen(x):
+    return float(np.sum(100.0 * (x[1:] - x[:-1] ** 2) ** 2 + (1 - x[:-1]) ** 2))
+
+
+def _rosen_grad(x):
+    g = np.zeros_like(x)
+    g[:-1] = -400 * x[:-1] * (x[1:] - x[:-1] ** 2) - 2 * (1 - x[:-1])
+    g[1:] += 200 * (x[1:] - x[:-1] ** 2)
+    return g
+
+
+@pytest.mark.parametrize('dim,iters', [(2, 50), (4, 50), (4, 400)])
+def test_scg_product_and_oracle_walk_the_same_path(dim, iters):
+    x0 = np.linspace(-1.2, 1.0, dim)
+    xa, fa, nfev, sa = H.scg(_rosen, _rosen_grad, x0, maxiters=iters)
+    xb, fb, sb = HO.scaled_conjugate_gradient(_rosen, _rosen_grad, x0, iterations=iters)
+    assert sa == sb
+    assert len(fa) == len(fb)
+    np.testing.assert_allclose(fa, fb, rtol=1e-12, atol=0)
+    np.testing.assert_allclose(xa, xb, rtol=1e-12, atol=1e-14)
+    assert fa[-1] < fa[0]
+    assert all(b <= a + 1e-12 for a, b in zip(fa, fa[1:])), 'SCG never accepts an uphill step'
+
+
+def test_scg_converges_on_a_quadratic():
+    A = np.diag([1.0, 10.0, 100.0])
+    b = np.array([1.0, -2.0, 3.0])
+    x, flog, nfev, status = H.scg(lambda x: 0.5 * x @ A @ x - b @ x, lambda x: A @ x - b, np.zeros(3),
+                                  maxiters=200)
+    np.testing.assert_allclose(x, np.linalg.solve(A, b), rtol=5e-3, atol=1e-5)  # stops on |df| < 1e-6
+    assert status.startswith('converged')
+
+
+def test_logexp_transform_roundtrip_and_gradfactor():
+    theta = np.array([1e-6, 0.01, 0.3, 1.0, 5.0, 35.9, 36.1, 100.0])
+    phi = H.logexp_inv(theta)
+    np.testing.assert_allclose(H.logexp(phi), theta, rtol=1e-12)
+    np.testing.assert_allclose(HO.softplus(phi), theta, rtol=1e-12)
+    np.testing.assert_allclose(HO.softplus_inv(theta), phi, rtol=1e-12, atol=1e-12)
+    eps = 1e-6
+    fd = (H.logexp(phi + eps) - H.logexp(phi - eps)) / (2 * eps)
+    np.testing.assert_allclose(H.logexp_gradfactor(theta), fd, rtol=1e-6)
+
+
+def test_oracle_map_objective_gradient_is_consistent():
+    """Finite differences on the CPU oracle's objective (pins the formula the GPU is tested against)."""
+    X, y, bounds = G.synthetic_gp_problem(60, 3, seed=4)
+    pri = G.default_priors(bounds, y)
+    obj = HO.MapObjective(X, y, pri)
+    phi = HO.softplus_inv(np.array([0.7, 1.3, 0.4, 0.2]))
+    g = obj.gradient(phi)
+    for i in range(4):
+        e = np.zeros(4)
+        e[i] = 1e-6
+        fd = (obj.value(phi + e) - obj.value(phi - e)) / 2e-6
+        assert abs(fd - g[i]) <= 1e-5 * (1 + abs(g[i])), (i, fd, g[i])
+
+
+def test_oracle_optimize_improves_the_objective():
+    X, y, bounds = G.synthetic_gp_problem(80, 2, seed=2)
+    pri = G.default_priors(bounds, y)
+    h0 = G.initial_hyper(y)
+    h, info = HO.optimize(X, y, h0, pri, max_iters=50)
+    assert info['objective'][-1] < info['objective'][0] - 1.0
+    assert all(v > 0 for v in h.values())
+
+
+# ---- LCBSC host logic --------------------------------------------------------------------
+class _Model:
+    parameter_names = ['a', 'b']
+    input_dim = 2
+    bounds = [(-2, 2), (-1, 1)]
+    n_evidence = 0
+    _handle = None
+
+
+def test_lcbsc_arguments_and_beta():
+    from elfi_amd import HipLCBSC
+    acq = HipLCBSC(_Model(), exploration_rate=10, seed=0)
+    # acquisition.py:256-260: beta_t = 2 log((t+1)^(2d+2) pi^2 / (3 delta)), delta = 1/exploration_rate
+    for t in (0, 3, 99):
+        assert acq._beta(t) == pytest.approx(2 * np.log((t + 1) ** 6 * np.pi ** 2 / (3 * 0.1)))
+        assert acq._beta(t) == pytest.approx(G.lcb_beta(t, 2, 10.))
+    assert HipLCBSC(_Model(), delta=0.25).exploration_rate == 4
+    assert HipLCBSC(_Model(), noise_var={'b': 0.2, 'a': 0.1}).noise_var == [0.1, 0.2]
+    assert HipLCBSC(_Model(), noise_var=0.3).noise_var == 0.3
+    with pytest.raises(ValueError):
+        HipLCBSC(_Model(), noise_var=-1.0)
+    with pytest.raises(ValueError):
+        HipLCBSC(_Model(), noise_var={'a': 0.1})
+    with pytest.raises(ValueError):
+        HipLCBSC(_Model(), noise_var={'a': 0.1, 'b': -0.2})
+    with pytest.raises(ValueError):
+        HipLCBSC(_Model(), noise_var='x')
+    with pytest.raises(NotImplementedError):
+        HipLCBSC(_Model(), constraints=[{}])
+
+
+def test_lcbsc_random_number_consumption_matches_the_reference_recipe():
+    """utils.py:72-79 draws the start points dimension by dimension from random_state.uniform;
+    acquisition.py:174-191 then draws the jitter dimension by dimension from truncnorm."""
+    import scipy.stats as ss
+    from elfi_amd import HipLCBSC
+    acq = HipLCBSC(_Model(), n_inits=7, noise_var=0.1, seed=123)
+    sp = acq._start_points()
+    rs = np.random.RandomState(123)
+    exp = np.empty((7, 2))
+    for i, b in enumerate(_Model.bounds):
+        exp[:, i] = rs.uniform(*b, 7)
+    assert np.array_equal(sp, exp)
+    x = np.tile(sp[0], (3, 1))
+    got = acq._add_noise(x.copy())
+    for i, (lo, hi) in enumerate(_Model.bounds):
+        std = np.sqrt(0.1)
+        e = ss.truncnorm.rvs((lo - x[:, i]) / std, (hi - x[:, i]) / std, loc=x[:, i], scale=std, size=3,
+                             random_state=rs)
+        assert np.array_equal(got[:, i], e)
+    assert np.all(got[:, 0] >= -2) and np.all(got[:, 0] <= 2) and np.all(np.abs(got[:, 1]) <= 1)
+
+
+def test_lcbsc_without_evidence_returns_a_start_point():
+    from elfi_amd import HipLCBSC
+    acq = HipLCBSC(_Model(), seed=5)
+    x = acq.acquire(4, t=0)
+    assert x.shape == (4, 2) and np.all(x == x[0])
+
+
+def test_hip_objects_pickle_without_device_state():
+    """ELFI pickles operations and models (clients/multiprocessing.py:50, elfi_model.py:401-438)."""
+    import elfi_amd
+    op = elfi_amd.HipDiscrepancy('minkowski', p=3, w=[1., 2.])
+    op2 = pickle.loads(pickle.dumps(op))
+    assert op2.dist.metric == 'minkowski' and op2.dist.p == 3 and np.array_equal(op2.dist.w, [1., 2.])
+    gp = elfi_amd.HipGPRegression(['a', 'b'], bounds={'a': (-2, 2), 'b': (-1, 1)})
+    gp2 = pickle.loads(pickle.dumps(gp))
+    assert gp2.bounds == [(-2, 2), (-1, 1)] and gp2.n_evidence == 0
+    mu, var = gp2.predict(np.zeros((3, 2)))
+    assert np.array_equal(mu, np.zeros((3, 1))) and np.array_equal(var, np.ones((3, 1)))   # :114-115
+    st = elfi_amd.AdaptiveDistanceState()
+    st2 = pickle.loads(pickle.dumps(st))
+    assert st2.state['w'] == [None]
