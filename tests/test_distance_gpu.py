@@ -252,23 +252,31 @@ def test_welford_vs_oracle(hip_ctx, n, m):
     rs = np.random.RandomState(n + m)
     ref = O.AdaptiveDistanceOracle()
     cnt, mean, M2 = 0, np.zeros(m), np.zeros(m)
+    M2_old, carry = np.zeros(m), np.zeros(m)
     for b in range(3):
         X = rs.randn(n, m) * rs.uniform(0.1, 100, m) + rs.uniform(-1000, 1000, m)
-        mean_old = np.array(ref.store[1], dtype=float) * np.ones(m)
+        mean_old = mean.copy()           # OUR previous mean: what the kernel subtracts in d1
         ref.add_data(X)
         cnt, mean, M2 = elfi_amd.welford_update(X, cnt, mean, M2)
         assert cnt == ref.store[0]
         np.testing.assert_allclose(mean, ref.store[1], rtol=1e-12)
-        # sum(d1*d2) cancels when |mean| >> std (first batch: mean_old = 0), for the reference
-        # just as for us; the honest bound is relative to the sum of |terms| (both sides are
-        # different summation orders of the same numbers)
-        scale = np.sum(np.abs((X - mean_old) * (X - ref.store[1])), axis=0) + np.abs(ref.store[2])
-        # ... plus the sensitivity of sum(d1*(x - mean_new)) to the last bits of mean_new itself:
-        # d M2 / d mean_new = -sum(d1), and the two sides' means legitimately differ by a few ulp
-        # (different summation order of sum(d1)); with mean_old = 0 and |mean| >> std this term
-        # dominates (|sum d1| = N |mean|).
-        mean_slack = np.abs(np.sum(X - mean_old, axis=0)) * 16 * np.spacing(np.abs(ref.store[1]))
-        assert np.all(np.abs(M2 - ref.store[2]) <= 1e-13 * scale + mean_slack)
+        # M2 += sum(d1 * (x - mean_new)) has derivative -sum(d1) = -N (mean_new - mean_old) w.r.t.
+        # mean_new, so the few-ulp difference between the two sides' means (different but fixed
+        # summation orders, checked above) is amplified by up to N |mean| when mean_old = 0 -- for
+        # the reference exactly as for us.  The honest statement is therefore: given OUR mean_new,
+        # our M2 increment equals the update formula evaluated in extended precision, to 1e-13 of
+        # the sum of absolute terms; and it agrees with the reference's to that plus the
+        # first-order effect of the observed mean difference.
+        Xl = X.astype(np.longdouble)
+        d1 = Xl - mean_old.astype(np.longdouble)
+        exact_inc = np.sum(d1 * (Xl - mean.astype(np.longdouble)), axis=0)
+        scale = np.sum(np.abs(d1 * (Xl - mean.astype(np.longdouble))), axis=0).astype(float)
+        inc = M2.astype(np.longdouble) - M2_old.astype(np.longdouble)
+        assert np.all(np.abs((inc - exact_inc).astype(float)) <= 1e-13 * scale + 4 * np.spacing(np.abs(M2)))
+        amplified = np.abs(np.sum(d1, axis=0).astype(float)) * np.abs(mean - ref.store[1])
+        assert np.all(np.abs(M2 - ref.store[2]) <= 2e-13 * (scale + np.abs(M2)) + 2 * amplified + carry)
+        carry = np.abs(M2 - ref.store[2])   # differences of earlier batches carry over additively
+        M2_old = M2.copy()
 
 
 def test_determinism(hip_ctx):
