@@ -252,14 +252,18 @@ def test_welford_vs_oracle(hip_ctx, n, m):
     rs = np.random.RandomState(n + m)
     ref = O.AdaptiveDistanceOracle()
     cnt, mean, M2 = 0, np.zeros(m), np.zeros(m)
-    M2_old, carry = np.zeros(m), np.zeros(m)
+    M2_old, carry, carry_mean = np.zeros(m), np.zeros(m), np.zeros(m)
     for b in range(3):
         X = rs.randn(n, m) * rs.uniform(0.1, 100, m) + rs.uniform(-1000, 1000, m)
         mean_old = mean.copy()           # OUR previous mean: what the kernel subtracts in d1
         ref.add_data(X)
         cnt, mean, M2 = elfi_amd.welford_update(X, cnt, mean, M2)
         assert cnt == ref.store[0]
-        np.testing.assert_allclose(mean, ref.store[1], rtol=1e-12)
+        # mean = mean_old + sum(x - mean_old)/N: error relative to the size of the summed terms
+        tol_mean = 1e-13 * np.mean(np.abs(X - mean_old), axis=0) + 4 * np.spacing(np.abs(ref.store[1])) + carry_mean
+        worst = np.argmax(np.abs(mean - ref.store[1]) / tol_mean)
+        assert np.all(np.abs(mean - ref.store[1]) <= tol_mean), (
+            b, worst, mean[worst], ref.store[1][worst], tol_mean[worst])
         # M2 += sum(d1 * (x - mean_new)) has derivative -sum(d1) = -N (mean_new - mean_old) w.r.t.
         # mean_new, so the few-ulp difference between the two sides' means (different but fixed
         # summation orders, checked above) is amplified by up to N |mean| when mean_old = 0 -- for
@@ -272,10 +276,17 @@ def test_welford_vs_oracle(hip_ctx, n, m):
         exact_inc = np.sum(d1 * (Xl - mean.astype(np.longdouble)), axis=0)
         scale = np.sum(np.abs(d1 * (Xl - mean.astype(np.longdouble))), axis=0).astype(float)
         inc = M2.astype(np.longdouble) - M2_old.astype(np.longdouble)
-        assert np.all(np.abs((inc - exact_inc).astype(float)) <= 1e-13 * scale + 4 * np.spacing(np.abs(M2)))
+        e1 = np.abs((inc - exact_inc).astype(float))
+        t1 = 1e-13 * scale + 4 * np.spacing(np.abs(M2))
+        w1 = np.argmax(e1 / t1)
+        assert np.all(e1 <= t1), ('formula', b, w1, e1[w1], t1[w1], scale[w1], M2[w1])
         amplified = np.abs(np.sum(d1, axis=0).astype(float)) * np.abs(mean - ref.store[1])
-        assert np.all(np.abs(M2 - ref.store[2]) <= 2e-13 * (scale + np.abs(M2)) + 2 * amplified + carry)
+        e2 = np.abs(M2 - ref.store[2])
+        t2 = 2e-13 * (scale + np.abs(M2)) + 2 * amplified + carry
+        w2 = np.argmax(e2 / t2)
+        assert np.all(e2 <= t2), ('vs reference', b, w2, e2[w2], t2[w2], amplified[w2], carry[w2])
         carry = np.abs(M2 - ref.store[2])   # differences of earlier batches carry over additively
+        carry_mean = np.abs(mean - ref.store[1])
         M2_old = M2.copy()
 
 
