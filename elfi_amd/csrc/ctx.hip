@@ -1,16 +1,43 @@
 // Context lifecycle, error text, stream adoption and event timing for libelfihip.so.
 #include "common.hpp"
 
+#include <cstdlib>
+
 namespace elfihip {
 thread_local std::string g_err;
 
+// Streams of the GP factorisation.  The CU mask has one bit per CU; on gfx950 the driver deals the
+// bits round-robin over the 8 XCDs (bit i -> XCD i % 8), so "i % 8 >= 8 - R" reserves R whole XCDs
+// (their CUs AND their L2) for the latency-critical chain.  Should a driver enumerate differently the
+// same mask still reserves R/8 of the CUs: a speed matter only.  ELFIHIP_RESERVED_XCDS overrides R
+// (0 = no partition).
 int ctx_aux(elfihip_ctx* ctx) {
   if (ctx->hi_stream) return ELFIHIP_OK;
-  int lo = 0, hi = 0;
-  ELFIHIP_CHECK_HIP(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));
-  ELFIHIP_CHECK_HIP(ctx, hipStreamCreateWithPriority(&ctx->hi_stream, hipStreamNonBlocking, hi));
-  ELFIHIP_CHECK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_a, hipEventDisableTiming));
-  ELFIHIP_CHECK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_b, hipEventDisableTiming));
+  int reserved = 2;
+  if (const char* e = getenv("ELFIHIP_RESERVED_XCDS")) reserved = atoi(e);
+  if (reserved < 0) reserved = 0;
+  if (reserved > 4) reserved = 4;
+  const int words = (ctx->cu_count + 31) / 32;
+  if (reserved > 0 && ctx->cu_count % 8 == 0) {
+    std::vector<uint32_t> crit((size_t)words, 0u), bulk((size_t)words, 0u);
+    for (int i = 0; i < ctx->cu_count; ++i) {
+      const bool r = (i % 8) >= 8 - reserved;
+      (r ? crit : bulk)[(size_t)(i / 32)] |= 1u << (i % 32);
+    }
+    ELFIHIP_CHECK_HIP(ctx, hipExtStreamCreateWithCUMask(&ctx->hi_stream, (uint32_t)words, crit.data()));
+    ELFIHIP_CHECK_HIP(ctx, hipExtStreamCreateWithCUMask(&ctx->bulk_stream, (uint32_t)words, bulk.data()));
+  } else {
+    int lo = 0, hi = 0;
+    ELFIHIP_CHECK_HIP(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));
+    ELFIHIP_CHECK_HIP(ctx, hipStreamCreateWithPriority(&ctx->hi_stream, hipStreamNonBlocking, hi));
+    ELFIHIP_CHECK_HIP(ctx, hipStreamCreateWithFlags(&ctx->bulk_stream, hipStreamNonBlocking));
+  }
+  // device-scope release: these events only order kernels on this GPU, no host visibility needed
+  unsigned flags = hipEventDisableTiming | hipEventReleaseToDevice;
+  if (const char* e = getenv("ELFIHIP_EVENT_SYSTEM_SCOPE"))
+    if (atoi(e)) flags = hipEventDisableTiming;
+  ELFIHIP_CHECK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_a, flags));
+  ELFIHIP_CHECK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_b, flags));
   return ELFIHIP_OK;
 }
 }  // namespace elfihip
@@ -85,6 +112,7 @@ int elfihip_ctx_destroy(elfihip_ctx* ctx) {
     if (ctx->ev_a) (void)hipEventDestroy(ctx->ev_a);
     if (ctx->ev_b) (void)hipEventDestroy(ctx->ev_b);
     if (ctx->hi_stream) (void)hipStreamDestroy(ctx->hi_stream);
+    if (ctx->bulk_stream) (void)hipStreamDestroy(ctx->bulk_stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   }
   delete ctx;

@@ -140,33 +140,31 @@ __device__ __forceinline__ void sqrt_rsqrt(double p, double& s, double& y) {
 }
 
 constexpr int SP = 129;   // pitch of the 128x128 working block S in LDS
-constexpr int PP = 18;    // pitch of the 16-wide panel copy / the tile inverse
-constexpr int POTF2_LDS_DOUBLES = NB * SP + NB + 16 * PP + 144 * PP;
-
-// Lower-triangular 16x16 tile held ENTIRELY in one lane's registers (every lane of the wave
-// computes the same thing): the serial pivot chain then needs no cross-lane traffic at all.
-struct Tile16 {
-  double a[136];  // packed lower triangle, row-major: (i, c) at i*(i+1)/2 + c
-  __device__ __forceinline__ double& at(int i, int c) { return a[i * (i + 1) / 2 + c]; }
-};
+constexpr int PP = 18;    // pitch of the dense copy of the solved 16-wide panel
+constexpr int POTF2_LDS_DOUBLES = NB * SP + NB + NB * PP + 128;  // + per-lane trash slots
 
 // S holds two triangles at once: entries (i, c <= i) are the block of Ky being turned into
 // L11; entries (r, c > r) are the rows of the appended identity being turned into L11^-T
 // (its diagonal lives in bd[]).  Eliminating 16 columns at a time:
-//   phase 1  wave 0 factors the 16x16 diagonal tile T = L L^T and inverts L, all in registers;
-//   phase 2  the other 128 rows (112-c0 below + c0+16 identity rows above) get their panel
-//            entries multiplied by L^-T on the matrix cores (X = P W^T, W = L^-1);
-//   phase 3  rank-16 update of everything right of the panel, 16x16 MFMA tiles.
+//   phase A  every row that has entries in the panel -- the 16 rows of the diagonal tile, the rows
+//            below it and the identity rows above -- is held by ONE LANE (16 doubles in
+//            registers).  Eliminating column j is then the same three vector instructions for
+//            every row: scale entry j by 1/sqrt(pivot), subtract entry j times l_cj from entry c.
+//            The pivot and the l_cj come from the tile rows by v_readlane (SGPR broadcast); each
+//            wave keeps its own copy of the tile rows in lanes 0-15 (redundant, so no cross-wave
+//            traffic or barrier inside the panel) and 32 other rows in lanes 16-47.  This factors
+//            the tile, solves the panel below it and carries the identity rows along in one go.
+//   phase B  rank-16 update of everything right of the panel, 16x16 f64 MFMA tiles; a wave owns
+//            whole tile rows (A fragment loaded once) and runs two independent accumulators.
 __global__ __launch_bounds__(256) void potf2_aug_kernel(double* Akk, int64_t lda, double* Wkk, int64_t ldw,
                                                         double* W11, int* info, int kblock, int skip) {
   extern __shared__ __align__(16) double sm[];
   double* S = sm;
   double* bd = S + NB * SP;
-  double* Wt = bd + NB;        // 16 x PP : inverse of the current tile, Wt[i][c] = (L^-1)[i][c]
-  double* P2 = Wt + 16 * PP;   // 144 x PP: dense copy of the panel entries of the 128 other rows
+  double* P2 = bd + NB;        // 128 x PP: solved panel entries of the 128 non-tile rows, dense
   const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
   long long tc[6] = {0, 0, 0, 0, 0, 0};
-  const long long t_begin = clock64(), r_begin = wall_clock64();
+  const long long t_begin = clock64();
 
   // block load, lower triangle only (plus the diagonal pair): 16-byte loads, 8 in flight
 #pragma unroll
@@ -194,162 +192,145 @@ __global__ __launch_bounds__(256) void potf2_aug_kernel(double* Akk, int64_t lda
   for (int p = 0; p < NB / 16; ++p) {
     const int c0 = 16 * p;
     const int ntop = NB - 16 - c0;  // rows below the tile
+    // ---- phase A: one lane per row, column elimination in registers
     long long t0 = clock64();
-    // ---- phase 1 (wave 0): tile Cholesky + inverse, lane-redundant, straight-line
-    if (w == 0 && !(skip & 1)) {
-      Tile16 T;
+    if (!(skip & 1)) {
+      // role of this lane: tile row (l < 16), other row o = 32 w + (l - 16) (16 <= l < 48), or idle
+      const bool is_tile = l < 16;
+      const int o = 32 * w + (l - 16);
+      const bool is_other = l >= 16 && l < 48;
+      const bool below = is_other && o < ntop;
+      const int srow = is_tile ? c0 + l : (below ? c0 + 16 + o : o - ntop);  // row of S (aug: identity row r)
+      // branch-free loads: every lane reads 16 in-range words of its row; a 16-bit mask per lane
+      // (bit c = entry c is a real entry of this row) drives the selects.  Bit tricks instead of
+      // boolean expressions: hipcc turns short-circuit logic on divergent values into branches.
+      const bool is_aug = is_other && !below;
+      const bool live = is_tile || is_other;
+      const int rrow = live ? srow : 0;
+      const int t = srow - c0;                       // aug rows: first panel column that is right of the diagonal is t + 1
+      const unsigned upto_l = (2u << (l & 15)) - 1u;  // bits 0..l
+      const unsigned right_of_diag = t < 0 ? 0xFFFFu : (t >= 15 ? 0u : (0xFFFFu & ~((2u << (t & 15)) - 1u)));
+      const unsigned keep_r = is_tile ? upto_l : (below ? 0xFFFFu : (is_aug ? right_of_diag : 0u));
+      const unsigned diag_m = (is_aug && t >= 0 && t < 16) ? (1u << (t & 15)) : 0u;
+      const double* rp = S + rrow * SP + c0;
+      const double bdv = bd[rrow];
+      double a[16];
 #pragma unroll
-      for (int i = 0; i < 16; ++i)
+      for (int c = 0; c < 16; ++c) a[c] = rp[c];
+      // pin the 16 loads (issued back to back, one wait): hipcc would otherwise sink each of them
+      // into its select as an exec-masked branch with its own s_waitcnt
+      asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
+                        "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]),
+                        "+v"(a[15]));
 #pragma unroll
-        for (int c = 0; c <= i; ++c) T.at(i, c) = S[(c0 + i) * SP + c0 + c];  // broadcast reads
-      double rinv[16];
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const double pj = T.at(j, j);
-        double sj, yj;
-        sqrt_rsqrt(pj, sj, yj);
-        const bool ok = pj > 0.0;
-        if (!ok && bad == 0) bad = kblock * NB + c0 + j + 1;
-        sj = ok ? sj : 0.0;
-        yj = ok ? yj : 0.0;
-        rinv[j] = yj;
-        T.at(j, j) = sj;
-#pragma unroll
-        for (int i = j + 1; i < 16; ++i) T.at(i, j) *= yj;
-#pragma unroll
-        for (int c = j + 1; c < 16; ++c)
-#pragma unroll
-          for (int i = c; i < 16; ++i) T.at(i, c) = fma(-T.at(i, j), T.at(c, j), T.at(i, c));
-      }
-      // column (l & 15) of W = L^-1 by forward substitution on a unit vector: lanes work in parallel
-      const int wc = l & 15;
-      double wv[16];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        double acc = (i == wc) ? 1.0 : 0.0;
-#pragma unroll
-        for (int k = 0; k < i; ++k) acc = fma(-T.at(i, k), wv[k], acc);
-        wv[i] = acc * rinv[i];   // entries above the diagonal (i < wc) come out exactly 0
-      }
-      if (l < 16) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) Wt[i * PP + wc] = wv[i];
-      }
-      if (l == 0) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i)
-#pragma unroll
-          for (int c = 0; c <= i; ++c) S[(c0 + i) * SP + c0 + c] = T.at(i, c);
-      }
-    }
-    tc[0] += clock64() - t0;
-    t0 = clock64();
-    // ---- phase 2a: dense copy of the other 128 rows' panel entries (identity rows unmasked here)
-    const bool top = tid < ntop;
-    const int row = top ? (c0 + 16 + tid) : (tid - ntop);  // S row (bottom: identity row r)
-    if (tid < NB && !(skip & 2)) {
-      double x[16];  // all loads first, then all stores: LDS reads are not serialised behind the writes
+      for (int c = 0; c < 16; ++c) a[c] = ((keep_r >> c) & 1u) ? a[c] : (((diag_m >> c) & 1u) ? bdv : 0.0);
+      tc[0] += clock64() - t0;
+      t0 = clock64();
+      double sdiag = 0.0;  // tile lane l: L[l][l]
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
-        const int col = c0 + c;
-        if (top)
-          x[c] = S[row * SP + col];
-        else
-          x[c] = col > row ? S[row * SP + col] : (col == row ? bd[row] : 0.0);
+        // left-looking: bring entry c of every row up to date with row c of the tile factor
+        // (broadcast from lane c, consumed at once: short SGPR live ranges), two accumulators
+        double acc0 = a[c], acc1 = 0.0;
+#pragma unroll
+        for (int j = 0; j < c; ++j) {
+          const double lcj = readlane_f64(a[j], c);
+          if (j & 1)
+            acc1 = fma(-a[j], lcj, acc1);
+          else
+            acc0 = fma(-a[j], lcj, acc0);
+        }
+        a[c] = acc0 + acc1;
+        // pivot: rsq + two Newton steps, scale the column
+        const double pc = readlane_f64(a[c], c);
+        double yc = __builtin_amdgcn_rsq(pc);
+        const double hc = -0.5 * pc;
+        yc = yc * fma(hc * yc, yc, 1.5);
+        yc = yc * fma(hc * yc, yc, 1.5);
+        if (!(pc > 0.0) && bad == 0) bad = kblock * NB + c0 + c + 1;  // NaNs follow; the caller discards
+        a[c] = a[c] * yc;
+        double sc = pc * yc;                       // sqrt(p) with one correction step, off the chain
+        sc = fma(0.5 * fma(-sc, sc, pc), yc, sc);
+        if (l == c) sdiag = sc;
       }
+      if (is_tile) {
 #pragma unroll
-      for (int c = 0; c < 16; c += 2) *reinterpret_cast<double2*>(P2 + tid * PP + c) = make_double2(x[c], x[c + 1]);
-    }
-    __syncthreads();
-    tc[1] += clock64() - t0;
-    t0 = clock64();
-    // ---- phase 2b: X = P W^T on the matrix cores, two 16-row tiles per wave, in place
-    if (!(skip & 2)) {
-      double av[2][4], bv[4];
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        bv[kk] = Wt[(l & 15) * PP + 4 * kk + (l >> 4)];  // B[k][c] = W[c][k]
-#pragma unroll
-        for (int m = 0; m < 2; ++m) av[m][kk] = P2[((2 * w + m) * 16 + (l & 15)) * PP + 4 * kk + (l >> 4)];
+        for (int c = 0; c < 16; ++c)
+          if (c == l) a[c] = sdiag;
       }
-      v4d x[2];
+      tc[1] += clock64() - t0;
+      t0 = clock64();
+      // write back, branch-free: masked-off words go to a per-lane trash slot.  Tile rows (wave 0
+      // only, lower part) and other rows into S / bd; other rows also densely into P2.
+      {
+        double* wp = S + rrow * SP + c0;
+        double* trash = P2 + NB * PP + 2 * l;
+        const unsigned keep_w = is_tile ? (w == 0 ? upto_l : 0u) : keep_r;
+        double bdn = bdv;
 #pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        x[m] = (v4d){0, 0, 0, 0};
+        for (int c = 0; c < 16; ++c) {
+          double* dst = ((keep_w >> c) & 1u) ? wp + c : trash;
+          *dst = a[c];
+          bdn = ((diag_m >> c) & 1u) ? a[c] : bdn;
+        }
+        double* bdp = diag_m ? bd + rrow : trash + 1;
+        *bdp = bdn;
+        if (is_other) {
+          double* pp = P2 + o * PP;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) x[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m][kk], bv[kk], x[m], 0, 0, 0);
+          for (int c = 0; c < 16; c += 2) *reinterpret_cast<double2*>(pp + c) = make_double2(a[c], a[c + 1]);
+        }
       }
-      // each wave owns its two row tiles: reads above are complete (registers) before these writes
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) P2[((2 * w + m) * 16 + (l >> 4) + 4 * r) * PP + (l & 15)] = x[m][r];
     }
     __syncthreads();
     tc[2] += clock64() - t0;
     t0 = clock64();
-    // ---- phase 2c: solved panel entries back into S / bd (columns of the panel only)
-    if (tid < NB && !(skip & 2)) {
-      double x[16];
-#pragma unroll
-      for (int c = 0; c < 16; c += 2) {
-        const double2 v = *reinterpret_cast<const double2*>(P2 + tid * PP + c);
-        x[c] = v.x;
-        x[c + 1] = v.y;
-      }
-#pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        const int col = c0 + c;
-        if (top || col > row)
-          S[row * SP + col] = x[c];
-        else if (col == row)
-          bd[row] = x[c];
-      }
-    }
-    tc[3] += clock64() - t0;
-    t0 = clock64();
-    // ---- phase 3: rank-16 update right of the panel, one 16x16 MFMA tile at a time per wave.
-    // Cholesky rows: tiles (a >= b) of the ntop x ntop lower triangle; identity rows: (rt <= p, b).
+    // ---- phase B: rank-16 update right of the panel.  Tile rows [0, Tn): Cholesky rows (columns
+    // b <= tr, lower triangle); [Tn, Tn + p + 1): identity rows rt = tr - Tn (all Tn columns).
     const int Tn = ntop / 16;
-    const int ntiles = Tn * (Tn + 1) / 2 + (p + 1) * Tn;
     if (!(skip & 4)) {
-      for (int t = w; t < ntiles; t += 4) {
-        int prow, pcol, srow, diag = 0;
-        if (t < Tn * (Tn + 1) / 2) {
-          int a = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-          while (a * (a + 1) / 2 > t) --a;
-          while ((a + 1) * (a + 2) / 2 <= t) ++a;
-          const int b2 = t - a * (a + 1) / 2;
-          prow = 16 * a;
-          pcol = 16 * b2;
-          srow = c0 + 16 + 16 * a;
-          diag = (a == b2);
-        } else {
-          const int u = t - Tn * (Tn + 1) / 2;
-          const int rt = u / Tn;
-          pcol = 16 * (u - rt * Tn);
-          prow = ntop + 16 * rt;
-          srow = 16 * rt;
-        }
-        const int scol = c0 + 16 + pcol;
-        v4d c;
+      const int R = Tn + p + 1;
+      for (int tr = w; tr < R; tr += 4) {
+        const bool chol = tr < Tn;
+        const int prow = chol ? 16 * tr : ntop + 16 * (tr - Tn);
+        const int srow = chol ? c0 + 16 + 16 * tr : 16 * (tr - Tn);
+        const int ncol = chol ? tr + 1 : Tn;
+        double am[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) c[r] = S[(srow + (l >> 4) + 4 * r) * SP + scol + (l & 15)];
+        for (int kk = 0; kk < 4; ++kk) am[kk] = -P2[(prow + (l & 15)) * PP + 4 * kk + (l >> 4)];
+        for (int b = 0; b < ncol; b += 2) {
+          const bool two = b + 1 < ncol;
+          const int b1 = two ? b + 1 : b;
+          const int sc0 = c0 + 16 + 16 * b, sc1 = c0 + 16 + 16 * b1;
+          double bv0[4], bv1[4];
+          v4d x0, x1;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-          const double a_ = -P2[(prow + (l & 15)) * PP + 4 * kk + (l >> 4)];
-          const double b_ = P2[(pcol + (l & 15)) * PP + 4 * kk + (l >> 4)];
-          c = __builtin_amdgcn_mfma_f64_16x16x4f64(a_, b_, c, 0, 0, 0);
-        }
+          for (int kk = 0; kk < 4; ++kk) {
+            bv0[kk] = P2[(16 * b + (l & 15)) * PP + 4 * kk + (l >> 4)];
+            bv1[kk] = P2[(16 * b1 + (l & 15)) * PP + 4 * kk + (l >> 4)];
+          }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int rr = (l >> 4) + 4 * r, cc = l & 15;
-          if (!diag || cc <= rr) S[(srow + rr) * SP + scol + cc] = c[r];
+          for (int r = 0; r < 4; ++r) {
+            x0[r] = S[(srow + (l >> 4) + 4 * r) * SP + sc0 + (l & 15)];
+            x1[r] = S[(srow + (l >> 4) + 4 * r) * SP + sc1 + (l & 15)];
+          }
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(am[kk], bv0[kk], x0, 0, 0, 0);
+            x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(am[kk], bv1[kk], x1, 0, 0, 0);
+          }
+          const bool d0 = chol && b == tr, d1 = chol && b1 == tr;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int rr = (l >> 4) + 4 * r, cc = l & 15;
+            if (!d0 || cc <= rr) S[(srow + rr) * SP + sc0 + cc] = x0[r];
+            if (two && (!d1 || cc <= rr)) S[(srow + rr) * SP + sc1 + cc] = x1[r];
+          }
         }
       }
     }
     __syncthreads();
-    tc[4] += clock64() - t0;
+    tc[3] += clock64() - t0;
   }
   if (bad != 0 && tid == 0) atomicCAS(info, 0, bad);
   const long long t_mid = clock64();
@@ -380,12 +361,11 @@ __global__ __launch_bounds__(256) void potf2_aug_kernel(double* Akk, int64_t lda
       *reinterpret_cast<double2*>(W11 + i * NB + c) = q;
     }
   }
-  if ((skip & 8) && tid == 0) {  // developer probe: cycle counts (shader clock) and 100 MHz wall ticks
+  if ((skip & 8) && tid == 0) {  // developer probe: shader-clock cycle counts
     double* dbg = W11 + NB * NB;
-    for (int q = 0; q < 5; ++q) dbg[q] = (double)tc[q];
-    dbg[5] = (double)(t_mid - t_begin);
-    dbg[6] = (double)(clock64() - t_begin);
-    dbg[7] = (double)(wall_clock64() - r_begin);
+    for (int q = 0; q < 4; ++q) dbg[q] = (double)tc[q];
+    dbg[4] = (double)(t_mid - t_begin);
+    dbg[5] = (double)(clock64() - t_begin);
   }
 }
 
@@ -610,15 +590,19 @@ int gp_factorize_impl(elfihip_gp* gp) {
   P.W11 = gp->W11;
   P.lda = gp->lda;
   P.nb = nb;
-  // Two streams: `hi` carries the critical path  potf2(k) -> trsm(k) -> update of block column
-  // k+1,  `st` carries the bulk of the trailing update (block columns >= k+2), which overlaps the
-  // next panel factorisation.  Hazards: the column-(k+1) update must follow the previous bulk
-  // update (same tiles), the bulk update must follow trsm(k) (reads its panels).
+  // Two streams besides the caller's: `hi` carries the critical path  potf2(k) -> trsm(k) -> update of
+  // block column k+1  and is confined (CU mask) to a few reserved XCDs, `bulk` carries the rest of the
+  // trailing update (block columns >= k+2) on the other XCDs, overlapping the next panel
+  // factorisation.  Without the partition the bulk tiles fill every CU's registers and LDS and the
+  // short critical kernels queue behind them (rocprof: 41 us for a 5 us column update).
+  // Hazards: the column-(k+1) update must follow the previous bulk update (same tiles), the bulk
+  // update must follow trsm(k) (reads its panels).
   ELFIHIP_TRY(ctx_aux(ctx));
-  hipStream_t hi = ctx->hi_stream;
-  ELFIHIP_CHECK_HIP(ctx, hipEventRecord(ctx->ev_b, st));  // 'previous bulk update' of step -1
+  hipStream_t hi = ctx->hi_stream, bulk = ctx->bulk_stream;
   ELFIHIP_CHECK_HIP(ctx, hipEventRecord(ctx->ev_a, st));
   ELFIHIP_CHECK_HIP(ctx, hipStreamWaitEvent(hi, ctx->ev_a, 0));
+  ELFIHIP_CHECK_HIP(ctx, hipStreamWaitEvent(bulk, ctx->ev_a, 0));
+  bool bulk_pending = false;
   for (int k = 0; k < nb; ++k) {
     P.k = k;
     double* Akk = gp->A + ((int64_t)k * NB) * gp->lda + (int64_t)k * NB;
@@ -629,21 +613,26 @@ int gp_factorize_impl(elfihip_gp* gp) {
     hipLaunchKernelGGL(trsm_gemm_kernel, dim3(4 * nrows), dim3(256), GEMM32_LDS_DOUBLES * sizeof(double), hi, P);
     const int m = nb - 1 - k;
     if (m > 0) {
-      ELFIHIP_CHECK_HIP(ctx, hipEventRecord(ctx->ev_a, hi));       // trsm(k) done
-      ELFIHIP_CHECK_HIP(ctx, hipStreamWaitEvent(hi, ctx->ev_b, 0));  // previous bulk update done
+      // column k+1 first and alone (it gates the next diagonal block), then the bulk of step k, which
+      // runs in the shadow of potf2(k+1) / trsm(k+1) on the other stream
+      if (bulk_pending) ELFIHIP_CHECK_HIP(ctx, hipStreamWaitEvent(hi, ctx->ev_b, 0));  // bulk(k-1) wrote column k+1
       hipLaunchKernelGGL(trailing_update_col_kernel, dim3(4 * (m + 1 + (k + 1))), dim3(256),
                          GEMM32_LDS_DOUBLES * sizeof(double), hi, P, k + 1);
       if (m > 1) {
         const int mc = m - 1;
         const int tiles = mc * (mc + 1) / 2 + mc + (k + 1) * mc;
-        ELFIHIP_CHECK_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_a, 0));
-        hipLaunchKernelGGL(trailing_update_kernel, dim3(tiles), dim3(256), gemm_lds, st, P, k + 2, 0);
-        ELFIHIP_CHECK_HIP(ctx, hipEventRecord(ctx->ev_b, st));
+        ELFIHIP_CHECK_HIP(ctx, hipEventRecord(ctx->ev_a, hi));        // trsm(k) and column k+1 done
+        ELFIHIP_CHECK_HIP(ctx, hipStreamWaitEvent(bulk, ctx->ev_a, 0));
+        hipLaunchKernelGGL(trailing_update_kernel, dim3(tiles), dim3(256), gemm_lds, bulk, P, k + 2, 0);
+        ELFIHIP_CHECK_HIP(ctx, hipEventRecord(ctx->ev_b, bulk));
+        bulk_pending = true;
       }
     }
   }
   ELFIHIP_CHECK_HIP(ctx, hipEventRecord(ctx->ev_a, hi));
   ELFIHIP_CHECK_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_a, 0));
+  ELFIHIP_CHECK_HIP(ctx, hipEventRecord(ctx->ev_b, bulk));
+  ELFIHIP_CHECK_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_b, 0));
   ELFIHIP_TRY(launch_status(ctx, "cholesky sweep"));
   const double* z = gp->A + np * gp->lda;  // row np of A: z = L^-1 y
   hipLaunchKernelGGL(alpha_kernel, dim3((unsigned)((np * 64 + 255) / 256)), dim3(256), 0, st, gp->WT, z, gp->alpha,
@@ -800,10 +789,10 @@ int elfihip_debug_potf2(elfihip_gp* gp, int skip, int reps, float* ms) {
   ELFIHIP_CHECK_HIP(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
   *ms /= (float)reps;
   if (skip & 8) {
-    double dbg[8];
+    double dbg[6];
     ELFIHIP_CHECK_HIP(ctx, hipMemcpy(dbg, gp->W11 + NB * NB, sizeof dbg, hipMemcpyDeviceToHost));
-    fprintf(stderr, "potf2 cycles: p1 %.0f p2a %.0f p2b %.0f p2c %.0f p3 %.0f | loop-end %.0f total %.0f | wall100MHz %.0f\n",
-            dbg[0], dbg[1], dbg[2], dbg[3], dbg[4], dbg[5], dbg[6], dbg[7]);
+    fprintf(stderr, "potf2 cycles: A-load %.0f A-elim %.0f A-store+barrier %.0f B+barrier %.0f | loop-end %.0f total %.0f\n", dbg[0],
+            dbg[1], dbg[2], dbg[3], dbg[4], dbg[5]);
   }
   return ELFIHIP_OK;
 }
