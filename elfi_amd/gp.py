@@ -72,6 +72,15 @@ class GPHandle:
         self._check(self.lib.elfihip_gp_append(self.h, _lib.ptr(X), _lib.ptr(y), X.shape[0]))
         self.n += X.shape[0]
 
+    def extend(self, X, y):
+        """Append evidence and update the factorisation by bordering (O(n^2) per point)."""
+        X = np.ascontiguousarray(X, dtype=np.float64).reshape(-1, self.d)
+        y = np.ascontiguousarray(y, dtype=np.float64).reshape(-1)
+        lz = C.c_double()
+        self._check(self.lib.elfihip_gp_extend(self.h, _lib.ptr(X), _lib.ptr(y), X.shape[0], C.byref(lz)))
+        self.n += X.shape[0]
+        return lz.value
+
     def factorize(self):
         lz = C.c_double()
         self._check(self.lib.elfihip_gp_factorize(self.h, C.byref(lz)))
@@ -348,12 +357,21 @@ class HipGPRegression:
             old.close()
         return True
 
+    # Points added per update() up to which the factorisation is extended by bordering (O(n^2) each)
+    # instead of rebuilt (O(n^3)); the reference always rebuilds (gpy_regression.py:304-312), the
+    # results agree to rounding.  0 disables the incremental path.
+    incremental_limit = 64
+
     def _append_and_fit(self, x, y):
         n_old = self._X.shape[0]
         self._X = np.r_[self._X, x]
         self._Y = np.r_[self._Y, y]
         if self._ensure_capacity(self._X.shape[0]) or n_old != self._handle.n:
             self._handle.set_data(self._X, self._Y)
+        elif (0 < x.shape[0] <= self.incremental_limit and n_old > 0
+              and getattr(self, '_fitted_hyper', None) == self._hyper):
+            self._log_marginal = self._handle.extend(x, y)   # hyper-parameters unchanged since the last fit
+            return
         else:
             self._handle.append(x, y)
         self._refit()
@@ -362,6 +380,7 @@ class HipGPRegression:
         h = self._hyper
         self._handle.set_hyper(h['var'], h['ls'], h['bias'], h['noise'])
         self._log_marginal = self._handle.factorize()
+        self._fitted_hyper = dict(h)
 
     def update(self, x, y, optimize=False):
         """Add evidence and rebuild the GP (gpy_regression.py:286-315)."""

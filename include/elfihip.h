@@ -156,6 +156,13 @@ int elfihip_gp_nlml_grad(elfihip_gp* gp, double* log_marginal, double* grad);
 /* Materialise K^-1 (GPy's posterior.woodbury_inv, read by gpy_regression.py:158) for
  * elfihip_gp_get(gp, 5, ...).  Not needed by predict / gradients / nlml_grad. */
 int elfihip_gp_form_kinv(elfihip_gp* gp);
+/* GPyRegression.update with unchanged hyper-parameters (what elfi.BOLFI does for every batch between
+ * two hyper-parameter optimisations, bolfi.py:219 -> gpy_regression.py:304-312): append k evidence
+ * points and bring L, L^-T, alpha and the log marginal up to date by bordering -- one new row /
+ * column per point, two passes over L^-T (O(n^2)) instead of the O(n^3) rebuild the reference
+ * performs.  Same result as elfihip_gp_append + elfihip_gp_factorize to rounding.  Falls back to
+ * exactly that when the GP is not factorised yet or the padded size (multiple of 128) grows. */
+int elfihip_gp_extend(elfihip_gp* gp, const double* X_new, const double* y_new, int64_t k, double* log_marginal);
 int elfihip_gp_size(const elfihip_gp* gp, int64_t* n, int64_t* capacity, int* d);
 /* Copy state to the host: 0 = L (n*n lower), 1 = L^-T (n*n upper), 2 = alpha (n),
  * 3 = X (n*d), 4 = y (n), 5 = K^-1 (n*n, after elfihip_gp_form_kinv). */

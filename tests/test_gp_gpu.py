@@ -128,7 +128,8 @@ def test_update_matches_rebuild(hip_ctx):
     m2._refit()
     xs = np.random.RandomState(1).uniform(-2, 2, (5, 2))
     a, b2 = m1.predict(xs), m2.predict(xs)
-    assert np.array_equal(a[0], b2[0]) and np.array_equal(a[1], b2[1])
+    _close(a[0], b2[0], 1e-9, 'mu: incremental updates vs one rebuild')
+    _close(a[1], b2[1], 1e-9, 'var: incremental updates vs one rebuild')
     assert m1.n_evidence == 260 and m1.X.shape == (260, 2) and m1.Y.shape == (260, 1)
     ref = G.Posterior(X, y, **{k: m1._hyper[k] for k in ('var', 'ls', 'bias', 'noise')})
     _close(a[0], ref.predict(xs)[0], 1e-8, 'mu after updates')
@@ -157,3 +158,57 @@ def test_metric_shape_n4096_d10(hip_ctx):
     assert np.all(var > 0) and np.all(var < h['var'] + h['bias'])
     kx = G.kern_K(X, X[:32], h['var'], h['ls'], h['bias'])
     assert np.max(np.abs(mu - kx.T @ alpha)) <= 1e-9 * np.max(np.abs(mu))
+
+
+@pytest.mark.parametrize('n0,k,d', [(100, 5, 2), (127, 1, 3), (128, 3, 2), (250, 10, 4), (1000, 30, 10)])
+def test_extend_matches_rebuild(hip_ctx, n0, k, d):
+    """Bordering (elfihip_gp_extend) == append + full factorisation, incl. crossing a 128 boundary."""
+    from elfi_amd.gp import GPHandle
+    X, y, bounds = _problem(n0 + k, d, seed=n0 + k)
+    h = G.default_hyper(bounds, y)
+    a = GPHandle(d, n0 + k)
+    a.set_hyper(h['var'], h['ls'], h['bias'], h['noise'])
+    a.set_data(X[:n0], y[:n0])
+    a.factorize()
+    lz_a = a.extend(X[n0:], y[n0:])
+    b = GPHandle(d, n0 + k)
+    b.set_hyper(h['var'], h['ls'], h['bias'], h['noise'])
+    b.set_data(X, y)
+    lz_b = b.factorize()
+    ref = G.Posterior(X, y, h['var'], h['ls'], h['bias'], h['noise'])
+    assert abs(lz_a - lz_b) <= 1e-10 * abs(lz_b) and abs(lz_a - ref.log_marginal) <= 1e-9 * abs(ref.log_marginal)
+    for which, tol in ((0, 1e-10), (1, 1e-9), (2, 1e-8)):
+        _close(a.get(which), b.get(which), tol, 'extend vs rebuild, item %d' % which)
+    _close(a.get(0), ref.L, 1e-10, 'L after extend')
+    xs = np.random.RandomState(1).uniform(-2, 2, (6, d))
+    ma, va = a.predict(xs, noiseless=True)
+    rm, rv = ref.predict(xs, noiseless=True)
+    _close(ma, rm, 1e-8, 'mu after extend')
+    assert np.max(np.abs(va - rv)) <= 1e-8 * (ref.var + ref.bias)
+    _, _, dmu, dvar = a.predict_grad(xs)
+    gmu, gvar = ref.predictive_gradients(xs)
+    _close(dmu, gmu, 1e-8, 'grad mu after extend')
+    _close(dvar, gvar, 1e-7, 'grad var after extend')
+    _, g = a.nlml_grad()
+    assert np.max(np.abs(g - ref.log_marginal_grad())) <= 1e-7 * np.max(np.abs(g))
+
+
+def test_bolfi_style_updates_use_the_incremental_path(hip_ctx):
+    from elfi_amd import HipGPRegression
+    X, y, bounds = _problem(300, 2, seed=21)
+    names = ['a', 'b']
+    m = HipGPRegression(names, bounds=dict(zip(names, bounds)))
+    m.update(X[:200], y[:200])
+    calls = []
+    orig = m._handle.extend
+    m._handle.extend = lambda *a: (calls.append(1), orig(*a))[1]
+    for i in range(200, 300):
+        m.update(X[i:i + 1], y[i:i + 1])
+    assert len(calls) == 100 and m.n_evidence == 300
+    ref = G.Posterior(X, y, **m._hyper)
+    xs = np.random.RandomState(0).uniform(-2, 2, (7, 2))
+    _close(m.predict(xs)[0], ref.predict(xs)[0], 1e-8, 'mu after 100 single-point updates')
+    assert abs(m._log_marginal - ref.log_marginal) <= 1e-9 * abs(ref.log_marginal)
+    m._hyper = dict(m._hyper, ls=0.7)      # a hyper-parameter change forces a rebuild
+    m.update(X[:1], y[:1])
+    assert len(calls) == 100
