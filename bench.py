@@ -145,13 +145,20 @@ def main():
     # one independent batch per rank (seeded by rank), observed row from a fixed seed.
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
-    X = torch.randn(n, m, dtype=torch.float64, device=dev, generator=gen)
+    # NBUF independent batches, visited round-robin: the working set (NBUF x 8nm bytes) exceeds the
+    # 256 MiB Infinity Cache, so every step streams its batch from HBM instead of re-hitting the MALL
+    NBUF = 3
+    Xs = [torch.randn(n, m, dtype=torch.float64, device=dev, generator=gen) for _ in range(NBUF)]
     y = torch.from_numpy(np.random.RandomState(1).randn(1, m)).to(dev)
     out = torch.empty(n, dtype=torch.float64, device=dev)
     gathered = [torch.empty(n, dtype=torch.float64, device=dev) for _ in range(world)] \
         if (world > 1 and rank == 0) else None
 
+    counter = [0]
+
     def step():
+        X = Xs[counter[0] % NBUF]
+        counter[0] += 1
         ctx.call("elfihip_dist_rows_dev", 0, X.data_ptr(), n, m, m, y.data_ptr(), None,
                  2.0, out.data_ptr())
 
@@ -190,6 +197,7 @@ def main():
     if rank == 0:
         import distance_oracle as O
         idx = np.arange(0, n, max(1, n // 4096))[:4096]
+        X = Xs[(counter[0] - 1) % NBUF]   # the batch of the last step
         ref = O.cdist_rows(X[idx].cpu().numpy(), y.cpu().numpy(), 'euclidean')
         assert np.array_equal(out[idx].cpu().numpy(), ref), "bench output differs from the oracle"
 
@@ -204,10 +212,11 @@ def main():
             "config": {"workload": "configs[1]: synthetic Gaussian summaries, %d samples x %d summaries per "
                                    "GPU per step, elfi.Distance('euclidean'), inputs resident in HBM" % (n, m),
                        "samples_per_gpu": n, "summaries": m, "layout": "row-major (n,m) f64",
+                       "batches_in_rotation": NBUF,
                        "exchange": "one RCCL gather of the final distance shard per job" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "dist_rows_kernel<euclidean>", "kernel_ms": kernel_ms,
+                         "kernel": "dist_rows_pipe_kernel<euclidean>", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "frac_of_measured_copy_peak_6290": achieved / 6290.0},
         }

@@ -101,6 +101,7 @@ struct RowArgs {
   int m, mp;      // mp = m | 1: LDS row pitch in doubles
   int K;          // multi-weight: number of weight rows in aux
   int vec2;       // 16-byte loads are legal (m, ldx even; X 16-byte aligned)
+  int R;          // pipelined kernels: rows per tile (<= blockDim.x); T * U >= R * m / 2
   FastDiv div_h;  // by m/2 (vec2) or m
 };
 
@@ -154,6 +155,121 @@ __device__ __forceinline__ void load_tile(const RowArgs& A, double* tile, int64_
       for (int u = 0; u < U; ++u) {
         uint32_t idx = base + (uint32_t)(u * T + tid);
         if (idx < nel) tile[r[u] * (uint32_t)A.mp + j[u]] = v[u];
+      }
+    }
+  }
+}
+
+// ---- software-pipelined tile streaming (16-byte loads, whole tile in one batch) -------------
+// fetch: issue the global loads of one tile into registers (nothing waits on them here);
+// commit: drop the registers into the LDS tile.  With the loads of tile t+1 issued before the
+// row sums of tile t are computed, every workgroup keeps a full tile of HBM requests in flight
+// while it does its LDS/VALU work, instead of alternating between the two.
+template <int U>
+__device__ __forceinline__ void tile_fetch(const RowArgs& A, int64_t row0, int rows, double2 (&v)[U]) {
+  const int T = blockDim.x, tid = threadIdx.x;
+  const double* __restrict__ X = A.X + row0 * A.ldx;
+  const uint32_t h = (uint32_t)A.m >> 1;
+  const uint32_t npairs = (uint32_t)rows * h;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const uint32_t idx = (uint32_t)(u * T + tid);
+    const bool ok = idx < npairs;
+    const uint32_t q = fastdiv(ok ? idx : 0u, A.div_h);
+    const uint32_t jj = (ok ? idx : 0u) - q * h;
+    v[u] = make_double2(0.0, 0.0);
+    if (ok) v[u] = *reinterpret_cast<const double2*>(X + (int64_t)q * A.ldx + 2 * jj);
+  }
+}
+
+template <int U>
+__device__ __forceinline__ void tile_commit(const RowArgs& A, double* tile, int rows, const double2 (&v)[U]) {
+  const int T = blockDim.x, tid = threadIdx.x;
+  const uint32_t h = (uint32_t)A.m >> 1;
+  const uint32_t npairs = (uint32_t)rows * h;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const uint32_t idx = (uint32_t)(u * T + tid);
+    if (idx < npairs) {
+      const uint32_t q = fastdiv(idx, A.div_h);
+      const uint32_t jj = idx - q * h;
+      double* dst = tile + q * (uint32_t)A.mp + 2 * jj;
+      dst[0] = v[u].x;
+      dst[1] = v[u].y;
+    }
+  }
+}
+
+// Pipelined form of dist_rows_kernel: requires vec2 and T * U >= T * m / 2 (whole tile per batch).
+template <int METRIC, bool W, int U>
+__global__ __launch_bounds__(256) void dist_rows_pipe_kernel(RowArgs A) {
+  extern __shared__ __align__(16) double lds[];
+  const int T = blockDim.x, tid = threadIdx.x, m = A.m;
+  double* tile = lds;
+  const int R = A.R;
+  double* ys = tile + (size_t)R * A.mp;
+  double* as = ys + m;
+  for (int j = tid; j < m; j += T) {
+    ys[j] = A.y[j];
+    if constexpr (W) as[j] = A.aux[j];
+  }
+  const int64_t ntiles = (A.n + R - 1) / R;
+  double2 v[U];
+  int64_t t = blockIdx.x;
+  if (t < ntiles) tile_fetch<U>(A, t * R, (int)((A.n - t * R) < R ? (A.n - t * R) : R), v);
+  for (; t < ntiles; t += gridDim.x) {
+    const int64_t row0 = t * R;
+    const int rows = (int)((A.n - row0) < R ? (A.n - row0) : R);
+    __syncthreads();  // tile free (previous readers done); ys/as visible on the first trip
+    tile_commit<U>(A, tile, rows, v);
+    const int64_t tn = t + gridDim.x;
+    if (tn < ntiles) tile_fetch<U>(A, tn * R, (int)((A.n - tn * R) < R ? (A.n - tn * R) : R), v);
+    __syncthreads();
+    if (tid < rows) {
+      const double* row = tile + (size_t)tid * A.mp;
+      double s = Op<METRIC, W>::init();
+#pragma unroll 8
+      for (int j = 0; j < m; ++j) s = Op<METRIC, W>::step(s, row[j], ys[j], W ? as[j] : 1.0, A.p);
+      A.out[row0 + tid] = Op<METRIC, W>::finish(s, A.inv_p);
+    }
+  }
+}
+
+// Pipelined K-weight form (AdaptiveDistance.nested_distance).
+template <int U>
+__global__ __launch_bounds__(256) void dist_multiw_pipe_kernel(RowArgs A) {
+  extern __shared__ __align__(16) double lds[];
+  const int T = blockDim.x, tid = threadIdx.x, m = A.m, K = A.K;
+  double* tile = lds;
+  const int R = A.R;
+  double* ys = tile + (size_t)R * A.mp;
+  double* ws = ys + m;  // (K, m)
+  for (int j = tid; j < m; j += T) ys[j] = A.y[j];
+  for (int j = tid; j < K * m; j += T) ws[j] = A.aux[j];
+  const int64_t ntiles = (A.n + R - 1) / R;
+  double2 v[U];
+  int64_t t = blockIdx.x;
+  if (t < ntiles) tile_fetch<U>(A, t * R, (int)((A.n - t * R) < R ? (A.n - t * R) : R), v);
+  for (; t < ntiles; t += gridDim.x) {
+    const int64_t row0 = t * R;
+    const int rows = (int)((A.n - row0) < R ? (A.n - row0) : R);
+    __syncthreads();
+    tile_commit<U>(A, tile, rows, v);
+    const int64_t tn = t + gridDim.x;
+    if (tn < ntiles) tile_fetch<U>(A, tn * R, (int)((A.n - tn * R) < R ? (A.n - tn * R) : R), v);
+    __syncthreads();
+    if (tid < rows) {
+      double* row = tile + (size_t)tid * A.mp;
+      for (int j = 0; j < m; ++j) {  // (x-y)^2 once, reused by every weight vector
+        double d = row[j] - ys[j];
+        row[j] = d * d;
+      }
+      for (int k = 0; k < K; ++k) {
+        const double* w = ws + (size_t)k * m;
+        double s = 0.0;
+#pragma unroll 4
+        for (int j = 0; j < m; ++j) s = s + w[j] * row[j];
+        A.out[(row0 + tid) * K + k] = sqrt(s);
       }
     }
   }
@@ -393,6 +509,20 @@ static int launch_rows(elfihip_ctx* ctx, RowArgs A) {
   const int T = pick_block(A.m, 2 * (size_t)A.m, &lds);
   const int64_t ntiles = (A.n + T - 1) / T;
   const int g = grid_for(ctx, ntiles, lds, T);
+  if (A.vec2 && A.m <= 128) {
+    // pipelined form: 128 threads, 16 (m <= 16: 8) register pairs each = one whole tile of R rows
+    const int Tp = 128, U = A.m <= 16 ? 8 : 16;
+    int R = 2 * Tp * U / A.m;
+    if (R > Tp) R = Tp;
+    A.R = R;
+    const size_t ldsp = ((size_t)R * A.mp + 2 * (size_t)A.m) * sizeof(double);
+    const int gp = grid_for(ctx, (A.n + R - 1) / R, ldsp, Tp);
+    if (U == 8)
+      hipLaunchKernelGGL((dist_rows_pipe_kernel<METRIC, W, 8>), dim3(gp), dim3(Tp), ldsp, ctx->stream, A);
+    else
+      hipLaunchKernelGGL((dist_rows_pipe_kernel<METRIC, W, 16>), dim3(gp), dim3(Tp), ldsp, ctx->stream, A);
+    return launch_status(ctx, "dist_rows_pipe_kernel");
+  }
   if (T == 64) {
     ELFIHIP_TRY(set_lds(ctx, dist_rows_kernel<METRIC, W, 16>, lds));
     hipLaunchKernelGGL((dist_rows_kernel<METRIC, W, 16>), dim3(g), dim3(T), lds, ctx->stream, A);
@@ -464,6 +594,7 @@ static RowArgs make_row_args(const double* dX, int64_t n, int m, int64_t ldx, co
   A.m = m;
   A.mp = m | 1;
   A.K = 0;
+  A.R = 0;
   A.vec2 = (m % 2 == 0) && (ldx % 2 == 0) && aligned16(dX);
   A.div_h = make_fastdiv((uint32_t)(A.vec2 ? m / 2 : m));
   return A;
@@ -554,6 +685,18 @@ static int dist_multiw_dev_impl(elfihip_ctx* ctx, const double* dX, int64_t n, i
   int T = pick_block(m, (size_t)m + (size_t)K * m, &lds);
   ELFIHIP_REQUIRE(ctx, lds <= 160 * 1024, "m=%d with K=%d weight vectors does not fit LDS", m, K);
   const int g = grid_for(ctx, (n + T - 1) / T, lds, T);
+  if (A.vec2 && m <= 128) {
+    const int Tp = 128, U = 16;
+    int R = 2 * Tp * U / m;
+    if (R > Tp) R = Tp;
+    A.R = R;
+    const size_t ldsp = ((size_t)R * A.mp + (size_t)m + (size_t)K * m) * sizeof(double);
+    if (ldsp <= 64 * 1024) {
+      const int gp = grid_for(ctx, (n + R - 1) / R, ldsp, Tp);
+      hipLaunchKernelGGL((dist_multiw_pipe_kernel<16>), dim3(gp), dim3(Tp), ldsp, ctx->stream, A);
+      return launch_status(ctx, "dist_multiw_pipe_kernel");
+    }
+  }
   ELFIHIP_TRY(set_lds(ctx, dist_multiw_kernel<8>, lds));
   hipLaunchKernelGGL((dist_multiw_kernel<8>), dim3(g), dim3(T), lds, ctx->stream, A);
   return launch_status(ctx, "dist_multiw_kernel");
