@@ -201,6 +201,17 @@ def main():
         ref = O.cdist_rows(X[idx].cpu().numpy(), y.cpu().numpy(), 'euclidean')
         assert np.array_equal(out[idx].cpu().numpy(), ref), "bench output differs from the oracle"
 
+    # HBM traffic per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 +
+    # WRITE_SIZE, profiles/r01_distance_pmc.md); PMC cannot be sampled from inside this process
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "distance_pmc.json")) as f:
+            pmc = json.load(f)
+        if pmc["n"] == n and pmc["m"] == m:
+            traffic = pmc["traffic_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
+
     result = None
     if rank == 0:
         value = world * n * args.steps / elapsed
@@ -215,7 +226,7 @@ def main():
                        "batches_in_rotation": NBUF,
                        "exchange": "one RCCL gather of the final distance shard per job" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "dist_rows_pipe_kernel<euclidean>", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "frac_of_measured_copy_peak_6290": achieved / 6290.0},
