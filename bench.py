@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--n", type=int, default=10 ** 6, help="samples per GPU per step")
     ap.add_argument("--m", type=int, default=32, help="summaries per sample")
+    ap.add_argument("--workload", choices=["distance", "adaptive"], default="distance",
+                    help="distance: configs[1] (default, the headline); adaptive: configs[3] shape per GPU "
+                         "(1.25e6 x 64, AdaptiveDistance with K=3 nested weights, Welford merge + gather)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bolfi", action="store_true")
     ap.add_argument("--bolfi-iters", type=int, default=5)
@@ -111,6 +114,89 @@ def cpu_baseline_bolfi(n, d, S, budget_s=25.0):
                 ms_fit=1e3 * t_fit, ms_acquire=1e3 * t_acq_full)
 
 
+def run_adaptive(args, ctx, dev, world, rank):
+    """configs[3] per GPU: one SMC-ABC adaptive-distance round on this rank's shard
+    (elfi/model/elfi_model.py:1104-1151): Welford column statistics of the shard, all-gather +
+    fixed-order Chan merge of the (count, mean, M2) triples, K = 3 nested weighted distances of
+    every row, one gather of the (n, 3) distance shard to rank 0.  A step = that whole round."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from elfi_amd import sharding
+    n, m, K = (args.n if args.n != 10 ** 6 else 1250000), (args.m if args.m != 32 else 64), 3
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(100 + rank)
+    X = torch.randn(n, m, dtype=torch.float64, device=dev, generator=gen) * torch.linspace(0.5, 20, m, device=dev,
+                                                                                            dtype=torch.float64)
+    y = torch.from_numpy(np.random.RandomState(1).randn(1, m)).to(dev)
+    out = torch.empty(n, K, dtype=torch.float64, device=dev)
+    state = torch.zeros(1 + 2 * m, dtype=torch.float64, device=dev)
+    W = torch.ones(K, m, dtype=torch.float64, device=dev)
+    gathered = [torch.empty(n, K, dtype=torch.float64, device=dev) for _ in range(world)] \
+        if (world > 1 and rank == 0) else None
+    states = [torch.empty_like(state) for _ in range(world)]
+
+    def step():
+        state.zero_()
+        ctx.call("elfihip_welford_update_dev", X.data_ptr(), n, m, m, state.data_ptr())
+        if world > 1:
+            dist.all_gather(states, state)
+            st = [s.cpu().numpy() for s in states]
+        else:
+            st = [state.cpu().numpy()]
+        N, mean, M2 = sharding.merge_welford([(v[0], v[1:1 + m], v[1 + m:]) for v in st])
+        w2 = 1.0 / (M2 / N)                      # (1/scale)^2, elfi_model.py:1129-1132
+        W[1].copy_(torch.from_numpy(w2))
+        W[2].copy_(torch.from_numpy(w2 * 0.5))   # a third, different weight vector (K = 3)
+        ctx.call("elfihip_dist_multiw_dev", X.data_ptr(), n, m, m, y.data_ptr(), W.data_ptr(), K, out.data_ptr())
+        if world > 1:
+            dist.gather(out, gathered, dst=0)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    torch.cuda.synchronize(dev)
+    ctx.timer_start()
+    for _ in range(args.steps):
+        ctx.call("elfihip_dist_multiw_dev", X.data_ptr(), n, m, m, y.data_ptr(), W.data_ptr(), K, out.data_ptr())
+    kernel_ms = ctx.timer_stop() / args.steps
+    alg_bytes = (8.0 * m + 8.0 * K) * n
+    if rank != 0:
+        return None
+    import distance_oracle as O
+    idx = np.arange(0, n, max(1, n // 2048))[:2048]
+    Wh = W.cpu().numpy()
+    ref = np.column_stack([O.cdist_rows(X[idx].cpu().numpy(), y.cpu().numpy(), 'euclidean', w=Wh[k]) for k in range(K)])
+    assert np.array_equal(out[idx].cpu().numpy(), ref), "adaptive bench output differs from the oracle"
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    return {
+        "metric": "ABC distances/sec", "value": world * n * args.steps / elapsed, "unit": "distances/s (rows; K=3 nested each)",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "configs[3] shape per GPU: AdaptiveDistance round, %d samples x %d summaries, K=%d nested "
+                               "weights, Welford + all-gather/merge + gather" % (n, m, K),
+                   "samples_per_gpu": n, "summaries": m, "K": K,
+                   "exchange": "all_gather of (1+2m) doubles + gather of the (n,K) shard" if world > 1 else "none"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "dist_multiw_pipe_kernel",
+                     "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes},
+    }
+
+
 def main():
     args = parse()
     import numpy as np
@@ -139,6 +225,15 @@ def main():
     stream = torch.cuda.Stream(dev)
     torch.cuda.set_stream(stream)
     ctx.set_stream(stream.cuda_stream)
+
+    if args.workload == "adaptive":
+        result = run_adaptive(args, ctx, dev, world, rank)
+        if rank == 0:
+            print(json.dumps(result), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     n, m = args.n, args.m
     # Synthetic Gaussian simulator outputs: N(0,1) summaries,

@@ -299,3 +299,25 @@ def test_determinism(hip_ctx):
     c1 = elfi_amd.welford_update(X, 0, np.zeros(33), np.zeros(33))
     c2 = elfi_amd.welford_update(X, 0, np.zeros(33), np.zeros(33))
     assert np.array_equal(c1[1], c2[1]) and np.array_equal(c1[2], c2[2])
+
+
+def test_sharding_module_with_the_hip_backend(hip_ctx):
+    """elfi_amd.sharding at world size 1 with the product backend == the oracle's AdaptiveDistance."""
+    from elfi_amd import sharding as S
+    rs = np.random.RandomState(3)
+    data = [rs.randn(500 + 13 * b, 6) * np.linspace(0.5, 30, 6) + b for b in range(4)]
+    y = rs.randn(1, 6)
+    ad = S.ShardedAdaptiveDistance(6)
+    ref = O.AdaptiveDistanceOracle()
+    for rnd in range(2):
+        for X in data:
+            ad.add_data(X)
+            ref.add_data(X)
+        np.testing.assert_allclose(ad.sync_scale(), ref.scale, rtol=1e-12)
+        ad.update_distance()
+        ref.update_distance()
+    got = np.vstack([ad.nested_distance(X, y) for X in data])
+    W = ad.weight_matrix()
+    exp = np.vstack([np.column_stack([O.cdist_rows(X, y, 'euclidean', w=w) for w in W]) for X in data])
+    assert np.array_equal(got, exp)
+    assert S.gather_rows(got)[0] is not None

@@ -1,0 +1,123 @@
+"""world_size-2 tests of the multi-GPU host logic on CPU (gloo).
+
+The sharding code (elfi_amd/sharding.py) is the one bench.py and a multi-GPU user run; here its
+GPU calls are replaced by a backend built on the oracle so that the partitioning, the gather into
+batch-index order and the fixed-order Welford merge can be checked without a GPU:
+  * sharded result == single-process oracle result on the concatenated batches (distances
+    bit-exact; scales to 1e-12 -- Chan's merge reorders the summation);
+  * every rank ends with bit-identical weights.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+import distance_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class OracleBackend:
+    """CPU stand-in for sharding.HipBackend (tests only)."""
+
+    def welford(self, X, count, mean, M2):
+        count = count + len(X)
+        d1 = X - mean
+        mean = mean + np.sum(d1, axis=0) / count
+        M2 = M2 + np.sum(d1 * (X - mean), axis=0)
+        return count, mean, M2
+
+    def nested(self, X, y, W):
+        return np.column_stack([O.cdist_rows(X, y, 'euclidean', w=w) for w in W])
+
+
+def _batches(n_batches, rows, m):
+    return [np.random.RandomState(100 + b).randn(rows + 7 * b, m) * np.linspace(0.5, 30, m) + b
+            for b in range(n_batches)]
+
+
+def _worker(rank, world, port, n_batches, rows, m, out_dir):
+    for p in (ROOT, os.path.join(ROOT, 'oracle'), os.path.join(ROOT, 'tests')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    from elfi_amd import sharding as S
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        data = _batches(n_batches, rows, m)
+        y = np.random.RandomState(7).randn(1, m)
+        mine = S.owned_batches(n_batches, rank, world)
+        ad = S.ShardedAdaptiveDistance(m, backend=OracleBackend())
+        weights = []
+        for rnd in range(2):
+            for b in mine:
+                ad.add_data(data[b])
+            weights.append(ad.sync_scale().copy())
+            ad.update_distance()
+        local = [ad.nested_distance(data[b], y) for b in mine]
+        stacked = np.vstack(local) if local else np.empty((0, 3))
+        got = S.gather_rows(stacked, dst=0)
+        np.save(os.path.join(out_dir, 'w_%d.npy' % rank), np.array(weights))
+        if rank == 0:
+            per_rank = []
+            for r in range(world):
+                lens = [len(data[b]) for b in S.owned_batches(n_batches, r, world)]
+                per_rank.append(np.split(got[r], np.cumsum(lens)[:-1]) if lens else [])
+            ordered = S.interleave_batches(per_rank, n_batches, world)
+            np.save(os.path.join(out_dir, 'dist.npy'), np.vstack(ordered))
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize('n_batches', [5, 2, 1])
+def test_sharded_adaptive_distance_matches_single_process(tmp_path, n_batches):
+    import torch.multiprocessing as mp
+    world, rows, m = 2, 300, 6
+    mp.spawn(_worker, args=(world, _free_port(), n_batches, rows, m, str(tmp_path)), nprocs=world, join=True)
+    w0, w1 = np.load(tmp_path / 'w_0.npy'), np.load(tmp_path / 'w_1.npy')
+    assert np.array_equal(w0, w1), 'every rank must hold bit-identical scales'
+    # single-process reference: the oracle's AdaptiveDistance over all batches in index order
+    data = _batches(n_batches, rows, m)
+    y = np.random.RandomState(7).randn(1, m)
+    ref = O.AdaptiveDistanceOracle()
+    for rnd in range(2):
+        for X in data:
+            ref.add_data(X)
+        np.testing.assert_allclose(w0[rnd], ref.scale, rtol=1e-12)
+        ref.update_distance()
+    got = np.load(tmp_path / 'dist.npy')
+    # distances with the sharded run's own weights are bit-exact cdist results, in batch order
+    W = [np.ones(m)] + [(1.0 / w) ** 2 for w in w0]
+    exp = np.vstack([np.column_stack([O.cdist_rows(X, y, 'euclidean', w=w) for w in W]) for X in data])
+    assert got.shape == exp.shape and np.array_equal(got, exp)
+    np.testing.assert_allclose(got, np.vstack([ref.nested_distance(X, y) for X in data]), rtol=1e-11)
+
+
+def test_merge_welford_equals_pooled_statistics():
+    from elfi_amd.sharding import merge_welford, batch_owner, owned_batches, interleave_batches
+    rs = np.random.RandomState(0)
+    parts = [rs.randn(n, 4) * 3 + 10 for n in (50, 1, 0, 200)]
+    states = []
+    for X in parts:
+        states.append((len(X), X.mean(0) if len(X) else np.zeros(4), ((X - X.mean(0)) ** 2).sum(0) if len(X) else np.zeros(4)))
+    N, mean, M2 = merge_welford(states)
+    allx = np.vstack(parts)
+    assert N == len(allx)
+    np.testing.assert_allclose(mean, allx.mean(0), rtol=1e-13)
+    np.testing.assert_allclose(np.sqrt(M2 / N), allx.std(0), rtol=1e-12)
+    assert [batch_owner(b, 4) for b in range(6)] == [0, 1, 2, 3, 0, 1]
+    assert owned_batches(7, 1, 3) == [1, 4]
+    per_rank = [[('b', b) for b in owned_batches(7, r, 3)] for r in range(3)]
+    assert interleave_batches(per_rank, 7, 3) == [('b', b) for b in range(7)]
