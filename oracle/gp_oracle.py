@@ -3,8 +3,9 @@
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
 Nothing under elfi_amd/ imports it; the product path has no CPU fallback.
 
-PARITY UNPINNED (hyper-parameter optimisation) / pinned relative to the reference's
-own closed forms (everything at fixed hyper-parameters):
+PARITY: pinned to the reference's own closed forms and LCBSC at fixed hyper-parameters
+(tests/test_oracle_pinning_gp.py against tests/golden/gp_*.npz, produced by executing the real
+reference classes, oracle/make_golden_gp.py); UNPINNED for the hyper-parameter optimisation:
 
   The reference delegates this arithmetic to the third-party library GPy
   (requirements.txt:5 `GPy>=1.0.9`, un-vendored, NOT installed here; upstream latest

@@ -80,3 +80,33 @@ def test_minimiser_edge_cases(hip_ctx):
     assert np.all(locs[:, 0] == 0.5)
     with pytest.raises(ValueError):
         m._handle.lcb_minimize(starts, [(1.0, -1.0), (0, 1)], beta)
+
+
+def test_against_the_reference_recorded_acquisition(hip_ctx):
+    """tests/golden/gp_acquisition.npz: the reference's own acquire() (real LCBSC + minimize + scipy
+    L-BFGS-B, oracle/make_golden_gp.py).  Same seed => same start points and same jitter stream;
+    our optimum must be as good as the reference's best start (1e-6 of the value scale) and, when
+    both land in the same basin, the acquired batch is the same to 1e-4."""
+    import os
+    from conftest import GOLDEN
+    from elfi_amd import HipGPRegression, HipLCBSC
+    g = np.load(os.path.join(GOLDEN, 'gp_acquisition.npz'))
+    for tag in g['cases']:
+        tag = str(tag)
+        X, y = g['X_' + tag], g['y_' + tag]
+        d = X.shape[1]
+        names = ['p%d' % i for i in range(d)]
+        m = HipGPRegression(names, bounds={k: (-2., 2.) for k in names})
+        m.update(X, y)
+        m._hyper = dict(zip(('var', 'ls', 'bias', 'noise'), (float(v) for v in g['hyper_' + tag])))
+        m._refit()
+        t, seed = int(g['t_' + tag]), int(g['seed_' + tag])
+        acq = HipLCBSC(m, n_inits=8, noise_var=0.1, exploration_rate=10, seed=seed)
+        x_acq = acq.acquire(3, t=t)
+        info = acq.last_opt
+        assert np.array_equal(info['starts'], g['starts_' + tag]), 'start points must be the reference draws'
+        scale = np.max(np.abs(g['vals_' + tag])) + 1.0
+        assert info['vals'].min() <= g['vals_' + tag].min() + 1e-6 * scale
+        k_ref = int(np.argmin(g['vals_' + tag]))
+        if np.max(np.abs(info['locs'][info['ind_min']] - g['locs_' + tag][k_ref])) <= 1e-3:
+            np.testing.assert_allclose(x_acq, g['x_acq_' + tag], rtol=0, atol=1e-3)

@@ -212,3 +212,30 @@ def test_bolfi_style_updates_use_the_incremental_path(hip_ctx):
     m._hyper = dict(m._hyper, ls=0.7)      # a hyper-parameter change forces a rebuild
     m.update(X[:1], y[:1])
     assert len(calls) == 100
+
+
+def test_against_the_reference_closed_forms(hip_ctx):
+    """tests/golden/gp_closed_forms.npz: outputs of the reference's own GPyRegression closed forms
+    (gpy_regression.py:127-140,206-218) and LCBSC (acquisition.py:256-301), see oracle/make_golden_gp.py."""
+    import os
+    from conftest import GOLDEN
+    from elfi_amd.gp import GPHandle
+    g = np.load(os.path.join(GOLDEN, 'gp_closed_forms.npz'))
+    for tag in g['cases']:
+        tag = str(tag)
+        X, y, xs = g['X_' + tag], g['y_' + tag], g['xs_' + tag]
+        var, ls, bias, noise = (float(v) for v in g['hyper_' + tag])
+        gp = GPHandle(X.shape[1], X.shape[0])
+        gp.set_hyper(var, ls, bias, noise)
+        gp.set_data(X, y)
+        gp.factorize()
+        mu, v = gp.predict(xs, noiseless=False)
+        _close(mu[:, 0], g['mu_' + tag], 1e-8, 'mu vs reference closed form ' + tag)
+        assert np.max(np.abs(v[:, 0] - g['var_' + tag])) <= 1e-8 * (var + bias + noise)
+        _, _, dmu, dvar = gp.predict_grad(xs)
+        _close(dmu, g['gmu_' + tag], 1e-8, 'grad mu vs reference closed form ' + tag)
+        _close(dvar, g['gvar_' + tag], 1e-7, 'grad var vs reference closed form ' + tag)
+        for t in (0, 17):
+            val, grad = gp.lcb(xs, float(g['beta_%s_%d' % (tag, t)]))
+            _close(val, g['lcb_%s_%d' % (tag, t)], 1e-8, 'LCB vs reference LCBSC ' + tag)
+            _close(grad, g['lcbg_%s_%d' % (tag, t)], 1e-7, 'LCB gradient vs reference LCBSC ' + tag)

@@ -1,0 +1,79 @@
+"""Pin oracle/gp_oracle.py to outputs of the REFERENCE'S OWN CODE (tests/golden/gp_*.npz, made by
+oracle/make_golden_gp.py: real GPyRegression closed forms gpy_regression.py:127-140,206-218 and the
+real LCBSC acquisition.py:256-301 executed under oracle/ref_shim.py).
+
+The closed forms and the [GPy-upstream] restatement (predict_noiseless / predictive_gradients) are
+different formulas for the same quantities; the reference's tests hold them equal with
+np.allclose (tests/unit/test_methods.py:110-122).  Tolerance here: 1e-9 relative to the scale of
+the quantity for values and mean gradients, 1e-7 for variance gradients (the reference's closed
+form solves with the Cholesky factor, the restatement multiplies with K^-1).
+"""
+import os
+
+import numpy as np
+import pytest
+
+import gp_oracle as G
+from conftest import GOLDEN
+
+
+def _post(g, tag):
+    var, ls, bias, noise = g['hyper_' + tag]
+    return G.Posterior(g['X_' + tag], g['y_' + tag], var, ls, bias, noise)
+
+
+def _close(a, b, tol):
+    return np.max(np.abs(np.asarray(a) - np.asarray(b))) <= tol * (np.max(np.abs(b)) + 1e-300)
+
+
+def test_oracle_predictions_equal_the_reference_closed_forms():
+    g = np.load(os.path.join(GOLDEN, 'gp_closed_forms.npz'))
+    for tag in g['cases']:
+        tag = str(tag)
+        post = _post(g, tag)
+        xs = g['xs_' + tag]
+        mu, var = post.predict(xs, noiseless=False)
+        assert _close(mu[:, 0], g['mu_' + tag], 1e-9), tag
+        assert np.max(np.abs(var[:, 0] - g['var_' + tag])) <= 1e-9 * (post.var + post.bias + post.noise), tag
+        gm, gv = post.predictive_gradients(xs)
+        assert _close(gm, g['gmu_' + tag], 1e-9), tag
+        assert _close(gv, g['gvar_' + tag], 1e-7), tag
+        # the oracle's own copy of the closed form is the reference's, digit for digit
+        for s in range(len(xs)):
+            cm, cv = post.predict_closed_form(xs[s])
+            assert cm[0, 0] == pytest.approx(g['mu_' + tag][s], rel=1e-13, abs=1e-15)
+            assert cv[0, 0] == pytest.approx(g['var_' + tag][s], rel=1e-12)
+
+
+def test_oracle_lcb_equals_the_reference_lcbsc():
+    g = np.load(os.path.join(GOLDEN, 'gp_closed_forms.npz'))
+    for tag in g['cases']:
+        tag = str(tag)
+        post = _post(g, tag)
+        d = post.X.shape[1]
+        xs = g['xs_' + tag]
+        for t in (0, 17):
+            assert G.lcb_beta(t, d) == pytest.approx(float(g['beta_%s_%d' % (tag, t)]), rel=1e-15)
+            np.testing.assert_allclose(G.lcb_evaluate(post, xs, t), g['lcb_%s_%d' % (tag, t)], rtol=1e-13)
+            np.testing.assert_allclose(G.lcb_evaluate_gradient(post, xs, t), g['lcbg_%s_%d' % (tag, t)], rtol=1e-12,
+                                       atol=1e-14)
+
+
+def test_oracle_multistart_reproduces_the_reference_acquire():
+    """minimize() of bo/utils.py:40-111 as recorded from the reference: same per-start optima."""
+    g = np.load(os.path.join(GOLDEN, 'gp_acquisition.npz'))
+    for tag in g['cases']:
+        tag = str(tag)
+        post = _post(g, tag)
+        d = post.X.shape[1]
+        t = int(g['t_' + tag])
+        bounds = [(-2., 2.)] * d
+        fun = lambda x: float(G.lcb_evaluate(post, x, t)[0, 0])
+        grad = lambda x: G.lcb_evaluate_gradient(post, x, t)[0]
+        x, f = G.minimize_multistart(fun, grad, bounds, g['starts_' + tag])
+        k = int(np.argmin(g['vals_' + tag]))
+        np.testing.assert_allclose(x, g['locs_' + tag][k], rtol=0, atol=1e-7)
+        assert f == pytest.approx(g['vals_' + tag][k], rel=1e-10)
+        # the recorded acquisition is that optimum plus truncated-normal jitter inside the bounds
+        assert g['x_acq_' + tag].shape == (3, d)
+        assert np.all(np.abs(g['x_acq_' + tag]) <= 2.0)
