@@ -62,6 +62,14 @@ PROTOTYPES = {
                                          C.POINTER(C.c_int64), C.c_void_p, C.c_void_p]),
     "elfihip_welford_update_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int64,
                                              C.c_void_p]),
+    "elfihip_row_summary": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_int,
+                                      C.c_void_p]),
+    "elfihip_row_summary_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_int,
+                                          C.c_void_p]),
+    "elfihip_ma2_distance": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_double,
+                                       C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "elfihip_ma2_distance_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_void_p,
+                                           C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
     "elfihip_gp_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, c_void_pp]),
     "elfihip_gp_free": (C.c_int, [C.c_void_p]),
     "elfihip_gp_set_hyper": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double]),

@@ -1,0 +1,282 @@
+// Row-wise summary statistics of simulator output on gfx950, and the fused MA2 path.
+//
+// Replaces the NumPy row reductions ELFI's example models use as Summary operations
+// (SURVEY.md section 8 row a6/a7):
+//     autocov(x, lag) = np.mean(x[:, lag:] * x[:, :-lag], axis=1)      elfi/examples/ma2.py:40-59
+//     ss_mean(y)      = np.mean(y, axis=1)                               elfi/examples/gauss.py:142-156
+//     ss_var(y)       = np.var(y, axis=1)                                elfi/examples/gauss.py:159-173
+//     MA2(t1, t2)     : x = w[:, 2:] + t1 * w[:, 1:-1] + t2 * w[:, :-2]  elfi/examples/ma2.py:11-37
+// HBM-bound streaming reductions (8 L bytes in, 8 bytes out per row).  A workgroup streams a tile
+// of rows with coalesced 16-byte loads into LDS (tile_stream.hpp); each lane then owns one row and
+// sums it in exactly NumPy's order -- np.add.reduce along a contiguous axis is a pairwise sum:
+// eight interleaved accumulators up to 128 elements, recursive halving (rounded to a multiple of 8)
+// above -- with FMA contraction off, so results are BIT-IDENTICAL to NumPy.
+//
+// The fused MA2 kernel takes the white-noise matrix w (drawn on the host from the reference's
+// MT19937 stream, which is what bit-parity requires) and produces both autocovariance summaries
+// and the euclidean distance to the observed summaries in one pass over w: 8 (L+2) bytes in, 24
+// bytes out per simulation, instead of the reference's seven full-size temporaries.
+#include "common.hpp"
+#include "tile_stream.hpp"
+
+#pragma clang fp contract(off)
+
+namespace elfihip {
+
+enum { SUM_MEAN = 0, SUM_VAR = 1, SUM_AUTOCOV = 2, SUM_MA2 = 3 };
+
+// NumPy's pairwise_sum over a[0..n): f(i) yields element i.
+template <class F>
+__device__ double np_pairwise(F f, int lo, int n) {
+  if (n < 8) {
+    double r = 0.0;
+    for (int i = 0; i < n; ++i) r += f(lo + i);
+    return r;
+  }
+  if (n <= 128) {
+    double r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = f(lo + j);
+    int i = 8;
+    for (; i < n - (n % 8); i += 8) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r[j] += f(lo + i + j);
+    }
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += f(lo + i);
+    return res;
+  }
+  int n2 = n / 2;
+  n2 -= n2 % 8;
+  return np_pairwise(f, lo, n2) + np_pairwise(f, lo + n2, n - n2);
+}
+
+struct SumArgs {
+  RowArgs R;        // X, n, ldx, m (= row length L), mp, vec2, div_h, R (rows per tile)
+  int lag;          // AUTOCOV
+  const double* t1; // MA2: per-row parameters (n)
+  const double* t2;
+  double obs1, obs2;
+  double* out1;     // MEAN/VAR/AUTOCOV: result; MA2: S1
+  double* out2;     // MA2: S2
+  double* out3;     // MA2: distance
+};
+
+template <int KIND, int U, bool PIPE>
+__global__ __launch_bounds__(256) void row_summary_kernel(SumArgs S) {
+  extern __shared__ __align__(16) double lds[];
+  const RowArgs& A = S.R;
+  const int tid = threadIdx.x, L = A.m, Rt = A.R;
+  double* tile = lds;
+  const int64_t ntiles = (A.n + Rt - 1) / Rt;
+  double2 v[U];
+  int64_t t = blockIdx.x;
+  if (PIPE && t < ntiles) tile_fetch<U>(A, t * Rt, (int)((A.n - t * Rt) < Rt ? (A.n - t * Rt) : Rt), v);
+  for (; t < ntiles; t += gridDim.x) {
+    const int64_t row0 = t * Rt;
+    const int rows = (int)((A.n - row0) < Rt ? (A.n - row0) : Rt);
+    __syncthreads();
+    if (PIPE) {
+      tile_commit<U>(A, tile, rows, v);
+      const int64_t tn = t + gridDim.x;
+      if (tn < ntiles) tile_fetch<U>(A, tn * Rt, (int)((A.n - tn * Rt) < Rt ? (A.n - tn * Rt) : Rt), v);
+    } else {
+      load_tile<8>(A, tile, row0, rows);
+    }
+    __syncthreads();
+    if (tid < rows) {
+      const double* row = tile + (size_t)tid * A.mp;
+      const int64_t gi = row0 + tid;
+      if constexpr (KIND == SUM_MEAN) {
+        S.out1[gi] = np_pairwise([&](int i) { return row[i]; }, 0, L) / (double)L;
+      } else if constexpr (KIND == SUM_VAR) {
+        const double mean = np_pairwise([&](int i) { return row[i]; }, 0, L) / (double)L;
+        S.out1[gi] = np_pairwise([&](int i) { const double d = row[i] - mean; return d * d; }, 0, L) / (double)L;
+      } else if constexpr (KIND == SUM_AUTOCOV) {
+        const int lag = S.lag, cnt = L - lag;
+        S.out1[gi] = np_pairwise([&](int i) { return row[i + lag] * row[i]; }, 0, cnt) / (double)cnt;
+      } else {  // SUM_MA2: row holds w (L = n_obs + 2); x_i = (w[i+2] + t1 w[i+1]) + t2 w[i], in place
+        const double a = S.t1[gi], b = S.t2[gi];
+        const int nobs = L - 2;
+        double* x = tile + (size_t)tid * A.mp;
+        for (int i = 0; i < nobs; ++i) x[i] = (x[i + 2] + a * x[i + 1]) + b * x[i];
+        const double s1 = np_pairwise([&](int i) { return x[i + 1] * x[i]; }, 0, nobs - 1) / (double)(nobs - 1);
+        const double s2 = np_pairwise([&](int i) { return x[i + 2] * x[i]; }, 0, nobs - 2) / (double)(nobs - 2);
+        S.out1[gi] = s1;
+        S.out2[gi] = s2;
+        const double d1 = s1 - S.obs1, d2 = s2 - S.obs2;   // cdist euclidean over the two summaries
+        S.out3[gi] = sqrt(d1 * d1 + d2 * d2);
+      }
+    }
+  }
+}
+
+template <int KIND>
+static int launch_summary(elfihip_ctx* ctx, SumArgs S) {
+  RowArgs& A = S.R;
+  const int L = A.m;
+  const bool pipe = A.vec2 && L <= 128;
+  int T, U = 16;
+  if (pipe) {
+    T = 128;
+    int R = 2 * T * U / L;
+    if (R > T) R = T;
+    A.R = R;
+  } else {
+    // generic path: as many rows per tile as fit a 48 KiB tile, at most 64
+    int R = (int)((48 * 1024) / ((size_t)A.mp * sizeof(double)));
+    if (R > 64) R = 64;
+    if (R < 1) R = 1;
+    A.R = R;
+    T = 64;
+  }
+  const size_t lds = (size_t)A.R * A.mp * sizeof(double);
+  if (lds > 160 * 1024) return fail(ctx, ELFIHIP_ERR_ARG, "rows of %d values do not fit the LDS tile", L);
+  int per_cu = (int)((160 * 1024) / lds);
+  if (per_cu > 8) per_cu = 8;
+  if (per_cu < 1) per_cu = 1;
+  int64_t g = (int64_t)ctx->cu_count * per_cu;
+  const int64_t ntiles = (A.n + A.R - 1) / A.R;
+  if (g > ntiles) g = ntiles;
+  if (pipe) {
+    auto k = row_summary_kernel<KIND, 16, true>;
+    if (lds > 64 * 1024)
+      ELFIHIP_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, dim3((unsigned)g), dim3(T), lds, ctx->stream, S);
+  } else {
+    auto k = row_summary_kernel<KIND, 1, false>;
+    if (lds > 64 * 1024)
+      ELFIHIP_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, dim3((unsigned)g), dim3(T), lds, ctx->stream, S);
+  }
+  return launch_status(ctx, "row_summary_kernel");
+}
+
+static RowArgs summary_row_args(const double* dX, int64_t n, int L, int64_t ldx) {
+  RowArgs A;
+  A.X = dX;
+  A.n = n;
+  A.ldx = ldx;
+  A.y = nullptr;
+  A.aux = nullptr;
+  A.out = nullptr;
+  A.p = 2.0;
+  A.inv_p = 0.5;
+  A.m = L;
+  A.mp = L | 1;
+  A.K = 0;
+  A.R = 0;
+  A.vec2 = (L % 2 == 0) && (ldx % 2 == 0) && tile_aligned16(dX);
+  A.div_h = make_fastdiv((uint32_t)(A.vec2 ? L / 2 : L));
+  return A;
+}
+
+static int summary_dev_impl(elfihip_ctx* ctx, int kind, const double* dX, int64_t n, int L, int64_t ldx, int lag,
+                            double* dout) {
+  ELFIHIP_REQUIRE(ctx, n >= 0 && L >= 1 && ldx >= L, "bad shape n=%lld L=%d ldx=%lld", (long long)n, L, (long long)ldx);
+  ELFIHIP_REQUIRE(ctx, kind != SUM_AUTOCOV || (lag >= 1 && lag < L), "lag %d outside [1, %d)", lag, L);
+  ELFIHIP_REQUIRE(ctx, n == 0 || (dX && dout), "NULL data pointer");
+  if (n == 0) return ELFIHIP_OK;
+  SumArgs S;
+  S.R = summary_row_args(dX, n, L, ldx);
+  S.lag = lag;
+  S.t1 = S.t2 = nullptr;
+  S.obs1 = S.obs2 = 0.0;
+  S.out1 = dout;
+  S.out2 = S.out3 = nullptr;
+  switch (kind) {
+    case SUM_MEAN:
+      return launch_summary<SUM_MEAN>(ctx, S);
+    case SUM_VAR:
+      return launch_summary<SUM_VAR>(ctx, S);
+    case SUM_AUTOCOV:
+      return launch_summary<SUM_AUTOCOV>(ctx, S);
+  }
+  return fail(ctx, ELFIHIP_ERR_ARG, "unknown summary kind %d", kind);
+}
+
+static int ma2_dev_impl(elfihip_ctx* ctx, const double* dW, int64_t n, int n_obs, int64_t ldw, const double* dt1,
+                        const double* dt2, double obs1, double obs2, double* dS1, double* dS2, double* dD) {
+  ELFIHIP_REQUIRE(ctx, n >= 0 && n_obs >= 3 && ldw >= n_obs + 2, "bad shape n=%lld n_obs=%d ldw=%lld", (long long)n,
+                  n_obs, (long long)ldw);
+  ELFIHIP_REQUIRE(ctx, n == 0 || (dW && dt1 && dt2 && dS1 && dS2 && dD), "NULL data pointer");
+  if (n == 0) return ELFIHIP_OK;
+  SumArgs S;
+  S.R = summary_row_args(dW, n, n_obs + 2, ldw);
+  S.lag = 0;
+  S.t1 = dt1;
+  S.t2 = dt2;
+  S.obs1 = obs1;
+  S.obs2 = obs2;
+  S.out1 = dS1;
+  S.out2 = dS2;
+  S.out3 = dD;
+  return launch_summary<SUM_MA2>(ctx, S);
+}
+
+}  // namespace elfihip
+
+using namespace elfihip;
+
+extern "C" {
+
+int elfihip_row_summary_dev(elfihip_ctx* ctx, int kind, const double* dX, int64_t n, int L, int64_t ldx, int lag,
+                            double* dout) {
+  if (!ctx) return fail(nullptr, ELFIHIP_ERR_ARG, "ctx is NULL");
+  DeviceGuard g(ctx->device);
+  return summary_dev_impl(ctx, kind, dX, n, L, ldx, lag, dout);
+}
+
+int elfihip_row_summary(elfihip_ctx* ctx, int kind, const double* X, int64_t n, int L, int64_t ldx, int lag,
+                        double* out) {
+  if (!ctx) return fail(nullptr, ELFIHIP_ERR_ARG, "ctx is NULL");
+  ELFIHIP_REQUIRE(ctx, n >= 0 && L >= 1 && ldx >= L, "bad shape n=%lld L=%d ldx=%lld", (long long)n, L, (long long)ldx);
+  ELFIHIP_REQUIRE(ctx, n == 0 || (X && out), "NULL data pointer");
+  if (n == 0) return ELFIHIP_OK;
+  DeviceGuard g(ctx->device);
+  ELFIHIP_CHECK_HIP(ctx, ctx->in.reserve((size_t)n * L * sizeof(double)));
+  ELFIHIP_CHECK_HIP(ctx, ctx->out.reserve((size_t)n * sizeof(double)));
+  double* dX = ctx->in.as<double>();
+  ELFIHIP_CHECK_HIP(ctx, hipMemcpy2DAsync(dX, (size_t)L * sizeof(double), X, (size_t)ldx * sizeof(double),
+                                          (size_t)L * sizeof(double), (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  ELFIHIP_TRY(summary_dev_impl(ctx, kind, dX, n, L, L, lag, ctx->out.as<double>()));
+  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(out, ctx->out.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ELFIHIP_OK;
+}
+
+int elfihip_ma2_distance_dev(elfihip_ctx* ctx, const double* dW, int64_t n, int n_obs, int64_t ldw, const double* dt1,
+                             const double* dt2, double obs1, double obs2, double* dS1, double* dS2, double* dD) {
+  if (!ctx) return fail(nullptr, ELFIHIP_ERR_ARG, "ctx is NULL");
+  DeviceGuard g(ctx->device);
+  return ma2_dev_impl(ctx, dW, n, n_obs, ldw, dt1, dt2, obs1, obs2, dS1, dS2, dD);
+}
+
+int elfihip_ma2_distance(elfihip_ctx* ctx, const double* W, int64_t n, int n_obs, const double* t1, const double* t2,
+                         double obs1, double obs2, double* S1, double* S2, double* D) {
+  if (!ctx) return fail(nullptr, ELFIHIP_ERR_ARG, "ctx is NULL");
+  ELFIHIP_REQUIRE(ctx, n >= 0 && n_obs >= 3, "bad shape n=%lld n_obs=%d", (long long)n, n_obs);
+  ELFIHIP_REQUIRE(ctx, n == 0 || (W && t1 && t2 && S1 && S2 && D), "NULL data pointer");
+  if (n == 0) return ELFIHIP_OK;
+  DeviceGuard g(ctx->device);
+  const int L = n_obs + 2;
+  ELFIHIP_CHECK_HIP(ctx, ctx->in.reserve(((size_t)n * L + 2 * (size_t)n) * sizeof(double)));
+  ELFIHIP_CHECK_HIP(ctx, ctx->out.reserve(3 * (size_t)n * sizeof(double)));
+  double* dW = ctx->in.as<double>();
+  double* dt1 = dW + (size_t)n * L;
+  double* dt2 = dt1 + n;
+  double* dS = ctx->out.as<double>();
+  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(dW, W, (size_t)n * L * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(dt1, t1, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(dt2, t2, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  ELFIHIP_TRY(ma2_dev_impl(ctx, dW, n, n_obs, L, dt1, dt2, obs1, obs2, dS, dS + n, dS + 2 * n));
+  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(S1, dS, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(S2, dS + n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(D, dS + 2 * n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ELFIHIP_OK;
+}
+
+}  // extern "C"

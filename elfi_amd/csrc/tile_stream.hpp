@@ -1,0 +1,141 @@
+// Streaming row tiles of a row-major f64 matrix through LDS (shared by the distance and the
+// summary kernels): a workgroup reads a tile of rows as one contiguous span with coalesced loads,
+// drops it into LDS with an odd row pitch, and then every lane owns one whole row, so per-row
+// arithmetic can follow the reference's sequential order exactly.
+#pragma once
+
+#include "common.hpp"
+
+namespace elfihip {
+
+struct FastDiv {
+  uint32_t mul, d;
+};
+static inline FastDiv make_fastdiv(uint32_t d) {
+  FastDiv f;
+  f.d = d;
+  uint64_t q = (1ull << 32) / d;
+  f.mul = q > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)q;
+  return f;
+}
+__device__ __forceinline__ uint32_t fastdiv(uint32_t x, FastDiv f) {
+  // floor(2^32/d) under-estimates by at most one; a single fix-up makes it exact.
+  uint32_t q = __umulhi(x, f.mul);
+  if (x - q * f.d >= f.d) ++q;
+  return q;
+}
+
+struct RowArgs {
+  const double* X;
+  int64_t n;
+  int64_t ldx;
+  const double* y;
+  const double* aux;
+  double* out;
+  double p, inv_p;
+  int m, mp;      // mp = m | 1: LDS row pitch in doubles
+  int K;          // multi-weight: number of weight rows in aux
+  int vec2;       // 16-byte loads are legal (m, ldx even; X 16-byte aligned)
+  int R;          // pipelined kernels: rows per tile (<= blockDim.x); T * U >= R * m / 2
+  FastDiv div_h;  // by m/2 (vec2) or m
+};
+
+// Stream one tile of `rows` rows starting at row0 into LDS (pitch mp).
+template <int U>
+__device__ __forceinline__ void load_tile(const RowArgs& A, double* tile, int64_t row0, int rows) {
+  const int T = blockDim.x, tid = threadIdx.x;
+  const double* __restrict__ X = A.X + row0 * A.ldx;
+  if (A.vec2) {
+    const uint32_t h = (uint32_t)A.m >> 1;
+    const uint32_t npairs = (uint32_t)rows * h;
+    for (uint32_t base = 0; base < npairs; base += (uint32_t)(T * U)) {
+      double2 v[U];
+      uint32_t r[U], jj[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        uint32_t idx = base + (uint32_t)(u * T + tid);
+        bool ok = idx < npairs;
+        uint32_t q = fastdiv(ok ? idx : 0u, A.div_h);
+        r[u] = q;
+        jj[u] = (ok ? idx : 0u) - q * h;
+        if (ok)
+          v[u] = *reinterpret_cast<const double2*>(X + (int64_t)q * A.ldx + 2 * jj[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        uint32_t idx = base + (uint32_t)(u * T + tid);
+        if (idx < npairs) {
+          double* dst = tile + r[u] * (uint32_t)A.mp + 2 * jj[u];
+          dst[0] = v[u].x;
+          dst[1] = v[u].y;
+        }
+      }
+    }
+  } else {
+    const uint32_t m = (uint32_t)A.m;
+    const uint32_t nel = (uint32_t)rows * m;
+    for (uint32_t base = 0; base < nel; base += (uint32_t)(T * U)) {
+      double v[U];
+      uint32_t r[U], j[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        uint32_t idx = base + (uint32_t)(u * T + tid);
+        bool ok = idx < nel;
+        uint32_t q = fastdiv(ok ? idx : 0u, A.div_h);
+        r[u] = q;
+        j[u] = (ok ? idx : 0u) - q * m;
+        if (ok) v[u] = X[(int64_t)q * A.ldx + j[u]];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        uint32_t idx = base + (uint32_t)(u * T + tid);
+        if (idx < nel) tile[r[u] * (uint32_t)A.mp + j[u]] = v[u];
+      }
+    }
+  }
+}
+
+// ---- software-pipelined tile streaming (16-byte loads, whole tile in one batch) -------------
+// fetch: issue the global loads of one tile into registers (nothing waits on them here);
+// commit: drop the registers into the LDS tile.  With the loads of tile t+1 issued before the
+// row sums of tile t are computed, every workgroup keeps a full tile of HBM requests in flight
+// while it does its LDS/VALU work, instead of alternating between the two.
+template <int U>
+__device__ __forceinline__ void tile_fetch(const RowArgs& A, int64_t row0, int rows, double2 (&v)[U]) {
+  const int T = blockDim.x, tid = threadIdx.x;
+  const double* __restrict__ X = A.X + row0 * A.ldx;
+  const uint32_t h = (uint32_t)A.m >> 1;
+  const uint32_t npairs = (uint32_t)rows * h;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const uint32_t idx = (uint32_t)(u * T + tid);
+    const bool ok = idx < npairs;
+    const uint32_t q = fastdiv(ok ? idx : 0u, A.div_h);
+    const uint32_t jj = (ok ? idx : 0u) - q * h;
+    v[u] = make_double2(0.0, 0.0);
+    if (ok) v[u] = *reinterpret_cast<const double2*>(X + (int64_t)q * A.ldx + 2 * jj);
+  }
+}
+
+template <int U>
+__device__ __forceinline__ void tile_commit(const RowArgs& A, double* tile, int rows, const double2 (&v)[U]) {
+  const int T = blockDim.x, tid = threadIdx.x;
+  const uint32_t h = (uint32_t)A.m >> 1;
+  const uint32_t npairs = (uint32_t)rows * h;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const uint32_t idx = (uint32_t)(u * T + tid);
+    if (idx < npairs) {
+      const uint32_t q = fastdiv(idx, A.div_h);
+      const uint32_t jj = idx - q * h;
+      double* dst = tile + q * (uint32_t)A.mp + 2 * jj;
+      dst[0] = v[u].x;
+      dst[1] = v[u].y;
+    }
+  }
+}
+
+
+static inline bool tile_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace elfihip

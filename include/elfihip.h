@@ -126,6 +126,29 @@ int elfihip_welford_update(elfihip_ctx* ctx, const double* X, int64_t n, int m, 
 int elfihip_welford_update_dev(elfihip_ctx* ctx, const double* dX, int64_t n, int m, int64_t ldx,
                                double* dstate);
 
+/* ------------------------------------------------------------------ summaries
+ * Row-wise summary statistics that ELFI's example models install as elfi.Summary operations, with
+ * NumPy's exact (pairwise) summation order, i.e. bit-identical results:
+ *   ELFIHIP_SUM_MEAN     np.mean(y, axis=1)                           elfi/examples/gauss.py:142-156
+ *   ELFIHIP_SUM_VAR      np.var(y, axis=1)                            elfi/examples/gauss.py:159-173
+ *   ELFIHIP_SUM_AUTOCOV  np.mean(x[:, lag:] * x[:, :-lag], axis=1)    elfi/examples/ma2.py:40-59
+ * X is row-major (n, L) with leading dimension ldx; out has n doubles; lag only for AUTOCOV. */
+enum { ELFIHIP_SUM_MEAN = 0, ELFIHIP_SUM_VAR = 1, ELFIHIP_SUM_AUTOCOV = 2 };
+int elfihip_row_summary(elfihip_ctx* ctx, int kind, const double* X, int64_t n, int L, int64_t ldx, int lag,
+                        double* out);
+int elfihip_row_summary_dev(elfihip_ctx* ctx, int kind, const double* dX, int64_t n, int L, int64_t ldx, int lag,
+                            double* dout);
+/* The whole MA2 example path after the random draw, fused (elfi/examples/ma2.py:11-59,62-92 +
+ * elfi.Distance('euclidean', S1, S2)): from the white noise W (n, n_obs + 2) -- drawn by the caller
+ * from the reference's MT19937 stream, random_state.randn(batch_size, n_obs + 2) -- and per-row
+ * parameters t1, t2 (n): x = w[:, 2:] + t1 w[:, 1:-1] + t2 w[:, :-2], S1 = autocov(x, 1),
+ * S2 = autocov(x, 2), D = sqrt((S1 - obs1)^2 + (S2 - obs2)^2), bit-identical to the reference's
+ * NumPy/SciPy results, in one pass over W. */
+int elfihip_ma2_distance(elfihip_ctx* ctx, const double* W, int64_t n, int n_obs, const double* t1, const double* t2,
+                         double obs1, double obs2, double* S1, double* S2, double* D);
+int elfihip_ma2_distance_dev(elfihip_ctx* ctx, const double* dW, int64_t n, int n_obs, int64_t ldw, const double* dt1,
+                             const double* dt2, double obs1, double obs2, double* dS1, double* dS2, double* dD);
+
 /* ------------------------------------------------------------------- GP surrogate
  * Replaces the GPy model behind elfi.methods.bo.gpy_regression.GPyRegression
  * (elfi/methods/bo/gpy_regression.py:15-364): kernel RBF(variance, lengthscale) + Bias
