@@ -17,13 +17,15 @@
 // The two triangular products stream L^-T once each (8 n^2 / 2 bytes): HBM/L3-bound for 16
 // columns, so they are split over (row block, k chunk) pairs to fill the chip and reduced
 // in a fixed order (deterministic).  WT's strictly-lower part is zero, so no masking.
+#include <type_traits>
+
 #include "gp.hpp"
 #include "mfma_f64.hpp"
 
 namespace elfihip {
 
 constexpr int PC = 16;    // columns (query points) per pass
-constexpr int KCH = 2;    // 128-blocks of k per workgroup
+constexpr int KCH = 1;    // 128-blocks of k per workgroup (one block: the partial index is the k block)
 constexpr int SLAB = 32;  // k-slab staged per step
 
 struct PredictWs {
@@ -80,66 +82,77 @@ struct TriArgs {
 
 template <bool TRANS>
 __global__ __launch_bounds__(256) void tri_apply_kernel(TriArgs T) {
+  // One workgroup per (row block ib, k block kb) inside the triangle; the 128 x 128 block of L^-T
+  // is streamed as four 32-deep slabs with the loads of the next two slabs in flight (registers)
+  // while the current one is multiplied -- these kernels are pure HBM/MALL streaming (S <= 16).
   // LDS: W slab + B slab.  TRANS: W as [k][i] pitch 144, B = kb as [s][k] pitch 34.
   //      !TRANS: W as [i][k] pitch 34, B = v as [k][s] pitch 16.
   extern __shared__ __align__(16) double sm[];
   constexpr int WP = TRANS ? 144 : 34;
   double* Ws = sm;
   double* Bs = sm + (TRANS ? SLAB * 144 : 128 * 34);
-  const int ib = blockIdx.x, kc = blockIdx.y;
+  const int ib = blockIdx.x, kb = blockIdx.y;
   const int t = threadIdx.x, l = t & 63, w = t >> 6;
-  int kb0 = kc * KCH, kb1 = kb0 + KCH;  // k-block range of this chunk
-  if (TRANS) {
-    if (kb1 > ib + 1) kb1 = ib + 1;     // k <= i
-  } else {
-    if (kb0 < ib) kb0 = ib;             // k >= i
-    if (kb1 > T.nb) kb1 = T.nb;
-  }
-  if (kb0 >= kb1) return;  // chunk lies outside the triangle (the reduction never reads it)
+  if (TRANS ? (kb > ib) : (kb < ib)) return;  // outside the triangle (the reduction never reads it)
   v4d acc[2];
   acc[0] = (v4d){0, 0, 0, 0};
   acc[1] = (v4d){0, 0, 0, 0};
-  const int64_t i0 = (int64_t)ib * NB;
-  for (int64_t k0 = (int64_t)kb0 * NB; k0 < (int64_t)kb1 * NB; k0 += SLAB) {
-    __syncthreads();
-    if (TRANS) {
-      // WT rows k0..k0+31, columns i0..i0+127: each row 1 KiB, one wave-instruction per row
+  const int64_t i0 = (int64_t)ib * NB, kbase = (int64_t)kb * NB;
+  constexpr int NSLAB = NB / SLAB;  // 4
+  // per-thread source / destination of pair p inside a slab (slab s adds s * step to the source)
+  auto src = [&](int p) -> const double* {
+    if (TRANS) return T.WT + (kbase + (t >> 6) + 4 * p) * T.lda + i0 + 2 * (t & 63);  // row k of the slab, 1 KiB per row
+    return T.WT + (i0 + (t >> 4) + 16 * p) * T.lda + kbase + 2 * (t & 15);            // row i, 256 B of the slab per row
+  };
+  auto dst = [&](int p) -> int {
+    if (TRANS) return ((t >> 6) + 4 * p) * 144 + 2 * (t & 63);
+    return ((t >> 4) + 16 * p) * 34 + 2 * (t & 15);
+  };
+  const int64_t step = TRANS ? (int64_t)SLAB * T.lda : (int64_t)SLAB;
+  typedef double v2d __attribute__((ext_vector_type(2)));
+  v2d r0[8], r1[8];
 #pragma unroll
-      for (int p = 0; p < 8; ++p) {
-        const int kr_ = (t >> 6) + 4 * p, ip = t & 63;
-        const double2 x = *reinterpret_cast<const double2*>(T.WT + (k0 + kr_) * T.lda + i0 + 2 * ip);
-        *reinterpret_cast<double2*>(Ws + kr_ * 144 + 2 * ip) = x;
-      }
-      // kb slab [16 s][32 k]
-      for (int e = t; e < PC * SLAB; e += 256) {
-        const int s = e >> 5, kk = e & 31;
-        const int64_t k = k0 + kk;
-        Bs[s * 34 + kk] = (k < T.n) ? (T.kr[(int64_t)s * T.np + k] + T.bias) : 0.0;
-      }
-    } else {
-      // WT rows i0..i0+127, columns k0..k0+31: 256 B per row = 16 lanes
+  for (int p = 0; p < 8; ++p) r0[p] = *reinterpret_cast<const v2d*>(src(p));
 #pragma unroll
-      for (int p = 0; p < 8; ++p) {
-        const int ir = (t >> 4) + 16 * p, kp = t & 15;
-        const double2 x = *reinterpret_cast<const double2*>(T.WT + (i0 + ir) * T.lda + k0 + 2 * kp);
-        *reinterpret_cast<double2*>(Ws + ir * 34 + 2 * kp) = x;
-      }
-      for (int e = t; e < SLAB * PC; e += 256) Bs[e] = T.vin[k0 * PC + e];  // [k][s], contiguous
-    }
-    __syncthreads();
-#pragma unroll
-    for (int ks = 0; ks < SLAB / 4; ++ks) {
-      const int kq = 4 * ks + (l >> 4);
-      const double b = TRANS ? Bs[(l & 15) * 34 + kq] : Bs[kq * PC + (l & 15)];
-#pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        const int i = (2 * w + m) * 16 + (l & 15);
-        const double a = TRANS ? Ws[kq * WP + i] : Ws[i * WP + kq];
-        acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[m], 0, 0, 0);
-      }
-    }
+  for (int p = 0; p < 8; ++p) r1[p] = *reinterpret_cast<const v2d*>(src(p) + step);
+  // four slabs, written out (compile-time slab index keeps r0 / r1 in registers)
+#define ELFIHIP_SLAB_STEP(sl, cur)                                                                        \
+  {                                                                                                      \
+    const int64_t k0 = kbase + (int64_t)(sl)*SLAB;                                                       \
+    __syncthreads();                                                                                     \
+    _Pragma("unroll") for (int p = 0; p < 8; ++p) *reinterpret_cast<v2d*>(Ws + dst(p)) = cur[p];    \
+    if ((sl) + 2 < NSLAB) {                                                                              \
+      _Pragma("unroll") for (int p = 0; p < 8; ++p) cur[p] =                                             \
+          *reinterpret_cast<const v2d*>(src(p) + ((sl) + 2) * step);                                     \
+    }                                                                                                    \
+    if (TRANS) {                                                                                         \
+      _Pragma("unroll") for (int e0 = 0; e0 < PC * SLAB; e0 += 256) {                                    \
+        const int e = e0 + t;                                                                            \
+        const int s_ = e >> 5, kk = e & 31;                                                              \
+        const int64_t k = k0 + kk;                                                                       \
+        Bs[s_ * 34 + kk] = (k < T.n) ? (T.kr[(int64_t)s_ * T.np + k] + T.bias) : 0.0;                    \
+      }                                                                                                  \
+    } else {                                                                                             \
+      _Pragma("unroll") for (int e0 = 0; e0 < SLAB * PC; e0 += 256) Bs[e0 + t] = T.vin[k0 * PC + e0 + t]; \
+    }                                                                                                    \
+    __syncthreads();                                                                                     \
+    _Pragma("unroll") for (int ks = 0; ks < SLAB / 4; ++ks) {                                            \
+      const int kq = 4 * ks + (l >> 4);                                                                  \
+      const double bq = TRANS ? Bs[(l & 15) * 34 + kq] : Bs[kq * PC + (l & 15)];                         \
+      _Pragma("unroll") for (int m = 0; m < 2; ++m) {                                                    \
+        const int i = (2 * w + m) * 16 + (l & 15);                                                       \
+        const double aq = TRANS ? Ws[kq * WP + i] : Ws[i * WP + kq];                                     \
+        acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(aq, bq, acc[m], 0, 0, 0);                          \
+      }                                                                                                  \
+    }                                                                                                    \
   }
-  double* out = T.part + ((int64_t)kc * T.np + i0) * PC;
+  ELFIHIP_SLAB_STEP(0, r0)
+  ELFIHIP_SLAB_STEP(1, r1)
+  ELFIHIP_SLAB_STEP(2, r0)
+  ELFIHIP_SLAB_STEP(3, r1)
+#undef ELFIHIP_SLAB_STEP
+  static_assert(NSLAB == 4, "slab sequence above is written out for four slabs");
+  double* out = T.part + ((int64_t)kb * T.np + i0) * PC;
 #pragma unroll
   for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -178,42 +191,38 @@ __global__ __launch_bounds__(256) void tri_reduce_kernel(const double* part, dou
 
 // ---- gradients ---------------------------------------------------------------------
 // g_part[s][chunk][0..dp) = sum_i alpha_i kr_si (x_s - X_i),  [dp..2dp) = sum_i u_is kr_si (x_s - X_i)
+// One evidence row per thread (256 rows per workgroup); per dimension a wave butterfly, then the four
+// wave partials in fixed order.
 __global__ __launch_bounds__(256) void grad_kernel(const double* X, const double* alpha, const double* xs,
                                                    const double* kr, const double* u, double* g_part, int64_t n,
                                                    int64_t np, int dp, int rows_per_block) {
-  __shared__ double red[256];
+  __shared__ double red[4][2];
   const int s = blockIdx.y;
-  const int64_t ibeg = (int64_t)blockIdx.x * rows_per_block;
-  int64_t iend = ibeg + rows_per_block;
-  if (iend > n) iend = n;
+  const int64_t i = (int64_t)blockIdx.x * rows_per_block + threadIdx.x;
   double* outp = g_part + ((int64_t)s * gridDim.x + blockIdx.x) * 2 * dp;
-  for (int a0 = 0; a0 < dp; a0 += 4) {
-    double g1[4] = {0, 0, 0, 0}, g2[4] = {0, 0, 0, 0};
-    for (int64_t i = ibeg + threadIdx.x; i < iend; i += 256) {
-      const double k = kr[(int64_t)s * np + i];
-      const double c1 = alpha[i] * k, c2 = u[i * PC + s] * k;
+  double c1 = 0.0, c2 = 0.0;
+  if (i < n) {
+    const double k = kr[(int64_t)s * np + i];
+    c1 = alpha[i] * k;
+    c2 = u[i * PC + s] * k;
+  }
+  const int64_t ic = i < n ? i : 0;
+  for (int a = 0; a < dp; ++a) {
+    const double diff = xs[s * dp + a] - X[ic * dp + a];
+    double v1 = c1 * diff, v2 = c2 * diff;
 #pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        const double diff = xs[s * dp + a0 + a] - X[i * dp + a0 + a];
-        g1[a] += c1 * diff;
-        g2[a] += c2 * diff;
-      }
+    for (int off = 32; off > 0; off >>= 1) {
+      v1 += __shfl_xor(v1, off, 64);
+      v2 += __shfl_xor(v2, off, 64);
     }
-    // wave butterfly, then the 4 wave partials in fixed order
-#pragma unroll
-    for (int a = 0; a < 8; ++a) {
-      double v = a < 4 ? g1[a] : g2[a - 4];
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-      if ((threadIdx.x & 63) == 0) red[(threadIdx.x >> 6) * 8 + a] = v;
-    }
-    __syncthreads();
-    if (threadIdx.x < 8) {
-      const int a = threadIdx.x;
-      const double v = ((red[a] + red[8 + a]) + red[16 + a]) + red[24 + a];
-      outp[(a < 4 ? 0 : dp) + a0 + (a & 3)] = v;
+    __syncthreads();  // red free
+    if ((threadIdx.x & 63) == 0) {
+      red[threadIdx.x >> 6][0] = v1;
+      red[threadIdx.x >> 6][1] = v2;
     }
     __syncthreads();
+    if (threadIdx.x < 2) outp[threadIdx.x * dp + a] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) +
+                                                      red[3][threadIdx.x];
   }
 }
 
@@ -233,33 +242,39 @@ __global__ __launch_bounds__(256) void finish_kernel(const double* mu_part, int 
   red_m[j][s] = m;
   red_q[j][s] = q;
   __syncthreads();
-  if (j != 0) return;
   double* mu = out;
   double* var = out + PC;
   double* val = out + 2 * PC;
   double* dmu = out + 3 * PC;
   double* dvar = dmu + PC * dp;
   double* grad = dvar + PC * dp;
-  if (s >= S) {
-    mu[s] = 0;
-    var[s] = 0;
-    val[s] = 0;
-    return;
+  __shared__ double vfin[PC];
+  if (j == 0) {
+    if (s >= S) {
+      mu[s] = 0;
+      var[s] = 0;
+      val[s] = 0;
+      vfin[s] = 1.0;
+    } else {
+      m = 0.0;
+      q = 0.0;
+      for (int g = 0; g < 16; ++g) {
+        m += red_m[g][s];
+        q += red_q[g][s];
+      }
+      double v = prior_var - q;
+      v = v > 1e-15 ? v : 1e-15;  // [GPy-upstream] predict clips the variance at 1e-15
+      mu[s] = m;
+      var[s] = v + noise_add;
+      val[s] = m - sqrt(beta * v);
+      vfin[s] = v;
+    }
   }
-  m = 0.0;
-  q = 0.0;
-  for (int g = 0; g < 16; ++g) {
-    m += red_m[g][s];
-    q += red_q[g][s];
-  }
-  double v = prior_var - q;
-  v = v > 1e-15 ? v : 1e-15;  // [GPy-upstream] predict clips the variance at 1e-15
-  mu[s] = m;
-  var[s] = v + noise_add;
-  val[s] = m - sqrt(beta * v);
-  if (with_grad) {
-    const double sc = sqrt(beta / v);
-    for (int a = 0; a < dp; ++a) {
+  __syncthreads();
+  if (with_grad && s < S) {
+    // lane (s, j) assembles dimensions a = j, j + 16, ...: chunk partials in fixed order
+    const double sc = sqrt(beta / vfin[s]);
+    for (int a = j; a < dp; a += 16) {
       double g1 = 0.0, g2 = 0.0;
       for (int c = 0; c < ngc; ++c) {
         g1 += g_part[((int64_t)s * ngc + c) * 2 * dp + a];
@@ -280,7 +295,7 @@ static int ensure_ws(elfihip_gp* gp, PredictWs* W, int64_t npass) {
   const int nb = (int)(np / NB);
   W->nblk_k = (int)((np + 255) / 256);
   W->nkc = (nb + KCH - 1) / KCH;
-  const int rows_per_block = 1024;
+  const int rows_per_block = 256;
   W->ngc = (int)((gp->n + rows_per_block - 1) / rows_per_block);
   size_t off = 0;
   auto take = [&](size_t doubles) {
@@ -374,7 +389,7 @@ int predict_impl(elfihip_gp* gp, const double* Xs, int64_t S, int mode, int nois
       hipLaunchKernelGGL(tri_reduce_kernel, dim3(rblocks), dim3(256), 0, st, W.part, W.u, (double*)nullptr, np,
                          W.nkc, 1, 0);
       hipLaunchKernelGGL(grad_kernel, dim3(W.ngc, PC), dim3(256), 0, st, gp->X, gp->alpha, xs, W.kr, W.u, W.g_part,
-                         gp->n, np, dp, 1024);
+                         gp->n, np, dp, 256);
     }
     hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(256), 0, st, W.mu_part, W.nblk_k, W.var_part, rblocks, W.g_part,
                        W.ngc, out, dp, sc, gp->var + gp->bias, noiseless ? 0.0 : gp->noise, inv_ls2, beta, mode);
