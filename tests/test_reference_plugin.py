@@ -1,0 +1,97 @@
+"""Plug-in plumbing against the REAL reference (build container only: needs /root/reference; the GPU
+box skips these).  No GPU arithmetic runs here -- what is checked is that our objects fit the
+reference's extension points:
+
+  * elfi.Distance / elfi.Discrepancy accept HipDistance / HipDiscrepancy as operations, the model
+    compiles, and the compiled + loaded net pickles (tests/functional/test_serialization.py);
+  * elfi.BOLFI accepts HipGPRegression / HipLCBSC as target_model / acquisition_method;
+  * the multi-GPU client (elfi_amd/gpu_client.py) drives a real Rejection run through worker
+    processes and reproduces the native client's sample bit for bit (the operations executed in
+    the workers are the reference's own CPU ones, so this runs without a GPU).
+"""
+import os
+import pickle
+import sys
+
+import numpy as np
+import pytest
+
+ORACLE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle')
+sys.path.insert(0, ORACLE)
+import ref_shim  # noqa: E402
+
+pytestmark = pytest.mark.skipif(not ref_shim.available(), reason='/root/reference not present')
+
+
+@pytest.fixture(scope='module')
+def elfi():
+    return ref_shim.install()
+
+
+def _ma2(elfi, seed_obs=4):
+    from elfi.examples import ma2
+    return ma2.get_model(seed_obs=seed_obs)
+
+
+def test_hip_operations_fit_the_node_api_and_pickle(elfi):
+    import elfi_amd
+    m = _ma2(elfi)
+    d1 = elfi.Distance(elfi_amd.HipDistance('euclidean'), m['S1'], m['S2'], name='d_hip')
+    d2 = elfi.Discrepancy(elfi_amd.HipDiscrepancy('minkowski', p=3), m['S1'], m['S2'], name='d_hip2')
+    s3 = elfi.Summary(elfi_amd.autocov, m['MA2'], 2, name='S3')
+    assert d1.state['attr_dict']['_operation'] is not None and d2.state['attr_dict']['_operation'] is not None
+    assert s3.parents[0].name == 'MA2'
+    # model save/copy path: operations must survive pickle (elfi_model.py:401-438)
+    blob = pickle.dumps(m)
+    m2 = pickle.loads(blob)
+    assert set(m2.nodes) >= {'d_hip', 'd_hip2', 'S3'}
+    # compiled + loaded net pickles with our operations inside (tests/functional/test_serialization.py:28-43)
+    from elfi.client import ClientBase
+    from elfi.model.elfi_model import ComputationContext
+    compiled = ClientBase.compile(m.source_net, ['d_hip', 'd_hip2', 'S3'])
+    loaded = ClientBase.load_data(compiled, ComputationContext(), 0)
+    loaded2 = pickle.loads(pickle.dumps(loaded))
+    op = loaded2.nodes['d_hip2']['operation'] if 'operation' in loaded2.nodes['d_hip2'] else None
+    assert op is not None
+
+
+def test_bolfi_accepts_the_hip_surrogate_and_acquisition(elfi):
+    import elfi_amd
+    m = _ma2(elfi)
+    log_d = elfi.Operation(np.log, m['d'], name='log_d')
+    bounds = {'t1': (-2, 2), 't2': (-1, 1)}
+    gp = elfi_amd.HipGPRegression(['t1', 't2'], bounds=bounds)
+    acq = elfi_amd.HipLCBSC(gp, noise_var=0.1, exploration_rate=10, seed=1)
+    bolfi = elfi.BOLFI(log_d, batch_size=1, initial_evidence=5, update_interval=10, bounds=bounds,
+                       target_model=gp, acquisition_method=acq, seed=1)
+    assert bolfi.target_model is gp and bolfi.acquisition_method is acq
+    assert bolfi.target_model.parameter_names == ['t1', 't2']
+    # the duck-type the reference's BO code reads (bolfi.py:86-137, acquisition.py:37-41)
+    for attr in ('input_dim', 'bounds', 'n_evidence', 'predict', 'predict_mean', 'predictive_gradients',
+                 'predictive_gradient_mean', 'update', 'optimize', 'copy', 'is_sampling'):
+        assert hasattr(gp, attr), attr
+    assert gp.n_evidence == 0 and gp.bounds == [(-2, 2), (-1, 1)]
+
+
+@pytest.mark.timeout(180)
+def test_gpu_client_reproduces_the_native_client(elfi):
+    import elfi.clients.native as native
+    m = _ma2(elfi)
+    native.set_as_default()
+    ref = elfi.Rejection(m['d'], batch_size=500, seed=123).sample(50, n_sim=3000)
+    import elfi_amd.gpu_client as gc
+    # spawned workers must be able to import ref_shim (to unpickle the initializer) and elfi_amd
+    root = os.path.dirname(ORACLE)
+    os.environ['PYTHONPATH'] = os.pathsep.join([ORACLE, root, os.environ.get('PYTHONPATH', '')])
+    client = gc.Client(num_gpus=2, worker_setup=ref_shim.install)
+    try:
+        elfi.set_client(client)
+        got = elfi.Rejection(m['d'], batch_size=500, seed=123).sample(50, n_sim=3000)
+    finally:
+        client.reset()
+        native.set_as_default()
+    assert got.n_sim == ref.n_sim == 3000
+    assert got.threshold == ref.threshold
+    for k in ('t1', 't2'):
+        assert np.array_equal(got.samples[k], ref.samples[k])
+    assert client.num_cores == 2
