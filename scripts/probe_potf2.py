@@ -8,7 +8,7 @@ h = G.default_hyper(b, y)
 gp = GPHandle(10, 512); gp.set_hyper(h['var'], h['ls'], h['bias'], h['noise']); gp.set_data(X, y); gp.factorize()
 lib = gp.lib
 lib.elfihip_debug_potf2.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]
-for skip, name in [(7, 'load/store only'), (6, '+phase1'), (5, '+phase2'), (3, '+phase3'), (0, 'all'), (8, 'all+probe')]:
+for skip, name in [(5, 'global load/store only'), (4, '+phase A'), (1, '+phase B'), (0, 'all'), (8, 'all+probe')]:
     ms = C.c_float()
     lib.elfihip_debug_potf2(gp.h, skip, 50, C.byref(ms))
     print('%-16s %.1f us' % (name, ms.value * 1e3))

@@ -33,3 +33,9 @@ for _ in range(R):
     gp.lcb(xs, 3.0, with_grad=False)
 t = (time.perf_counter() - t0) / R
 print("lcb S=10 value only: %.3f ms" % (t * 1e3))
+t0 = time.perf_counter()
+R = 5
+for _ in range(R):
+    gp.nlml_grad()
+t = (time.perf_counter() - t0) / R
+print("nlml_grad (K^-1 SYRK n^3/3 + contractions): %.3f ms  (%.1f TFLOP/s)" % (t * 1e3, n**3 / 3 / t / 1e12))
