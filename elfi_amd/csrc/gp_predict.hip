@@ -25,7 +25,7 @@
 namespace elfihip {
 
 constexpr int PC = 16;    // columns (query points) per pass
-constexpr int KCH = 1;    // 128-blocks of k per workgroup (one block: the partial index is the k block)
+constexpr int KCH = 2;    // 128-blocks of k per workgroup (fewer partial sums to reduce than with 1)
 constexpr int SLAB = 32;  // k-slab staged per step
 
 struct PredictWs {
@@ -82,23 +82,31 @@ struct TriArgs {
 
 template <bool TRANS>
 __global__ __launch_bounds__(256) void tri_apply_kernel(TriArgs T) {
-  // One workgroup per (row block ib, k block kb) inside the triangle; the 128 x 128 block of L^-T
-  // is streamed as four 32-deep slabs with the loads of the next two slabs in flight (registers)
-  // while the current one is multiplied -- these kernels are pure HBM/MALL streaming (S <= 16).
+  // One workgroup per (row block ib, chunk of KCH k blocks) inside the triangle; its part of L^-T is
+  // streamed as 32-deep slabs with the loads of the next two slabs in flight (registers) while the
+  // current one is multiplied -- these kernels are pure HBM/MALL streaming (S <= 16).
   // LDS: W slab + B slab.  TRANS: W as [k][i] pitch 144, B = kb as [s][k] pitch 34.
   //      !TRANS: W as [i][k] pitch 34, B = v as [k][s] pitch 16.
   extern __shared__ __align__(16) double sm[];
   constexpr int WP = TRANS ? 144 : 34;
   double* Ws = sm;
   double* Bs = sm + (TRANS ? SLAB * 144 : 128 * 34);
-  const int ib = blockIdx.x, kb = blockIdx.y;
+  const int ib = blockIdx.x, kc = blockIdx.y;
   const int t = threadIdx.x, l = t & 63, w = t >> 6;
-  if (TRANS ? (kb > ib) : (kb < ib)) return;  // outside the triangle (the reduction never reads it)
+  // k-block range of this chunk, clipped to the triangle (TRANS: k <= i, else k >= i)
+  int kb0 = kc * KCH, kb1 = kb0 + KCH;
+  if (TRANS) {
+    if (kb1 > ib + 1) kb1 = ib + 1;
+  } else {
+    if (kb0 < ib) kb0 = ib;
+    if (kb1 > T.nb) kb1 = T.nb;
+  }
+  if (kb0 >= kb1) return;  // chunk lies outside the triangle (the reduction never reads it)
+  const int nslab = (kb1 - kb0) * (NB / SLAB);  // 4 or 8
   v4d acc[2];
   acc[0] = (v4d){0, 0, 0, 0};
   acc[1] = (v4d){0, 0, 0, 0};
-  const int64_t i0 = (int64_t)ib * NB, kbase = (int64_t)kb * NB;
-  constexpr int NSLAB = NB / SLAB;  // 4
+  const int64_t i0 = (int64_t)ib * NB, kbase = (int64_t)kb0 * NB;
   // per-thread source / destination of pair p inside a slab (slab s adds s * step to the source)
   auto src = [&](int p) -> const double* {
     if (TRANS) return T.WT + (kbase + (t >> 6) + 4 * p) * T.lda + i0 + 2 * (t & 63);  // row k of the slab, 1 KiB per row
@@ -121,7 +129,7 @@ __global__ __launch_bounds__(256) void tri_apply_kernel(TriArgs T) {
     const int64_t k0 = kbase + (int64_t)(sl)*SLAB;                                                       \
     __syncthreads();                                                                                     \
     _Pragma("unroll") for (int p = 0; p < 8; ++p) *reinterpret_cast<v2d*>(Ws + dst(p)) = cur[p];    \
-    if ((sl) + 2 < NSLAB) {                                                                              \
+    if ((sl) + 2 < nslab) {                                                                              \
       _Pragma("unroll") for (int p = 0; p < 8; ++p) cur[p] =                                             \
           *reinterpret_cast<const v2d*>(src(p) + ((sl) + 2) * step);                                     \
     }                                                                                                    \
@@ -150,9 +158,15 @@ __global__ __launch_bounds__(256) void tri_apply_kernel(TriArgs T) {
   ELFIHIP_SLAB_STEP(1, r1)
   ELFIHIP_SLAB_STEP(2, r0)
   ELFIHIP_SLAB_STEP(3, r1)
+  if (nslab > 4) {  // workgroup-uniform: second k block of the chunk
+    ELFIHIP_SLAB_STEP(4, r0)
+    ELFIHIP_SLAB_STEP(5, r1)
+    ELFIHIP_SLAB_STEP(6, r0)
+    ELFIHIP_SLAB_STEP(7, r1)
+  }
 #undef ELFIHIP_SLAB_STEP
-  static_assert(NSLAB == 4, "slab sequence above is written out for four slabs");
-  double* out = T.part + ((int64_t)kb * T.np + i0) * PC;
+  static_assert(KCH * (NB / SLAB) == 8, "slab sequence above is written out for up to eight slabs");
+  double* out = T.part + ((int64_t)kc * T.np + i0) * PC;
 #pragma unroll
   for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -174,7 +188,14 @@ __global__ __launch_bounds__(256) void tri_reduce_kernel(const double* part, dou
     // chunks that can be non-zero: TRANS (kc_lo_is_row == 0): kc*KCH <= ib ; else kc*KCH+KCH > ib
     const int lo = kc_lo_is_row ? ib / KCH : 0;
     const int hi = kc_lo_is_row ? nkc : ib / KCH + 1;
-    for (int kc = lo; kc < hi; ++kc) v += part[(int64_t)kc * np * PC + e];
+    double v4[4] = {0, 0, 0, 0};
+    int kc = lo;
+    for (; kc + 4 <= hi; kc += 4) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v4[u] += part[(int64_t)(kc + u) * np * PC + e];
+    }
+    for (; kc < hi; ++kc) v4[0] += part[(int64_t)kc * np * PC + e];
+    v = (v4[0] + v4[1]) + (v4[2] + v4[3]);
     out[e] = v;
   }
   if (want_sq) {
@@ -238,7 +259,16 @@ __global__ __launch_bounds__(256) void finish_kernel(const double* mu_part, int 
   const int s = threadIdx.x & 15, j = threadIdx.x >> 4;
   double m = 0.0, q = 0.0;
   for (int b = j; b < nblk_k; b += 16) m += mu_part[s * nblk_k + b];
-  for (int b = j; b < nblk_v; b += 16) q += var_part[(int64_t)b * PC + s];
+  {
+    double q4[4] = {0, 0, 0, 0};  // independent accumulators: the loads pipeline
+    int b = j;
+    for (; b + 48 < nblk_v; b += 64) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) q4[u] += var_part[(int64_t)(b + 16 * u) * PC + s];
+    }
+    for (; b < nblk_v; b += 16) q4[0] += var_part[(int64_t)b * PC + s];
+    q = (q4[0] + q4[1]) + (q4[2] + q4[3]);
+  }
   red_m[j][s] = m;
   red_q[j][s] = q;
   __syncthreads();
@@ -272,16 +302,27 @@ __global__ __launch_bounds__(256) void finish_kernel(const double* mu_part, int 
   }
   __syncthreads();
   if (with_grad && s < S) {
-    // lane (s, j) assembles dimensions a = j, j + 16, ...: chunk partials in fixed order
+    // lane (s, j) assembles dimensions a = j, j + 16, ...: chunk partials in fixed order, four
+    // independent accumulators so the loads pipeline
     const double sc = sqrt(beta / vfin[s]);
     for (int a = j; a < dp; a += 16) {
-      double g1 = 0.0, g2 = 0.0;
-      for (int c = 0; c < ngc; ++c) {
-        g1 += g_part[((int64_t)s * ngc + c) * 2 * dp + a];
-        g2 += g_part[((int64_t)s * ngc + c) * 2 * dp + dp + a];
+      const double* gp1 = g_part + (int64_t)s * ngc * 2 * dp + a;
+      double g1[4] = {0, 0, 0, 0}, g2[4] = {0, 0, 0, 0};
+      int c = 0;
+      for (; c + 4 <= ngc; c += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          g1[u] += gp1[(int64_t)(c + u) * 2 * dp];
+          g2[u] += gp1[(int64_t)(c + u) * 2 * dp + dp];
+        }
       }
-      const double dm = -inv_ls2 * g1;
-      const double dv = 2.0 * inv_ls2 * g2;  // -2 * sum u_i dk_i, dk_i = -(k/l^2)(x - X_i)
+      for (; c < ngc; ++c) {
+        g1[0] += gp1[(int64_t)c * 2 * dp];
+        g2[0] += gp1[(int64_t)c * 2 * dp + dp];
+      }
+      const double s1 = (g1[0] + g1[1]) + (g1[2] + g1[3]), s2 = (g2[0] + g2[1]) + (g2[2] + g2[3]);
+      const double dm = -inv_ls2 * s1;
+      const double dv = 2.0 * inv_ls2 * s2;  // -2 * sum u_i dk_i, dk_i = -(k/l^2)(x - X_i)
       dmu[s * dp + a] = dm;
       dvar[s * dp + a] = dv;
       grad[s * dp + a] = dm - 0.5 * dv * sc;
