@@ -166,20 +166,21 @@ __global__ __launch_bounds__(256) void potf2_aug_kernel(double* Akk, int64_t lda
   long long tc[6] = {0, 0, 0, 0, 0, 0};
   const long long t_begin = clock64();
 
-  // block load, lower triangle only (plus the diagonal pair): 16-byte loads, 8 in flight
+  // block load, lower triangle only (plus the diagonal pair): 16-byte loads, all 32 per thread in
+  // flight at once -- one memory latency for the whole 128 x 128 block instead of four
+  {
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    v2d v[32];
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    double2 v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int e2 = tid + 256 * (8 * g + u);
+    for (int u = 0; u < 32; ++u) {
+      const int e2 = tid + 256 * u;
       const int i = e2 >> 6, c = 2 * (e2 & 63);
-      v[u] = make_double2(0.0, 0.0);
-      if (c <= i) v[u] = *reinterpret_cast<const double2*>(Akk + (int64_t)i * lda + c);
+      v[u] = (v2d){0.0, 0.0};
+      if (c <= i) v[u] = *reinterpret_cast<const v2d*>(Akk + (int64_t)i * lda + c);
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int e2 = tid + 256 * (8 * g + u);
+    for (int u = 0; u < 32; ++u) {
+      const int e2 = tid + 256 * u;
       const int i = e2 >> 6, c = 2 * (e2 & 63);
       S[i * SP + c] = (c <= i) ? v[u].x : 0.0;
       S[i * SP + c + 1] = (c + 1 <= i) ? v[u].y : 0.0;
@@ -377,7 +378,8 @@ struct PanelArgs {
   double* WT;
   const double* W11;
   int64_t lda;
-  int k, nb;
+  int k, nb;      // k: the panel being solved (panel_block / trsm)
+  int ku0, kun;   // trailing updates apply the panel group [ku0, ku0 + kun): K = 128 kun per pass over C
 };
 
 __device__ __forceinline__ double* panel_block(const PanelArgs& P, int idx) {
@@ -419,17 +421,17 @@ __global__ __launch_bounds__(256) void trailing_update_kernel(PanelArgs P, int c
     const int mrows = P.nb - c0;  // Cholesky row blocks c0..nb-1
     if (idx < mrows) {
       const int ib = c0 + idx;
-      Ap = P.A + ((int64_t)ib * NB) * P.lda + (int64_t)P.k * NB;
+      Ap = P.A + ((int64_t)ib * NB) * P.lda + (int64_t)P.ku0 * NB;
       C = P.A + ((int64_t)ib * NB) * P.lda + (int64_t)cblk * NB;
       same = (idx == 0);
     } else if (idx == mrows) {
-      Ap = P.A + ((int64_t)P.nb * NB) * P.lda + (int64_t)P.k * NB;
+      Ap = P.A + ((int64_t)P.nb * NB) * P.lda + (int64_t)P.ku0 * NB;
       C = P.A + ((int64_t)P.nb * NB) * P.lda + (int64_t)cblk * NB;
     } else {
       const int r = idx - mrows - 1;
-      Ap = P.WT + ((int64_t)r * NB) * P.lda + (int64_t)P.k * NB;
+      Ap = P.WT + ((int64_t)r * NB) * P.lda + (int64_t)P.ku0 * NB;
       C = P.WT + ((int64_t)r * NB) * P.lda + (int64_t)cblk * NB;
-      beta0 = (r == P.k);
+      beta0 = (r >= P.ku0);  // first group that touches this L^-T row: overwrite
     }
   } else {
     const int m = P.nb - c0;
@@ -441,29 +443,29 @@ __global__ __launch_bounds__(256) void trailing_update_kernel(PanelArgs P, int c
       const int c = idx - i * (i + 1) / 2;
       const int ib = c0 + i;
       cblk = c0 + c;
-      Ap = P.A + ((int64_t)ib * NB) * P.lda + (int64_t)P.k * NB;
+      Ap = P.A + ((int64_t)ib * NB) * P.lda + (int64_t)P.ku0 * NB;
       C = P.A + ((int64_t)ib * NB) * P.lda + (int64_t)cblk * NB;
       same = (i == c);
     } else if (idx < tA + m) {
       cblk = c0 + (idx - tA);
-      Ap = P.A + ((int64_t)P.nb * NB) * P.lda + (int64_t)P.k * NB;
+      Ap = P.A + ((int64_t)P.nb * NB) * P.lda + (int64_t)P.ku0 * NB;
       C = P.A + ((int64_t)P.nb * NB) * P.lda + (int64_t)cblk * NB;
     } else {
       idx -= tA + m;
       const int r = idx / m;
       cblk = c0 + (idx - r * m);
-      Ap = P.WT + ((int64_t)r * NB) * P.lda + (int64_t)P.k * NB;
+      Ap = P.WT + ((int64_t)r * NB) * P.lda + (int64_t)P.ku0 * NB;
       C = P.WT + ((int64_t)r * NB) * P.lda + (int64_t)cblk * NB;
-      beta0 = (r == P.k);
+      beta0 = (r >= P.ku0);  // first group that touches this L^-T row: overwrite
     }
   }
-  const double* Bp = P.A + ((int64_t)cblk * NB) * P.lda + (int64_t)P.k * NB;
+  const double* Bp = P.A + ((int64_t)cblk * NB) * P.lda + (int64_t)P.ku0 * NB;
   GemmAcc acc;
   acc.zero();
   if (same)
-    gemm_tile_nt<true>(acc, Ap, P.lda, Bp, P.lda, 0, NB, lds);
+    gemm_tile_nt<true>(acc, Ap, P.lda, Bp, P.lda, 0, P.kun * NB, lds);
   else
-    gemm_tile_nt<false>(acc, Ap, P.lda, Bp, P.lda, 0, NB, lds);
+    gemm_tile_nt<false>(acc, Ap, P.lda, Bp, P.lda, 0, P.kun * NB, lds);
   if (beta0)
     acc_foreach(acc, [&](int row, int col, double v) { C[(int64_t)row * P.lda + col] = -v; });
   else
@@ -481,23 +483,23 @@ __global__ __launch_bounds__(256) void trailing_update_col_kernel(PanelArgs P, i
   bool beta0 = false;
   if (rb < mrows) {
     const int ib = cblk + rb;
-    Ap = P.A + ((int64_t)ib * NB) * P.lda + (int64_t)P.k * NB;
+    Ap = P.A + ((int64_t)ib * NB) * P.lda + (int64_t)P.ku0 * NB;
     C = P.A + ((int64_t)ib * NB) * P.lda + (int64_t)cblk * NB;
   } else if (rb == mrows) {
-    Ap = P.A + ((int64_t)P.nb * NB) * P.lda + (int64_t)P.k * NB;
+    Ap = P.A + ((int64_t)P.nb * NB) * P.lda + (int64_t)P.ku0 * NB;
     C = P.A + ((int64_t)P.nb * NB) * P.lda + (int64_t)cblk * NB;
   } else {
     const int r = rb - mrows - 1;
-    Ap = P.WT + ((int64_t)r * NB) * P.lda + (int64_t)P.k * NB;
+    Ap = P.WT + ((int64_t)r * NB) * P.lda + (int64_t)P.ku0 * NB;
     C = P.WT + ((int64_t)r * NB) * P.lda + (int64_t)cblk * NB;
-    beta0 = (r == P.k);
+    beta0 = (r >= P.ku0);  // first group that touches this L^-T row: overwrite
   }
   Ap += (int64_t)sub * 32 * P.lda;
   C += (int64_t)sub * 32 * P.lda;
-  const double* Bp = P.A + ((int64_t)cblk * NB) * P.lda + (int64_t)P.k * NB;
+  const double* Bp = P.A + ((int64_t)cblk * NB) * P.lda + (int64_t)P.ku0 * NB;
   GemmAcc32 acc;
   acc.zero();
-  gemm_tile32_nt(acc, Ap, P.lda, Bp, P.lda, 0, NB, lds);
+  gemm_tile32_nt(acc, Ap, P.lda, Bp, P.lda, 0, P.kun * NB, lds);
   if (beta0)
     acc32_foreach(acc, [&](int row, int col, double v) { C[(int64_t)row * P.lda + col] = -v; });
   else
@@ -603,6 +605,17 @@ int gp_factorize_impl(elfihip_gp* gp) {
   ELFIHIP_CHECK_HIP(ctx, hipStreamWaitEvent(hi, ctx->ev_a, 0));
   ELFIHIP_CHECK_HIP(ctx, hipStreamWaitEvent(bulk, ctx->ev_a, 0));
   bool bulk_pending = false;
+  // Panel grouping: with group = 2 the bulk update is issued every second step and applies TWO
+  // panels per pass over the trailing matrix (K = 256): half the read-modify-write traffic on C
+  // (16 instead of 8 flop per byte) and half the cross-stream hand-offs.  The two block columns
+  // the next pair needs first are brought up to date on the critical stream itself.
+  int group = nb >= 48 ? 2 : 1;  // measured: pays from n ~ 6000 (n=8192: 15.1 -> 12.1 ms), neutral at 4096
+  if (const char* e = getenv("ELFIHIP_PANEL_GROUP")) group = atoi(e) == 2 ? 2 : 1;
+  const size_t lds32 = GEMM32_LDS_DOUBLES * sizeof(double);
+  auto col_update = [&](hipStream_t s_, int cblk) {  // every row block of block column cblk, 32-row workgroups
+    const int rows = (nb - cblk) + 1 + (P.ku0 + P.kun);
+    hipLaunchKernelGGL(trailing_update_col_kernel, dim3(4 * rows), dim3(256), lds32, s_, P, cblk);
+  };
   for (int k = 0; k < nb; ++k) {
     P.k = k;
     double* Akk = gp->A + ((int64_t)k * NB) * gp->lda + (int64_t)k * NB;
@@ -610,20 +623,43 @@ int gp_factorize_impl(elfihip_gp* gp) {
     hipLaunchKernelGGL(potf2_aug_kernel, dim3(1), dim3(256), potf2_lds, hi, Akk, gp->lda, Wkk, gp->lda, gp->W11,
                        gp->info, k, 0);
     const int nrows = (nb - 1 - k) + 1 + k;  // below + y block + L^-T rows above
-    hipLaunchKernelGGL(trsm_gemm_kernel, dim3(4 * nrows), dim3(256), GEMM32_LDS_DOUBLES * sizeof(double), hi, P);
-    const int m = nb - 1 - k;
-    if (m > 0) {
+    hipLaunchKernelGGL(trsm_gemm_kernel, dim3(4 * nrows), dim3(256), lds32, hi, P);
+    const int m = nb - 1 - k;  // block columns right of k
+    if (m == 0) break;
+    if (group == 1) {
       // column k+1 first and alone (it gates the next diagonal block), then the bulk of step k, which
       // runs in the shadow of potf2(k+1) / trsm(k+1) on the other stream
+      P.ku0 = k;
+      P.kun = 1;
       if (bulk_pending) ELFIHIP_CHECK_HIP(ctx, hipStreamWaitEvent(hi, ctx->ev_b, 0));  // bulk(k-1) wrote column k+1
-      hipLaunchKernelGGL(trailing_update_col_kernel, dim3(4 * (m + 1 + (k + 1))), dim3(256),
-                         GEMM32_LDS_DOUBLES * sizeof(double), hi, P, k + 1);
+      col_update(hi, k + 1);
       if (m > 1) {
         const int mc = m - 1;
         const int tiles = mc * (mc + 1) / 2 + mc + (k + 1) * mc;
         ELFIHIP_CHECK_HIP(ctx, hipEventRecord(ctx->ev_a, hi));        // trsm(k) and column k+1 done
         ELFIHIP_CHECK_HIP(ctx, hipStreamWaitEvent(bulk, ctx->ev_a, 0));
         hipLaunchKernelGGL(trailing_update_kernel, dim3(tiles), dim3(256), gemm_lds, bulk, P, k + 2, 0);
+        ELFIHIP_CHECK_HIP(ctx, hipEventRecord(ctx->ev_b, bulk));
+        bulk_pending = true;
+      }
+    } else if ((k & 1) == 0) {
+      // first panel of a pair: only the next block column needs it now
+      P.ku0 = k;
+      P.kun = 1;
+      col_update(hi, k + 1);
+    } else {
+      // second panel of a pair: both panels go into columns k+1 and k+2 here, into the rest on `bulk`
+      P.ku0 = k - 1;
+      P.kun = 2;
+      if (bulk_pending) ELFIHIP_CHECK_HIP(ctx, hipStreamWaitEvent(hi, ctx->ev_b, 0));  // previous pair's bulk
+      col_update(hi, k + 1);
+      if (m > 1) col_update(hi, k + 2);
+      if (m > 2) {
+        const int mc = m - 2;
+        const int tiles = mc * (mc + 1) / 2 + mc + (k + 1) * mc;
+        ELFIHIP_CHECK_HIP(ctx, hipEventRecord(ctx->ev_a, hi));
+        ELFIHIP_CHECK_HIP(ctx, hipStreamWaitEvent(bulk, ctx->ev_a, 0));
+        hipLaunchKernelGGL(trailing_update_kernel, dim3(tiles), dim3(256), gemm_lds, bulk, P, k + 3, 0);
         ELFIHIP_CHECK_HIP(ctx, hipEventRecord(ctx->ev_b, bulk));
         bulk_pending = true;
       }
