@@ -59,6 +59,7 @@ struct elfihip_ctx {
   hipStream_t hi_stream = nullptr;    // critical path, confined to the reserved XCDs
   hipStream_t bulk_stream = nullptr;  // bulk trailing update, every other XCD
   hipEvent_t ev_a = nullptr, ev_b = nullptr;
+  hipEvent_t ev_u[4] = {nullptr, nullptr, nullptr, nullptr};  // look-ahead window columns of the next panel group
   int cu_count = 0;
   std::string err;
   // staging buffers for the host entry points

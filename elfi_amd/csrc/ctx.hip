@@ -38,6 +38,7 @@ int ctx_aux(elfihip_ctx* ctx) {
     if (atoi(e)) flags = hipEventDisableTiming;
   ELFIHIP_CHECK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_a, flags));
   ELFIHIP_CHECK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_b, flags));
+  for (auto& e : ctx->ev_u) ELFIHIP_CHECK_HIP(ctx, hipEventCreateWithFlags(&e, flags));
   return ELFIHIP_OK;
 }
 }  // namespace elfihip
@@ -111,6 +112,8 @@ int elfihip_ctx_destroy(elfihip_ctx* ctx) {
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->ev_a) (void)hipEventDestroy(ctx->ev_a);
     if (ctx->ev_b) (void)hipEventDestroy(ctx->ev_b);
+    for (auto e : ctx->ev_u)
+      if (e) (void)hipEventDestroy(e);
     if (ctx->hi_stream) (void)hipStreamDestroy(ctx->hi_stream);
     if (ctx->bulk_stream) (void)hipStreamDestroy(ctx->bulk_stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);

@@ -605,17 +605,28 @@ int gp_factorize_impl(elfihip_gp* gp) {
   ELFIHIP_CHECK_HIP(ctx, hipStreamWaitEvent(hi, ctx->ev_a, 0));
   ELFIHIP_CHECK_HIP(ctx, hipStreamWaitEvent(bulk, ctx->ev_a, 0));
   bool bulk_pending = false;
-  // Panel grouping: with group = 2 the bulk update is issued every second step and applies TWO
-  // panels per pass over the trailing matrix (K = 256): half the read-modify-write traffic on C
-  // (16 instead of 8 flop per byte) and half the cross-stream hand-offs.  The two block columns
-  // the next pair needs first are brought up to date on the critical stream itself.
-  int group = nb >= 48 ? 2 : 1;  // measured: pays from n ~ 6000 (n=8192: 15.1 -> 12.1 ms), neutral at 4096
-  if (const char* e = getenv("ELFIHIP_PANEL_GROUP")) group = atoi(e) == 2 ? 2 : 1;
+  // Panel grouping.  Panels are eliminated in groups of G (1, 2 or 4).  Inside a group only the next
+  // block column is brought up to date after each panel (left-looking: it receives all panels of the
+  // group so far in one GEMM); when the group is complete the whole trailing matrix receives all G
+  // panels in ONE pass (K = 128 G): the read-modify-write traffic on the trailing tiles -- what
+  // limits a K = 128 update to 8 flop per byte -- drops by G, and so do the cross-stream hand-offs.
+  // Order on `bulk` after a group: first the G-1 block columns the next group touches before its
+  // own end (one launch and one event each, so the critical stream never waits for more than it
+  // needs), then the rest.
+  // measured rebuild times, G = 1 / 2 / 4:  n=4096: 3.38 / 3.30 / 3.36 ms;  n=8192: 15.3 / 12.2 / 11.7 ms;
+  // n=12288: 48.1 / 35.1 / 30.0 ms (41 TFLOP/s)
+  int group = nb >= 48 ? 4 : (nb >= 24 ? 2 : 1);
+  if (const char* e = getenv("ELFIHIP_PANEL_GROUP")) {
+    const int g_ = atoi(e);
+    group = (g_ == 2 || g_ == 4) ? g_ : 1;
+  }
   const size_t lds32 = GEMM32_LDS_DOUBLES * sizeof(double);
   auto col_update = [&](hipStream_t s_, int cblk) {  // every row block of block column cblk, 32-row workgroups
     const int rows = (nb - cblk) + 1 + (P.ku0 + P.kun);
     hipLaunchKernelGGL(trailing_update_col_kernel, dim3(4 * rows), dim3(256), lds32, s_, P, cblk);
   };
+  int g0 = 0;              // first panel of the current group
+  int urgent_pending = 0;  // window columns of this group still guarded by ev_u[0..)
   for (int k = 0; k < nb; ++k) {
     P.k = k;
     double* Akk = gp->A + ((int64_t)k * NB) * gp->lda + (int64_t)k * NB;
@@ -626,44 +637,35 @@ int gp_factorize_impl(elfihip_gp* gp) {
     hipLaunchKernelGGL(trsm_gemm_kernel, dim3(4 * nrows), dim3(256), lds32, hi, P);
     const int m = nb - 1 - k;  // block columns right of k
     if (m == 0) break;
-    if (group == 1) {
-      // column k+1 first and alone (it gates the next diagonal block), then the bulk of step k, which
-      // runs in the shadow of potf2(k+1) / trsm(k+1) on the other stream
-      P.ku0 = k;
-      P.kun = 1;
-      if (bulk_pending) ELFIHIP_CHECK_HIP(ctx, hipStreamWaitEvent(hi, ctx->ev_b, 0));  // bulk(k-1) wrote column k+1
+    const int j = k - g0;      // position inside the group
+    P.ku0 = g0;
+    P.kun = j + 1;
+    if (j < group - 1) {
+      // column k+1 was in the previous group's window: its update from that group must have landed
+      if (j < urgent_pending) ELFIHIP_CHECK_HIP(ctx, hipStreamWaitEvent(hi, ctx->ev_u[j], 0));
       col_update(hi, k + 1);
-      if (m > 1) {
-        const int mc = m - 1;
-        const int tiles = mc * (mc + 1) / 2 + mc + (k + 1) * mc;
-        ELFIHIP_CHECK_HIP(ctx, hipEventRecord(ctx->ev_a, hi));        // trsm(k) and column k+1 done
-        ELFIHIP_CHECK_HIP(ctx, hipStreamWaitEvent(bulk, ctx->ev_a, 0));
-        hipLaunchKernelGGL(trailing_update_kernel, dim3(tiles), dim3(256), gemm_lds, bulk, P, k + 2, 0);
-        ELFIHIP_CHECK_HIP(ctx, hipEventRecord(ctx->ev_b, bulk));
-        bulk_pending = true;
-      }
-    } else if ((k & 1) == 0) {
-      // first panel of a pair: only the next block column needs it now
-      P.ku0 = k;
-      P.kun = 1;
-      col_update(hi, k + 1);
-    } else {
-      // second panel of a pair: both panels go into columns k+1 and k+2 here, into the rest on `bulk`
-      P.ku0 = k - 1;
-      P.kun = 2;
-      if (bulk_pending) ELFIHIP_CHECK_HIP(ctx, hipStreamWaitEvent(hi, ctx->ev_b, 0));  // previous pair's bulk
-      col_update(hi, k + 1);
-      if (m > 1) col_update(hi, k + 2);
-      if (m > 2) {
-        const int mc = m - 2;
-        const int tiles = mc * (mc + 1) / 2 + mc + (k + 1) * mc;
-        ELFIHIP_CHECK_HIP(ctx, hipEventRecord(ctx->ev_a, hi));
-        ELFIHIP_CHECK_HIP(ctx, hipStreamWaitEvent(bulk, ctx->ev_a, 0));
-        hipLaunchKernelGGL(trailing_update_kernel, dim3(tiles), dim3(256), gemm_lds, bulk, P, k + 3, 0);
-        ELFIHIP_CHECK_HIP(ctx, hipEventRecord(ctx->ev_b, bulk));
-        bulk_pending = true;
-      }
+      continue;
     }
+    // group complete
+    if (bulk_pending) ELFIHIP_CHECK_HIP(ctx, hipStreamWaitEvent(hi, ctx->ev_b, 0));  // previous group's pass over C
+    col_update(hi, k + 1);
+    ELFIHIP_CHECK_HIP(ctx, hipEventRecord(ctx->ev_a, hi));  // panels g0..k solved, column k+1 current
+    ELFIHIP_CHECK_HIP(ctx, hipStreamWaitEvent(bulk, ctx->ev_a, 0));
+    urgent_pending = 0;
+    for (int u = 0; u < group - 1 && k + 2 + u < nb; ++u) {  // the next group's window, one column at a time
+      col_update(bulk, k + 2 + u);
+      ELFIHIP_CHECK_HIP(ctx, hipEventRecord(ctx->ev_u[u], bulk));
+      ++urgent_pending;
+    }
+    const int c0 = k + 1 + group;  // first block column left to the big pass
+    if (c0 < nb) {
+      const int mc = nb - c0;
+      const int tiles = mc * (mc + 1) / 2 + mc + (k + 1) * mc;
+      hipLaunchKernelGGL(trailing_update_kernel, dim3(tiles), dim3(256), gemm_lds, bulk, P, c0, 0);
+    }
+    ELFIHIP_CHECK_HIP(ctx, hipEventRecord(ctx->ev_b, bulk));
+    bulk_pending = true;
+    g0 = k + 1;
   }
   ELFIHIP_CHECK_HIP(ctx, hipEventRecord(ctx->ev_a, hi));
   ELFIHIP_CHECK_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_a, 0));
