@@ -62,6 +62,10 @@ PROTOTYPES = {
                                          C.POINTER(C.c_int64), C.c_void_p, C.c_void_p]),
     "elfihip_welford_update_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int64,
                                              C.c_void_p]),
+    "elfihip_topk_smallest": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p,
+                                        C.c_void_p]),
+    "elfihip_topk_smallest_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p,
+                                            C.c_void_p]),
     "elfihip_row_summary": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_int,
                                       C.c_void_p]),
     "elfihip_row_summary_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_int,

@@ -126,6 +126,18 @@ int elfihip_welford_update(elfihip_ctx* ctx, const double* X, int64_t n, int m, 
 int elfihip_welford_update_dev(elfihip_ctx* ctx, const double* dX, int64_t n, int m, int64_t ldx,
                                double* dstate);
 
+/* ------------------------------------------------------------------ selection
+ * The selection inside Rejection._merge_batch (elfi/methods/inference/samplers.py:209-237): the
+ * reference argsorts n_samples + batch_size distances on the host per batch; keeping the k smallest
+ * of the batch is equivalent and lets only k rows leave the GPU.  vals (k) / idx (k, row numbers)
+ * come back ascending by (distance, row); NaN last; k is clipped to n.  `stride` (in doubles) lets
+ * the _dev form read one column of an (n, K) nested-distance matrix in place; the _dev form leaves
+ * the k survivors unsorted (row order inside "< k-th" then "== k-th"). */
+int elfihip_topk_smallest(elfihip_ctx* ctx, const double* D, int64_t n, int64_t stride, int64_t k, double* vals,
+                          int64_t* idx);
+int elfihip_topk_smallest_dev(elfihip_ctx* ctx, const double* dD, int64_t n, int64_t stride, int64_t k,
+                              double* dvals, int64_t* didx);
+
 /* ------------------------------------------------------------------ summaries
  * Row-wise summary statistics that ELFI's example models install as elfi.Summary operations, with
  * NumPy's exact (pairwise) summation order, i.e. bit-identical results:

@@ -1,0 +1,61 @@
+"""GPU: k smallest distances / sampler merge vs NumPy (exact: selection moves values, it computes none)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(d, k):
+    d = np.asarray(d, dtype=np.float64)
+    order = np.lexsort((np.arange(len(d)), np.where(np.isnan(d), np.inf, d), np.isnan(d)))[:k]
+    return d[order], order
+
+
+@pytest.mark.parametrize('n,k', [(1, 1), (10, 3), (1000, 1000), (1000, 5000), (4097, 100), (10**6, 1000),
+                                 (10**6, 1), (300000, 10000)])
+def test_smallest_k_matches_numpy(hip_ctx, n, k):
+    import elfi_amd
+    rs = np.random.RandomState(n + k)
+    d = np.abs(rs.randn(n)) * rs.uniform(0.1, 10)
+    vals, idx = elfi_amd.smallest_k(d, k)
+    rv, ri = _ref(d, min(k, n))
+    assert np.array_equal(vals, rv) and np.array_equal(idx, ri)
+
+
+def test_smallest_k_ties_negatives_nan_inf(hip_ctx):
+    import elfi_amd
+    rs = np.random.RandomState(0)
+    d = rs.randint(-5, 5, 20000).astype(float)            # massive ties, negative values
+    d[::97] = np.nan
+    d[5::101] = np.inf
+    d[7::103] = -np.inf
+    for k in (1, 50, 777, 19999, 20000):
+        vals, idx = elfi_amd.smallest_k(d, k)
+        rv, ri = _ref(d, k)
+        assert np.array_equal(idx, ri)
+        assert np.array_equal(vals, rv, equal_nan=True)
+    assert elfi_amd.smallest_k(d, 0)[0].shape == (0,)
+    assert elfi_amd.smallest_k(np.empty(0), 5)[1].shape == (0,)
+    nested = np.column_stack([rs.rand(5000), rs.rand(5000)])
+    v, i = elfi_amd.smallest_k(nested, 10)                  # last column decides (samplers.py:233)
+    assert np.array_equal(i, np.argsort(nested[:, 1], kind='stable')[:10])
+
+
+def test_merge_batch_equals_the_reference_merge(hip_ctx):
+    """Rejection._merge_batch semantics (samplers.py:209-237) over several batches."""
+    import elfi_amd
+    rs = np.random.RandomState(3)
+    n_samples, bs = 200, 5000
+    state = None
+    ref = {'d': np.full(n_samples + bs, np.inf), 't1': np.empty(n_samples + bs), 'S': np.empty((n_samples + bs, 2))}
+    for b in range(4):
+        batch = {'d': np.abs(rs.randn(bs)), 't1': rs.rand(bs), 'S': rs.randn(bs, 2)}
+        state = elfi_amd.merge_batch(state, batch, 'd', n_samples)
+        for k_, v in ref.items():                           # the reference's steps, verbatim in spirit
+            v[-bs:] = batch[k_]
+        order = np.argsort(ref['d'])
+        for k_, v in ref.items():
+            v[:] = v[order]
+        for k_ in ref:
+            assert np.array_equal(state[k_], ref[k_][:n_samples]), (b, k_)
+    assert np.all(np.diff(state['d']) >= 0)
