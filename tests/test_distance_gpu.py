@@ -321,3 +321,27 @@ def test_sharding_module_with_the_hip_backend(hip_ctx):
     exp = np.vstack([np.column_stack([O.cdist_rows(X, y, 'euclidean', w=w) for w in W]) for X in data])
     assert np.array_equal(got, exp)
     assert S.gather_rows(got)[0] is not None
+
+
+def test_config4_shape_adaptive_round(hip_ctx):
+    """BASELINE configs[3] per-GPU shape: 1.25e6 x 64 summaries, one adaptive-distance round with
+    K = 3 nested weight vectors.  Scales vs np.std of the shard; every distance column bit-exact
+    against cdist on a 2^15-row sample and through exact properties on the full shard."""
+    import elfi_amd
+    n, m = 1250000, 64
+    X = np.random.RandomState(100).randn(n, m) * np.linspace(0.5, 20, m)
+    y = np.random.RandomState(1).randn(1, m)
+    ad = elfi_amd.AdaptiveDistanceState()
+    ad.add_data(X)
+    np.testing.assert_allclose(ad.state['scale'], np.std(X, axis=0), rtol=1e-11)
+    ad.update_distance()
+    ad.add_data(X[: n // 2])
+    ad.update_distance()
+    d = ad.nested_distance(X, y)
+    assert d.shape == (n, 3)
+    W = ad.weight_matrix(m)
+    idx = np.random.RandomState(2).choice(n, 1 << 15, replace=False)
+    for k in range(3):
+        assert np.array_equal(d[idx, k], O.cdist_rows(X[idx], y, 'euclidean', w=W[k])), k
+    assert np.array_equal(d[:, 0], elfi_amd.cdist_rows(X, y))              # unweighted column == plain euclidean
+    assert np.array_equal(ad.nested_distance(X[::-1].copy(), y), d[::-1])  # row-order equivariance
