@@ -385,6 +385,7 @@ static int launch_rows(elfihip_ctx* ctx, RowArgs A) {
   const int g = grid_for(ctx, ntiles, lds, T);
   if (A.vec2 && A.m <= 128) {
     // pipelined form: 128 threads, 16 (m <= 16: 8) register pairs each = one whole tile of R rows
+    // (measured on 10^6 x 32: 256-thread tiles 5.1 TB/s vs 5.25; non-temporal loads +-1 %: not used)
     const int Tp = 128, U = A.m <= 16 ? 8 : 16;
     int R = 2 * Tp * U / A.m;
     if (R > Tp) R = Tp;
@@ -469,6 +470,7 @@ static RowArgs make_row_args(const double* dX, int64_t n, int m, int64_t ldx, co
   A.mp = m | 1;
   A.K = 0;
   A.R = 0;
+  A.nt = 0;
   A.vec2 = (m % 2 == 0) && (ldx % 2 == 0) && aligned16(dX);
   A.div_h = make_fastdiv((uint32_t)(A.vec2 ? m / 2 : m));
   return A;

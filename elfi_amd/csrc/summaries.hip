@@ -168,6 +168,7 @@ static RowArgs summary_row_args(const double* dX, int64_t n, int L, int64_t ldx)
   A.mp = L | 1;
   A.K = 0;
   A.R = 0;
+  A.nt = 0;
   A.vec2 = (L % 2 == 0) && (ldx % 2 == 0) && tile_aligned16(dX);
   A.div_h = make_fastdiv((uint32_t)(A.vec2 ? L / 2 : L));
   return A;

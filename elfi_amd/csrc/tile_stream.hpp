@@ -37,6 +37,7 @@ struct RowArgs {
   int K;          // multi-weight: number of weight rows in aux
   int vec2;       // 16-byte loads are legal (m, ldx even; X 16-byte aligned)
   int R;          // pipelined kernels: rows per tile (<= blockDim.x); T * U >= R * m / 2
+  int nt;         // pipelined kernels: non-temporal loads
   FastDiv div_h;  // by m/2 (vec2) or m
 };
 
@@ -113,7 +114,15 @@ __device__ __forceinline__ void tile_fetch(const RowArgs& A, int64_t row0, int r
     const uint32_t q = fastdiv(ok ? idx : 0u, A.div_h);
     const uint32_t jj = (ok ? idx : 0u) - q * h;
     v[u] = make_double2(0.0, 0.0);
-    if (ok) v[u] = *reinterpret_cast<const double2*>(X + (int64_t)q * A.ldx + 2 * jj);
+    if (ok) {
+      const double2* src = reinterpret_cast<const double2*>(X + (int64_t)q * A.ldx + 2 * jj);
+      if (A.nt) {  // streamed once: do not keep the lines in L2 / MALL
+        v[u].x = __builtin_nontemporal_load(&src->x);
+        v[u].y = __builtin_nontemporal_load(&src->y);
+      } else {
+        v[u] = *src;
+      }
+    }
   }
 }
 
