@@ -24,6 +24,37 @@ import scipy.stats as ss
 logger = logging.getLogger(__name__)
 
 
+def _dist_rank_world():
+    try:
+        import torch.distributed as dist
+    except Exception:
+        return 0, 1
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def _allgather_starts(locs, vals, iters, n_starts, world, device):
+    """All-gather the per-rank optima and restore start order (start s came from rank s % world)."""
+    import torch
+    import torch.distributed as dist
+    d = locs.shape[1]
+    per = (n_starts + world - 1) // world
+    buf = np.full((per, d + 2), np.inf)
+    buf[:len(vals), :d] = locs
+    buf[:len(vals), d] = vals
+    buf[:len(vals), d + 1] = iters
+    t = torch.from_numpy(buf).to(device)
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    full_l, full_v, full_i = np.empty((n_starts, d)), np.empty(n_starts), np.empty(n_starts, dtype=np.int32)
+    for r, o in enumerate(out):
+        o = o.cpu().numpy()
+        idx = np.arange(r, n_starts, world)
+        full_l[idx], full_v[idx], full_i[idx] = o[:len(idx), :d], o[:len(idx), d], o[:len(idx), d + 1].astype(np.int32)
+    return full_l, full_v, full_i
+
+
 class HipLCBSC:
     """Lower Confidence Bound Selection Criterion (GP-LCB of Srinivas et al.), interface of
     elfi.methods.bo.acquisition.LCBSC."""
@@ -50,6 +81,11 @@ class HipLCBSC:
         self.name = 'lcbsc'
         self.label_fn = 'Confidence Bound'
         self.last_opt = None   # diagnostics of the latest acquire(): per-start optima, iterations
+        # Multi-GPU: when torch.distributed is initialised (one process per GPU, every rank holding the
+        # same evidence and therefore the same deterministic factorisation), the start points are dealt
+        # round-robin over the ranks and the optima are all-gathered (SURVEY.md section 8e, configs[4]).
+        self.shard_starts = True
+        self.dist_device = 'cpu'   # 'cuda' under the nccl (RCCL) backend
 
     # -- argument handling, same accepted forms and error texts as acquisition.py:75-109
     def _noise_spec(self, noise_var):
@@ -118,8 +154,18 @@ class HipLCBSC:
             # no evidence yet: the reference's GP predicts (0, 1) everywhere, every start is a minimum
             self.last_opt = None
             return np.array(start_points[0], dtype=float), float(-np.sqrt(self._beta(t)))
-        locs, vals, iters, n_eval = self.model._handle.lcb_minimize(start_points, bounds, self._beta(t),
-                                                                   maxiter=self.max_opt_iters)
+        rank, world = _dist_rank_world() if self.shard_starts else (0, 1)
+        mine = np.arange(rank, len(start_points), world)     # start s belongs to rank s % world
+        if len(mine):
+            locs, vals, iters, n_eval = self.model._handle.lcb_minimize(start_points[mine], bounds, self._beta(t),
+                                                                       maxiter=self.max_opt_iters)
+        else:
+            locs, vals = np.empty((0, len(bounds))), np.empty(0)
+            iters, n_eval = np.empty(0, dtype=np.int32), 0
+        if world > 1:
+            # ONE exchange: every rank's end points and values (S x (d+2) doubles in total), put
+            # back into start order so that the arg-min (ties: first) is the same on every rank
+            locs, vals, iters = _allgather_starts(locs, vals, iters, len(start_points), world, self.dist_device)
         ind_min = np.argmin(vals)
         xhat = locs[ind_min].copy()
         for i in range(len(bounds)):

@@ -121,3 +121,56 @@ def test_merge_welford_equals_pooled_statistics():
     assert owned_batches(7, 1, 3) == [1, 4]
     per_rank = [[('b', b) for b in owned_batches(7, r, 3)] for r in range(3)]
     assert interleave_batches(per_rank, 7, 3) == [('b', b) for b in range(7)]
+
+
+# ---- sharded acquisition starts (configs[4]: starts split over the GPUs, all-gather of the optima)
+class _FakeHandle:
+    """Stands in for GPHandle.lcb_minimize: a deterministic 'optimiser' (projected gradient steps on a
+    quadratic bowl) so that the sharding / gathering logic can run without a GPU."""
+
+    def lcb_minimize(self, starts, bounds, beta, maxiter=1000):
+        lo, hi = np.array(bounds).T
+        x = np.clip(np.asarray(starts, float), lo, hi)
+        c = np.linspace(-0.5, 0.7, x.shape[1])
+        for _ in range(50):
+            x = np.clip(x - 0.2 * 2 * (x - c), lo, hi)
+        f = np.sum((x - c) ** 2, axis=1) + 0.01 * np.sin(7 * np.asarray(starts)[:, 0])   # start-dependent tie-breaker
+        return x, f, np.full(len(x), 50, dtype=np.int32), 51 * len(x)
+
+
+class _FakeModel:
+    parameter_names = ['a', 'b', 'c']
+    input_dim = 3
+    bounds = [(-2, 2), (-1, 1), (0, 3)]
+    n_evidence = 10
+    _handle = _FakeHandle()
+
+
+def _acq_worker(rank, world, port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, 'oracle'), os.path.join(ROOT, 'tests')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    from elfi_amd import HipLCBSC
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        acq = HipLCBSC(_FakeModel(), n_inits=7, noise_var=0.05, seed=11)
+        x = acq.acquire(3, t=4)
+        np.save(os.path.join(out_dir, 'acq_%d.npy' % rank), x)
+        np.save(os.path.join(out_dir, 'vals_%d.npy' % rank), acq.last_opt['vals'])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_acquisition_starts(tmp_path):
+    import torch.multiprocessing as mp
+    from elfi_amd import HipLCBSC
+    mp.spawn(_acq_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    single = HipLCBSC(_FakeModel(), n_inits=7, noise_var=0.05, seed=11)
+    x1 = single.acquire(3, t=4)
+    a0, a1 = np.load(tmp_path / 'acq_0.npy'), np.load(tmp_path / 'acq_1.npy')
+    assert np.array_equal(a0, a1), 'every rank must acquire the same points'
+    assert np.array_equal(a0, x1), 'sharding the starts must not change the acquisition'
+    assert np.array_equal(np.load(tmp_path / 'vals_0.npy'), single.last_opt['vals'])
