@@ -15,7 +15,8 @@ implements on top of GPy can be executed unmodified if it is handed the posterio
 The reference's own tests assert closed form == GPy (tests/unit/test_methods.py:110-122), so a
 restatement that agrees with the closed forms agrees with GPy at that tolerance.
 
-    python oracle/make_golden.py gp        ->  tests/golden/gp_closed_forms.npz, gp_acquisition.npz
+    python oracle/make_golden.py gp        ->  tests/golden/gp_closed_forms.npz, gp_acquisition.npz,
+                                               gp_bolfi_trace.npz (the real BOLFI loop on MA2)
 """
 import os
 
@@ -123,3 +124,57 @@ def main(elfi, golden_dir):
     acq_out['cases'] = np.array(['150_2', '300_3'])
     np.savez_compressed(os.path.join(golden_dir, 'gp_acquisition.npz'), **acq_out)
     print('gp_acquisition: 2 cases')
+
+    make_bolfi_trace(elfi, golden_dir)
+
+
+def make_bolfi_trace(elfi, golden_dir):
+    """The reference's whole BOLFI loop (bolfi.py: BayesianOptimization.update / prepare_new_batch /
+    _should_optimize, the reference's LCBSC + minimize + scipy L-BFGS-B, ModelPrior start points) on
+    the MA2 example, with OracleGPRegression as `target_model`.  Recorded: every update() call the
+    loop makes (evidence, optimize flag, hyper-parameters afterwards) and every inner minimisation
+    (acquisition index t, optimum, value)."""
+    import elfi.methods.bo.acquisition as acq_mod
+    from elfi.examples import ma2
+    from oracle_gp_model import OracleGPRegression
+
+    m = ma2.get_model(seed_obs=4)
+    log_d = elfi.Operation(np.log, m['d'], name='log_d')
+    bounds = {'t1': (-2, 2), 't2': (-1, 1)}
+    tm = OracleGPRegression(['t1', 't2'], bounds=bounds, max_opt_iters=50)
+    mins = []
+    orig_minimize = acq_mod.minimize
+
+    def recording_minimize(fun, *a, **k):
+        x, f = orig_minimize(fun, *a, **k)
+        mins.append((tm.n_evidence, np.array(x, float), float(np.ravel(f)[0])))
+        return x, f
+
+    acq_mod.minimize = recording_minimize
+    try:
+        bolfi = elfi.BOLFI(log_d, batch_size=1, initial_evidence=20, update_interval=10, bounds=bounds,
+                           target_model=tm, acq_noise_var=0.1, seed=1)
+        ts = []
+        orig_acquire = bolfi.acquisition_method.acquire
+
+        def recording_acquire(n, t=None):
+            ts.append(t)
+            return orig_acquire(n, t=t)
+
+        bolfi.acquisition_method.acquire = recording_acquire
+        bolfi.fit(n_evidence=50)
+    finally:
+        acq_mod.minimize = orig_minimize
+    out = {'n_updates': np.int64(len(tm.log)), 'n_min': np.int64(len(mins))}
+    for i, (x, y, opt, h) in enumerate(tm.log):
+        out['u%d_x' % i], out['u%d_y' % i] = x, y
+        out['u%d_opt' % i] = np.bool_(opt)
+        out['u%d_hyper' % i] = np.array([h['var'], h['ls'], h['bias'], h['noise']])
+    for i, (n_ev, x, f) in enumerate(mins):
+        out['m%d_n' % i], out['m%d_x' % i], out['m%d_f' % i] = np.int64(n_ev), x, np.float64(f)
+        out['m%d_t' % i] = np.int64(ts[i])
+    out['final_X'], out['final_Y'] = tm.X, tm.Y
+    np.savez_compressed(os.path.join(golden_dir, 'gp_bolfi_trace.npz'), **out)
+    n_opt = sum(1 for r in tm.log if r[2])
+    print('gp_bolfi_trace: %d updates (%d with optimisation), %d acquisitions, final hyper %s'
+          % (len(tm.log), n_opt, len(mins), {k: round(v, 4) for k, v in tm.hyper.items()}))
