@@ -16,6 +16,7 @@ from ._lib import LIB_PATH, Context, ElfiHipError, default_context, device_count
 from .distance import (AdaptiveDistanceState, HipDiscrepancy, HipDistance, cdist_cols,  # noqa: F401
                        cdist_rows, nested_weighted_euclidean, welford_update)
 
+from .gmix import GMDistribution  # noqa: F401
 from .gp import GPHandle, HipGPRegression  # noqa: F401
 from .selection import merge_batch, smallest_k  # noqa: F401
 from .summaries import autocov, ma2_distance, ss_mean, ss_var  # noqa: F401

@@ -1,0 +1,132 @@
+// Gaussian-mixture proposal density of SMC-ABC on gfx950.
+//
+// Replaces GMDistribution.pdf / logpdf (elfi/methods/utils.py:142-198), which the SMC sampler
+// evaluates for every new particle against the whole previous population
+// (elfi/methods/inference/samplers.py:508-549): the reference loops over the N mixture components
+// on the host and calls scipy.stats.multivariate_normal.pdf on all M points for each of them,
+// O(N M d^2) with N Python-level iterations.  SURVEY.md section 8f, rank 2.
+//
+//   pdf(x) = sum_i w_i exp(-0.5 (c + |(x - m_i) U|^2)),   c = rank log(2 pi) + log pdet(cov)
+//
+// with U = eigenvectors * sqrt(1 / eigenvalues) of the shared covariance, exactly the
+// factorisation SciPy's multivariate_normal uses ([SciPy] _PSD); the deviation x - m_i is formed
+// first and then whitened, as SciPy does, and the components are accumulated in index order, so
+// the only difference to the reference is the device exp() (relative 1e-13 class).
+// One thread per evaluation point; the component means stream through LDS in tiles of 256.  The
+// kernel is VALU/exp-bound (M N (d^2 + d) FMAs + M N exps), HBM traffic is negligible.
+#include "common.hpp"
+
+namespace elfihip {
+
+struct GmArgs {
+  const double* x;       // (M, d)
+  const double* means;   // (N, d)
+  const double* w;       // (N)
+  const double* U;       // (d, d) row-major: U[k][j]
+  double* out;           // (M)
+  int64_t M, N;
+  int d;
+  double c;              // rank log(2 pi) + log pdet
+};
+
+template <int DP>
+__global__ __launch_bounds__(256) void gm_pdf_kernel(GmArgs G) {
+  __shared__ double Us[DP * DP];
+  __shared__ double ms[256 * DP];
+  __shared__ double ws[256];
+  const int d = G.d, tid = threadIdx.x;
+  for (int e = tid; e < DP * DP; e += 256) {
+    const int k = e / DP, j = e - k * DP;
+    Us[e] = (k < d && j < d) ? G.U[k * d + j] : 0.0;
+  }
+  const int64_t row = (int64_t)blockIdx.x * 256 + tid;
+  double x[DP];
+#pragma unroll
+  for (int k = 0; k < DP; ++k) x[k] = (row < G.M && k < d) ? G.x[row * d + k] : 0.0;
+  double acc = 0.0;
+  for (int64_t i0 = 0; i0 < G.N; i0 += 256) {
+    const int cnt = (int)((G.N - i0) < 256 ? (G.N - i0) : 256);
+    __syncthreads();
+    for (int e = tid; e < cnt * DP; e += 256) {
+      const int i = e / DP, k = e - i * DP;
+      ms[e] = k < d ? G.means[(i0 + i) * d + k] : 0.0;
+    }
+    if (tid < cnt) ws[tid] = G.w[i0 + tid];
+    __syncthreads();
+    for (int i = 0; i < cnt; ++i) {
+      double dev[DP];
+#pragma unroll
+      for (int k = 0; k < DP; ++k) dev[k] = x[k] - ms[i * DP + k];
+      double maha = 0.0;
+#pragma unroll
+      for (int j = 0; j < DP; ++j) {
+        double z = 0.0;
+#pragma unroll
+        for (int k = 0; k < DP; ++k) z += dev[k] * Us[k * DP + j];
+        maha += z * z;
+      }
+      acc += ws[i] * exp(-0.5 * (G.c + maha));
+    }
+  }
+  if (row < G.M) G.out[row] = acc;
+}
+
+static int gm_pdf_dev_impl(elfihip_ctx* ctx, GmArgs G) {
+  ELFIHIP_REQUIRE(ctx, G.M >= 0 && G.N >= 1 && G.d >= 1 && G.d <= 16, "bad shape M=%lld N=%lld d=%d (d <= 16)",
+                  (long long)G.M, (long long)G.N, G.d);
+  if (G.M == 0) return ELFIHIP_OK;
+  const unsigned grid = (unsigned)((G.M + 255) / 256);
+  if (G.d <= 2)
+    hipLaunchKernelGGL((gm_pdf_kernel<2>), dim3(grid), dim3(256), 0, ctx->stream, G);
+  else if (G.d <= 4)
+    hipLaunchKernelGGL((gm_pdf_kernel<4>), dim3(grid), dim3(256), 0, ctx->stream, G);
+  else if (G.d <= 8)
+    hipLaunchKernelGGL((gm_pdf_kernel<8>), dim3(grid), dim3(256), 0, ctx->stream, G);
+  else
+    hipLaunchKernelGGL((gm_pdf_kernel<16>), dim3(grid), dim3(256), 0, ctx->stream, G);
+  return launch_status(ctx, "gm_pdf_kernel");
+}
+
+}  // namespace elfihip
+
+using namespace elfihip;
+
+extern "C" {
+
+int elfihip_gm_pdf(elfihip_ctx* ctx, const double* x, int64_t M, int d, const double* means, int64_t N,
+                   const double* weights, const double* U, double log_norm, double* out) {
+  if (!ctx) return fail(nullptr, ELFIHIP_ERR_ARG, "ctx is NULL");
+  ELFIHIP_REQUIRE(ctx, M >= 0 && N >= 1 && d >= 1 && d <= 16, "bad shape M=%lld N=%lld d=%d (d <= 16)", (long long)M,
+                  (long long)N, d);
+  ELFIHIP_REQUIRE(ctx, means && weights && U && (M == 0 || (x && out)), "NULL data pointer");
+  if (M == 0) return ELFIHIP_OK;
+  DeviceGuard g(ctx->device);
+  const size_t nx = (size_t)M * d, nm = (size_t)N * d, nu = (size_t)d * d;
+  ELFIHIP_CHECK_HIP(ctx, ctx->in.reserve((nx + nm + (size_t)N + nu) * sizeof(double)));
+  ELFIHIP_CHECK_HIP(ctx, ctx->out.reserve((size_t)M * sizeof(double)));
+  double* dx = ctx->in.as<double>();
+  double* dm = dx + nx;
+  double* dw = dm + nm;
+  double* dU = dw + N;
+  hipStream_t st = ctx->stream;
+  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(dx, x, nx * sizeof(double), hipMemcpyHostToDevice, st));
+  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(dm, means, nm * sizeof(double), hipMemcpyHostToDevice, st));
+  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(dw, weights, (size_t)N * sizeof(double), hipMemcpyHostToDevice, st));
+  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(dU, U, nu * sizeof(double), hipMemcpyHostToDevice, st));
+  GmArgs G;
+  G.x = dx;
+  G.means = dm;
+  G.w = dw;
+  G.U = dU;
+  G.out = ctx->out.as<double>();
+  G.M = M;
+  G.N = N;
+  G.d = d;
+  G.c = log_norm;
+  ELFIHIP_TRY(gm_pdf_dev_impl(ctx, G));
+  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(out, ctx->out.p, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, st));
+  ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(st));
+  return ELFIHIP_OK;
+}
+
+}  // extern "C"

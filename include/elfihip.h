@@ -138,6 +138,14 @@ int elfihip_topk_smallest(elfihip_ctx* ctx, const double* D, int64_t n, int64_t 
 int elfihip_topk_smallest_dev(elfihip_ctx* ctx, const double* dD, int64_t n, int64_t stride, int64_t k,
                               double* dvals, int64_t* didx);
 
+/* ------------------------------------------------------------------ SMC proposal density
+ * GMDistribution.pdf (elfi/methods/utils.py:142-183): density of a Gaussian mixture with shared
+ * covariance at M points, out[r] = sum_i weights[i] * N(x_r; means[i], cov).  The caller passes the
+ * covariance in the factored form SciPy's multivariate_normal uses: U (d x d, row-major) with
+ * cov^+ = U U^T, and log_norm = rank*log(2 pi) + log pdet(cov); weights already normalised.  d <= 16. */
+int elfihip_gm_pdf(elfihip_ctx* ctx, const double* x, int64_t M, int d, const double* means, int64_t N,
+                   const double* weights, const double* U, double log_norm, double* out);
+
 /* ------------------------------------------------------------------ summaries
  * Row-wise summary statistics that ELFI's example models install as elfi.Summary operations, with
  * NumPy's exact (pairwise) summation order, i.e. bit-identical results:

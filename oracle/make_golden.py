@@ -200,16 +200,44 @@ def make_metrics(elfi):
     print('metrics:', len(cases), 'cases')
 
 
+def make_gm(elfi):
+    """GMDistribution.pdf / logpdf of the real reference (elfi/methods/utils.py:139-198)."""
+    from elfi.methods.utils import GMDistribution
+    rs = np.random.RandomState(777)
+    out, cases = {}, []
+    for k, (M, N, d) in enumerate([(50, 7, 1), (200, 40, 2), (300, 120, 3), (120, 300, 5), (64, 33, 10)]):
+        means = rs.randn(N, d) * 2.0
+        x = np.vstack([means[rs.randint(0, N, M // 2)] + 0.3 * rs.randn(M // 2, d), rs.randn(M - M // 2, d) * 3])
+        A = rs.randn(d, d)
+        cov = 0.2 * (A @ A.T + d * np.eye(d)) / d
+        w = rs.uniform(0.1, 2.0, N)
+        if d == 1:
+            means_in, x_in, cov_in = means[:, 0], x[:, 0], float(cov[0, 0])
+        else:
+            means_in, x_in, cov_in = means, x, cov
+        out['x_%d' % k], out['means_%d' % k], out['cov_%d' % k], out['w_%d' % k] = x_in, means_in, np.asarray(cov_in), w
+        out['pdf_%d' % k] = GMDistribution.pdf(x_in, means_in, cov=cov_in, weights=w)
+        out['logpdf_%d' % k] = GMDistribution.logpdf(x_in, means_in, cov=cov_in, weights=w)
+        out['pdf_now_%d' % k] = GMDistribution.pdf(x_in, means_in, cov=cov_in)      # weights=None
+        cases.append(k)
+    out['pdf_single'] = GMDistribution.pdf(out['x_1'][3], out['means_1'], cov=out['cov_1'], weights=out['w_1'])
+    out['cases'] = np.array(cases)
+    np.savez_compressed(os.path.join(GOLDEN, 'gm_pdf.npz'), **out)
+    print('gm_pdf:', len(cases), 'cases')
+
+
 def main(argv):
     os.makedirs(GOLDEN, exist_ok=True)
     elfi = ref_shim.install()
-    which = set(argv) or {'ma2', 'adaptive', 'metrics', 'gp'}
+    which = set(argv) or {'ma2', 'adaptive', 'metrics', 'gp', 'gm'}
     if 'ma2' in which:
         make_ma2(elfi)
     if 'adaptive' in which:
         make_adaptive(elfi)
     if 'metrics' in which:
         make_metrics(elfi)
+    if 'gm' in which:
+        make_gm(elfi)
     if 'gp' in which:
         try:
             import make_golden_gp

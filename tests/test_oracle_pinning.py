@@ -128,3 +128,17 @@ def test_adaptive_trace_replay(tag, doc):
             assert sha(out) == str(g['e%d_sha' % i])
     assert np.allclose(np.array(ws), np.array(doc), rtol=0, atol=5e-9)  # doc prints 8 decimals
     assert np.array_equal(np.array(ws), g['final_w'])
+
+
+def test_gm_oracle_equals_the_reference_class(golden_dir):
+    """oracle/gm_oracle.py vs outputs of the real elfi.methods.utils.GMDistribution."""
+    import os
+    import gm_oracle as GM
+    g = np.load(os.path.join(golden_dir, 'gm_pdf.npz'))
+    for k in g['cases']:
+        cov = g['cov_%d' % k]
+        cov = float(cov) if cov.ndim == 0 else cov
+        args = (g['x_%d' % k], g['means_%d' % k])
+        assert np.array_equal(GM.pdf(*args, cov=cov, weights=g['w_%d' % k]), g['pdf_%d' % k])
+        assert np.array_equal(GM.logpdf(*args, cov=cov, weights=g['w_%d' % k]), g['logpdf_%d' % k])
+        assert np.array_equal(GM.pdf(*args, cov=cov), g['pdf_now_%d' % k])
