@@ -173,8 +173,8 @@ class _Part:
 
 class _GPShim:
     """`target_model._gp` / `.instance` for code that reaches into GPy
-    (tests/unit/test_bo.py:41 reads _gp.X; acquisition.py:754 calls _gp.kern.K;
-    posteriors.py:296 reads _gp.param_array)."""
+    (tests/unit/test_bo.py:41 reads _gp.X; posteriors.py:296 reads _gp.param_array;
+    gpy_regression.py:151-158 reads kern.rbf / kern.bias / posterior.woodbury_*)."""
 
     def __init__(self, model):
         self._m = model
@@ -196,10 +196,10 @@ class _GPShim:
         m = self._m
 
         def K(X, X2=None):
-            X = np.asarray(X, dtype=float)
-            X2 = X if X2 is None else np.asarray(X2, dtype=float)
-            r2 = np.sum(X**2, 1)[:, None] + np.sum(X2**2, 1)[None, :] - 2. * X.dot(X2.T)
-            return m._hyper['var'] * np.exp(-0.5 * np.clip(r2, 0, np.inf) / m._hyper['ls']**2) + m._hyper['bias']
+            # acquisition.py:754 (ExpIntVar) evaluates the kernel matrix through GPy; that rule is outside
+            # this package's scope and the product has no host-side arithmetic
+            raise NotImplementedError('kern.K: the kernel matrix is not exposed; ExpIntVar needs the reference '
+                                      'GPyRegression')
 
         return _Part(K=K, rbf=_Part(variance=_Param(m._hyper['var']), lengthscale=_Param(m._hyper['ls'])),
                      bias=_Part(variance=_Param(m._hyper['bias']),
