@@ -33,6 +33,9 @@ struct elfihip_gp {
   // prediction workspace (grown on demand)
   elfihip::DevBuf ws;
   int64_t ws_S = 0;
+  // pinned host staging for the query points / results of a prediction call (one H2D, one D2H)
+  double* h_stage = nullptr;
+  size_t h_cap = 0;  // doubles
 };
 
 namespace elfihip {

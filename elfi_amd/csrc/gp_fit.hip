@@ -745,6 +745,7 @@ int elfihip_gp_free(elfihip_gp* gp) {
   for (double* p : {gp->X, gp->x2, gp->y, gp->A, gp->WT, gp->Kinv, gp->W11, gp->alpha, gp->red})
     if (p) (void)hipFree(p);
   if (gp->info) (void)hipFree(gp->info);
+  if (gp->h_stage) (void)hipHostFree(gp->h_stage);
   gp->ws.release();
   delete gp;
   return ELFIHIP_OK;

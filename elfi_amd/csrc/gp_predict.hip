@@ -384,10 +384,19 @@ int predict_impl(elfihip_gp* gp, const double* Xs, int64_t S, int mode, int nois
   // All S points go up in one copy, every pass runs back to back on the stream (the per-pass
   // scratch is reused in stream order), all results come down in one copy: one host sync per call.
   const size_t outsz = (size_t)3 * PC + 3 * PC * dp;
-  static thread_local std::vector<double> hx, hout;
-  hx.assign((size_t)npass * PC * dp + (size_t)npass * PC, 0.0);
-  hout.resize((size_t)npass * outsz);
-  double* hx2 = hx.data() + (size_t)npass * PC * dp;
+  const size_t n_in = (size_t)npass * PC * dp + (size_t)npass * PC, n_out = (size_t)npass * outsz;
+  if (gp->h_cap < n_in + n_out) {  // pinned staging: the copies below are true async DMA, no bounce buffer
+    if (gp->h_stage) ELFIHIP_CHECK_HIP(ctx, hipHostFree(gp->h_stage));
+    gp->h_stage = nullptr;
+    gp->h_cap = 0;
+    const size_t want = 2 * (n_in + n_out) + 1024;
+    ELFIHIP_CHECK_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&gp->h_stage), want * sizeof(double), hipHostMallocDefault));
+    gp->h_cap = want;
+  }
+  double* hx = gp->h_stage;
+  double* hout = gp->h_stage + n_in;
+  std::fill(hx, hx + n_in, 0.0);
+  double* hx2 = hx + (size_t)npass * PC * dp;
   for (int64_t s = 0; s < S; ++s) {
     double q = 0.0;
     for (int c = 0; c < d; ++c) {
@@ -397,9 +406,8 @@ int predict_impl(elfihip_gp* gp, const double* Xs, int64_t S, int mode, int nois
     }
     hx2[s] = q;
   }
-  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(W.xs, hx.data(), (size_t)npass * PC * dp * sizeof(double),
-                                        hipMemcpyHostToDevice, st));
-  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(W.xs2, hx2, (size_t)npass * PC * sizeof(double), hipMemcpyHostToDevice, st));
+  // W.xs and W.xs2 are adjacent in the workspace (PC * dp is a multiple of the 16-double granule)
+  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(W.xs, hx, n_in * sizeof(double), hipMemcpyHostToDevice, st));
   const size_t lds_t = (SLAB * 144 + PC * 34) * sizeof(double);
   const size_t lds_n = (128 * 34 + SLAB * PC) * sizeof(double);
   for (int64_t pass = 0; pass < npass; ++pass) {
@@ -436,10 +444,10 @@ int predict_impl(elfihip_gp* gp, const double* Xs, int64_t S, int mode, int nois
                        W.ngc, out, dp, sc, gp->var + gp->bias, noiseless ? 0.0 : gp->noise, inv_ls2, beta, mode);
   }
   ELFIHIP_TRY(launch_status(ctx, "predict kernels"));
-  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(hout.data(), W.out, hout.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(hout, W.out, n_out * sizeof(double), hipMemcpyDeviceToHost, st));
   ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(st));
   for (int64_t s = 0; s < S; ++s) {
-    const double* o = hout.data() + (size_t)(s / PC) * outsz;
+    const double* o = hout + (size_t)(s / PC) * outsz;
     const int q = (int)(s % PC);
     if (mu) mu[s] = o[q];
     if (var) var[s] = o[PC + q];
