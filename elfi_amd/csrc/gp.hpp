@@ -39,6 +39,26 @@ struct elfihip_gp {
 };
 
 namespace elfihip {
+struct PredictWs {
+  double *xs, *xs2, *kr, *part, *v, *u, *mu_part, *var_part, *g_part, *out;
+  int nblk_k;   // blocks of the kstar kernel along i
+  int nkc;      // k chunks
+  int ngc;      // i chunks of the gradient kernel
+};
+
+// One prediction call split into host-side preparation, input fill, device enqueue and result read.
+struct PredictPlan {
+  PredictWs ws;
+  int64_t npass = 0;
+  size_t n_in = 0, n_out = 0, outsz = 0;  // doubles
+  double* hx = nullptr;                   // pinned: query points + their squared norms
+  double* hout = nullptr;                 // pinned: results
+};
+int predict_prepare(elfihip_gp* gp, int64_t S, PredictPlan* P);
+void predict_fill(const elfihip_gp* gp, const PredictPlan& P, const double* Xs, int64_t S);
+int predict_enqueue(elfihip_gp* gp, const PredictPlan& P, int64_t S_active, int mode, int noiseless, double beta);
+void predict_read(const elfihip_gp* gp, const PredictPlan& P, int64_t S, double* mu, double* var, double* dmu,
+                  double* dvar, double* val, double* grad);
 // gp_predict.hip: mean / variance / gradients / LCB for S host points (one stream sync per call).
 // mode 0 = values only, 1 = + gradients.  Any output pointer may be NULL.
 int predict_impl(elfihip_gp* gp, const double* Xs, int64_t S, int mode, int noiseless, double beta, double* mu,

@@ -28,12 +28,6 @@ constexpr int PC = 16;    // columns (query points) per pass
 constexpr int KCH = 2;    // 128-blocks of k per workgroup (fewer partial sums to reduce than with 1)
 constexpr int SLAB = 32;  // k-slab staged per step
 
-struct PredictWs {
-  double *xs, *xs2, *kr, *part, *v, *u, *mu_part, *var_part, *g_part, *out;
-  int nblk_k;   // blocks of the kstar kernel along i
-  int nkc;      // k chunks
-  int ngc;      // i chunks of the gradient kernel
-};
 
 // ---- kr[s][i], partial mu ----------------------------------------------------------
 __global__ __launch_bounds__(256) void kstar_kernel(const double* X, const double* x2, const double* alpha,
@@ -364,58 +358,71 @@ static int ensure_ws(elfihip_gp* gp, PredictWs* W, int64_t npass) {
   return ELFIHIP_OK;
 }
 
-// mode: 0 = mean/var only, 1 = + gradients (and LCB)
-int predict_impl(elfihip_gp* gp, const double* Xs, int64_t S, int mode, int noiseless, double beta,
-                        double* mu, double* var, double* dmu, double* dvar, double* val, double* grad) {
+// ---- a prediction call in four steps: host preparation, input fill, device enqueue, result read.
+// (Replaying the enqueue part from a hipGraph was measured and is slower here: +90 us per launch on
+// this stack for a 9-node graph with two copy nodes, against ~25 us of plain launch cost.)
+int predict_prepare(elfihip_gp* gp, int64_t S, PredictPlan* P) {
   elfihip_ctx* ctx = gp->ctx;
-  ELFIHIP_REQUIRE(ctx, S >= 0, "negative S");
-  if (S == 0) return ELFIHIP_OK;
-  ELFIHIP_REQUIRE(ctx, Xs, "Xs is NULL");
   if (!gp->factored)
     return fail(ctx, ELFIHIP_ERR_STATE, "GP is not factorised (call elfihip_gp_factorize after changing data)");
-  hipStream_t st = ctx->stream;
+  P->npass = (S + PC - 1) / PC;
   PredictWs W;
-  const int64_t npass = (S + PC - 1) / PC;
-  ELFIHIP_TRY(ensure_ws(gp, &W, npass));
-  const int dp = gp->dp, d = gp->d;
-  const int64_t np = gp->np;
-  const int nb = (int)(np / NB);
-  const double inv_ls2 = 1.0 / (gp->ls * gp->ls);
-  // All S points go up in one copy, every pass runs back to back on the stream (the per-pass
-  // scratch is reused in stream order), all results come down in one copy: one host sync per call.
-  const size_t outsz = (size_t)3 * PC + 3 * PC * dp;
-  const size_t n_in = (size_t)npass * PC * dp + (size_t)npass * PC, n_out = (size_t)npass * outsz;
-  if (gp->h_cap < n_in + n_out) {  // pinned staging: the copies below are true async DMA, no bounce buffer
+  ELFIHIP_TRY(ensure_ws(gp, &W, P->npass));
+  P->ws = W;
+  const int dp = gp->dp;
+  P->outsz = (size_t)3 * PC + 3 * PC * dp;
+  P->n_in = (size_t)P->npass * PC * dp + (size_t)P->npass * PC;
+  P->n_out = (size_t)P->npass * P->outsz;
+  if (gp->h_cap < P->n_in + P->n_out) {  // pinned staging: the copies are true async DMA, no bounce buffer
     if (gp->h_stage) ELFIHIP_CHECK_HIP(ctx, hipHostFree(gp->h_stage));
     gp->h_stage = nullptr;
     gp->h_cap = 0;
-    const size_t want = 2 * (n_in + n_out) + 1024;
+    const size_t want = 2 * (P->n_in + P->n_out) + 1024;
     ELFIHIP_CHECK_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&gp->h_stage), want * sizeof(double), hipHostMallocDefault));
     gp->h_cap = want;
   }
-  double* hx = gp->h_stage;
-  double* hout = gp->h_stage + n_in;
-  std::fill(hx, hx + n_in, 0.0);
-  double* hx2 = hx + (size_t)npass * PC * dp;
+  P->hx = gp->h_stage;
+  P->hout = gp->h_stage + P->n_in;
+  return ELFIHIP_OK;
+}
+
+void predict_fill(const elfihip_gp* gp, const PredictPlan& P, const double* Xs, int64_t S) {
+  const int dp = gp->dp, d = gp->d;
+  std::fill(P.hx, P.hx + P.n_in, 0.0);
+  double* hx2 = P.hx + (size_t)P.npass * PC * dp;
   for (int64_t s = 0; s < S; ++s) {
     double q = 0.0;
     for (int c = 0; c < d; ++c) {
       const double x = Xs[s * d + c];
-      hx[(size_t)s * dp + c] = x;
+      P.hx[(size_t)s * dp + c] = x;
       q += x * x;
     }
     hx2[s] = q;
   }
+}
+
+// All points go up in one copy, every pass runs back to back on the stream (the per-pass scratch is
+// reused in stream order), all results come down in one copy; no synchronisation here.
+// S_active: number of real points (columns beyond it are computed on zero inputs and ignored).
+int predict_enqueue(elfihip_gp* gp, const PredictPlan& P, int64_t S_active, int mode, int noiseless, double beta) {
+  elfihip_ctx* ctx = gp->ctx;
+  hipStream_t st = ctx->stream;
+  const PredictWs& W = P.ws;
+  const int dp = gp->dp;
+  const int64_t np = gp->np;
+  const int nb = (int)(np / NB);
+  const double inv_ls2 = 1.0 / (gp->ls * gp->ls);
   // W.xs and W.xs2 are adjacent in the workspace (PC * dp is a multiple of the 16-double granule)
-  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(W.xs, hx, n_in * sizeof(double), hipMemcpyHostToDevice, st));
+  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(W.xs, P.hx, P.n_in * sizeof(double), hipMemcpyHostToDevice, st));
   const size_t lds_t = (SLAB * 144 + PC * 34) * sizeof(double);
   const size_t lds_n = (128 * 34 + SLAB * PC) * sizeof(double);
-  for (int64_t pass = 0; pass < npass; ++pass) {
+  for (int64_t pass = 0; pass < P.npass; ++pass) {
     const int64_t s0 = pass * PC;
-    const int sc = (int)((S - s0) < PC ? (S - s0) : PC);
+    int sc = (int)((S_active - s0) < PC ? (S_active - s0) : PC);
+    if (sc < 0) sc = 0;
     const double* xs = W.xs + (size_t)pass * PC * dp;
     const double* xs2 = W.xs2 + (size_t)pass * PC;
-    double* out = W.out + (size_t)pass * outsz;
+    double* out = W.out + (size_t)pass * P.outsz;
     hipLaunchKernelGGL(kstar_kernel, dim3(W.nblk_k, PC), dim3(256), 0, st, gp->X, gp->x2, gp->alpha, xs, xs2,
                        W.kr, W.mu_part, gp->n, np, dp, gp->var, -0.5 * inv_ls2, gp->bias);
     TriArgs T;
@@ -443,11 +450,15 @@ int predict_impl(elfihip_gp* gp, const double* Xs, int64_t S, int mode, int nois
     hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(256), 0, st, W.mu_part, W.nblk_k, W.var_part, rblocks, W.g_part,
                        W.ngc, out, dp, sc, gp->var + gp->bias, noiseless ? 0.0 : gp->noise, inv_ls2, beta, mode);
   }
-  ELFIHIP_TRY(launch_status(ctx, "predict kernels"));
-  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(hout, W.out, n_out * sizeof(double), hipMemcpyDeviceToHost, st));
-  ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(st));
+  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(P.hout, W.out, P.n_out * sizeof(double), hipMemcpyDeviceToHost, st));
+  return ELFIHIP_OK;
+}
+
+void predict_read(const elfihip_gp* gp, const PredictPlan& P, int64_t S, double* mu, double* var, double* dmu,
+                  double* dvar, double* val, double* grad) {
+  const int dp = gp->dp, d = gp->d;
   for (int64_t s = 0; s < S; ++s) {
-    const double* o = hout + (size_t)(s / PC) * outsz;
+    const double* o = P.hout + (size_t)(s / PC) * P.outsz;
     const int q = (int)(s % PC);
     if (mu) mu[s] = o[q];
     if (var) var[s] = o[PC + q];
@@ -458,6 +469,22 @@ int predict_impl(elfihip_gp* gp, const double* Xs, int64_t S, int mode, int nois
       if (grad) grad[s * d + c] = o[3 * PC + 2 * PC * dp + q * dp + c];
     }
   }
+}
+
+// mode: 0 = mean/var only, 1 = + gradients (and LCB)
+int predict_impl(elfihip_gp* gp, const double* Xs, int64_t S, int mode, int noiseless, double beta,
+                        double* mu, double* var, double* dmu, double* dvar, double* val, double* grad) {
+  elfihip_ctx* ctx = gp->ctx;
+  ELFIHIP_REQUIRE(ctx, S >= 0, "negative S");
+  if (S == 0) return ELFIHIP_OK;
+  ELFIHIP_REQUIRE(ctx, Xs, "Xs is NULL");
+  PredictPlan P;
+  ELFIHIP_TRY(predict_prepare(gp, S, &P));
+  predict_fill(gp, P, Xs, S);
+  ELFIHIP_TRY(predict_enqueue(gp, P, S, mode, noiseless, beta));
+  ELFIHIP_TRY(launch_status(ctx, "predict kernels"));
+  ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  predict_read(gp, P, S, mu, var, dmu, dvar, val, grad);
   return ELFIHIP_OK;
 }
 
