@@ -11,8 +11,8 @@ samples x 32 summaries per GPU, euclidean distance to the observed summaries
 (elfi.Distance('euclidean'), elfi/model/elfi_model.py:1037).  A step is one pass of
 the distance path over the rank's batch, inputs already resident in HBM.  Weak
 scaling: every rank owns an independent batch (independent ABC batches,
-elfi/methods/parameter_inference.py:283-292); the only exchange is one RCCL gather of
-the final distance shard to rank 0 inside the timed region.
+elfi/methods/parameter_inference.py:283-292); the only exchange, inside the timed
+region, is a device top-k per rank and one RCCL gather of the k best (distance, row) pairs to rank 0.
 
 The same line carries
   "roofline"      HBM roofline of the distance kernel (HIP events on the library's stream)
@@ -246,8 +246,19 @@ def main():
     Xs = [torch.randn(n, m, dtype=torch.float64, device=dev, generator=gen) for _ in range(NBUF)]
     y = torch.from_numpy(np.random.RandomState(1).randn(1, m)).to(dev)
     out = torch.empty(n, dtype=torch.float64, device=dev)
-    gathered = [torch.empty(n, dtype=torch.float64, device=dev) for _ in range(world)] \
-        if (world > 1 and rank == 0) else None
+    # The one exchange of a multi-GPU job: every rank selects its K_BEST smallest
+    # distances on the GPU (elfihip_topk_smallest_dev, what Rejection keeps of a batch) and rank 0
+    # gathers those (value, row) pairs -- 16 KB per rank instead of the 8 MB distance shard.
+    K_BEST = min(1000, n)
+    best_v = torch.empty(K_BEST, dtype=torch.float64, device=dev)
+    best_i = torch.empty(K_BEST, dtype=torch.int64, device=dev)
+    gath_v = [torch.empty_like(best_v) for _ in range(world)] if (world > 1 and rank == 0) else None
+    gath_i = [torch.empty_like(best_i) for _ in range(world)] if (world > 1 and rank == 0) else None
+
+    def exchange():
+        ctx.call("elfihip_topk_smallest_dev", out.data_ptr(), n, 1, K_BEST, best_v.data_ptr(), best_i.data_ptr())
+        dist.gather(best_v, gath_v, dst=0)
+        dist.gather(best_i, gath_i, dst=0)
 
     counter = [0]
 
@@ -264,14 +275,14 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    if world > 1:  # warm the gather path too
-        dist.gather(out, gathered, dst=0)
+    if world > 1:  # warm the exchange path too
+        exchange()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     if world > 1:
-        dist.gather(out, gathered, dst=0)  # the one exchange: final distance shards -> rank 0
+        exchange()  # the one exchange: each rank's best K_BEST (distance, row) pairs -> rank 0
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -295,6 +306,12 @@ def main():
         X = Xs[(counter[0] - 1) % NBUF]   # the batch of the last step
         ref = O.cdist_rows(X[idx].cpu().numpy(), y.cpu().numpy(), 'euclidean')
         assert np.array_equal(out[idx].cpu().numpy(), ref), "bench output differs from the oracle"
+        # ... and on the selection used by the multi-GPU exchange (exercised here at every N)
+        ctx.call("elfihip_topk_smallest_dev", out.data_ptr(), n, 1, K_BEST, best_v.data_ptr(), best_i.data_ptr())
+        torch.cuda.synchronize(dev)
+        dh = out.cpu().numpy()
+        assert np.array_equal(np.sort(best_v.cpu().numpy()), np.sort(dh)[:K_BEST]), "top-k differs from numpy"
+        assert np.array_equal(dh[best_i.cpu().numpy()], best_v.cpu().numpy())
 
     # HBM traffic per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 +
     # WRITE_SIZE, profiles/r01_distance_pmc.md); PMC cannot be sampled from inside this process
@@ -319,7 +336,8 @@ def main():
                                    "GPU per step, elfi.Distance('euclidean'), inputs resident in HBM" % (n, m),
                        "samples_per_gpu": n, "summaries": m, "layout": "row-major (n,m) f64",
                        "batches_in_rotation": NBUF,
-                       "exchange": "one RCCL gather of the final distance shard per job" if world > 1 else "none"},
+                       "exchange": "per job: device top-%d of the last batch per rank + one RCCL gather of the "
+                                   "(distance, row) pairs to rank 0" % K_BEST if world > 1 else "none"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "dist_rows_pipe_kernel<euclidean>", "kernel_ms": kernel_ms,
