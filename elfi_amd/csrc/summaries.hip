@@ -51,6 +51,28 @@ __device__ double np_pairwise(F f, int lo, int n) {
   return np_pairwise(f, lo, n2) + np_pairwise(f, lo + n2, n - n2);
 }
 
+// The same sum for n <= 128 computed by EIGHT lanes: NumPy's eight interleaved accumulators are
+// independent chains (r[j] takes elements j, j+8, ...), so lane j of an aligned 8-lane group owns
+// r[j]; the fixed combine tree ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) is three xor-shuffles (fp addition
+// is commutative, so both partners of a pair hold the same bits) and the tail is added in order by
+// every lane.  Bit-identical to np_pairwise, eight times the lanes per row.
+template <class F>
+__device__ __forceinline__ double np_pairwise8(F f, int n, int j) {
+  if (n < 8) {
+    double r = 0.0;
+    for (int i = 0; i < n; ++i) r += f(i);
+    return r;
+  }
+  const int nfull = n - (n % 8);
+  double r = f(j);
+  for (int i = 8; i < nfull; i += 8) r += f(i + j);
+  r += __shfl_xor(r, 1, 64);
+  r += __shfl_xor(r, 2, 64);
+  r += __shfl_xor(r, 4, 64);
+  for (int i = nfull; i < n; ++i) r += f(i);
+  return r;
+}
+
 struct SumArgs {
   RowArgs R;        // X, n, ldx, m (= row length L), mp, vec2, div_h, R (rows per tile)
   int lag;          // AUTOCOV
@@ -84,7 +106,42 @@ __global__ __launch_bounds__(256) void row_summary_kernel(SumArgs S) {
       load_tile<8>(A, tile, row0, rows);
     }
     __syncthreads();
-    if (tid < rows) {
+    const int red_len = KIND == SUM_AUTOCOV ? L - S.lag : (KIND == SUM_MA2 ? L - 3 : L);  // longest reduction
+    if (red_len <= 128) {
+      // eight lanes per row (np_pairwise8): 16 rows at a time with 128 threads
+      const int j = tid & 7, gpr = blockDim.x >> 3;
+      const int rounds = (rows + gpr - 1) / gpr;
+      for (int q = 0; q < rounds; ++q) {
+        const int r = q * gpr + (tid >> 3);
+        const bool live = r < rows;
+        const double* row = tile + (size_t)(live ? r : 0) * A.mp;
+        const int64_t gi = row0 + r;
+        if constexpr (KIND == SUM_MEAN) {
+          const double v = np_pairwise8([&](int i) { return row[i]; }, L, j) / (double)L;
+          if (live && j == 0) S.out1[gi] = v;
+        } else if constexpr (KIND == SUM_VAR) {
+          const double mean = np_pairwise8([&](int i) { return row[i]; }, L, j) / (double)L;
+          const double v = np_pairwise8([&](int i) { const double d = row[i] - mean; return d * d; }, L, j) / (double)L;
+          if (live && j == 0) S.out1[gi] = v;
+        } else if constexpr (KIND == SUM_AUTOCOV) {
+          const int lag = S.lag, cnt = L - lag;
+          const double v = np_pairwise8([&](int i) { return row[i + lag] * row[i]; }, cnt, j) / (double)cnt;
+          if (live && j == 0) S.out1[gi] = v;
+        } else {  // SUM_MA2: row holds w (L = n_obs + 2); x_i = (w[i+2] + t1 w[i+1]) + t2 w[i], formed on the fly
+          const double a = live ? S.t1[gi] : 0.0, b = live ? S.t2[gi] : 0.0;
+          const int nobs = L - 2;
+          auto x = [&](int i) { return (row[i + 2] + a * row[i + 1]) + b * row[i]; };
+          const double s1 = np_pairwise8([&](int i) { return x(i + 1) * x(i); }, nobs - 1, j) / (double)(nobs - 1);
+          const double s2 = np_pairwise8([&](int i) { return x(i + 2) * x(i); }, nobs - 2, j) / (double)(nobs - 2);
+          if (live && j == 0) {
+            S.out1[gi] = s1;
+            S.out2[gi] = s2;
+            const double d1 = s1 - S.obs1, d2 = s2 - S.obs2;   // cdist euclidean over the two summaries
+            S.out3[gi] = sqrt(d1 * d1 + d2 * d2);
+          }
+        }
+      }
+    } else if (tid < rows) {
       const double* row = tile + (size_t)tid * A.mp;
       const int64_t gi = row0 + tid;
       if constexpr (KIND == SUM_MEAN) {

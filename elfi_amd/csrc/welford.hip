@@ -80,12 +80,28 @@ __global__ void welford_partial_kernel(WelfordArgs A) {
 }
 
 // state = [N, mean (m), M2 (m)].  PASS 1 writes mean_new to scratch; PASS 2 commits.
+// One workgroup per 32 columns: thread (c, j) sums the block partials b = j, j+8, ... of column c with
+// four independent accumulators (the loads pipeline), the eight j-sums are combined in fixed order.
 template <int PASS>
-__global__ void welford_finish_kernel(const double* partial, int nblocks, int m, double nrows,
-                                      double* state, double* mean_new) {
-  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < m; c += gridDim.x * blockDim.x) {
+__global__ __launch_bounds__(256) void welford_finish_kernel(const double* partial, int nblocks, int m, double nrows,
+                                                             double* state, double* mean_new) {
+  __shared__ double red[8][32];
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), j = threadIdx.x >> 5;
+  double a4[4] = {0, 0, 0, 0};
+  if (c < m) {
+    int b = j;
+    for (; b + 24 < nblocks; b += 32) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) a4[u] += partial[(size_t)(b + 8 * u) * m + c];
+    }
+    for (; b < nblocks; b += 8) a4[0] += partial[(size_t)b * m + c];
+  }
+  red[j][threadIdx.x & 31] = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+  __syncthreads();
+  if (j == 0 && c < m) {
     double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * m + c];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s += red[q][threadIdx.x];
     if constexpr (PASS == 1) {
       const double N = state[0] + nrows;
       mean_new[c] = state[1 + c] + s / N;
@@ -113,7 +129,7 @@ static int welford_dev_impl(elfihip_ctx* ctx, const double* dX, int64_t n, int m
   A.m = m;
   A.rpi = m <= T ? T / m : 1;
   int64_t groups = (n + A.rpi - 1) / A.rpi;
-  int64_t g = (int64_t)ctx->cu_count * 8;
+  int64_t g = (int64_t)ctx->cu_count * 4;  // enough loads in flight; fewer partials for the finish kernels
   if (g > groups) g = groups;
   if (g < 1) g = 1;
   ELFIHIP_CHECK_HIP(ctx, ctx->scratch.reserve(((size_t)g * m + m) * sizeof(double)));
@@ -121,7 +137,7 @@ static int welford_dev_impl(elfihip_ctx* ctx, const double* dX, int64_t n, int m
   double* mean_new = A.partial + (size_t)g * m;
   A.mean_old = dstate + 1;
   A.mean_new = mean_new;
-  const int fb = (m + 255) / 256;
+  const int fb = (m + 31) / 32;
   hipLaunchKernelGGL((welford_partial_kernel<1>), dim3((unsigned)g), dim3(T), T * sizeof(double), ctx->stream, A);
   hipLaunchKernelGGL((welford_finish_kernel<1>), dim3(fb), dim3(256), 0, ctx->stream, A.partial, (int)g, m,
                      (double)n, dstate, mean_new);

@@ -1,0 +1,111 @@
+"""Developer benchmark: device-resident throughput of every streaming kernel + the host (PCIe-inclusive) path.
+
+    python scripts/bench_kernels.py            # prints one markdown table
+"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import elfi_amd
+
+dev = torch.device('cuda', 0)
+ctx = elfi_amd.Context(0)
+stream = torch.cuda.Stream(dev)
+torch.cuda.set_stream(stream)
+ctx.set_stream(stream.cuda_stream)
+
+
+def timed(fn, reps=30, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ctx.timer_start()
+    for _ in range(reps):
+        fn()
+    return ctx.timer_stop() / reps
+
+
+rows = []
+NB = 3
+for (n, m) in ((10**6, 32), (1250000, 64), (4 * 10**6, 2)):
+    Xs = [torch.randn(n, m, dtype=torch.float64, device=dev) for _ in range(NB)]
+    y = torch.randn(1, m, dtype=torch.float64, device=dev)
+    w = torch.rand(m, dtype=torch.float64, device=dev) + 0.5
+    out = torch.empty(n, dtype=torch.float64, device=dev)
+    c = [0]
+
+    def nxt():
+        c[0] += 1
+        return Xs[c[0] % NB]
+    for name, metric, aux, p in (('euclidean', 0, None, 2.0), ('euclidean+w', 0, w, 2.0), ('cityblock', 2, None, 2.0),
+                                 ('minkowski p=3', 4, None, 3.0)):
+        ms = timed(lambda: ctx.call('elfihip_dist_rows_dev', metric, nxt().data_ptr(), n, m, m, y.data_ptr(),
+                                    aux.data_ptr() if aux is not None else None, p, out.data_ptr()))
+        rows.append(('dist_rows %s' % name, n, m, ms, (8 * m + 8) * n))
+    K = 3
+    W = torch.rand(K, m, dtype=torch.float64, device=dev) + 0.5
+    outk = torch.empty(n, K, dtype=torch.float64, device=dev)
+    ms = timed(lambda: ctx.call('elfihip_dist_multiw_dev', nxt().data_ptr(), n, m, m, y.data_ptr(), W.data_ptr(), K,
+                                outk.data_ptr()))
+    rows.append(('dist_multiw K=3', n, m, ms, (8 * m + 8 * K) * n))
+    state = torch.zeros(1 + 2 * m, dtype=torch.float64, device=dev)
+    ms = timed(lambda: ctx.call('elfihip_welford_update_dev', nxt().data_ptr(), n, m, m, state.data_ptr()))
+    rows.append(('welford (2 passes)', n, m, ms, 2 * 8 * m * n))
+    XT = [x.t().contiguous() for x in Xs[:2]]   # column-major (m, n): column j at j*n
+    ms = timed(lambda: ctx.call('elfihip_dist_cols_dev', 0, XT[c[0] % 2].data_ptr(), n, m, n, y.data_ptr(), None, 2.0,
+                                out.data_ptr()))
+    rows.append(('dist_cols euclidean', n, m, ms, (8 * m + 8) * n))
+    del Xs, XT
+# summaries: MA2-shaped rows
+n, L = 2 * 10**6, 100
+Xs = [torch.randn(n, L, dtype=torch.float64, device=dev) for _ in range(2)]
+out = torch.empty(n, dtype=torch.float64, device=dev)
+c = [0]
+for kind, name in ((0, 'row mean'), (1, 'row var'), (2, 'autocov lag 1')):
+    def f():
+        c[0] += 1
+        ctx.call('elfihip_row_summary_dev', kind, Xs[c[0] % 2].data_ptr(), n, L, L, 1, out.data_ptr())
+    rows.append((name, n, L, timed(f), (8 * L + 8) * n))
+n, L = 2 * 10**6, 102
+W = [torch.randn(n, L, dtype=torch.float64, device=dev) for _ in range(2)]
+t1 = torch.rand(n, dtype=torch.float64, device=dev)
+t2 = torch.rand(n, dtype=torch.float64, device=dev)
+o1, o2, o3 = (torch.empty(n, dtype=torch.float64, device=dev) for _ in range(3))
+def f():
+    c[0] += 1
+    ctx.call('elfihip_ma2_distance_dev', W[c[0] % 2].data_ptr(), n, L - 2, L, t1.data_ptr(), t2.data_ptr(), 0.1, 0.2,
+             o1.data_ptr(), o2.data_ptr(), o3.data_ptr())
+rows.append(('fused MA2 -> S1,S2,d', n, L, timed(f), (8 * L + 16 + 24) * n))
+# top-k
+n = 10**6
+d_ = torch.rand(n, dtype=torch.float64, device=dev)
+bv = torch.empty(1000, dtype=torch.float64, device=dev)
+bi = torch.empty(1000, dtype=torch.int64, device=dev)
+rows.append(('top-1000 of 10^6', n, 1, timed(lambda: ctx.call('elfihip_topk_smallest_dev', d_.data_ptr(), n, 1, 1000,
+                                                               bv.data_ptr(), bi.data_ptr())), 10 * 8 * n))
+print('| kernel | rows | width | ms | algorithmic GB/s | of 8 TB/s |')
+print('|---|---|---|---|---|---|')
+for name, n, m, ms, by in rows:
+    gbs = by / (ms * 1e-3) / 1e9
+    print('| %s | %d | %d | %.4f | %.0f | %.2f |' % (name, n, m, ms, gbs, gbs / 8000))
+# host (PCIe-inclusive) path
+n, m = 10**6, 32
+X = np.random.randn(n, m)
+yh = np.random.randn(1, m)
+elfi_amd.cdist_rows(X, yh)
+t0 = time.perf_counter()
+for _ in range(5):
+    elfi_amd.cdist_rows(X, yh)
+t = (time.perf_counter() - t0) / 5
+print('\nhost-buffer path (H2D of %d MB + kernel + D2H, pageable NumPy memory): %.1f ms = %.1f M dist/s, %.1f GB/s'
+      % (n * m * 8 // 2**20, t * 1e3, n / t / 1e6, n * m * 8 / t / 1e9))
+cols = [np.ascontiguousarray(X[:, j]) for j in range(m)]
+op = elfi_amd.HipDiscrepancy('euclidean')
+obs = tuple(yh[:, j] for j in range(m))
+op(*cols, observed=obs)
+t0 = time.perf_counter()
+for _ in range(5):
+    op(*cols, observed=obs)
+t = (time.perf_counter() - t0) / 5
+print('HipDiscrepancy on 32 separate host columns (no column_stack): %.1f ms = %.1f M dist/s' % (t * 1e3, n / t / 1e6))
