@@ -64,8 +64,18 @@ __device__ __forceinline__ double np_pairwise8(F f, int n, int j) {
     return r;
   }
   const int nfull = n - (n % 8);
-  double r = f(j);
-  for (int i = 8; i < nfull; i += 8) r += f(i + j);
+  // all (at most 16) elements of this lane's chain are fetched first, back to back, then added in
+  // order: the loads pipeline instead of sitting one LDS latency apart on the dependent adds
+  double e[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int i = 8 * k + j;
+    e[k] = f(i < nfull ? i : j);  // clamped index keeps the load unconditional; the value is unused beyond nfull
+  }
+  double r = e[0];
+#pragma unroll
+  for (int k = 1; k < 16; ++k)
+    if (8 * k < nfull) r += e[k];  // uniform condition
   r += __shfl_xor(r, 1, 64);
   r += __shfl_xor(r, 2, 64);
   r += __shfl_xor(r, 4, 64);
@@ -107,7 +117,7 @@ __global__ __launch_bounds__(256) void row_summary_kernel(SumArgs S) {
     }
     __syncthreads();
     const int red_len = KIND == SUM_AUTOCOV ? L - S.lag : (KIND == SUM_MA2 ? L - 3 : L);  // longest reduction
-    if (red_len <= 128) {
+    if (PIPE || red_len <= 128) {  // the pipelined kernel is only launched for L <= 128
       // eight lanes per row (np_pairwise8): 16 rows at a time with 128 threads
       const int j = tid & 7, gpr = blockDim.x >> 3;
       const int rounds = (rows + gpr - 1) / gpr;
@@ -127,12 +137,31 @@ __global__ __launch_bounds__(256) void row_summary_kernel(SumArgs S) {
           const int lag = S.lag, cnt = L - lag;
           const double v = np_pairwise8([&](int i) { return row[i + lag] * row[i]; }, cnt, j) / (double)cnt;
           if (live && j == 0) S.out1[gi] = v;
-        } else {  // SUM_MA2: row holds w (L = n_obs + 2); x_i = (w[i+2] + t1 w[i+1]) + t2 w[i], formed on the fly
+        } else {  // SUM_MA2: row holds w (L = n_obs + 2); x_i = (w[i+2] + t1 w[i+1]) + t2 w[i]
           const double a = live ? S.t1[gi] : 0.0, b = live ? S.t2[gi] : 0.0;
           const int nobs = L - 2;
-          auto x = [&](int i) { return (row[i + 2] + a * row[i + 1]) + b * row[i]; };
-          const double s1 = np_pairwise8([&](int i) { return x(i + 1) * x(i); }, nobs - 1, j) / (double)(nobs - 1);
-          const double s2 = np_pairwise8([&](int i) { return x(i + 2) * x(i); }, nobs - 2, j) / (double)(nobs - 2);
+          // x replaces w in place: every lane first forms ITS x values (i = j, j+8, ...) in registers
+          // from w, then stores them.  The eight lanes of a row sit in one wavefront, whose LDS
+          // operations execute in program order, so all reads of w precede the first store.
+          double* xr = tile + (size_t)(live ? r : 0) * A.mp;
+          // (two halves of 64 elements: the stores of the first half only touch w[0..63], which the
+          // second half no longer reads -- half the registers)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            double xv[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              const int i = 64 * h + 8 * k + j, ic = i < nobs ? i : 0;
+              xv[k] = (xr[ic + 2] + a * xr[ic + 1]) + b * xr[ic];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              const int i = 64 * h + 8 * k + j;
+              if (live && i < nobs) xr[i] = xv[k];
+            }
+          }
+          const double s1 = np_pairwise8([&](int i) { return xr[i + 1] * xr[i]; }, nobs - 1, j) / (double)(nobs - 1);
+          const double s2 = np_pairwise8([&](int i) { return xr[i + 2] * xr[i]; }, nobs - 2, j) / (double)(nobs - 2);
           if (live && j == 0) {
             S.out1[gi] = s1;
             S.out2[gi] = s2;
@@ -141,7 +170,8 @@ __global__ __launch_bounds__(256) void row_summary_kernel(SumArgs S) {
           }
         }
       }
-    } else if (tid < rows) {
+    } else if constexpr (!PIPE) {
+     if (tid < rows) {
       const double* row = tile + (size_t)tid * A.mp;
       const int64_t gi = row0 + tid;
       if constexpr (KIND == SUM_MEAN) {
@@ -164,6 +194,7 @@ __global__ __launch_bounds__(256) void row_summary_kernel(SumArgs S) {
         const double d1 = s1 - S.obs1, d2 = s2 - S.obs2;   // cdist euclidean over the two summaries
         S.out3[gi] = sqrt(d1 * d1 + d2 * d2);
       }
+     }
     }
   }
 }
