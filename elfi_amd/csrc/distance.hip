@@ -133,17 +133,30 @@ __global__ __launch_bounds__(256) void dist_multiw_pipe_kernel(RowArgs A) {
     if (tn < ntiles) tile_fetch<U>(A, tn * R, (int)((A.n - tn * R) < R ? (A.n - tn * R) : R), v);
     __syncthreads();
     if (tid < rows) {
-      double* row = tile + (size_t)tid * A.mp;
-      for (int j = 0; j < m; ++j) {  // (x-y)^2 once, reused by every weight vector
-        double d = row[j] - ys[j];
-        row[j] = d * d;
-      }
-      for (int k = 0; k < K; ++k) {
-        const double* w = ws + (size_t)k * m;
-        double s = 0.0;
+      const double* row = tile + (size_t)tid * A.mp;
+      // four weight vectors per sweep over the row: (x-y)^2 is formed once per element and feeds four
+      // independent left-to-right sums (each still in cdist's order)
+      for (int k0 = 0; k0 < K; k0 += 4) {
+        const int kn = K - k0 < 4 ? K - k0 : 4;
+        const double* w0 = ws + (size_t)k0 * m;
+        const double* w1 = ws + (size_t)(k0 + (kn > 1 ? 1 : 0)) * m;
+        const double* w2 = ws + (size_t)(k0 + (kn > 2 ? 2 : 0)) * m;
+        const double* w3 = ws + (size_t)(k0 + (kn > 3 ? 3 : 0)) * m;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll 4
-        for (int j = 0; j < m; ++j) s = s + w[j] * row[j];
-        A.out[(row0 + tid) * K + k] = sqrt(s);
+        for (int j = 0; j < m; ++j) {
+          const double d = row[j] - ys[j];
+          const double d2 = d * d;
+          s0 = s0 + w0[j] * d2;
+          s1 = s1 + w1[j] * d2;
+          s2 = s2 + w2[j] * d2;
+          s3 = s3 + w3[j] * d2;
+        }
+        double* o = A.out + (row0 + tid) * K + k0;
+        o[0] = sqrt(s0);
+        if (kn > 1) o[1] = sqrt(s1);
+        if (kn > 2) o[2] = sqrt(s2);
+        if (kn > 3) o[3] = sqrt(s3);
       }
     }
   }
@@ -227,17 +240,30 @@ __global__ void dist_multiw_kernel(RowArgs A) {
     load_tile<U>(A, tile, row0, rows);
     __syncthreads();
     if (tid < rows) {
-      double* row = tile + (size_t)tid * A.mp;
-      for (int j = 0; j < m; ++j) {  // (x-y)^2 once, reused by every weight vector
-        double d = row[j] - ys[j];
-        row[j] = d * d;
-      }
-      for (int k = 0; k < K; ++k) {
-        const double* w = ws + (size_t)k * m;
-        double s = 0.0;
+      const double* row = tile + (size_t)tid * A.mp;
+      // four weight vectors per sweep over the row: (x-y)^2 is formed once per element and feeds four
+      // independent left-to-right sums (each still in cdist's order)
+      for (int k0 = 0; k0 < K; k0 += 4) {
+        const int kn = K - k0 < 4 ? K - k0 : 4;
+        const double* w0 = ws + (size_t)k0 * m;
+        const double* w1 = ws + (size_t)(k0 + (kn > 1 ? 1 : 0)) * m;
+        const double* w2 = ws + (size_t)(k0 + (kn > 2 ? 2 : 0)) * m;
+        const double* w3 = ws + (size_t)(k0 + (kn > 3 ? 3 : 0)) * m;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll 4
-        for (int j = 0; j < m; ++j) s = s + w[j] * row[j];
-        A.out[(row0 + tid) * K + k] = sqrt(s);
+        for (int j = 0; j < m; ++j) {
+          const double d = row[j] - ys[j];
+          const double d2 = d * d;
+          s0 = s0 + w0[j] * d2;
+          s1 = s1 + w1[j] * d2;
+          s2 = s2 + w2[j] * d2;
+          s3 = s3 + w3[j] * d2;
+        }
+        double* o = A.out + (row0 + tid) * K + k0;
+        o[0] = sqrt(s0);
+        if (kn > 1) o[1] = sqrt(s1);
+        if (kn > 2) o[2] = sqrt(s2);
+        if (kn > 3) o[3] = sqrt(s3);
       }
     }
   }
