@@ -44,6 +44,7 @@ struct PredictWs {
   int nblk_k;   // blocks of the kstar kernel along i
   int nkc;      // k chunks
   int ngc;      // i chunks of the gradient kernel
+  int group;    // 16-point passes per set of launches (kr .. g_part hold this many slices)
 };
 
 // One prediction call split into host-side preparation, input fill, device enqueue and result read.

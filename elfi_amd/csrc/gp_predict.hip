@@ -27,6 +27,7 @@ namespace elfihip {
 constexpr int PC = 16;    // columns (query points) per pass
 constexpr int KCH = 2;    // 128-blocks of k per workgroup (fewer partial sums to reduce than with 1)
 constexpr int SLAB = 32;  // k-slab staged per step
+constexpr int MAX_GROUP = 8;  // 16-point passes handled by one set of launches
 
 
 // ---- kr[s][i], partial mu ----------------------------------------------------------
@@ -36,6 +37,11 @@ __global__ __launch_bounds__(256) void kstar_kernel(const double* X, const doubl
                                                     double neg_half_inv_ls2, double bias) {
   __shared__ double red[256];
   const int s = blockIdx.y;
+  // several 16-point passes in one launch (blockIdx.z): per-pass slices of the query points and outputs
+  xs += (int64_t)blockIdx.z * PC * dp;
+  xs2 += (int64_t)blockIdx.z * PC;
+  kr += (int64_t)blockIdx.z * PC * np;
+  mu_part += (int64_t)blockIdx.z * PC * gridDim.x;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   double contrib = 0.0;
   if (i < np) {
@@ -71,6 +77,7 @@ struct TriArgs {
   double* part;
   int64_t lda, n, np;
   int nb, nkc;
+  int npass;   // 16-point passes in this launch (see the blockIdx mapping in the kernel)
   double bias;
 };
 
@@ -85,8 +92,15 @@ __global__ __launch_bounds__(256) void tri_apply_kernel(TriArgs T) {
   constexpr int WP = TRANS ? 144 : 34;
   double* Ws = sm;
   double* Bs = sm + (TRANS ? SLAB * 144 : 128 * 34);
-  const int ib = blockIdx.x, kc = blockIdx.y;
+  // blockIdx.x = (ib / 8 * npass + pass) * 8 + ib % 8: workgroups are dealt to the 8 XCDs round-robin, so the
+  // passes of one ib land on the same XCD, 8 dispatch slots apart, and share the L^-T block in that XCD's L2
+  const int ib_lo = blockIdx.x & 7, bq = blockIdx.x >> 3;
+  const int ib = (bq / T.npass) * 8 + ib_lo, pass = bq % T.npass, kc = blockIdx.y;
+  if (ib >= T.nb) return;
   const int t = threadIdx.x, l = t & 63, w = t >> 6;
+  T.kr += (int64_t)pass * PC * T.np;                               // per-pass slices
+  if (!TRANS) T.vin += (int64_t)pass * T.np * PC;
+  T.part += (int64_t)pass * T.nkc * T.np * PC;
   // k-block range of this chunk, clipped to the triangle (TRANS: k <= i, else k >= i)
   int kb0 = kc * KCH, kb1 = kb0 + KCH;
   if (TRANS) {
@@ -174,6 +188,9 @@ __global__ __launch_bounds__(256) void tri_apply_kernel(TriArgs T) {
 __global__ __launch_bounds__(256) void tri_reduce_kernel(const double* part, double* out, double* sq_part,
                                                          int64_t np, int nkc, int kc_lo_is_row, int want_sq) {
   __shared__ double red[256];
+  part += (int64_t)blockIdx.y * nkc * np * PC;   // per-pass slices (blockIdx.y = pass)
+  out += (int64_t)blockIdx.y * np * PC;
+  if (want_sq) sq_part += (int64_t)blockIdx.y * gridDim.x * PC;
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;  // element (i, s), 16 rows per block
   double v = 0.0;
   if (e < np * PC) {
@@ -213,6 +230,10 @@ __global__ __launch_bounds__(256) void grad_kernel(const double* X, const double
                                                    int64_t np, int dp, int rows_per_block) {
   __shared__ double red[4][2];
   const int s = blockIdx.y;
+  xs += (int64_t)blockIdx.z * PC * dp;                 // per-pass slices (blockIdx.z = pass)
+  kr += (int64_t)blockIdx.z * PC * np;
+  u += (int64_t)blockIdx.z * np * PC;
+  g_part += (int64_t)blockIdx.z * PC * gridDim.x * 2 * dp;
   const int64_t i = (int64_t)blockIdx.x * rows_per_block + threadIdx.x;
   double* outp = g_part + ((int64_t)s * gridDim.x + blockIdx.x) * 2 * dp;
   double c1 = 0.0, c2 = 0.0;
@@ -245,8 +266,14 @@ __global__ __launch_bounds__(256) void grad_kernel(const double* X, const double
 // out layout per pass: mu[16] var[16] val[16] dmu[16*dp] dvar[16*dp] grad[16*dp]
 __global__ __launch_bounds__(256) void finish_kernel(const double* mu_part, int nblk_k, const double* var_part,
                                                      int nblk_v, const double* g_part, int ngc, double* out, int dp,
-                                                     int S, double prior_var, double noise_add, double inv_ls2,
+                                                     int S_left, double prior_var, double noise_add, double inv_ls2,
                                                      double beta, int with_grad) {
+  // one workgroup per pass (blockIdx.x); S_left = real points from the first pass of this launch on
+  mu_part += (int64_t)blockIdx.x * PC * nblk_k;
+  var_part += (int64_t)blockIdx.x * nblk_v * PC;
+  g_part += (int64_t)blockIdx.x * PC * ngc * 2 * dp;
+  out += (int64_t)blockIdx.x * (3 * PC + 3 * PC * dp);
+  const int S = S_left - (int)blockIdx.x * PC;   // columns >= S are padding
   // 16 groups of 16 lanes: lane (s, j) sums the partial blocks b = j, j+16, ... of column s;
   // the 16 group sums are then added in a fixed order.
   __shared__ double red_m[16][PC], red_q[16][PC];
@@ -338,11 +365,17 @@ static int ensure_ws(elfihip_gp* gp, PredictWs* W, int64_t npass) {
     off += (doubles + 15) & ~(size_t)15;
     return o;
   };
-  const size_t o_xs = take((size_t)npass * PC * gp->dp), o_xs2 = take((size_t)npass * PC), o_kr = take((size_t)PC * np),
-               o_part = take((size_t)W->nkc * np * PC), o_v = take((size_t)np * PC), o_u = take((size_t)np * PC),
-               o_mu = take((size_t)PC * W->nblk_k), o_var = take((size_t)(np * PC / 256 + 1) * PC),
-               o_g = take((size_t)PC * W->ngc * 2 * gp->dp),
-               o_out = take((size_t)npass * (3 * PC + 3 * PC * gp->dp));
+  // passes run `group` at a time in one set of launches; the scratch below is per pass of a group
+  const size_t per_pass = (size_t)(W->nkc + 3) * np * PC * sizeof(double);
+  int64_t group = (int64_t)(((size_t)768 << 20) / per_pass);
+  group = group < 1 ? 1 : (group > MAX_GROUP ? MAX_GROUP : group);
+  if (group > npass) group = npass;
+  W->group = (int)group;
+  const size_t g = (size_t)group;
+  const size_t o_xs = take((size_t)npass * PC * gp->dp), o_xs2 = take((size_t)npass * PC),
+               o_kr = take(g * PC * np), o_part = take(g * W->nkc * np * PC), o_v = take(g * np * PC),
+               o_u = take(g * np * PC), o_mu = take(g * PC * W->nblk_k), o_var = take(g * (np * PC / 256) * PC + 16),
+               o_g = take(g * PC * W->ngc * 2 * gp->dp), o_out = take((size_t)npass * (3 * PC + 3 * PC * gp->dp));
   ELFIHIP_CHECK_HIP(ctx, gp->ws.reserve(off * sizeof(double)));
   double* base = gp->ws.as<double>();
   W->xs = base + o_xs;
@@ -401,8 +434,8 @@ void predict_fill(const elfihip_gp* gp, const PredictPlan& P, const double* Xs, 
   }
 }
 
-// All points go up in one copy, every pass runs back to back on the stream (the per-pass scratch is
-// reused in stream order), all results come down in one copy; no synchronisation here.
+// All points go up in one copy; the 16-point passes run `group` at a time inside each launch (the
+// group scratch is reused in stream order); all results come down in one copy; no synchronisation here.
 // S_active: number of real points (columns beyond it are computed on zero inputs and ignored).
 int predict_enqueue(elfihip_gp* gp, const PredictPlan& P, int64_t S_active, int mode, int noiseless, double beta) {
   elfihip_ctx* ctx = gp->ctx;
@@ -416,14 +449,16 @@ int predict_enqueue(elfihip_gp* gp, const PredictPlan& P, int64_t S_active, int 
   ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(W.xs, P.hx, P.n_in * sizeof(double), hipMemcpyHostToDevice, st));
   const size_t lds_t = (SLAB * 144 + PC * 34) * sizeof(double);
   const size_t lds_n = (128 * 34 + SLAB * PC) * sizeof(double);
-  for (int64_t pass = 0; pass < P.npass; ++pass) {
-    const int64_t s0 = pass * PC;
-    int sc = (int)((S_active - s0) < PC ? (S_active - s0) : PC);
-    if (sc < 0) sc = 0;
-    const double* xs = W.xs + (size_t)pass * PC * dp;
-    const double* xs2 = W.xs2 + (size_t)pass * PC;
-    double* out = W.out + (size_t)pass * P.outsz;
-    hipLaunchKernelGGL(kstar_kernel, dim3(W.nblk_k, PC), dim3(256), 0, st, gp->X, gp->x2, gp->alpha, xs, xs2,
+  const int rblocks = (int)(np * PC / 256);
+  const unsigned nb8 = (unsigned)((nb + 7) / 8 * 8);
+  for (int64_t pass0 = 0; pass0 < P.npass; pass0 += W.group) {
+    const unsigned g = (unsigned)((P.npass - pass0) < W.group ? (P.npass - pass0) : W.group);
+    int s_left = (int)(S_active - pass0 * PC);
+    if (s_left < 0) s_left = 0;
+    const double* xs = W.xs + (size_t)pass0 * PC * dp;
+    const double* xs2 = W.xs2 + (size_t)pass0 * PC;
+    double* out = W.out + (size_t)pass0 * P.outsz;
+    hipLaunchKernelGGL(kstar_kernel, dim3(W.nblk_k, PC, g), dim3(256), 0, st, gp->X, gp->x2, gp->alpha, xs, xs2,
                        W.kr, W.mu_part, gp->n, np, dp, gp->var, -0.5 * inv_ls2, gp->bias);
     TriArgs T;
     T.WT = gp->WT;
@@ -435,20 +470,21 @@ int predict_enqueue(elfihip_gp* gp, const PredictPlan& P, int64_t S_active, int 
     T.np = np;
     T.nb = nb;
     T.nkc = W.nkc;
+    T.npass = (int)g;
     T.bias = gp->bias;
-    hipLaunchKernelGGL((tri_apply_kernel<true>), dim3(nb, W.nkc), dim3(256), lds_t, st, T);
-    const int rblocks = (int)(np * PC / 256);
-    hipLaunchKernelGGL(tri_reduce_kernel, dim3(rblocks), dim3(256), 0, st, W.part, W.v, W.var_part, np, W.nkc, 0, 1);
+    hipLaunchKernelGGL((tri_apply_kernel<true>), dim3(nb8 * g, W.nkc), dim3(256), lds_t, st, T);
+    hipLaunchKernelGGL(tri_reduce_kernel, dim3(rblocks, g), dim3(256), 0, st, W.part, W.v, W.var_part, np, W.nkc, 0,
+                       1);
     if (mode == 1) {
       T.vin = W.v;
-      hipLaunchKernelGGL((tri_apply_kernel<false>), dim3(nb, W.nkc), dim3(256), lds_n, st, T);
-      hipLaunchKernelGGL(tri_reduce_kernel, dim3(rblocks), dim3(256), 0, st, W.part, W.u, (double*)nullptr, np,
+      hipLaunchKernelGGL((tri_apply_kernel<false>), dim3(nb8 * g, W.nkc), dim3(256), lds_n, st, T);
+      hipLaunchKernelGGL(tri_reduce_kernel, dim3(rblocks, g), dim3(256), 0, st, W.part, W.u, (double*)nullptr, np,
                          W.nkc, 1, 0);
-      hipLaunchKernelGGL(grad_kernel, dim3(W.ngc, PC), dim3(256), 0, st, gp->X, gp->alpha, xs, W.kr, W.u, W.g_part,
-                         gp->n, np, dp, 256);
+      hipLaunchKernelGGL(grad_kernel, dim3(W.ngc, PC, g), dim3(256), 0, st, gp->X, gp->alpha, xs, W.kr, W.u,
+                         W.g_part, gp->n, np, dp, 256);
     }
-    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(256), 0, st, W.mu_part, W.nblk_k, W.var_part, rblocks, W.g_part,
-                       W.ngc, out, dp, sc, gp->var + gp->bias, noiseless ? 0.0 : gp->noise, inv_ls2, beta, mode);
+    hipLaunchKernelGGL(finish_kernel, dim3(g), dim3(256), 0, st, W.mu_part, W.nblk_k, W.var_part, rblocks, W.g_part,
+                       W.ngc, out, dp, s_left, gp->var + gp->bias, noiseless ? 0.0 : gp->noise, inv_ls2, beta, mode);
   }
   ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(P.hout, W.out, P.n_out * sizeof(double), hipMemcpyDeviceToHost, st));
   return ELFIHIP_OK;
@@ -576,17 +612,18 @@ static int extend_one(elfihip_gp* gp, const double* x, double ynew) {
   T.np = np;
   T.nb = nb;
   T.nkc = W.nkc;
+  T.npass = 1;
   T.bias = gp->bias;
   const size_t lds_t = (SLAB * 144 + PC * 34) * sizeof(double);
   const size_t lds_n = (128 * 34 + SLAB * PC) * sizeof(double);
   const int rblocks = (int)(np * PC / 256);
-  hipLaunchKernelGGL((tri_apply_kernel<true>), dim3(nb, W.nkc), dim3(256), lds_t, st, T);
+  hipLaunchKernelGGL((tri_apply_kernel<true>), dim3((nb + 7) / 8 * 8, W.nkc), dim3(256), lds_t, st, T);
   hipLaunchKernelGGL(tri_reduce_kernel, dim3(rblocks), dim3(256), 0, st, W.part, W.v, W.var_part, np, W.nkc, 0, 1);
   const double* z = gp->A + np * gp->lda;
   hipLaunchKernelGGL(extend_scalars_kernel, dim3(1), dim3(256), 0, st, W.v, z, W.var_part, rblocks,
                      gp->var + gp->bias + gp->noise + GP_JITTER, ynew, n, gp->red, gp->info, (int)n + 1);
   T.vin = W.v;
-  hipLaunchKernelGGL((tri_apply_kernel<false>), dim3(nb, W.nkc), dim3(256), lds_n, st, T);
+  hipLaunchKernelGGL((tri_apply_kernel<false>), dim3((nb + 7) / 8 * 8, W.nkc), dim3(256), lds_n, st, T);
   hipLaunchKernelGGL(tri_reduce_kernel, dim3(rblocks), dim3(256), 0, st, W.part, W.u, (double*)nullptr, np, W.nkc, 1, 0);
   hipLaunchKernelGGL(extend_write_kernel, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, st, W.v, W.u, gp->red,
                      gp->A, gp->WT, gp->alpha, gp->lda, n, np);
