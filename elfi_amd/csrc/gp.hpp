@@ -16,7 +16,7 @@ struct elfihip_gp {
   int64_t n = 0, np = 0;      // current evidence count, padded to a multiple of NB
   int64_t lda = 0;            // row pitch (doubles) of A and WT
   double var = 1, ls = 1, bias = 0, noise = 1;
-  bool factored = false, has_kinv = false;
+  bool factored = false, has_kinv = false, wl_valid = false;
   double logdet = 0, yKy = 0;
 
   // device memory
@@ -25,6 +25,8 @@ struct elfihip_gp {
   double* y = nullptr;      // (cap)
   double* A = nullptr;      // (cap + NB, lda): K -> L (lower); row block [np, np+NB) carries y -> z = L^-1 y
   double* WT = nullptr;     // (cap, lda): L^-T (upper triangular, strictly-lower part kept zero)
+  double* WL = nullptr;     // (cap, lda): L^-1 = WT^T (lower), mirrored from WT on first use after a factorisation
+                            //             (wl_valid); the second triangular product of the predictor reads it row-wise
   double* Kinv = nullptr;   // (cap, lda): K^-1 (lower tiles), only for the hyper-parameter gradient
   double* W11 = nullptr;    // (NB, NB) inverse of the diagonal block being eliminated (lower)
   double* alpha = nullptr;  // (cap) K^-1 y
@@ -36,11 +38,12 @@ struct elfihip_gp {
   // pinned host staging for the query points / results of a prediction call (one H2D, one D2H)
   double* h_stage = nullptr;
   size_t h_cap = 0;  // doubles
+  unsigned long long done_seq = 0;  // value of the completion flag after the latest single-pass prediction
 };
 
 namespace elfihip {
 struct PredictWs {
-  double *xs, *xs2, *kr, *part, *v, *u, *mu_part, *var_part, *g_part, *out;
+  double *xs, *xs2, *kr, *kb, *part, *v, *u, *mu_part, *var_part, *g_part, *out;
   int nblk_k;   // blocks of the kstar kernel along i
   int nkc;      // k chunks
   int ngc;      // i chunks of the gradient kernel
@@ -54,10 +57,13 @@ struct PredictPlan {
   size_t n_in = 0, n_out = 0, outsz = 0;  // doubles
   double* hx = nullptr;                   // pinned: query points + their squared norms
   double* hout = nullptr;                 // pinned: results
+  unsigned long long* flag = nullptr;     // pinned: completion flag (single-pass calls)
+  bool direct = false;                    // kernels read hx / write hout themselves, no copies
 };
 int predict_prepare(elfihip_gp* gp, int64_t S, PredictPlan* P);
 void predict_fill(const elfihip_gp* gp, const PredictPlan& P, const double* Xs, int64_t S);
 int predict_enqueue(elfihip_gp* gp, const PredictPlan& P, int64_t S_active, int mode, int noiseless, double beta);
+int predict_wait(elfihip_gp* gp, const PredictPlan& P);
 void predict_read(const elfihip_gp* gp, const PredictPlan& P, int64_t S, double* mu, double* var, double* dmu,
                   double* dvar, double* val, double* grad);
 // gp_predict.hip: mean / variance / gradients / LCB for S host points (one stream sync per call).

@@ -690,6 +690,7 @@ int gp_factorize_impl(elfihip_gp* gp) {
   gp->yKy = red[1];
   gp->factored = true;
   gp->has_kinv = false;
+  gp->wl_valid = false;
   return ELFIHIP_OK;
 }
 
@@ -723,6 +724,7 @@ int elfihip_gp_create(elfihip_ctx* ctx, int d, int64_t capacity, elfihip_gp** ou
   alloc(&gp->y, (size_t)gp->cap * sizeof(double));
   alloc(&gp->A, (size_t)(gp->cap + NB) * mat);
   alloc(&gp->WT, (size_t)gp->cap * mat);
+  alloc(&gp->WL, (size_t)gp->cap * mat);
   alloc(&gp->W11, ((size_t)NB * NB + 64) * sizeof(double));
   alloc(&gp->alpha, (size_t)gp->cap * sizeof(double));
   alloc(&gp->red, 64 * sizeof(double));
@@ -742,7 +744,7 @@ int elfihip_gp_free(elfihip_gp* gp) {
   if (!gp) return ELFIHIP_OK;
   DeviceGuard g(gp->ctx->device);
   (void)hipStreamSynchronize(gp->ctx->stream);
-  for (double* p : {gp->X, gp->x2, gp->y, gp->A, gp->WT, gp->Kinv, gp->W11, gp->alpha, gp->red})
+  for (double* p : {gp->X, gp->x2, gp->y, gp->A, gp->WT, gp->WL, gp->Kinv, gp->W11, gp->alpha, gp->red})
     if (p) (void)hipFree(p);
   if (gp->info) (void)hipFree(gp->info);
   if (gp->h_stage) (void)hipHostFree(gp->h_stage);

@@ -14,9 +14,14 @@
 //   dmu_s    = sum_i alpha_i dk_si,   dvar_s = -2 sum_i u[i][s] dk_si,
 //              dk_si = -(kr[s][i] / l^2) (x_s - X_i)                  (RBF part only, as GPy)
 //
-// The two triangular products stream L^-T once each (8 n^2 / 2 bytes): HBM/L3-bound for 16
-// columns, so they are split over (row block, k chunk) pairs to fill the chip and reduced
-// in a fixed order (deterministic).  WT's strictly-lower part is zero, so no masking.
+// The two triangular products stream a triangle of n^2/2 doubles once each: HBM/L3-bound for 16
+// columns, so they are split over (32-row block, 256-deep k chunk) pairs -- about a thousand
+// workgroups of <= 64 KiB at n = 4096, enough for the dispatcher to balance the triangle over the
+// 256 CUs -- and reduced in a fixed order (deterministic).  Both products read their matrix
+// row-wise along k (v from L^-T, u from its mirror image L^-1, gp->WL), so one kernel serves both.
+// The strictly-lower part of WT (strictly-upper of WL) is zero, so no masking on the diagonal.
+#include <chrono>
+#include <cstdlib>
 #include <type_traits>
 
 #include "gp.hpp"
@@ -25,36 +30,49 @@
 namespace elfihip {
 
 constexpr int PC = 16;    // columns (query points) per pass
-constexpr int KCH = 2;    // 128-blocks of k per workgroup (fewer partial sums to reduce than with 1)
-constexpr int SLAB = 32;  // k-slab staged per step
+constexpr int KCH = 2;    // 128-blocks of k per chunk of the triangular products
+constexpr int KC = KCH * NB;  // = 256 k per workgroup
+constexpr int RB = 32;    // output rows per workgroup of the triangular products
 constexpr int MAX_GROUP = 8;  // 16-point passes handled by one set of launches
 
 
 // ---- kr[s][i], partial mu ----------------------------------------------------------
 __global__ __launch_bounds__(256) void kstar_kernel(const double* X, const double* x2, const double* alpha,
-                                                    const double* xs, const double* xs2, double* kr, double* mu_part,
-                                                    int64_t n, int64_t np, int dp, double var,
-                                                    double neg_half_inv_ls2, double bias) {
+                                                    const double* xs, const double* xs2, double* kr, double* kb,
+                                                    double* mu_part, int64_t n, int64_t np, int dp, double var,
+                                                    double neg_half_inv_ls2, double bias, double* xs_copy) {
   __shared__ double red[256];
+  __shared__ double sx[256 + 1];  // this workgroup's query point and its squared norm
   const int s = blockIdx.y;
   // several 16-point passes in one launch (blockIdx.z): per-pass slices of the query points and outputs
   xs += (int64_t)blockIdx.z * PC * dp;
   xs2 += (int64_t)blockIdx.z * PC;
   kr += (int64_t)blockIdx.z * PC * np;
+  kb += (int64_t)blockIdx.z * PC * np;
   mu_part += (int64_t)blockIdx.z * PC * gridDim.x;
+  // xs may be pinned host memory (single-pass calls skip the upload): one parallel read, not dp serial ones;
+  // workgroup column 0 leaves a device copy of its point for the gradient kernel
+  if ((int)threadIdx.x < dp) {
+    const double x = xs[s * dp + threadIdx.x];
+    sx[threadIdx.x] = x;
+    if (xs_copy && blockIdx.x == 0) xs_copy[s * dp + threadIdx.x] = x;
+  }
+  if (threadIdx.x == 0) sx[256] = xs2[s];
+  __syncthreads();
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   double contrib = 0.0;
   if (i < np) {
     double k = 0.0;
     if (i < n) {
       double dot = 0.0;
-      for (int c = 0; c < dp; ++c) dot += xs[s * dp + c] * X[i * dp + c];
-      double r2 = (xs2[s] + x2[i]) + (-2.0 * dot);
+      for (int c = 0; c < dp; ++c) dot += sx[c] * X[i * dp + c];
+      double r2 = (sx[256] + x2[i]) + (-2.0 * dot);
       r2 = r2 > 0.0 ? r2 : 0.0;
       k = var * exp(r2 * neg_half_inv_ls2);
       contrib = (k + bias) * alpha[i];
     }
     kr[(int64_t)s * np + i] = k;
+    kb[i * PC + s] = i < n ? k + bias : 0.0;  // right-hand side of the first triangular product, [k][s]
   }
   red[threadIdx.x] = contrib;
   __syncthreads();
@@ -66,122 +84,100 @@ __global__ __launch_bounds__(256) void kstar_kernel(const double* X, const doubl
 }
 
 // ---- triangular skinny products on the matrix cores ------------------------------------
-// TRANS = true :  out[i][s] += sum_k WT[k][i] * (kr[s][k] + bias [k < n])      (v = L^-1 kb)
-// TRANS = false:  out[i][s] += sum_k WT[i][k] * vin[k][s]                        (u = L^-T v)
-// Workgroup (ib, kc): rows i in block ib, k in blocks [kc*KCH, kc*KCH+KCH) clipped to the
-// triangle.  Writes part[kc][i][s] (zeros if the chunk is outside the triangle).
+// LOWER = false:  out[i][s] = sum_{k <= i} W[k][i] bin[k][s],  W = L^-T (gp->WT),  bin = kb     (v = L^-1 kb)
+// LOWER = true :  out[i][s] = sum_{k >= i} W[k][i] bin[k][s],  W = L^-1 (gp->WL),  bin = v      (u = L^-T v)
+// Workgroup (rb, kc): rows i in [32 rb, 32 rb + 32), k in chunk kc clipped to the triangle (a multiple
+// of 32 long).  Writes part[kc][i][s]; chunks outside the triangle are never read by the reduction.
 struct TriArgs {
-  const double* WT;
-  const double* kr;    // TRANS
-  const double* vin;   // !TRANS
+  const double* W;
+  const double* bin;   // [k][s], np x 16 per pass
   double* part;
-  int64_t lda, n, np;
-  int nb, nkc;
+  int64_t lda, np;
+  int nrb, nkc;
   int npass;   // 16-point passes in this launch (see the blockIdx mapping in the kernel)
-  double bias;
 };
 
-template <bool TRANS>
+template <bool LOWER>
 __global__ __launch_bounds__(256) void tri_apply_kernel(TriArgs T) {
-  // One workgroup per (row block ib, chunk of KCH k blocks) inside the triangle; its part of L^-T is
-  // streamed as 32-deep slabs with the loads of the next two slabs in flight (registers) while the
-  // current one is multiplied -- these kernels are pure HBM/MALL streaming (S <= 16).
-  // LDS: W slab + B slab.  TRANS: W as [k][i] pitch 144, B = kb as [s][k] pitch 34.
-  //      !TRANS: W as [i][k] pitch 34, B = v as [k][s] pitch 16.
-  extern __shared__ __align__(16) double sm[];
-  constexpr int WP = TRANS ? 144 : 34;
-  double* Ws = sm;
-  double* Bs = sm + (TRANS ? SLAB * 144 : 128 * 34);
-  // blockIdx.x = (ib / 8 * npass + pass) * 8 + ib % 8: workgroups are dealt to the 8 XCDs round-robin, so the
-  // passes of one ib land on the same XCD, 8 dispatch slots apart, and share the L^-T block in that XCD's L2
-  const int ib_lo = blockIdx.x & 7, bq = blockIdx.x >> 3;
-  const int ib = (bq / T.npass) * 8 + ib_lo, pass = bq % T.npass, kc = blockIdx.y;
-  if (ib >= T.nb) return;
-  const int t = threadIdx.x, l = t & 63, w = t >> 6;
-  T.kr += (int64_t)pass * PC * T.np;                               // per-pass slices
-  if (!TRANS) T.vin += (int64_t)pass * T.np * PC;
-  T.part += (int64_t)pass * T.nkc * T.np * PC;
-  // k-block range of this chunk, clipped to the triangle (TRANS: k <= i, else k >= i)
-  int kb0 = kc * KCH, kb1 = kb0 + KCH;
-  if (TRANS) {
-    if (kb1 > ib + 1) kb1 = ib + 1;
+  // No LDS staging of the matrix: a lane's 16-byte load IS its MFMA operand.  Lane (kq = l >> 4, ip = l & 15)
+  // of wave w loads W[k][i0 + 2 ip .. + 1] for k = k0 + 16 q + 4 w + kq, q = 0 .. len/16: one instruction covers
+  // 4 rows x 256 contiguous bytes, and its two doubles feed two v_mfma_f64_16x16x4 (even rows i / odd rows i)
+  // against B[k][s] from LDS.  All (up to 16) loads of a lane are issued before the first MFMA, so a workgroup
+  // has its whole <= 64 KiB in flight at once; the four waves' partial tiles are added in fixed order at the end.
+  __shared__ __align__(16) double Bs[KC * PC];  // right-hand sides of this chunk [k][s]; later the wave partials
+  // blockIdx.x = (rb / 8 * npass + pass) * 8 + rb % 8: workgroups are dealt to the 8 XCDs round-robin, so the
+  // passes of one rb land on the same XCD, 8 dispatch slots apart, and share the rows of W in that XCD's L2
+  const int x_lo = blockIdx.x & 7, bq = blockIdx.x >> 3;
+  const int rb = (bq / T.npass) * 8 + x_lo, pass = bq % T.npass, kc = blockIdx.y;
+  if (rb >= T.nrb) return;
+  const int64_t i0 = (int64_t)rb * RB;
+  int64_t k0 = (int64_t)kc * KC, k1 = k0 + KC;
+  if (LOWER) {
+    if (k0 < i0) k0 = i0;
+    if (k1 > T.np) k1 = T.np;
   } else {
-    if (kb0 < ib) kb0 = ib;
-    if (kb1 > T.nb) kb1 = T.nb;
+    if (k1 > i0 + RB) k1 = i0 + RB;
   }
-  if (kb0 >= kb1) return;  // chunk lies outside the triangle (the reduction never reads it)
-  const int nslab = (kb1 - kb0) * (NB / SLAB);  // 4 or 8
-  v4d acc[2];
-  acc[0] = (v4d){0, 0, 0, 0};
-  acc[1] = (v4d){0, 0, 0, 0};
-  const int64_t i0 = (int64_t)ib * NB, kbase = (int64_t)kb0 * NB;
-  // per-thread source / destination of pair p inside a slab (slab s adds s * step to the source)
-  auto src = [&](int p) -> const double* {
-    if (TRANS) return T.WT + (kbase + (t >> 6) + 4 * p) * T.lda + i0 + 2 * (t & 63);  // row k of the slab, 1 KiB per row
-    return T.WT + (i0 + (t >> 4) + 16 * p) * T.lda + kbase + 2 * (t & 15);            // row i, 256 B of the slab per row
-  };
-  auto dst = [&](int p) -> int {
-    if (TRANS) return ((t >> 6) + 4 * p) * 144 + 2 * (t & 63);
-    return ((t >> 4) + 16 * p) * 34 + 2 * (t & 15);
-  };
-  const int64_t step = TRANS ? (int64_t)SLAB * T.lda : (int64_t)SLAB;
+  if (k0 >= k1) return;  // chunk lies outside the triangle
+  const int len = (int)(k1 - k0);
+  const int t = threadIdx.x, l = t & 63, w = t >> 6;
   typedef double v2d __attribute__((ext_vector_type(2)));
-  v2d r0[8], r1[8];
+  const double* bin = T.bin + ((int64_t)pass * T.np + k0) * PC;
+  const int nbr = len / 32, nq = len / 16;  // 16-byte pieces of B per thread, MFMA pairs per wave
+  // Straight-line code for every chunk length: pieces past the end of a clipped chunk re-read its last piece
+  // (cache hit) and are multiplied by zero right-hand sides.
+  v2d breg[8], wr[16];
 #pragma unroll
-  for (int p = 0; p < 8; ++p) r0[p] = *reinterpret_cast<const v2d*>(src(p));
-#pragma unroll
-  for (int p = 0; p < 8; ++p) r1[p] = *reinterpret_cast<const v2d*>(src(p) + step);
-  // four slabs, written out (compile-time slab index keeps r0 / r1 in registers)
-#define ELFIHIP_SLAB_STEP(sl, cur)                                                                        \
-  {                                                                                                      \
-    const int64_t k0 = kbase + (int64_t)(sl)*SLAB;                                                       \
-    __syncthreads();                                                                                     \
-    _Pragma("unroll") for (int p = 0; p < 8; ++p) *reinterpret_cast<v2d*>(Ws + dst(p)) = cur[p];    \
-    if ((sl) + 2 < nslab) {                                                                              \
-      _Pragma("unroll") for (int p = 0; p < 8; ++p) cur[p] =                                             \
-          *reinterpret_cast<const v2d*>(src(p) + ((sl) + 2) * step);                                     \
-    }                                                                                                    \
-    if (TRANS) {                                                                                         \
-      _Pragma("unroll") for (int e0 = 0; e0 < PC * SLAB; e0 += 256) {                                    \
-        const int e = e0 + t;                                                                            \
-        const int s_ = e >> 5, kk = e & 31;                                                              \
-        const int64_t k = k0 + kk;                                                                       \
-        Bs[s_ * 34 + kk] = (k < T.n) ? (T.kr[(int64_t)s_ * T.np + k] + T.bias) : 0.0;                    \
-      }                                                                                                  \
-    } else {                                                                                             \
-      _Pragma("unroll") for (int e0 = 0; e0 < SLAB * PC; e0 += 256) Bs[e0 + t] = T.vin[k0 * PC + e0 + t]; \
-    }                                                                                                    \
-    __syncthreads();                                                                                     \
-    _Pragma("unroll") for (int ks = 0; ks < SLAB / 4; ++ks) {                                            \
-      const int kq = 4 * ks + (l >> 4);                                                                  \
-      const double bq = TRANS ? Bs[(l & 15) * 34 + kq] : Bs[kq * PC + (l & 15)];                         \
-      _Pragma("unroll") for (int m = 0; m < 2; ++m) {                                                    \
-        const int i = (2 * w + m) * 16 + (l & 15);                                                       \
-        const double aq = TRANS ? Ws[kq * WP + i] : Ws[i * WP + kq];                                     \
-        acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(aq, bq, acc[m], 0, 0, 0);                          \
-      }                                                                                                  \
-    }                                                                                                    \
+  for (int p = 0; p < 8; ++p) {
+    const int pp = p < nbr ? p : nbr - 1;
+    const v2d x = *reinterpret_cast<const v2d*>(bin + pp * 512 + 2u * (unsigned)t);
+    breg[p] = p < nbr ? x : (v2d){0.0, 0.0};
   }
-  ELFIHIP_SLAB_STEP(0, r0)
-  ELFIHIP_SLAB_STEP(1, r1)
-  ELFIHIP_SLAB_STEP(2, r0)
-  ELFIHIP_SLAB_STEP(3, r1)
-  if (nslab > 4) {  // workgroup-uniform: second k block of the chunk
-    ELFIHIP_SLAB_STEP(4, r0)
-    ELFIHIP_SLAB_STEP(5, r1)
-    ELFIHIP_SLAB_STEP(6, r0)
-    ELFIHIP_SLAB_STEP(7, r1)
+  // uniform row base + 32-bit lane offset
+  const double* wbase = T.W + k0 * T.lda + i0;
+  const unsigned lane_off = (unsigned)(4 * w + (l >> 4)) * (unsigned)T.lda + 2u * (l & 15);
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int qq = q < nq ? q : nq - 1;
+    wr[q] = *reinterpret_cast<const v2d*>(wbase + (int64_t)16 * qq * T.lda + lane_off);
   }
-#undef ELFIHIP_SLAB_STEP
-  static_assert(KCH * (NB / SLAB) == 8, "slab sequence above is written out for up to eight slabs");
-  double* out = T.part + ((int64_t)kc * T.np + i0) * PC;
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+  for (int p = 0; p < 8; ++p) *reinterpret_cast<v2d*>(Bs + p * 512 + 2 * t) = breg[p];
+  __syncthreads();
+  v4d acc0 = (v4d){0, 0, 0, 0}, acc1 = (v4d){0, 0, 0, 0};
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = (2 * w + m) * 16 + (l >> 4) + 4 * r;
-      out[row * PC + (l & 15)] = acc[m][r];
-    }
+  for (int q = 0; q < 16; ++q) {
+    const double b = Bs[(16 * q + 4 * w + (l >> 4)) * PC + (l & 15)];
+    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(wr[q].x, b, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(wr[q].y, b, acc1, 0, 0, 0);
+  }
+  __syncthreads();
+  // wave partials -> LDS as [w][i local][s] (i local = 2 * (MFMA row) + even/odd), then fixed-order sums
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int ip = (l >> 4) + 4 * r;
+    Bs[(w * RB + 2 * ip) * PC + (l & 15)] = acc0[r];
+    Bs[(w * RB + 2 * ip + 1) * PC + (l & 15)] = acc1[r];
+  }
+  __syncthreads();
+  double* out = T.part + (((int64_t)pass * T.nkc + kc) * T.np + i0) * PC;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int e = t + 256 * h;  // (i local, s) = (e >> 4, e & 15)
+    out[e] = ((Bs[e] + Bs[RB * PC + e]) + Bs[2 * RB * PC + e]) + Bs[3 * RB * PC + e];
+  }
+}
+
+// Sum of the chunk partials of element e = i * 16 + s, chunks [lo, hi), in the one fixed order every consumer uses.
+__device__ inline double sum_partials(const double* __restrict__ part, int64_t np, int64_t e, int lo, int hi) {
+  double v4[4] = {0, 0, 0, 0};
+  int kc = lo;
+  for (; kc + 4 <= hi; kc += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v4[u] += part[(int64_t)(kc + u) * np * PC + e];
+  }
+  for (; kc < hi; ++kc) v4[0] += part[(int64_t)kc * np * PC + e];
+  return (v4[0] + v4[1]) + (v4[2] + v4[3]);
 }
 
 // v[i][s] = sum_kc part[kc][i][s] (fixed order); optional per-block partials of sum_i v^2.
@@ -196,17 +192,10 @@ __global__ __launch_bounds__(256) void tri_reduce_kernel(const double* part, dou
   if (e < np * PC) {
     const int64_t i = e / PC;
     const int ib = (int)(i / NB);
-    // chunks that can be non-zero: TRANS (kc_lo_is_row == 0): kc*KCH <= ib ; else kc*KCH+KCH > ib
+    // chunks inside the triangle: first product (kc_lo_is_row == 0): kc*KCH <= ib ; second: kc*KCH+KCH > ib
     const int lo = kc_lo_is_row ? ib / KCH : 0;
     const int hi = kc_lo_is_row ? nkc : ib / KCH + 1;
-    double v4[4] = {0, 0, 0, 0};
-    int kc = lo;
-    for (; kc + 4 <= hi; kc += 4) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u) v4[u] += part[(int64_t)(kc + u) * np * PC + e];
-    }
-    for (; kc < hi; ++kc) v4[0] += part[(int64_t)kc * np * PC + e];
-    v = (v4[0] + v4[1]) + (v4[2] + v4[3]);
+    v = sum_partials(part, np, e, lo, hi);
     out[e] = v;
   }
   if (want_sq) {
@@ -223,42 +212,65 @@ __global__ __launch_bounds__(256) void tri_reduce_kernel(const double* part, dou
 
 // ---- gradients ---------------------------------------------------------------------
 // g_part[s][chunk][0..dp) = sum_i alpha_i kr_si (x_s - X_i),  [dp..2dp) = sum_i u_is kr_si (x_s - X_i)
-// One evidence row per thread (256 rows per workgroup); per dimension a wave butterfly, then the four
-// wave partials in fixed order.
-__global__ __launch_bounds__(256) void grad_kernel(const double* X, const double* alpha, const double* xs,
-                                                   const double* kr, const double* u, double* g_part, int64_t n,
-                                                   int64_t np, int dp, int rows_per_block) {
-  __shared__ double red[4][2];
-  const int s = blockIdx.y;
-  xs += (int64_t)blockIdx.z * PC * dp;                 // per-pass slices (blockIdx.z = pass)
-  kr += (int64_t)blockIdx.z * PC * np;
-  u += (int64_t)blockIdx.z * np * PC;
-  g_part += (int64_t)blockIdx.z * PC * gridDim.x * 2 * dp;
-  const int64_t i = (int64_t)blockIdx.x * rows_per_block + threadIdx.x;
-  double* outp = g_part + ((int64_t)s * gridDim.x + blockIdx.x) * 2 * dp;
-  double c1 = 0.0, c2 = 0.0;
-  if (i < n) {
-    const double k = kr[(int64_t)s * np + i];
-    c1 = alpha[i] * k;
-    c2 = u[i * PC + s] * k;
-  }
-  const int64_t ic = i < n ? i : 0;
-  for (int a = 0; a < dp; ++a) {
-    const double diff = xs[s * dp + a] - X[ic * dp + a];
-    double v1 = c1 * diff, v2 = c2 * diff;
+// Workgroup = 64 evidence rows x the 16 query points; thread (s = t & 15, ig = t >> 4) owns rows ig, ig + 16,
+// ig + 32, ig + 48 of the chunk.  u is summed here from the chunk partials of the second triangular product
+// (same order as tri_reduce_kernel), which saves that kernel on the prediction path.  Four dimensions at a time:
+// register sums over the thread's rows, two butterfly steps over the wave's row groups, the four waves in order.
+constexpr int GR = 64;
+__global__ __launch_bounds__(256) void grad_kernel(const double* __restrict__ X, const double* __restrict__ alpha,
+                                                   const double* __restrict__ xs, const double* __restrict__ kr,
+                                                   const double* __restrict__ part, int nkc,
+                                                   double* __restrict__ g_part, int64_t n, int64_t np, int dp) {
+  __shared__ double red[4][PC][8];
+  const int t = threadIdx.x, s = t & 15, ig = t >> 4, w = t >> 6;
+  xs += (int64_t)blockIdx.y * PC * dp;                 // per-pass slices (blockIdx.y = pass)
+  kr += (int64_t)blockIdx.y * PC * np;
+  part += (int64_t)blockIdx.y * nkc * np * PC;
+  g_part += (int64_t)blockIdx.y * PC * gridDim.x * 2 * dp;
+  const int64_t i0 = (int64_t)blockIdx.x * GR;
+  double c1[4], c2[4];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      v1 += __shfl_xor(v1, off, 64);
-      v2 += __shfl_xor(v2, off, 64);
+  for (int r = 0; r < 4; ++r) {
+    const int64_t i = i0 + ig + 16 * r;
+    c1[r] = 0.0;
+    c2[r] = 0.0;
+    if (i < n) {
+      const double k = kr[(int64_t)s * np + i];
+      c1[r] = alpha[i] * k;
+      c2[r] = sum_partials(part, np, i * PC + s, (int)(i / KC), nkc) * k;
+    }
+  }
+  typedef double v4 __attribute__((ext_vector_type(4)));
+  for (int a0 = 0; a0 < dp; a0 += 4) {
+    const v4 x4 = *reinterpret_cast<const v4*>(xs + s * dp + a0);
+    v4 g1 = (v4){0, 0, 0, 0}, g2 = (v4){0, 0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const v4 diff = x4 - *reinterpret_cast<const v4*>(X + (i0 + ig + 16 * r) * dp + a0);  // rows < np exist (zeros)
+      g1 += c1[r] * diff;
+      g2 += c2[r] * diff;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      g1[j] += __shfl_xor(g1[j], 16, 64);
+      g2[j] += __shfl_xor(g2[j], 16, 64);
+      g1[j] += __shfl_xor(g1[j], 32, 64);
+      g2[j] += __shfl_xor(g2[j], 32, 64);
     }
     __syncthreads();  // red free
-    if ((threadIdx.x & 63) == 0) {
-      red[threadIdx.x >> 6][0] = v1;
-      red[threadIdx.x >> 6][1] = v2;
+    if ((t & 63) < 16) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        red[w][s][j] = g1[j];
+        red[w][s][4 + j] = g2[j];
+      }
     }
     __syncthreads();
-    if (threadIdx.x < 2) outp[threadIdx.x * dp + a] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) +
-                                                      red[3][threadIdx.x];
+    if (t < PC * 8) {
+      const int ss = t >> 3, j = t & 7;
+      const double v = ((red[0][ss][j] + red[1][ss][j]) + red[2][ss][j]) + red[3][ss][j];
+      g_part[((int64_t)ss * gridDim.x + blockIdx.x) * 2 * dp + (j < 4 ? a0 + j : dp + a0 + j - 4)] = v;
+    }
   }
 }
 
@@ -267,7 +279,8 @@ __global__ __launch_bounds__(256) void grad_kernel(const double* X, const double
 __global__ __launch_bounds__(256) void finish_kernel(const double* mu_part, int nblk_k, const double* var_part,
                                                      int nblk_v, const double* g_part, int ngc, double* out, int dp,
                                                      int S_left, double prior_var, double noise_add, double inv_ls2,
-                                                     double beta, int with_grad) {
+                                                     double beta, int with_grad, unsigned long long* done_flag,
+                                                     unsigned long long done_value) {
   // one workgroup per pass (blockIdx.x); S_left = real points from the first pass of this launch on
   mu_part += (int64_t)blockIdx.x * PC * nblk_k;
   var_part += (int64_t)blockIdx.x * nblk_v * PC;
@@ -349,6 +362,60 @@ __global__ __launch_bounds__(256) void finish_kernel(const double* mu_part, int 
       grad[s * dp + a] = dm - 0.5 * dv * sc;
     }
   }
+  if (done_flag) {
+    // `out` is pinned host memory here: make the results visible to the host, then raise the flag it polls
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(done_flag, done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// WL = WT^T in 64 x 64 tiles through LDS (upper tiles of WT -> lower tiles of WL).
+__global__ __launch_bounds__(256) void mirror_kernel(const double* WT, double* WL, int64_t lda) {
+  __shared__ double tile[64][65];
+  const int bi = blockIdx.y, bj = blockIdx.x;
+  if (bi > bj) return;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = ty + 4 * r;
+    tile[row][tx] = WT[((int64_t)bi * 64 + row) * lda + (int64_t)bj * 64 + tx];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = ty + 4 * r;
+    WL[((int64_t)bj * 64 + row) * lda + (int64_t)bi * 64 + tx] = tile[tx][row];
+  }
+}
+
+// L^-1 (row-wise) for the second triangular product: mirrored from L^-T once per factorisation, on first use
+// (hyper-parameter searches factorise many times without predicting).
+static int ensure_wl(elfihip_gp* gp) {
+  if (gp->wl_valid) return ELFIHIP_OK;
+  const unsigned nt = (unsigned)(gp->np / 64);
+  hipLaunchKernelGGL(mirror_kernel, dim3(nt, nt), dim3(256), 0, gp->ctx->stream, gp->WT, gp->WL, gp->lda);
+  ELFIHIP_TRY(launch_status(gp->ctx, "mirror_kernel"));
+  gp->wl_valid = true;
+  return ELFIHIP_OK;
+}
+
+// One triangular product for `g` passes: part[pass][kc][i][s] from bin[pass][k][s].
+static void launch_tri(const elfihip_gp* gp, const PredictWs& W, bool lower, const double* bin, unsigned g) {
+  TriArgs T;
+  T.W = lower ? gp->WL : gp->WT;
+  T.bin = bin;
+  T.part = W.part;
+  T.lda = gp->lda;
+  T.np = gp->np;
+  T.nrb = (int)(gp->np / RB);
+  T.nkc = W.nkc;
+  T.npass = (int)g;
+  const dim3 grid((unsigned)((T.nrb + 7) / 8 * 8) * g, (unsigned)W.nkc);
+  if (lower)
+    hipLaunchKernelGGL((tri_apply_kernel<true>), grid, dim3(256), 0, gp->ctx->stream, T);
+  else
+    hipLaunchKernelGGL((tri_apply_kernel<false>), grid, dim3(256), 0, gp->ctx->stream, T);
 }
 
 static int ensure_ws(elfihip_gp* gp, PredictWs* W, int64_t npass) {
@@ -357,8 +424,7 @@ static int ensure_ws(elfihip_gp* gp, PredictWs* W, int64_t npass) {
   const int nb = (int)(np / NB);
   W->nblk_k = (int)((np + 255) / 256);
   W->nkc = (nb + KCH - 1) / KCH;
-  const int rows_per_block = 256;
-  W->ngc = (int)((gp->n + rows_per_block - 1) / rows_per_block);
+  W->ngc = (int)((gp->n + GR - 1) / GR);
   size_t off = 0;
   auto take = [&](size_t doubles) {
     size_t o = off;
@@ -366,14 +432,14 @@ static int ensure_ws(elfihip_gp* gp, PredictWs* W, int64_t npass) {
     return o;
   };
   // passes run `group` at a time in one set of launches; the scratch below is per pass of a group
-  const size_t per_pass = (size_t)(W->nkc + 3) * np * PC * sizeof(double);
+  const size_t per_pass = (size_t)(W->nkc + 4) * np * PC * sizeof(double);
   int64_t group = (int64_t)(((size_t)768 << 20) / per_pass);
   group = group < 1 ? 1 : (group > MAX_GROUP ? MAX_GROUP : group);
   if (group > npass) group = npass;
   W->group = (int)group;
   const size_t g = (size_t)group;
   const size_t o_xs = take((size_t)npass * PC * gp->dp), o_xs2 = take((size_t)npass * PC),
-               o_kr = take(g * PC * np), o_part = take(g * W->nkc * np * PC), o_v = take(g * np * PC),
+               o_kr = take(g * PC * np), o_kb = take(g * PC * np), o_part = take(g * W->nkc * np * PC), o_v = take(g * np * PC),
                o_u = take(g * np * PC), o_mu = take(g * PC * W->nblk_k), o_var = take(g * (np * PC / 256) * PC + 16),
                o_g = take(g * PC * W->ngc * 2 * gp->dp), o_out = take((size_t)npass * (3 * PC + 3 * PC * gp->dp));
   ELFIHIP_CHECK_HIP(ctx, gp->ws.reserve(off * sizeof(double)));
@@ -381,6 +447,7 @@ static int ensure_ws(elfihip_gp* gp, PredictWs* W, int64_t npass) {
   W->xs = base + o_xs;
   W->xs2 = base + o_xs2;
   W->kr = base + o_kr;
+  W->kb = base + o_kb;
   W->part = base + o_part;
   W->v = base + o_v;
   W->u = base + o_u;
@@ -394,6 +461,11 @@ static int ensure_ws(elfihip_gp* gp, PredictWs* W, int64_t npass) {
 // ---- a prediction call in four steps: host preparation, input fill, device enqueue, result read.
 // (Replaying the enqueue part from a hipGraph was measured and is slower here: +90 us per launch on
 // this stack for a 9-node graph with two copy nodes, against ~25 us of plain launch cost.)
+static bool zero_copy_disabled() {
+  static const bool off = std::getenv("ELFIHIP_NO_ZERO_COPY") != nullptr;  // developer switch: always stage through copies
+  return off;
+}
+
 int predict_prepare(elfihip_gp* gp, int64_t S, PredictPlan* P) {
   elfihip_ctx* ctx = gp->ctx;
   if (!gp->factored)
@@ -406,16 +478,24 @@ int predict_prepare(elfihip_gp* gp, int64_t S, PredictPlan* P) {
   P->outsz = (size_t)3 * PC + 3 * PC * dp;
   P->n_in = (size_t)P->npass * PC * dp + (size_t)P->npass * PC;
   P->n_out = (size_t)P->npass * P->outsz;
-  if (gp->h_cap < P->n_in + P->n_out) {  // pinned staging: the copies are true async DMA, no bounce buffer
+  // pinned, device-visible staging: [completion flag | query points | results].  Calls of one pass (S <= 16, every
+  // step of the acquisition search) skip both copies: the kernels read the points from and write the results to
+  // this buffer directly, and the host polls the flag the last kernel raises.
+  if (gp->h_cap < P->n_in + P->n_out + 16) {
     if (gp->h_stage) ELFIHIP_CHECK_HIP(ctx, hipHostFree(gp->h_stage));
     gp->h_stage = nullptr;
     gp->h_cap = 0;
     const size_t want = 2 * (P->n_in + P->n_out) + 1024;
-    ELFIHIP_CHECK_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&gp->h_stage), want * sizeof(double), hipHostMallocDefault));
+    ELFIHIP_CHECK_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&gp->h_stage), want * sizeof(double),
+                                         hipHostMallocMapped | hipHostMallocCoherent));
     gp->h_cap = want;
+    *reinterpret_cast<unsigned long long*>(gp->h_stage) = 0;
+    gp->done_seq = 0;
   }
-  P->hx = gp->h_stage;
-  P->hout = gp->h_stage + P->n_in;
+  P->direct = P->npass == 1 && !zero_copy_disabled();
+  P->flag = reinterpret_cast<unsigned long long*>(gp->h_stage);
+  P->hx = gp->h_stage + 16;
+  P->hout = P->hx + P->n_in;
   return ELFIHIP_OK;
 }
 
@@ -443,50 +523,57 @@ int predict_enqueue(elfihip_gp* gp, const PredictPlan& P, int64_t S_active, int 
   const PredictWs& W = P.ws;
   const int dp = gp->dp;
   const int64_t np = gp->np;
-  const int nb = (int)(np / NB);
   const double inv_ls2 = 1.0 / (gp->ls * gp->ls);
   // W.xs and W.xs2 are adjacent in the workspace (PC * dp is a multiple of the 16-double granule)
-  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(W.xs, P.hx, P.n_in * sizeof(double), hipMemcpyHostToDevice, st));
-  const size_t lds_t = (SLAB * 144 + PC * 34) * sizeof(double);
-  const size_t lds_n = (128 * 34 + SLAB * PC) * sizeof(double);
+  if (!P.direct) ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(W.xs, P.hx, P.n_in * sizeof(double), hipMemcpyHostToDevice, st));
+  if (mode == 1) ELFIHIP_TRY(ensure_wl(gp));
   const int rblocks = (int)(np * PC / 256);
-  const unsigned nb8 = (unsigned)((nb + 7) / 8 * 8);
   for (int64_t pass0 = 0; pass0 < P.npass; pass0 += W.group) {
     const unsigned g = (unsigned)((P.npass - pass0) < W.group ? (P.npass - pass0) : W.group);
     int s_left = (int)(S_active - pass0 * PC);
     if (s_left < 0) s_left = 0;
-    const double* xs = W.xs + (size_t)pass0 * PC * dp;
-    const double* xs2 = W.xs2 + (size_t)pass0 * PC;
-    double* out = W.out + (size_t)pass0 * P.outsz;
-    hipLaunchKernelGGL(kstar_kernel, dim3(W.nblk_k, PC, g), dim3(256), 0, st, gp->X, gp->x2, gp->alpha, xs, xs2,
-                       W.kr, W.mu_part, gp->n, np, dp, gp->var, -0.5 * inv_ls2, gp->bias);
-    TriArgs T;
-    T.WT = gp->WT;
-    T.kr = W.kr;
-    T.vin = nullptr;
-    T.part = W.part;
-    T.lda = gp->lda;
-    T.n = gp->n;
-    T.np = np;
-    T.nb = nb;
-    T.nkc = W.nkc;
-    T.npass = (int)g;
-    T.bias = gp->bias;
-    hipLaunchKernelGGL((tri_apply_kernel<true>), dim3(nb8 * g, W.nkc), dim3(256), lds_t, st, T);
+    const double* xs = W.xs + (size_t)pass0 * PC * dp;  // device copy (filled by the upload or by kstar_kernel)
+    const double* xs_src = P.direct ? P.hx : xs;
+    const double* xs2 = P.direct ? P.hx + (size_t)PC * dp : W.xs2 + (size_t)pass0 * PC;
+    double* out = P.direct ? P.hout : W.out + (size_t)pass0 * P.outsz;
+    hipLaunchKernelGGL(kstar_kernel, dim3(W.nblk_k, PC, g), dim3(256), 0, st, gp->X, gp->x2, gp->alpha, xs_src, xs2,
+                       W.kr, W.kb, W.mu_part, gp->n, np, dp, gp->var, -0.5 * inv_ls2, gp->bias,
+                       P.direct ? W.xs : (double*)nullptr);
+    launch_tri(gp, W, false, W.kb, g);
     hipLaunchKernelGGL(tri_reduce_kernel, dim3(rblocks, g), dim3(256), 0, st, W.part, W.v, W.var_part, np, W.nkc, 0,
                        1);
     if (mode == 1) {
-      T.vin = W.v;
-      hipLaunchKernelGGL((tri_apply_kernel<false>), dim3(nb8 * g, W.nkc), dim3(256), lds_n, st, T);
-      hipLaunchKernelGGL(tri_reduce_kernel, dim3(rblocks, g), dim3(256), 0, st, W.part, W.u, (double*)nullptr, np,
-                         W.nkc, 1, 0);
-      hipLaunchKernelGGL(grad_kernel, dim3(W.ngc, PC, g), dim3(256), 0, st, gp->X, gp->alpha, xs, W.kr, W.u,
-                         W.g_part, gp->n, np, dp, 256);
+      launch_tri(gp, W, true, W.v, g);
+      hipLaunchKernelGGL(grad_kernel, dim3(W.ngc, g), dim3(256), 0, st, gp->X, gp->alpha, xs, W.kr, W.part, W.nkc,
+                         W.g_part, gp->n, np, dp);
     }
     hipLaunchKernelGGL(finish_kernel, dim3(g), dim3(256), 0, st, W.mu_part, W.nblk_k, W.var_part, rblocks, W.g_part,
-                       W.ngc, out, dp, s_left, gp->var + gp->bias, noiseless ? 0.0 : gp->noise, inv_ls2, beta, mode);
+                       W.ngc, out, dp, s_left, gp->var + gp->bias, noiseless ? 0.0 : gp->noise, inv_ls2, beta, mode,
+                       P.direct ? P.flag : (unsigned long long*)nullptr, (unsigned long long)(gp->done_seq + 1));
   }
-  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(P.hout, W.out, P.n_out * sizeof(double), hipMemcpyDeviceToHost, st));
+  if (P.direct)
+    ++gp->done_seq;
+  else
+    ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(P.hout, W.out, P.n_out * sizeof(double), hipMemcpyDeviceToHost, st));
+  return ELFIHIP_OK;
+}
+
+// Completion of an enqueued call.  Single-pass calls poll the flag in pinned memory (a few hundred ns after the
+// last kernel's store, against the ~10 us wake-up of a stream wait); if it does not arrive within the budget the
+// stream wait takes over and reports whatever went wrong.
+int predict_wait(elfihip_gp* gp, const PredictPlan& P) {
+  elfihip_ctx* ctx = gp->ctx;
+  if (P.direct) {
+    const unsigned long long want = gp->done_seq;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spin = 0;; ++spin) {
+      if (__atomic_load_n(P.flag, __ATOMIC_ACQUIRE) == want) return ELFIHIP_OK;
+      if ((spin & 1023u) == 1023u &&
+          std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200))
+        break;
+    }
+  }
+  ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return ELFIHIP_OK;
 }
 
@@ -519,7 +606,7 @@ int predict_impl(elfihip_gp* gp, const double* Xs, int64_t S, int mode, int nois
   predict_fill(gp, P, Xs, S);
   ELFIHIP_TRY(predict_enqueue(gp, P, S, mode, noiseless, beta));
   ELFIHIP_TRY(launch_status(ctx, "predict kernels"));
-  ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ELFIHIP_TRY(predict_wait(gp, P));
   predict_read(gp, P, S, mu, var, dmu, dvar, val, grad);
   return ELFIHIP_OK;
 }
@@ -559,7 +646,7 @@ __global__ __launch_bounds__(256) void extend_scalars_kernel(const double* v, co
 }
 
 __global__ __launch_bounds__(256) void extend_write_kernel(const double* v, const double* u, const double* red,
-                                                           double* A, double* WT, double* alpha, int64_t lda,
+                                                           double* A, double* WT, double* WL, double* alpha, int64_t lda,
                                                            int64_t n, int64_t np) {
   const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const double d = red[8], zn = red[9];
@@ -567,10 +654,12 @@ __global__ __launch_bounds__(256) void extend_write_kernel(const double* v, cons
     A[n * lda + j] = v[j * PC];              // new row of L
     const double w = -u[j * PC] / d;         // new column of L^-T
     WT[j * lda + n] = w;
+    WL[n * lda + j] = w;                     // ... and its mirror image, row n of L^-1
     alpha[j] += w * zn;
   } else if (j == n) {
     A[n * lda + n] = d;
     WT[n * lda + n] = 1.0 / d;
+    WL[n * lda + n] = 1.0 / d;
     alpha[n] = zn / d;
     A[np * lda + n] = zn;                    // z = L^-1 y lives in row np of A
   }
@@ -583,7 +672,6 @@ static int extend_one(elfihip_gp* gp, const double* x, double ynew) {
   ELFIHIP_TRY(ensure_ws(gp, &W, 1));
   const int dp = gp->dp, d = gp->d;
   const int64_t np = gp->np, n = gp->n;
-  const int nb = (int)(np / NB);
   const double inv_ls2 = 1.0 / (gp->ls * gp->ls);
   static thread_local std::vector<double> hx;
   hx.assign((size_t)PC * dp + PC, 0.0);
@@ -600,33 +688,19 @@ static int extend_one(elfihip_gp* gp, const double* x, double ynew) {
   ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(gp->x2 + n, hx.data() + (size_t)PC * dp, sizeof(double), hipMemcpyHostToDevice, st));
   hx[(size_t)PC * dp + 1] = ynew;
   ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(gp->y + n, hx.data() + (size_t)PC * dp + 1, sizeof(double), hipMemcpyHostToDevice, st));
+  ELFIHIP_TRY(ensure_wl(gp));
   hipLaunchKernelGGL(kstar_kernel, dim3(W.nblk_k, PC), dim3(256), 0, st, gp->X, gp->x2, gp->alpha, W.xs, W.xs2, W.kr,
-                     W.mu_part, n, np, dp, gp->var, -0.5 * inv_ls2, gp->bias);
-  TriArgs T;
-  T.WT = gp->WT;
-  T.kr = W.kr;
-  T.vin = nullptr;
-  T.part = W.part;
-  T.lda = gp->lda;
-  T.n = n;
-  T.np = np;
-  T.nb = nb;
-  T.nkc = W.nkc;
-  T.npass = 1;
-  T.bias = gp->bias;
-  const size_t lds_t = (SLAB * 144 + PC * 34) * sizeof(double);
-  const size_t lds_n = (128 * 34 + SLAB * PC) * sizeof(double);
+                     W.kb, W.mu_part, n, np, dp, gp->var, -0.5 * inv_ls2, gp->bias, (double*)nullptr);
   const int rblocks = (int)(np * PC / 256);
-  hipLaunchKernelGGL((tri_apply_kernel<true>), dim3((nb + 7) / 8 * 8, W.nkc), dim3(256), lds_t, st, T);
+  launch_tri(gp, W, false, W.kb, 1);
   hipLaunchKernelGGL(tri_reduce_kernel, dim3(rblocks), dim3(256), 0, st, W.part, W.v, W.var_part, np, W.nkc, 0, 1);
   const double* z = gp->A + np * gp->lda;
   hipLaunchKernelGGL(extend_scalars_kernel, dim3(1), dim3(256), 0, st, W.v, z, W.var_part, rblocks,
                      gp->var + gp->bias + gp->noise + GP_JITTER, ynew, n, gp->red, gp->info, (int)n + 1);
-  T.vin = W.v;
-  hipLaunchKernelGGL((tri_apply_kernel<false>), dim3((nb + 7) / 8 * 8, W.nkc), dim3(256), lds_n, st, T);
+  launch_tri(gp, W, true, W.v, 1);
   hipLaunchKernelGGL(tri_reduce_kernel, dim3(rblocks), dim3(256), 0, st, W.part, W.u, (double*)nullptr, np, W.nkc, 1, 0);
   hipLaunchKernelGGL(extend_write_kernel, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, st, W.v, W.u, gp->red,
-                     gp->A, gp->WT, gp->alpha, gp->lda, n, np);
+                     gp->A, gp->WT, gp->WL, gp->alpha, gp->lda, n, np);
   ELFIHIP_TRY(launch_status(ctx, "extend kernels"));
   double sc[2];
   int info = 0;
