@@ -57,7 +57,8 @@ struct PredictPlan {
   size_t n_in = 0, n_out = 0, outsz = 0;  // doubles
   double* hx = nullptr;                   // pinned: query points + their squared norms
   double* hout = nullptr;                 // pinned: results
-  unsigned long long* flag = nullptr;     // pinned: completion flag (single-pass calls)
+  unsigned long long* flag = nullptr;     // pinned: completion flags, one per query column (single-pass calls)
+  int n_flags = 0;                        // columns in use
   bool direct = false;                    // kernels read hx / write hout themselves, no copies
 };
 int predict_prepare(elfihip_gp* gp, int64_t S, PredictPlan* P);

@@ -36,11 +36,20 @@ constexpr int RB = 32;    // output rows per workgroup of the triangular product
 constexpr int MAX_GROUP = 8;  // 16-point passes handled by one set of launches
 
 
+// Query points of a single-pass call travel in the kernel arguments (the argument block is written by the host and
+// read from device memory): [point][dimension, padded to 16] and the squared norms.
+struct QueryArgs {
+  double x[PC][16];
+  double x2[PC];
+};
+constexpr int QUERY_ARGS_MAX_DP = 16;
+
 // ---- kr[s][i], partial mu ----------------------------------------------------------
 __global__ __launch_bounds__(256) void kstar_kernel(const double* X, const double* x2, const double* alpha,
                                                     const double* xs, const double* xs2, double* kr, double* kb,
                                                     double* mu_part, int64_t n, int64_t np, int dp, double var,
-                                                    double neg_half_inv_ls2, double bias, double* xs_copy) {
+                                                    double neg_half_inv_ls2, double bias, double* xs_copy,
+                                                    int from_args, QueryArgs q) {
   __shared__ double red[256];
   __shared__ double sx[256 + 1];  // this workgroup's query point and its squared norm
   const int s = blockIdx.y;
@@ -50,14 +59,24 @@ __global__ __launch_bounds__(256) void kstar_kernel(const double* X, const doubl
   kr += (int64_t)blockIdx.z * PC * np;
   kb += (int64_t)blockIdx.z * PC * np;
   mu_part += (int64_t)blockIdx.z * PC * gridDim.x;
-  // xs may be pinned host memory (single-pass calls skip the upload): one parallel read, not dp serial ones;
-  // workgroup column 0 leaves a device copy of its point for the gradient kernel
-  if ((int)threadIdx.x < dp) {
-    const double x = xs[s * dp + threadIdx.x];
-    sx[threadIdx.x] = x;
-    if (xs_copy && blockIdx.x == 0) xs_copy[s * dp + threadIdx.x] = x;
+  if (from_args) {
+    // single-pass call: the point comes with the arguments (uniform index: two wide scalar loads); workgroup
+    // column 0 leaves a device copy of it for the gradient kernel
+    double row[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) row[c] = q.x[s][c];
+    if (threadIdx.x < 16) {
+      double x = 0.0;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) x = (int)threadIdx.x == c ? row[c] : x;
+      sx[threadIdx.x] = x;
+      if (blockIdx.x == 0 && (int)threadIdx.x < dp) xs_copy[s * dp + threadIdx.x] = x;
+    }
+    if (threadIdx.x == 0) sx[256] = q.x2[s];
+  } else {
+    if ((int)threadIdx.x < dp) sx[threadIdx.x] = xs[s * dp + threadIdx.x];
+    if (threadIdx.x == 0) sx[256] = xs2[s];
   }
-  if (threadIdx.x == 0) sx[256] = xs2[s];
   __syncthreads();
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   double contrib = 0.0;
@@ -168,16 +187,22 @@ __global__ __launch_bounds__(256) void tri_apply_kernel(TriArgs T) {
   }
 }
 
-// Sum of the chunk partials of element e = i * 16 + s, chunks [lo, hi), in the one fixed order every consumer uses.
+// Sum of the chunk partials of element e = i * 16 + s over chunks [lo, hi), in the one fixed order every consumer
+// uses: chunk kc goes to accumulator kc & 3 in increasing kc, then (a0 + a1) + (a2 + a3).  Sixteen loads are issued
+// together (chunks outside the range contribute an exact 0.0), so the sum costs one memory round trip per 16 chunks.
 __device__ inline double sum_partials(const double* __restrict__ part, int64_t np, int64_t e, int lo, int hi) {
-  double v4[4] = {0, 0, 0, 0};
-  int kc = lo;
-  for (; kc + 4 <= hi; kc += 4) {
+  double acc[4] = {0, 0, 0, 0};
+  for (int base = lo & ~3; base < hi; base += 16) {
+    double v[16];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) v4[u] += part[(int64_t)(kc + u) * np * PC + e];
+    for (int u = 0; u < 16; ++u) {
+      const int kc = base + u;
+      v[u] = (kc >= lo && kc < hi) ? part[(int64_t)kc * np * PC + e] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc[u & 3] += v[u];
   }
-  for (; kc < hi; ++kc) v4[0] += part[(int64_t)kc * np * PC + e];
-  return (v4[0] + v4[1]) + (v4[2] + v4[3]);
+  return (acc[0] + acc[1]) + (acc[2] + acc[3]);
 }
 
 // v[i][s] = sum_kc part[kc][i][s] (fixed order); optional per-block partials of sum_i v^2.
@@ -276,97 +301,104 @@ __global__ __launch_bounds__(256) void grad_kernel(const double* __restrict__ X,
 
 // ---- final assembly: mu, var, dmu, dvar, LCB value and gradient ---------------------------
 // out layout per pass: mu[16] var[16] val[16] dmu[16*dp] dvar[16*dp] grad[16*dp]
+// One workgroup per query point (blockIdx.x = column s, blockIdx.y = pass): every sum below is a fixed-order
+// reduction of that column's partials.  S_left = real points from the first pass of this launch on.
+__device__ inline double block_sum_256(double* red, double v) {  // fixed tree; every thread gets the total
+  const int t = threadIdx.x;
+  __syncthreads();
+  red[t] = v;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (t < off) red[t] += red[t + off];
+    __syncthreads();
+  }
+  return red[0];
+}
+
 __global__ __launch_bounds__(256) void finish_kernel(const double* mu_part, int nblk_k, const double* var_part,
                                                      int nblk_v, const double* g_part, int ngc, double* out, int dp,
                                                      int S_left, double prior_var, double noise_add, double inv_ls2,
-                                                     double beta, int with_grad, unsigned long long* done_flag,
-                                                     unsigned long long done_value) {
-  // one workgroup per pass (blockIdx.x); S_left = real points from the first pass of this launch on
-  mu_part += (int64_t)blockIdx.x * PC * nblk_k;
-  var_part += (int64_t)blockIdx.x * nblk_v * PC;
-  g_part += (int64_t)blockIdx.x * PC * ngc * 2 * dp;
-  out += (int64_t)blockIdx.x * (3 * PC + 3 * PC * dp);
-  const int S = S_left - (int)blockIdx.x * PC;   // columns >= S are padding
-  // 16 groups of 16 lanes: lane (s, j) sums the partial blocks b = j, j+16, ... of column s;
-  // the 16 group sums are then added in a fixed order.
-  __shared__ double red_m[16][PC], red_q[16][PC];
-  const int s = threadIdx.x & 15, j = threadIdx.x >> 4;
-  double m = 0.0, q = 0.0;
-  for (int b = j; b < nblk_k; b += 16) m += mu_part[s * nblk_k + b];
-  {
-    double q4[4] = {0, 0, 0, 0};  // independent accumulators: the loads pipeline
-    int b = j;
-    for (; b + 48 < nblk_v; b += 64) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u) q4[u] += var_part[(int64_t)(b + 16 * u) * PC + s];
-    }
-    for (; b < nblk_v; b += 16) q4[0] += var_part[(int64_t)b * PC + s];
-    q = (q4[0] + q4[1]) + (q4[2] + q4[3]);
-  }
-  red_m[j][s] = m;
-  red_q[j][s] = q;
-  __syncthreads();
+                                                     double beta, int with_grad, double* host_out,
+                                                     unsigned long long* done_flags, unsigned long long done_value) {
+  __shared__ double red[256];
+  __shared__ double gs[8][32];
+  __shared__ double gtot[2 * 256];
+  const int t = threadIdx.x, s = blockIdx.x;
+  mu_part += (int64_t)blockIdx.y * PC * nblk_k;
+  var_part += (int64_t)blockIdx.y * nblk_v * PC;
+  g_part += (int64_t)blockIdx.y * PC * ngc * 2 * dp;
+  out += (int64_t)blockIdx.y * (3 * PC + 3 * PC * dp);
+  const int S = S_left - (int)blockIdx.y * PC;  // columns >= S are padding
   double* mu = out;
   double* var = out + PC;
   double* val = out + 2 * PC;
   double* dmu = out + 3 * PC;
   double* dvar = dmu + PC * dp;
   double* grad = dvar + PC * dp;
-  __shared__ double vfin[PC];
-  if (j == 0) {
-    if (s >= S) {
+  if (s >= S) {
+    if (t == 0) {
       mu[s] = 0;
       var[s] = 0;
       val[s] = 0;
-      vfin[s] = 1.0;
-    } else {
-      m = 0.0;
-      q = 0.0;
-      for (int g = 0; g < 16; ++g) {
-        m += red_m[g][s];
-        q += red_q[g][s];
-      }
-      double v = prior_var - q;
-      v = v > 1e-15 ? v : 1e-15;  // [GPy-upstream] predict clips the variance at 1e-15
-      mu[s] = m;
-      var[s] = v + noise_add;
-      val[s] = m - sqrt(beta * v);
-      vfin[s] = v;
     }
+    return;
   }
-  __syncthreads();
-  if (with_grad && s < S) {
-    // lane (s, j) assembles dimensions a = j, j + 16, ...: chunk partials in fixed order, four
-    // independent accumulators so the loads pipeline
-    const double sc = sqrt(beta / vfin[s]);
-    for (int a = j; a < dp; a += 16) {
-      const double* gp1 = g_part + (int64_t)s * ngc * 2 * dp + a;
-      double g1[4] = {0, 0, 0, 0}, g2[4] = {0, 0, 0, 0};
-      int c = 0;
-      for (; c + 4 <= ngc; c += 4) {
+  double m = 0.0, q = 0.0;
+  for (int b = t; b < nblk_k; b += 256) m += mu_part[s * nblk_k + b];
+  for (int b = t; b < nblk_v; b += 256) q += var_part[(int64_t)b * PC + s];
+  m = block_sum_256(red, m);
+  q = block_sum_256(red, q);
+  double v = prior_var - q;
+  v = v > 1e-15 ? v : 1e-15;  // [GPy-upstream] predict clips the variance at 1e-15
+  if (t == 0) {
+    mu[s] = m;
+    var[s] = v + noise_add;
+    val[s] = m - sqrt(beta * v);
+  }
+  if (with_grad) {
+    // 32 values of the 2 dp gradient sums at a time: thread (value t & 31, slice t >> 5) adds chunks slice, slice + 8,
+    // ... in order, then the eight slices are added in order
+    const double* gp1 = g_part + (int64_t)s * ngc * 2 * dp;
+    for (int a0 = 0; a0 < 2 * dp; a0 += 32) {
+      const int idx = a0 + (t & 31), cs = t >> 5;
+      double acc = 0.0;
+      if (idx < 2 * dp)
+        for (int c = cs; c < ngc; c += 8) acc += gp1[(int64_t)c * 2 * dp + idx];
+      __syncthreads();
+      gs[cs][t & 31] = acc;
+      __syncthreads();
+      if (t < 32 && idx < 2 * dp) {
+        double tot = 0.0;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          g1[u] += gp1[(int64_t)(c + u) * 2 * dp];
-          g2[u] += gp1[(int64_t)(c + u) * 2 * dp + dp];
-        }
+        for (int k = 0; k < 8; ++k) tot += gs[k][t];
+        gtot[idx] = tot;
       }
-      for (; c < ngc; ++c) {
-        g1[0] += gp1[(int64_t)c * 2 * dp];
-        g2[0] += gp1[(int64_t)c * 2 * dp + dp];
-      }
-      const double s1 = (g1[0] + g1[1]) + (g1[2] + g1[3]), s2 = (g2[0] + g2[1]) + (g2[2] + g2[3]);
-      const double dm = -inv_ls2 * s1;
-      const double dv = 2.0 * inv_ls2 * s2;  // -2 * sum u_i dk_i, dk_i = -(k/l^2)(x - X_i)
+    }
+    __syncthreads();
+    const double sc = sqrt(beta / v);
+    for (int a = t; a < dp; a += 256) {
+      const double dm = -inv_ls2 * gtot[a];
+      const double dv = 2.0 * inv_ls2 * gtot[dp + a];  // -2 * sum u_i dk_i, dk_i = -(k/l^2)(x - X_i)
       dmu[s * dp + a] = dm;
       dvar[s * dp + a] = dv;
       grad[s * dp + a] = dm - 0.5 * dv * sc;
     }
   }
-  if (done_flag) {
-    // `out` is pinned host memory here: make the results visible to the host, then raise the flag it polls
-    __threadfence_system();
+  if (host_out) {
+    // single-pass call: one wave copies this column's results to pinned host memory, makes them visible to the
+    // host and raises the column's flag (the host polls the flags of the columns it asked for)
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(done_flag, done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (t < 64) {
+      if (t < 3) host_out[t * PC + s] = out[t * PC + s];
+      if (with_grad)
+        for (int e = t; e < 3 * dp; e += 64) {
+          const int which = e / dp, a = e - which * dp;
+          const int o = 3 * PC + which * PC * dp + s * dp + a;
+          host_out[o] = out[o];
+        }
+      __threadfence_system();
+      if (t == 0) __hip_atomic_store(done_flags + s, done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
 
@@ -478,9 +510,9 @@ int predict_prepare(elfihip_gp* gp, int64_t S, PredictPlan* P) {
   P->outsz = (size_t)3 * PC + 3 * PC * dp;
   P->n_in = (size_t)P->npass * PC * dp + (size_t)P->npass * PC;
   P->n_out = (size_t)P->npass * P->outsz;
-  // pinned, device-visible staging: [completion flag | query points | results].  Calls of one pass (S <= 16, every
-  // step of the acquisition search) skip both copies: the kernels read the points from and write the results to
-  // this buffer directly, and the host polls the flag the last kernel raises.
+  // pinned, device-visible staging: [completion flag | query points | results].  Calls of one pass (S <= 16 points
+  // of <= 16 dimensions: every step of the acquisition search) skip both copies: the points ride in the kernel
+  // arguments, the last kernel writes the results into this buffer and raises the flag the host polls.
   if (gp->h_cap < P->n_in + P->n_out + 16) {
     if (gp->h_stage) ELFIHIP_CHECK_HIP(ctx, hipHostFree(gp->h_stage));
     gp->h_stage = nullptr;
@@ -489,11 +521,12 @@ int predict_prepare(elfihip_gp* gp, int64_t S, PredictPlan* P) {
     ELFIHIP_CHECK_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&gp->h_stage), want * sizeof(double),
                                          hipHostMallocMapped | hipHostMallocCoherent));
     gp->h_cap = want;
-    *reinterpret_cast<unsigned long long*>(gp->h_stage) = 0;
+    for (int f = 0; f < PC; ++f) reinterpret_cast<unsigned long long*>(gp->h_stage)[f] = 0;
     gp->done_seq = 0;
   }
-  P->direct = P->npass == 1 && !zero_copy_disabled();
+  P->direct = P->npass == 1 && gp->dp <= QUERY_ARGS_MAX_DP && !zero_copy_disabled();
   P->flag = reinterpret_cast<unsigned long long*>(gp->h_stage);
+  P->n_flags = (int)(S < PC ? S : PC);
   P->hx = gp->h_stage + 16;
   P->hout = P->hx + P->n_in;
   return ELFIHIP_OK;
@@ -528,17 +561,23 @@ int predict_enqueue(elfihip_gp* gp, const PredictPlan& P, int64_t S_active, int 
   if (!P.direct) ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(W.xs, P.hx, P.n_in * sizeof(double), hipMemcpyHostToDevice, st));
   if (mode == 1) ELFIHIP_TRY(ensure_wl(gp));
   const int rblocks = (int)(np * PC / 256);
+  static thread_local QueryArgs qa;  // only filled (and read by the kernel) for single-pass calls
   for (int64_t pass0 = 0; pass0 < P.npass; pass0 += W.group) {
     const unsigned g = (unsigned)((P.npass - pass0) < W.group ? (P.npass - pass0) : W.group);
     int s_left = (int)(S_active - pass0 * PC);
     if (s_left < 0) s_left = 0;
     const double* xs = W.xs + (size_t)pass0 * PC * dp;  // device copy (filled by the upload or by kstar_kernel)
-    const double* xs_src = P.direct ? P.hx : xs;
-    const double* xs2 = P.direct ? P.hx + (size_t)PC * dp : W.xs2 + (size_t)pass0 * PC;
-    double* out = P.direct ? P.hout : W.out + (size_t)pass0 * P.outsz;
-    hipLaunchKernelGGL(kstar_kernel, dim3(W.nblk_k, PC, g), dim3(256), 0, st, gp->X, gp->x2, gp->alpha, xs_src, xs2,
-                       W.kr, W.kb, W.mu_part, gp->n, np, dp, gp->var, -0.5 * inv_ls2, gp->bias,
-                       P.direct ? W.xs : (double*)nullptr);
+    const double* xs2 = W.xs2 + (size_t)pass0 * PC;
+    double* out = W.out + (size_t)pass0 * P.outsz;
+    if (P.direct) {
+      for (int s = 0; s < PC; ++s) {
+        for (int c = 0; c < 16; ++c) qa.x[s][c] = c < dp ? P.hx[(size_t)s * dp + c] : 0.0;
+        qa.x2[s] = P.hx[(size_t)PC * dp + s];
+      }
+    }
+    hipLaunchKernelGGL(kstar_kernel, dim3(W.nblk_k, PC, g), dim3(256), 0, st, gp->X, gp->x2, gp->alpha, xs, xs2,
+                       W.kr, W.kb, W.mu_part, gp->n, np, dp, gp->var, -0.5 * inv_ls2, gp->bias, W.xs,
+                       P.direct ? 1 : 0, qa);
     launch_tri(gp, W, false, W.kb, g);
     hipLaunchKernelGGL(tri_reduce_kernel, dim3(rblocks, g), dim3(256), 0, st, W.part, W.v, W.var_part, np, W.nkc, 0,
                        1);
@@ -547,9 +586,9 @@ int predict_enqueue(elfihip_gp* gp, const PredictPlan& P, int64_t S_active, int 
       hipLaunchKernelGGL(grad_kernel, dim3(W.ngc, g), dim3(256), 0, st, gp->X, gp->alpha, xs, W.kr, W.part, W.nkc,
                          W.g_part, gp->n, np, dp);
     }
-    hipLaunchKernelGGL(finish_kernel, dim3(g), dim3(256), 0, st, W.mu_part, W.nblk_k, W.var_part, rblocks, W.g_part,
+    hipLaunchKernelGGL(finish_kernel, dim3(PC, g), dim3(256), 0, st, W.mu_part, W.nblk_k, W.var_part, rblocks, W.g_part,
                        W.ngc, out, dp, s_left, gp->var + gp->bias, noiseless ? 0.0 : gp->noise, inv_ls2, beta, mode,
-                       P.direct ? P.flag : (unsigned long long*)nullptr, (unsigned long long)(gp->done_seq + 1));
+                       P.direct ? P.hout : (double*)nullptr, P.flag, (unsigned long long)(gp->done_seq + 1));
   }
   if (P.direct)
     ++gp->done_seq;
@@ -566,8 +605,10 @@ int predict_wait(elfihip_gp* gp, const PredictPlan& P) {
   if (P.direct) {
     const unsigned long long want = gp->done_seq;
     const auto t0 = std::chrono::steady_clock::now();
+    int s = 0;  // columns 0 .. s-1 have reported
     for (unsigned spin = 0;; ++spin) {
-      if (__atomic_load_n(P.flag, __ATOMIC_ACQUIRE) == want) return ELFIHIP_OK;
+      while (s < P.n_flags && __atomic_load_n(P.flag + s, __ATOMIC_ACQUIRE) == want) ++s;
+      if (s == P.n_flags) return ELFIHIP_OK;
       if ((spin & 1023u) == 1023u &&
           std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200))
         break;
@@ -690,7 +731,7 @@ static int extend_one(elfihip_gp* gp, const double* x, double ynew) {
   ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(gp->y + n, hx.data() + (size_t)PC * dp + 1, sizeof(double), hipMemcpyHostToDevice, st));
   ELFIHIP_TRY(ensure_wl(gp));
   hipLaunchKernelGGL(kstar_kernel, dim3(W.nblk_k, PC), dim3(256), 0, st, gp->X, gp->x2, gp->alpha, W.xs, W.xs2, W.kr,
-                     W.kb, W.mu_part, n, np, dp, gp->var, -0.5 * inv_ls2, gp->bias, (double*)nullptr);
+                     W.kb, W.mu_part, n, np, dp, gp->var, -0.5 * inv_ls2, gp->bias, (double*)nullptr, 0, QueryArgs());
   const int rblocks = (int)(np * PC / 256);
   launch_tri(gp, W, false, W.kb, 1);
   hipLaunchKernelGGL(tri_reduce_kernel, dim3(rblocks), dim3(256), 0, st, W.part, W.v, W.var_part, np, W.nkc, 0, 1);
