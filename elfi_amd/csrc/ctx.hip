@@ -6,14 +6,13 @@
 namespace elfihip {
 thread_local std::string g_err;
 
-// Streams of the GP factorisation.  The CU mask has one bit per CU; on gfx950 the driver deals the
-// bits round-robin over the 8 XCDs (bit i -> XCD i % 8), so "i % 8 >= 8 - R" reserves R whole XCDs
-// (their CUs AND their L2) for the latency-critical chain.  Should a driver enumerate differently the
-// same mask still reserves R/8 of the CUs: a speed matter only.  ELFIHIP_RESERVED_XCDS overrides R
-// (0 = no partition).
+// Streams of the GP factorisation: `hi` (high priority) carries the critical chain, `bulk` the rest of the
+// trailing update.  A CU-mask partition of the two (hipExtStreamCreateWithCUMask, ELFIHIP_RESERVED_XCDS = R
+// reserves i % 8 >= 8 - R) is kept as an option but is OFF: on this stack a masked stream still runs on all
+// 256 CUs (scripts/native/cumask_probe.hip prints the XCC / CU ids the workgroups of each stream land on).
 int ctx_aux(elfihip_ctx* ctx) {
   if (ctx->hi_stream) return ELFIHIP_OK;
-  int reserved = 2;
+  int reserved = 0;
   if (const char* e = getenv("ELFIHIP_RESERVED_XCDS")) reserved = atoi(e);
   if (reserved < 0) reserved = 0;
   if (reserved > 4) reserved = 4;
