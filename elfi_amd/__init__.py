@@ -21,5 +21,7 @@ from .gp import GPHandle, HipGPRegression  # noqa: F401
 from .selection import merge_batch, smallest_k  # noqa: F401
 from .summaries import autocov, ma2_distance, ss_mean, ss_var  # noqa: F401
 from .lcb_acquisition import HipLCBSC  # noqa: F401
+from .posterior import HipBolfiPosterior, sample_posterior  # noqa: F401
+from . import chains  # noqa: F401
 
 __version__ = "0.1.0"

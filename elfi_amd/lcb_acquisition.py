@@ -55,6 +55,25 @@ def _allgather_starts(locs, vals, iters, n_starts, world, device):
     return full_l, full_v, full_i
 
 
+def draw_start_points(bounds, n, prior=None, random_state=None):
+    """Start points of a multi-start search, drawn as the reference's minimize() draws them
+    (elfi/methods/bo/utils.py:72-88) so that the random stream is consumed identically: uniform in the bounds
+    without a prior (one uniform() call per dimension), else prior.rvs clipped to the bounds."""
+    ndim = len(bounds)
+    if prior is None:
+        rs = random_state or np.random
+        pts = np.empty((n, ndim))
+        for i in range(ndim):
+            pts[:, i] = rs.uniform(*bounds[i], n)
+        return pts
+    pts = np.asarray(prior.rvs(n, random_state=random_state), dtype=float)
+    if pts.ndim == 1:
+        pts = pts[:, None]
+    lo = np.array([b[0] for b in bounds], dtype=float)
+    hi = np.array([b[1] for b in bounds], dtype=float)
+    return np.clip(pts, lo, hi)
+
+
 class HipLCBSC:
     """Lower Confidence Bound Selection Criterion (GP-LCB of Srinivas et al.), interface of
     elfi.methods.bo.acquisition.LCBSC."""
@@ -127,23 +146,8 @@ class HipLCBSC:
         grad_mean, grad_var = self.model.predictive_gradients(x)
         return grad_mean - 0.5 * grad_var * np.sqrt(self._beta(t) / var)
 
-    # -- start points exactly as minimize() draws them: utils.py:72-88
     def _start_points(self):
-        bounds = self.model.bounds
-        ndim = len(bounds)
-        n = self.n_inits
-        start_points = np.empty((n, ndim))
-        if self.prior is None:
-            random_state = self.random_state or np.random
-            for i in range(ndim):
-                start_points[:, i] = random_state.uniform(*bounds[i], n)
-        else:
-            start_points = self.prior.rvs(n, random_state=self.random_state)
-            if len(start_points.shape) == 1:
-                start_points = start_points[:, None]
-            for i in range(ndim):
-                start_points[:, i] = np.clip(start_points[:, i], *bounds[i])
-        return start_points
+        return draw_start_points(self.model.bounds, self.n_inits, self.prior, self.random_state)
 
     def minimize(self, t=None, start_points=None):
         """All starts in lock-step on the device; returns (xhat, value) like utils.minimize."""

@@ -229,7 +229,7 @@ def make_gm(elfi):
 def main(argv):
     os.makedirs(GOLDEN, exist_ok=True)
     elfi = ref_shim.install()
-    which = set(argv) or {'ma2', 'adaptive', 'metrics', 'gp', 'gm'}
+    which = set(argv) or {'ma2', 'adaptive', 'metrics', 'gp', 'gm', 'posterior'}
     if 'ma2' in which:
         make_ma2(elfi)
     if 'adaptive' in which:
@@ -245,6 +245,9 @@ def main(argv):
             print('gp fixtures: generator not present yet')
         else:
             make_golden_gp.main(elfi, GOLDEN)
+    if 'posterior' in which:
+        import make_golden_posterior
+        make_golden_posterior.main(elfi, GOLDEN)
 
 
 if __name__ == '__main__':

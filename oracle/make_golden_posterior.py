@@ -1,0 +1,88 @@
+"""TEST INFRASTRUCTURE ONLY -- posterior / MCMC fixtures produced by the REFERENCE'S OWN CODE.
+
+    python oracle/make_golden.py posterior   ->  tests/golden/mcmc_chains.npz, bolfi_posterior.npz
+
+* mcmc_chains: elfi.methods.mcmc.nuts / metropolis (mcmc.py:114-429), the real functions, on an analytic
+  bounded target (a correlated Gaussian with a quartic term, -inf outside a box), four chains each.
+* bolfi_posterior: the real elfi.methods.posteriors.BolfiPosterior (posteriors.py:20-212) over the real
+  GPyRegression class carrying the oracle's posterior quantities (the stand-in `_gp` of make_golden_gp.py),
+  with the real ModelPrior of a two-parameter ElfiModel with uniform priors: logpdf / gradient_logpdf at
+  points inside and outside the bounds, for a given threshold and for the threshold the reference finds
+  itself (minimum of the GP mean, posteriors.py:66-79).
+"""
+import os
+
+import numpy as np
+
+import gp_oracle as G
+from make_golden_gp import standin_gp
+
+LO, HI = np.array([-3., -2.]), np.array([3., 4.])
+A = np.array([[2.0, 0.6], [0.6, 1.0]])
+
+
+def mcmc_target(x):
+    x = np.asarray(x, float)
+    if np.any(x < LO) or np.any(x > HI):
+        return -np.inf
+    return float(-0.5 * x @ A @ x - 0.1 * x[0] ** 4)
+
+
+def mcmc_grad(x):
+    x = np.asarray(x, float)
+    if np.any(x < LO) or np.any(x > HI):
+        return np.zeros_like(x)
+    g = -A @ x
+    g[0] -= 0.4 * x[0] ** 3
+    return g
+
+
+def main(elfi, golden_dir):
+    from elfi.methods import mcmc
+    from elfi.methods.bo.gpy_regression import GPyRegression
+    from elfi.methods.posteriors import BolfiPosterior
+    from elfi.model.extensions import ModelPrior
+
+    inits = np.array([[0.5, 0.5], [-1., 2.], [2., -1.], [0., 3.5]])
+    seeds = np.array([11, 12, 13, 14])
+    sig = np.array([0.5, 0.7])
+    nuts = np.array([mcmc.nuts(300, inits[c], mcmc_target, mcmc_grad, n_adapt=150, seed=int(seeds[c]))
+                     for c in range(4)])
+    nuts_fixed = np.array([mcmc.nuts(120, inits[c], mcmc_target, mcmc_grad, n_adapt=40, seed=int(seeds[c]),
+                                     stepsize=0.3, max_depth=3, target_prob=0.7) for c in range(4)])
+    metro = np.array([mcmc.metropolis(500, inits[c], mcmc_target, sig, warmup=100, seed=int(seeds[c]))
+                      for c in range(4)])
+    np.savez_compressed(os.path.join(golden_dir, 'mcmc_chains.npz'), inits=inits, seeds=seeds, sigma=sig, nuts=nuts,
+                        nuts_fixed=nuts_fixed, metropolis=metro, lo=LO, hi=HI, A=A)
+    print('mcmc_chains: nuts', nuts.shape, 'metropolis', metro.shape)
+
+    out = {}
+    n, d, seed = 200, 2, 31
+    X, y, bounds = G.synthetic_gp_problem(n, d, seed=seed)
+    h = G.default_hyper(bounds, y)
+    post = G.Posterior(X, y, h['var'], h['ls'], h['bias'], h['noise'])
+    names = ['p0', 'p1']
+    ref = GPyRegression(names, bounds=dict(zip(names, bounds)))
+    ref._gp = standin_gp(post)
+    ref._kernel_is_default = True
+    m = elfi.new_model()
+    for nm, (a, b) in zip(names, bounds):
+        elfi.Prior('uniform', a, b - a, model=m, name=nm)
+    prior = ModelPrior(m, parameter_names=names)
+    rs = np.random.RandomState(5)
+    xs = rs.uniform(-2.4, 2.4, (24, d))          # a few rows fall outside the bounds [-2, 2]^2
+    xs[0] = X[int(np.argmin(y))]
+    thr = float(np.min(y) + 0.3)
+    bp = BolfiPosterior(ref, threshold=thr, prior=prior)
+    out.update(X=X, y=y, hyper=np.array([h['var'], h['ls'], h['bias'], h['noise']]), bounds=np.array(bounds), xs=xs,
+               threshold=np.float64(thr),
+               logpdf=np.array([bp.logpdf(x) for x in xs], dtype=float),
+               grad=np.array([bp.gradient_logpdf(x) for x in xs], dtype=float),
+               loglik=np.asarray(bp._unnormalized_loglikelihood(xs), dtype=float),
+               gradlik=np.asarray(bp._gradient_unnormalized_loglikelihood(xs), dtype=float),
+               prior_logpdf=np.asarray(prior.logpdf(xs), dtype=float))
+    bp2 = BolfiPosterior(ref, threshold=None, prior=prior, n_inits=10, seed=0)
+    out['threshold_auto'] = np.float64(bp2.threshold)
+    out['min_of_mean_over_evidence'] = np.float64(np.min(post.predict(X)[0]))
+    np.savez_compressed(os.path.join(golden_dir, 'bolfi_posterior.npz'), **out)
+    print('bolfi_posterior: %d points, threshold %.4f, auto threshold %.6f' % (len(xs), thr, bp2.threshold))

@@ -77,3 +77,23 @@ def test_oracle_multistart_reproduces_the_reference_acquire():
         # the recorded acquisition is that optimum plus truncated-normal jitter inside the bounds
         assert g['x_acq_' + tag].shape == (3, d)
         assert np.all(np.abs(g['x_acq_' + tag]) <= 2.0)
+
+
+def test_posterior_oracle_equals_the_reference_bolfi_posterior():
+    """oracle/posterior_oracle.py against the real BolfiPosterior + ModelPrior (bolfi_posterior.npz)."""
+    import posterior_oracle as PO
+    g = np.load(os.path.join(GOLDEN, 'bolfi_posterior.npz'))
+    post = G.Posterior(g['X'], g['y'], *g['hyper'])
+    bounds = [tuple(b) for b in g['bounds']]
+    po = PO.PosteriorOracle(post, bounds, float(g['threshold']))
+    xs = g['xs']
+    inside = np.all((xs >= -2) & (xs <= 2), axis=1)
+    assert 0 < inside.sum() < len(xs), 'the fixture has points on both sides of the bounds'
+    np.testing.assert_allclose(po.loglik(xs), g['loglik'], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(po.grad_loglik(xs), g['gradlik'], rtol=1e-8, atol=1e-10)
+    np.testing.assert_array_equal(po.prior.logpdf(xs), g['prior_logpdf'])
+    lp, gr = po.logpdf_and_gradient(xs)
+    np.testing.assert_allclose(lp, g['logpdf'], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(gr, g['grad'], rtol=1e-8, atol=1e-8)   # the reference's prior gradient is numerical
+    # the threshold the reference finds on its own is the minimum of the GP mean in the box
+    assert float(g['threshold_auto']) <= float(g['min_of_mean_over_evidence']) + 1e-9
