@@ -87,4 +87,63 @@ int elfihip_gp_lcb_minimize(elfihip_gp* gp, const double* starts, int64_t S, con
   return lcb_minimize_impl(gp, starts, S, lower, upper, beta, maxiter, x_out, f_out, iters_out, n_eval_out);
 }
 
+// ---- reverse-communication form for objectives assembled on the host (include/elfihip.h) ----------
+struct elfihip_lbfgsb {
+  int d = 0;
+  std::vector<elfihip::Lbfgsb> opt;
+  std::vector<int64_t> waiting;  // searches handed out by the last pending() call
+};
+
+int elfihip_lbfgsb_create(int d, int64_t S, const double* lower, const double* upper, const double* starts,
+                          int maxiter, elfihip_lbfgsb** out) {
+  if (!out) return ELFIHIP_ERR_ARG;
+  *out = nullptr;
+  if (d < 1 || S < 1 || !lower || !upper || !starts || maxiter < 0) return ELFIHIP_ERR_ARG;
+  for (int c = 0; c < d; ++c)
+    if (!(lower[c] <= upper[c])) return ELFIHIP_ERR_ARG;
+  elfihip_lbfgsb* h = new elfihip_lbfgsb();
+  h->d = d;
+  h->opt.resize((size_t)S);
+  for (int64_t i = 0; i < S; ++i) h->opt[(size_t)i].init(d, lower, upper, starts + i * d, maxiter);
+  *out = h;
+  return ELFIHIP_OK;
+}
+
+int64_t elfihip_lbfgsb_pending(elfihip_lbfgsb* h, int64_t* idx, double* x) {
+  if (!h || !idx || !x) return -1;
+  h->waiting.clear();
+  for (size_t i = 0; i < h->opt.size(); ++i)
+    if (!h->opt[i].done()) {
+      const int64_t k = (int64_t)h->waiting.size();
+      idx[k] = (int64_t)i;
+      std::copy(h->opt[i].x(), h->opt[i].x() + h->d, x + k * h->d);
+      h->waiting.push_back((int64_t)i);
+    }
+  return (int64_t)h->waiting.size();
+}
+
+int elfihip_lbfgsb_feed(elfihip_lbfgsb* h, int64_t n, const double* f, const double* g) {
+  if (!h || !f || !g || n != (int64_t)h->waiting.size()) return ELFIHIP_ERR_ARG;
+  for (int64_t k = 0; k < n; ++k) h->opt[(size_t)h->waiting[(size_t)k]].feed(f[k], g + k * h->d);
+  h->waiting.clear();
+  return ELFIHIP_OK;
+}
+
+int elfihip_lbfgsb_result(const elfihip_lbfgsb* h, double* x, double* f, int* iters, int* status) {
+  if (!h || !x) return ELFIHIP_ERR_ARG;
+  for (size_t i = 0; i < h->opt.size(); ++i) {
+    const elfihip::Lbfgsb& o = h->opt[i];
+    std::copy(o.best_x(), o.best_x() + h->d, x + i * h->d);
+    if (f) f[i] = o.best_f();
+    if (iters) iters[i] = o.iterations();
+    if (status) status[i] = static_cast<int>(o.status());
+  }
+  return ELFIHIP_OK;
+}
+
+int elfihip_lbfgsb_free(elfihip_lbfgsb* h) {
+  delete h;
+  return ELFIHIP_OK;
+}
+
 }  // extern "C"

@@ -227,13 +227,33 @@ int elfihip_gp_lcb(elfihip_gp* gp, const double* Xs, int64_t S, double beta, dou
  * minimize(), elfi/methods/bo/utils.py:40-111) for the LCBSC rule: minimise
  * a(x) = mu(x) - sqrt(beta var(x)) inside the box [lower, upper] from S start points (S, d).
  * The reference runs scipy L-BFGS-B from each start in turn, one GP prediction per evaluation;
- * here all starts advance in lock-step with ONE batched device evaluation per step
- * (bound-projected L-BFGS, memory 10, scipy's default tolerances; see csrc/gp_acq.hip).
+ * here all starts advance in lock-step with ONE batched device evaluation per step; each start
+ * is an L-BFGS-B state machine with scipy's defaults (csrc/lbfgsb.hpp, csrc/gp_acq.hip).
  * x_out (S,d) and f_out (S) receive every start's end point / value (the caller takes the
  * arg-min, utils.py:105-109); iters_out (S) and n_eval_out (total point evaluations) may be NULL. */
 int elfihip_gp_lcb_minimize(elfihip_gp* gp, const double* starts, int64_t S, const double* lower,
                             const double* upper, double beta, int maxiter, double* x_out, double* f_out,
                             int* iters_out, int64_t* n_eval_out);
+
+/* ---- the same multi-start search for objectives the HOST assembles -----------------------
+ * scipy.optimize.minimize(method='L-BFGS-B') as the reference calls it from minimize()
+ * (elfi/methods/bo/utils.py:97-103: jac given, bounds, maxiter, SciPy's default tolerances), turned
+ * inside out so that S searches share batched evaluations: the acquisition rules other than LCBSC
+ * (MaxVar.acquire, acquisition.py:349-384) combine device predictions with host-side formulas, so their
+ * objective cannot live inside the library.  Usage: create with the S start points; then repeat
+ *   n = pending(idx, x)        the searches that wait for an evaluation and where (n == 0: all done)
+ *   feed(n, f, g)              objective values (n) and gradients (n, d) at those points, same order
+ * and read every search's end point.  Pure host code (no device, no context). */
+typedef struct elfihip_lbfgsb elfihip_lbfgsb;
+int elfihip_lbfgsb_create(int d, int64_t S, const double* lower, const double* upper, const double* starts,
+                          int maxiter, elfihip_lbfgsb** out);
+/* idx (S) / x (S, d) receive the waiting searches' indices and points; returns their number, < 0 on error. */
+int64_t elfihip_lbfgsb_pending(elfihip_lbfgsb* h, int64_t* idx, double* x);
+int elfihip_lbfgsb_feed(elfihip_lbfgsb* h, int64_t n, const double* f, const double* g);
+/* x (S, d), f (S), iters (S), status (S: 1 projected gradient, 2 relative reduction, 3 maxiter, 4 abnormal);
+ * any of f / iters / status may be NULL. */
+int elfihip_lbfgsb_result(const elfihip_lbfgsb* h, double* x, double* f, int* iters, int* status);
+int elfihip_lbfgsb_free(elfihip_lbfgsb* h);
 
 #ifdef __cplusplus
 }

@@ -1,6 +1,6 @@
 """TEST INFRASTRUCTURE ONLY -- posterior / MCMC fixtures produced by the REFERENCE'S OWN CODE.
 
-    python oracle/make_golden.py posterior   ->  tests/golden/mcmc_chains.npz, bolfi_posterior.npz
+    python oracle/make_golden.py posterior   ->  tests/golden/mcmc_chains.npz, bolfi_posterior.npz, maxvar.npz
 
 * mcmc_chains: elfi.methods.mcmc.nuts / metropolis (mcmc.py:114-429), the real functions, on an analytic
   bounded target (a correlated Gaussian with a quartic term, -inf outside a box), four chains each.
@@ -9,6 +9,9 @@
   with the real ModelPrior of a two-parameter ElfiModel with uniform priors: logpdf / gradient_logpdf at
   points inside and outside the bounds, for a given threshold and for the threshold the reference finds
   itself (minimum of the GP mean, posteriors.py:66-79).
+* maxvar: the real MaxVar / RandMaxVar classes (acquisition.py:304-626) over the same stand-in GP and ModelPrior:
+  evaluate / evaluate_gradient at points, MaxVar.acquire (threshold, maximiser), RandMaxVar.acquire with both
+  samplers (n = 1: the chain's last point; n = 3: a permutation of the post-warmup samples).
 """
 import os
 
@@ -86,3 +89,35 @@ def main(elfi, golden_dir):
     out['min_of_mean_over_evidence'] = np.float64(np.min(post.predict(X)[0]))
     np.savez_compressed(os.path.join(golden_dir, 'bolfi_posterior.npz'), **out)
     print('bolfi_posterior: %d points, threshold %.4f, auto threshold %.6f' % (len(xs), thr, bp2.threshold))
+    make_maxvar(elfi, golden_dir)
+
+
+def make_maxvar(elfi, golden_dir):
+    from elfi.methods.bo.acquisition import MaxVar, RandMaxVar
+    from elfi.methods.bo.gpy_regression import GPyRegression
+    from elfi.model.extensions import ModelPrior
+
+    n, d, seed = 150, 2, 41
+    X, y, bounds = G.synthetic_gp_problem(n, d, seed=seed)
+    h = G.default_hyper(bounds, y)
+    post = G.Posterior(X, y, h['var'], h['ls'], h['bias'], h['noise'])
+    names = ['p0', 'p1']
+    ref = GPyRegression(names, bounds=dict(zip(names, bounds)))
+    ref._gp = standin_gp(post)
+    ref._kernel_is_default = True
+    m = elfi.new_model()
+    for nm, (a, b) in zip(names, bounds):
+        elfi.Prior('uniform', a, b - a, model=m, name=nm)
+    prior = ModelPrior(m, parameter_names=names)
+    out = dict(X=X, y=y, hyper=np.array([h['var'], h['ls'], h['bias'], h['noise']]), bounds=np.array(bounds))
+    mv = MaxVar(ref, prior, quantile_eps=0.05, n_inits=8, seed=7)
+    theta = mv.acquire(2)
+    xs = np.random.RandomState(3).uniform(-2, 2, (12, d))
+    out.update(eps=np.float64(mv.eps), theta_max=theta, xs=xs, value=mv.evaluate(xs), gradient=mv.evaluate_gradient(xs))
+    for sampler in ('nuts', 'metropolis'):
+        r1 = RandMaxVar(ref, prior, quantile_eps=0.05, sampler=sampler, n_samples=40, seed=9)
+        out['rand_%s_1' % sampler] = r1.acquire(1)
+        r3 = RandMaxVar(ref, prior, quantile_eps=0.05, sampler=sampler, n_samples=40, seed=9)
+        out['rand_%s_3' % sampler] = r3.acquire(3)
+    np.savez_compressed(os.path.join(golden_dir, 'maxvar.npz'), **out)
+    print('maxvar: eps %.4f theta_max %s' % (mv.eps, theta[0]))

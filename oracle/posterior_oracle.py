@@ -27,6 +27,9 @@ class BoxPrior:
         inside = np.all((x >= self.lo) & (x <= self.hi), axis=1)
         return np.where(inside, -np.sum(np.log(self.hi - self.lo)), -np.inf)
 
+    def pdf(self, x):
+        return np.exp(self.logpdf(x))
+
     def gradient_logpdf(self, x):
         return np.zeros_like(np.asarray(x, float).reshape((-1, len(self.lo))))
 
