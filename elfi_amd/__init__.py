@@ -23,6 +23,6 @@ from .summaries import autocov, ma2_distance, ss_mean, ss_var  # noqa: F401
 from .lcb_acquisition import HipLCBSC  # noqa: F401
 from .posterior import HipBolfiPosterior, sample_posterior  # noqa: F401
 from . import chains, multistart  # noqa: F401
-from .maxvar_acquisition import HipMaxVar, HipRandMaxVar  # noqa: F401
+from .maxvar_acquisition import HipExpIntVar, HipMaxVar, HipRandMaxVar  # noqa: F401
 
 __version__ = "0.1.0"

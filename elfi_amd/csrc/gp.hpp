@@ -32,6 +32,12 @@ struct elfihip_gp {
   double* alpha = nullptr;  // (cap) K^-1 y
   double* red = nullptr;    // small reduction scratch
   int* info = nullptr;      // device: 1-based index of the first non-positive pivot, 0 if none
+  // integration points of ExpIntVar (elfihip_gp_set_integration_points): V_P = L^-1 K(X, P) stored k-major
+  double* VP = nullptr;     // (np, m_pad)
+  double* Pint = nullptr;   // (m_pad, dp) the points, zero padded
+  int64_t n_int = 0, m_pad = 0;
+  unsigned long long fact_gen = 0, vp_gen = 0;  // factorisation counter / the one VP belongs to
+  elfihip::DevBuf ws2;      // partials and result tile of the dense product V_P^T v
   // prediction workspace (grown on demand)
   elfihip::DevBuf ws;
   int64_t ws_S = 0;

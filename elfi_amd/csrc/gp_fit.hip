@@ -691,6 +691,7 @@ int gp_factorize_impl(elfihip_gp* gp) {
   gp->factored = true;
   gp->has_kinv = false;
   gp->wl_valid = false;
+  ++gp->fact_gen;
   return ELFIHIP_OK;
 }
 
@@ -748,7 +749,10 @@ int elfihip_gp_free(elfihip_gp* gp) {
     if (p) (void)hipFree(p);
   if (gp->info) (void)hipFree(gp->info);
   if (gp->h_stage) (void)hipHostFree(gp->h_stage);
+  if (gp->VP) (void)hipFree(gp->VP);
+  if (gp->Pint) (void)hipFree(gp->Pint);
   gp->ws.release();
+  gp->ws2.release();
   delete gp;
   return ELFIHIP_OK;
 }

@@ -103,8 +103,9 @@ __global__ __launch_bounds__(256) void kstar_kernel(const double* X, const doubl
 }
 
 // ---- triangular skinny products on the matrix cores ------------------------------------
-// LOWER = false:  out[i][s] = sum_{k <= i} W[k][i] bin[k][s],  W = L^-T (gp->WT),  bin = kb     (v = L^-1 kb)
-// LOWER = true :  out[i][s] = sum_{k >= i} W[k][i] bin[k][s],  W = L^-1 (gp->WL),  bin = v      (u = L^-T v)
+// MODE 0 (upper):  out[i][s] = sum_{k <= i} W[k][i] bin[k][s],  W = L^-T (gp->WT),  bin = kb     (v = L^-1 kb)
+// MODE 1 (lower):  out[i][s] = sum_{k >= i} W[k][i] bin[k][s],  W = L^-1 (gp->WL),  bin = v      (u = L^-T v)
+// MODE 2 (dense):  out[i][s] = sum_k        W[k][i] bin[k][s],  W = V_P (gp->VP),   bin = v      (V_P^T v)
 // Workgroup (rb, kc): rows i in [32 rb, 32 rb + 32), k in chunk kc clipped to the triangle (a multiple
 // of 32 long).  Writes part[kc][i][s]; chunks outside the triangle are never read by the reduction.
 struct TriArgs {
@@ -112,11 +113,12 @@ struct TriArgs {
   const double* bin;   // [k][s], np x 16 per pass
   double* part;
   int64_t lda, np;
+  int64_t nout;  // rows of the output (np for the triangular products, the padded point count for the dense one)
   int nrb, nkc;
   int npass;   // 16-point passes in this launch (see the blockIdx mapping in the kernel)
 };
 
-template <bool LOWER>
+template <int MODE>
 __global__ __launch_bounds__(256) void tri_apply_kernel(TriArgs T) {
   // No LDS staging of the matrix: a lane's 16-byte load IS its MFMA operand.  Lane (kq = l >> 4, ip = l & 15)
   // of wave w loads W[k][i0 + 2 ip .. + 1] for k = k0 + 16 q + 4 w + kq, q = 0 .. len/16: one instruction covers
@@ -131,11 +133,13 @@ __global__ __launch_bounds__(256) void tri_apply_kernel(TriArgs T) {
   if (rb >= T.nrb) return;
   const int64_t i0 = (int64_t)rb * RB;
   int64_t k0 = (int64_t)kc * KC, k1 = k0 + KC;
-  if (LOWER) {
+  if (MODE == 1) {
     if (k0 < i0) k0 = i0;
     if (k1 > T.np) k1 = T.np;
-  } else {
+  } else if (MODE == 0) {
     if (k1 > i0 + RB) k1 = i0 + RB;
+  } else {
+    if (k1 > T.np) k1 = T.np;
   }
   if (k0 >= k1) return;  // chunk lies outside the triangle
   const int len = (int)(k1 - k0);
@@ -179,7 +183,7 @@ __global__ __launch_bounds__(256) void tri_apply_kernel(TriArgs T) {
     Bs[(w * RB + 2 * ip + 1) * PC + (l & 15)] = acc1[r];
   }
   __syncthreads();
-  double* out = T.part + (((int64_t)pass * T.nkc + kc) * T.np + i0) * PC;
+  double* out = T.part + (((int64_t)pass * T.nkc + kc) * T.nout + i0) * PC;
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const int e = t + 256 * h;  // (i local, s) = (e >> 4, e & 15)
@@ -218,8 +222,8 @@ __global__ __launch_bounds__(256) void tri_reduce_kernel(const double* part, dou
     const int64_t i = e / PC;
     const int ib = (int)(i / NB);
     // chunks inside the triangle: first product (kc_lo_is_row == 0): kc*KCH <= ib ; second: kc*KCH+KCH > ib
-    const int lo = kc_lo_is_row ? ib / KCH : 0;
-    const int hi = kc_lo_is_row ? nkc : ib / KCH + 1;
+    const int lo = kc_lo_is_row == 1 ? ib / KCH : 0;              // kc_lo_is_row == 2: dense product, every chunk
+    const int hi = kc_lo_is_row == 0 ? ib / KCH + 1 : nkc;
     v = sum_partials(part, np, e, lo, hi);
     out[e] = v;
   }
@@ -440,14 +444,15 @@ static void launch_tri(const elfihip_gp* gp, const PredictWs& W, bool lower, con
   T.part = W.part;
   T.lda = gp->lda;
   T.np = gp->np;
+  T.nout = gp->np;
   T.nrb = (int)(gp->np / RB);
   T.nkc = W.nkc;
   T.npass = (int)g;
   const dim3 grid((unsigned)((T.nrb + 7) / 8 * 8) * g, (unsigned)W.nkc);
   if (lower)
-    hipLaunchKernelGGL((tri_apply_kernel<true>), grid, dim3(256), 0, gp->ctx->stream, T);
+    hipLaunchKernelGGL((tri_apply_kernel<1>), grid, dim3(256), 0, gp->ctx->stream, T);
   else
-    hipLaunchKernelGGL((tri_apply_kernel<false>), grid, dim3(256), 0, gp->ctx->stream, T);
+    hipLaunchKernelGGL((tri_apply_kernel<0>), grid, dim3(256), 0, gp->ctx->stream, T);
 }
 
 static int ensure_ws(elfihip_gp* gp, PredictWs* W, int64_t npass) {
@@ -756,6 +761,151 @@ static int extend_one(elfihip_gp* gp, const double* x, double ynew) {
   gp->yKy += sc[1] * sc[1];
   gp->n = n + 1;
   gp->has_kinv = false;
+  ++gp->fact_gen;
+  return ELFIHIP_OK;
+}
+
+// ---- posterior covariance between a fixed point set and query points (ExpIntVar) ---------------------
+// cov(p_i, q_s) = k(p_i, q_s) - k(p_i, X) K^-1 k(X, q_s) = k(p_i, q_s) - V_P[:, i] . v_s,   V = L^-1 k(X, .)
+// (what ExpIntVar.evaluate builds with cho_solve per call, elfi/methods/bo/acquisition.py:800-808).  V_P is made
+// once per point set by the batched first triangular product and kept k-major, so the per-query part is the
+// same streaming kernel as the predictor's products in its dense mode.
+__global__ __launch_bounds__(256) void scatter_v_kernel(const double* v, double* VP, int64_t ldvp, int64_t np,
+                                                        int64_t col0) {
+  // VP[k][col0 + 16 pass + s] = v[pass][k][s]
+  v += (int64_t)blockIdx.y * np * PC;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e < np * PC) VP[(e / PC) * ldvp + col0 + (int64_t)blockIdx.y * PC + (e % PC)] = v[e];
+}
+
+__global__ __launch_bounds__(256) void cross_finish_kernel(const double* Pint, const double* xs, const double* dot,
+                                                           double* cov, int64_t M, int64_t m_pad, int dp, int64_t S,
+                                                           int64_t s0, double var, double neg_half_inv_ls2,
+                                                           double bias) {
+  // one thread per (point i, query column s) of pass blockIdx.y: cov[i][s0 + 16 pass + s]
+  xs += (int64_t)blockIdx.y * PC * dp;
+  dot += (int64_t)blockIdx.y * m_pad * PC;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t i = e / PC;
+  const int sq = (int)(e % PC);
+  const int64_t col = s0 + (int64_t)blockIdx.y * PC + sq;
+  if (i >= M || col >= S) return;
+  double r2 = 0.0;
+  for (int c = 0; c < dp; ++c) {
+    const double t = Pint[i * dp + c] - xs[sq * dp + c];
+    r2 += t * t;
+  }
+  cov[i * S + col] = (var * exp(r2 * neg_half_inv_ls2) + bias) - dot[i * PC + sq];
+}
+
+// first triangular product for `g` passes whose points are already in W.xs / W.xs2: W.v, W.var_part, W.mu_part
+static void enqueue_v(elfihip_gp* gp, const PredictWs& W, int64_t pass0, unsigned g) {
+  hipStream_t st = gp->ctx->stream;
+  const int dp = gp->dp;
+  const int64_t np = gp->np;
+  const double inv_ls2 = 1.0 / (gp->ls * gp->ls);
+  hipLaunchKernelGGL(kstar_kernel, dim3(W.nblk_k, PC, g), dim3(256), 0, st, gp->X, gp->x2, gp->alpha,
+                     W.xs + (size_t)pass0 * PC * dp, W.xs2 + (size_t)pass0 * PC, W.kr, W.kb, W.mu_part, gp->n, np, dp,
+                     gp->var, -0.5 * inv_ls2, gp->bias, (double*)nullptr, 0, QueryArgs());
+  launch_tri(gp, W, false, W.kb, g);
+  hipLaunchKernelGGL(tri_reduce_kernel, dim3((unsigned)(np * PC / 256), g), dim3(256), 0, st, W.part, W.v, W.var_part,
+                     np, W.nkc, 0, 1);
+}
+
+static int upload_points(elfihip_gp* gp, const double* Xs, int64_t S, PredictPlan* P) {
+  ELFIHIP_TRY(predict_prepare(gp, S, P));
+  P->direct = false;
+  predict_fill(gp, *P, Xs, S);
+  ELFIHIP_CHECK_HIP(gp->ctx, hipMemcpyAsync(P->ws.xs, P->hx, P->n_in * sizeof(double), hipMemcpyHostToDevice,
+                                            gp->ctx->stream));
+  return ELFIHIP_OK;
+}
+
+static int set_integration_points_impl(elfihip_gp* gp, const double* Pts, int64_t M) {
+  elfihip_ctx* ctx = gp->ctx;
+  hipStream_t st = ctx->stream;
+  ELFIHIP_REQUIRE(ctx, M >= 1 && Pts, "bad arguments");
+  const int64_t np = gp->np, m_pad = round_up(M, RB);
+  const int dp = gp->dp;
+  if (gp->VP) ELFIHIP_CHECK_HIP(ctx, hipFree(gp->VP));
+  if (gp->Pint) ELFIHIP_CHECK_HIP(ctx, hipFree(gp->Pint));
+  gp->VP = gp->Pint = nullptr;
+  gp->n_int = 0;
+  ELFIHIP_CHECK_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&gp->VP), (size_t)np * m_pad * sizeof(double)));
+  ELFIHIP_CHECK_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&gp->Pint), (size_t)m_pad * dp * sizeof(double)));
+  ELFIHIP_CHECK_HIP(ctx, hipMemsetAsync(gp->VP, 0, (size_t)np * m_pad * sizeof(double), st));
+  ELFIHIP_CHECK_HIP(ctx, hipMemsetAsync(gp->Pint, 0, (size_t)m_pad * dp * sizeof(double), st));
+  PredictPlan P;
+  ELFIHIP_TRY(upload_points(gp, Pts, M, &P));
+  // the padded points are exactly the rows the upload staged ([pass][16][dp], zero padded)
+  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(gp->Pint, P.ws.xs, (size_t)M * dp * sizeof(double), hipMemcpyDeviceToDevice, st));
+  const PredictWs& W = P.ws;
+  for (int64_t pass0 = 0; pass0 < P.npass; pass0 += W.group) {
+    const unsigned g = (unsigned)((P.npass - pass0) < W.group ? (P.npass - pass0) : W.group);
+    enqueue_v(gp, W, pass0, g);
+    // columns beyond m_pad (the last pass of a point count that is not a multiple of 32 rounds up to 16) stay inside
+    // the allocation: m_pad is a multiple of 32 >= 16 * npass
+    hipLaunchKernelGGL(scatter_v_kernel, dim3((unsigned)(np * PC / 256), g), dim3(256), 0, st, W.v, gp->VP, m_pad, np,
+                       pass0 * PC);
+  }
+  ELFIHIP_TRY(launch_status(ctx, "integration points"));
+  ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(st));
+  gp->n_int = M;
+  gp->m_pad = m_pad;
+  gp->vp_gen = gp->fact_gen;
+  return ELFIHIP_OK;
+}
+
+static int cross_cov_impl(elfihip_gp* gp, const double* Q, int64_t S, double* cov, double* var_q) {
+  elfihip_ctx* ctx = gp->ctx;
+  hipStream_t st = ctx->stream;
+  ELFIHIP_REQUIRE(ctx, S >= 1 && Q && cov, "bad arguments");
+  if (!(gp->n_int > 0 && gp->vp_gen == gp->fact_gen))
+    return fail(ctx, ELFIHIP_ERR_STATE,
+                "no integration points for the current factorisation (call elfihip_gp_set_integration_points)");
+  const int64_t np = gp->np, M = gp->n_int, m_pad = gp->m_pad;
+  const int dp = gp->dp;
+  PredictPlan P;
+  ELFIHIP_TRY(upload_points(gp, Q, S, &P));
+  const PredictWs& W = P.ws;
+  // scratch of the dense product: partials [g][nkc][m_pad][16], result [g][m_pad][16], covariance (M, S)
+  const size_t n_part = (size_t)W.group * W.nkc * m_pad * PC, n_dot = (size_t)W.group * m_pad * PC;
+  ELFIHIP_CHECK_HIP(ctx, gp->ws2.reserve((n_part + n_dot + (size_t)M * S) * sizeof(double)));
+  double* part2 = gp->ws2.as<double>();
+  double* dot = part2 + n_part;
+  double* cov_dev = dot + n_dot;
+  const double inv_ls2 = 1.0 / (gp->ls * gp->ls);
+  const int rblocks = (int)(np * PC / 256);
+  for (int64_t pass0 = 0; pass0 < P.npass; pass0 += W.group) {
+    const unsigned g = (unsigned)((P.npass - pass0) < W.group ? (P.npass - pass0) : W.group);
+    enqueue_v(gp, W, pass0, g);
+    int s_left = (int)(S - pass0 * PC);
+    hipLaunchKernelGGL(finish_kernel, dim3(PC, g), dim3(256), 0, st, W.mu_part, W.nblk_k, W.var_part, rblocks, W.g_part,
+                       W.ngc, W.out + (size_t)pass0 * P.outsz, dp, s_left, gp->var + gp->bias, 0.0, inv_ls2, 0.0, 0,
+                       (double*)nullptr, (unsigned long long*)nullptr, 0ull);
+    TriArgs T;
+    T.W = gp->VP;
+    T.bin = W.v;
+    T.part = part2;
+    T.lda = m_pad;
+    T.np = np;
+    T.nout = m_pad;
+    T.nrb = (int)(m_pad / RB);
+    T.nkc = W.nkc;
+    T.npass = (int)g;
+    hipLaunchKernelGGL((tri_apply_kernel<2>), dim3((unsigned)((T.nrb + 7) / 8 * 8) * g, (unsigned)W.nkc), dim3(256), 0,
+                       st, T);
+    hipLaunchKernelGGL(tri_reduce_kernel, dim3((unsigned)(m_pad * PC / 256), g), dim3(256), 0, st, part2, dot,
+                       (double*)nullptr, m_pad, W.nkc, 2, 0);
+    hipLaunchKernelGGL(cross_finish_kernel, dim3((unsigned)((M * PC + 255) / 256), g), dim3(256), 0, st, gp->Pint,
+                       W.xs + (size_t)pass0 * PC * dp, dot, cov_dev, M, m_pad, dp, S, pass0 * PC, gp->var,
+                       -0.5 * inv_ls2, gp->bias);
+  }
+  ELFIHIP_TRY(launch_status(ctx, "cross covariance"));
+  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(cov, cov_dev, (size_t)M * S * sizeof(double), hipMemcpyDeviceToHost, st));
+  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(P.hout, W.out, P.n_out * sizeof(double), hipMemcpyDeviceToHost, st));
+  ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(st));
+  if (var_q) predict_read(gp, P, S, nullptr, var_q, nullptr, nullptr, nullptr, nullptr);
   return ELFIHIP_OK;
 }
 
@@ -806,6 +956,22 @@ int elfihip_gp_extend(elfihip_gp* gp, const double* X_new, const double* y_new, 
   if (log_marginal)
     *log_marginal = 0.5 * (-(double)gp->n * 1.8378770664093453 /* log(2 pi) */ - gp->logdet - gp->yKy);
   return ELFIHIP_OK;
+}
+
+int elfihip_gp_set_integration_points(elfihip_gp* gp, const double* P, int64_t M) {
+  if (!gp) return fail(nullptr, ELFIHIP_ERR_ARG, "gp is NULL");
+  if (!gp->factored)
+    return fail(gp->ctx, ELFIHIP_ERR_STATE, "GP is not factorised (call elfihip_gp_factorize first)");
+  DeviceGuard g(gp->ctx->device);
+  return set_integration_points_impl(gp, P, M);
+}
+
+int elfihip_gp_cross_cov(elfihip_gp* gp, const double* Q, int64_t S, double* cov, double* var_q) {
+  if (!gp) return fail(nullptr, ELFIHIP_ERR_ARG, "gp is NULL");
+  if (!gp->factored)
+    return fail(gp->ctx, ELFIHIP_ERR_STATE, "GP is not factorised (call elfihip_gp_factorize first)");
+  DeviceGuard g(gp->ctx->device);
+  return cross_cov_impl(gp, Q, S, cov, var_q);
 }
 
 }  // extern "C"

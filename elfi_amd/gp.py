@@ -113,6 +113,21 @@ class GPHandle:
                                                      _lib.ptr(dmu), _lib.ptr(dvar)))
         return mu, var, dmu, dvar
 
+    def set_integration_points(self, points):
+        """Fix the point set P (M, d) of the following cross_cov() calls (until the GP changes)."""
+        pts = self._xs(points)
+        self._check(self.lib.elfihip_gp_set_integration_points(self.h, _lib.ptr(pts), pts.shape[0]))
+        self._n_int = pts.shape[0]
+
+    def cross_cov(self, x):
+        """Posterior covariance (M, S) between the integration points and x (S, d), noiseless variance (S,) of x."""
+        x = self._xs(x)
+        S = x.shape[0]
+        cov = np.empty((self._n_int, S))
+        var = np.empty(S)
+        self._check(self.lib.elfihip_gp_cross_cov(self.h, _lib.ptr(x), S, _lib.ptr(cov), _lib.ptr(var)))
+        return cov, var
+
     def lcb(self, x, beta, with_grad=True):
         x = self._xs(x)
         S = x.shape[0]
@@ -315,6 +330,15 @@ class HipGPRegression:
 
     def predictive_gradient_mean(self, x):
         return self.predictive_gradients(x)[0]
+
+    # -- posterior covariance against a fixed point set (ExpIntVar, acquisition.py:775-808) -------------
+    def set_integration_points(self, points):
+        self._handle.set_integration_points(np.asanyarray(points).reshape((-1, self.input_dim)))
+
+    def cross_cov(self, x):
+        """(cov (M, S), var (S,)): covariance of the GP between the integration points and the rows of x, and the
+        noiseless predictive variance of the rows of x."""
+        return self._handle.cross_cov(np.asanyarray(x).reshape((-1, self.input_dim)))
 
     # -- batched LCB used by elfi_amd.acquisition (one device pass for all start points) -------
     def lcb(self, x, beta, with_grad=True):

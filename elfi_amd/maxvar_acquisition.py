@@ -199,3 +199,95 @@ class HipRandMaxVar(HipMaxVar):
                 batch_theta = samples[-1:]
             break
         return batch_theta
+
+
+def finite_difference_objective(fun_batch, bounds, step=1e-8):
+    """fun_batch(X (k, d)) -> (k,) turned into the (value, gradient) batch objective of the lock-step search, with
+    the forward differences SciPy's L-BFGS-B takes when it is given no gradient, as the reference does for ExpIntVar
+    (acquisition.py:766-775 -> scipy.optimize.minimize(jac=None): absolute step 1e-8, the step of a coordinate
+    turned backwards where it would leave the upper bound).  All k (d + 1) points of a round are ONE batch."""
+    hi = np.array([b[1] for b in bounds], dtype=float)
+
+    def value_and_gradient(X):
+        k, d = X.shape
+        pts = np.repeat(X, d + 1, axis=0)  # per search: the point, then its d displaced copies
+        steps = np.full((k, d), step)
+        steps[X + step > hi] = -step
+        for i in range(d):
+            pts[i + 1::d + 1, i] = X[:, i] + steps[:, i]
+        f = np.asarray(fun_batch(pts), dtype=float).reshape(k, d + 1)
+        moved = pts.reshape(k, d + 1, d)[:, 1:, :][:, np.arange(d), np.arange(d)] - X
+        return f[:, 0], (f[:, 1:] - f[:, :1]) / moved
+
+    return value_and_gradient
+
+
+class HipExpIntVar(HipMaxVar):
+    """elfi.methods.bo.acquisition.ExpIntVar (acquisition.py:629-821): the next point minimises the expected
+    integrated variance of the unnormalised posterior over a set of integration points (a grid, or importance
+    samples of the MaxVar surface).
+
+    The reference's evaluate() factorises the n x n covariance matrix and solves with it on EVERY call
+    (cho_factor + cho_solve, :806-808) to get the GP covariance between the integration points and the candidate.
+    Here that covariance comes from the device factorisation already in place: the model keeps
+    V_P = L^-1 k(X, P) for the point set (set_integration_points, once per acquire) and cross_cov streams it once
+    per batch of candidates (elfihip_gp_cross_cov); all starts of the minimisation and the d + 1 points of each
+    finite-difference gradient are one batch per round."""
+
+    def __init__(self, model, prior, quantile_eps=.01, integration='grid', d_grid=.2, n_samples_imp=100, iter_imp=2,
+                 sampler='nuts', n_samples=2000, sigma_proposals=None, **opts):
+        super(HipExpIntVar, self).__init__(model, prior, quantile_eps, **opts)
+        if getattr(model, 'cross_cov', None) is None:
+            raise TypeError('model must provide set_integration_points / cross_cov (elfi_amd.HipGPRegression)')
+        self.name = 'exp_int_var'
+        self.label_fn = 'Expected Loss'
+        self._integration = integration
+        self._n_samples_imp = n_samples_imp
+        self._iter_imp = iter_imp
+        if self._integration == 'importance':
+            self.density_is = HipRandMaxVar(model=self.model, prior=self.prior, n_inits=self.n_inits, seed=self.seed,
+                                            quantile_eps=self.quantile_eps, sampler=sampler, n_samples=n_samples,
+                                            sigma_proposals=sigma_proposals)
+        elif self._integration == 'grid':
+            grid_param = [slice(b[0], b[1], d_grid) for b in self.model.bounds]
+            self.points_int = np.mgrid[grid_param].reshape(len(self.model.bounds), -1).T
+
+    def acquire(self, n, t):
+        logger.debug('Acquiring the next batch of %d values', n)
+        gp = self.model
+        self.sigma2_n = gp.noise
+        self.eps = np.percentile(gp.Y, self.quantile_eps * 100)
+        if self._integration == 'importance' and t % self._iter_imp == 0:
+            self.points_int = self.density_is.acquire(self._n_samples_imp)
+        self.mean_int, self.var_int = gp.predict(self.points_int, noiseless=True)
+        self.priors_int = (self.prior.pdf(self.points_int) ** 2)[np.newaxis, :]
+        if self._integration == 'importance' and t % self._iter_imp == 0:
+            omegas_int_unnormalised = (1 / HipMaxVar.evaluate(self, self.points_int)).T
+            self.omegas_int = omegas_int_unnormalised / np.sum(omegas_int_unnormalised, axis=1)[:, np.newaxis]
+        elif self._integration == 'grid':
+            self.omegas_int = np.empty(len(self.points_int))
+            self.omegas_int.fill(1 / len(self.points_int))
+        gp.set_integration_points(self.points_int)  # in place of K, k_int_old and the per-call Cholesky (:788-793)
+        self.phi_int = ss.norm.cdf(self.eps, loc=self.mean_int.T, scale=np.sqrt(self.sigma2_n + self.var_int.T))
+        starts = _multistart.draw_start_points(gp.bounds, self.n_inits, self.prior, self.random_state)
+        res = _multistart.minimize_lockstep(finite_difference_objective(self.evaluate, gp.bounds), starts, gp.bounds,
+                                            maxiter=self.max_opt_iters)
+        k = int(np.argmin(res['vals']))
+        theta_min = res['locs'][k].copy()
+        for i in range(len(gp.bounds)):
+            theta_min[i] = np.clip(theta_min[i], *gp.bounds[i])
+        self.last_opt = dict(starts=starts, ind_min=k, **res)
+        return np.tile(theta_min, (n, 1))
+
+    def evaluate(self, theta_new, t=None):
+        theta_new = np.asanyarray(theta_new, dtype=float).reshape((-1, self.model.input_dim))
+        cov, var_new = self.model.cross_cov(theta_new)           # (M, S), (S,)
+        cov_int = cov.T
+        var_new = np.asarray(var_new).reshape(-1, 1)
+        # acquisition.py:809-819
+        delta_var_int = cov_int ** 2 / (self.sigma2_n + var_new)
+        a = np.sqrt((self.sigma2_n + self.var_int.T - delta_var_int) / (self.sigma2_n + self.var_int.T + delta_var_int))
+        phi_skew_imp = ss.skewnorm.cdf(self.eps, a, loc=self.mean_int.T, scale=np.sqrt(self.sigma2_n + self.var_int.T))
+        w = ((self.phi_int - phi_skew_imp) / 2)
+        loss_theta_new = 2 * np.sum(self.omegas_int * self.priors_int * w, axis=1)
+        return np.where(self.prior.pdf(theta_new) == 0, np.finfo(float).max, loss_theta_new)

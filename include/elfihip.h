@@ -235,6 +235,15 @@ int elfihip_gp_lcb_minimize(elfihip_gp* gp, const double* starts, int64_t S, con
                             const double* upper, double beta, int maxiter, double* x_out, double* f_out,
                             int* iters_out, int64_t* n_eval_out);
 
+/* ExpIntVar (elfi/methods/bo/acquisition.py:629-821) needs the GP's posterior covariance between its M
+ * integration points and each candidate: cov(p_i, q) = k(p_i, q) - k(p_i, X) K^-1 k(X, q), which the
+ * reference forms per evaluate() call with cho_factor + cho_solve of the n x n matrix (:800-808).
+ * set_integration_points stores V_P = L^-1 k(X, P) for P (M, d) once (valid until the evidence or the
+ * hyper-parameters change); cross_cov then returns cov (M, S) row-major and, optionally, the noiseless
+ * predictive variance var_q (S) of the S candidates Q (S, d): one streaming pass over V_P per 128 candidates. */
+int elfihip_gp_set_integration_points(elfihip_gp* gp, const double* P, int64_t M);
+int elfihip_gp_cross_cov(elfihip_gp* gp, const double* Q, int64_t S, double* cov, double* var_q);
+
 /* ---- the same multi-start search for objectives the HOST assembles -----------------------
  * scipy.optimize.minimize(method='L-BFGS-B') as the reference calls it from minimize()
  * (elfi/methods/bo/utils.py:97-103: jac given, bounds, maxiter, SciPy's default tolerances), turned

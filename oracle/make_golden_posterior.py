@@ -119,5 +119,15 @@ def make_maxvar(elfi, golden_dir):
         out['rand_%s_1' % sampler] = r1.acquire(1)
         r3 = RandMaxVar(ref, prior, quantile_eps=0.05, sampler=sampler, n_samples=40, seed=9)
         out['rand_%s_3' % sampler] = r3.acquire(3)
+    from elfi.methods.bo.acquisition import ExpIntVar
+    ev = ExpIntVar(ref, prior, quantile_eps=0.05, integration='grid', d_grid=0.4, n_inits=5, seed=11)
+    th = ev.acquire(1, t=4)
+    out.update(eiv_grid_theta=th, eiv_grid_points=ev.points_int, eiv_grid_loss=ev.evaluate(xs),
+               eiv_grid_loss_at_theta=ev.evaluate(th))
+    ei = ExpIntVar(ref, prior, quantile_eps=0.05, integration='importance', n_samples_imp=24, iter_imp=2,
+                   sampler='metropolis', n_samples=60, n_inits=4, seed=13)
+    thi = ei.acquire(1, t=2)
+    out.update(eiv_imp_theta=thi, eiv_imp_points=ei.points_int, eiv_imp_omegas=ei.omegas_int,
+               eiv_imp_loss=ei.evaluate(xs))
     np.savez_compressed(os.path.join(golden_dir, 'maxvar.npz'), **out)
     print('maxvar: eps %.4f theta_max %s' % (mv.eps, theta[0]))

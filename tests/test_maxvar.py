@@ -33,6 +33,17 @@ class OracleModel:
     def predictive_gradients(self, x):
         return self.post.predictive_gradients(np.asarray(x, float).reshape(-1, self.input_dim))
 
+    # what ExpIntVar.acquire / evaluate build from kern.K and cho_solve (acquisition.py:788-808)
+    def set_integration_points(self, points):
+        self._pts = np.asarray(points, float).reshape(-1, self.input_dim)
+
+    def cross_cov(self, x):
+        x = np.asarray(x, float).reshape(-1, self.input_dim)
+        p = self.post
+        K = lambda a, b: G.kern_K(a, b, p.var, p.ls, p.bias)
+        cov = K(self._pts, x) - K(self._pts, self.X) @ p.Kinv @ K(self.X, x)
+        return cov, p.predict(x, noiseless=True)[1][:, 0]
+
 
 def check_against_fixture(make_model, value_tol, loc_tol):
     import elfi_amd
@@ -100,3 +111,50 @@ def test_lockstep_multistart_equals_scipy_start_by_start():
     assert val <= np.min(batch(np.clip(loc[None, :], -1.5, 0.8))[0]) + 1e-12
     with pytest.raises(ValueError):
         multistart.minimize_lockstep(batch, starts, [(1.0, -1.0)] * 6)
+
+
+def check_expintvar(make_model, loss_tol, min_tol):
+    import elfi_amd
+    g = np.load(os.path.join(GOLDEN, 'maxvar.npz'))
+    model = make_model(g)
+    prior = PO.BoxPrior(model.bounds)
+    xs = g['xs']
+    # grid integration
+    ev = elfi_amd.HipExpIntVar(model, prior, quantile_eps=0.05, integration='grid', d_grid=0.4, n_inits=5, seed=11)
+    np.testing.assert_array_equal(ev.points_int, g['eiv_grid_points'])
+    th = ev.acquire(1, t=4)
+    scale = np.max(np.abs(g['eiv_grid_loss']))
+    np.testing.assert_allclose(ev.evaluate(xs), g['eiv_grid_loss'], rtol=0, atol=loss_tol * scale)
+    # the minimiser runs on finite-difference gradients of a flat surface: compare the loss reached, and the location
+    # where the surface is curved enough to pin it
+    ours, ref = float(ev.evaluate(th)[0]), float(np.ravel(g['eiv_grid_loss_at_theta'])[0])
+    assert ours <= ref + min_tol * scale, (ours, ref)
+    assert th.shape == (1, 2) and np.all(np.abs(th) <= 2)
+    # importance sampling: integration points from the RandMaxVar chain, weights 1 / MaxVar surface
+    ei = elfi_amd.HipExpIntVar(model, prior, quantile_eps=0.05, integration='importance', n_samples_imp=24, iter_imp=2,
+                               sampler='metropolis', n_samples=60, n_inits=4, seed=13)
+    thi = ei.acquire(1, t=2)
+    return g, ev, ei, thi
+
+
+def test_expintvar_on_the_oracle_gp_equals_the_reference():
+    g, ev, ei, thi = check_expintvar(OracleModel, 1e-9, 1e-6)
+    np.testing.assert_allclose(ei.points_int, g['eiv_imp_points'], rtol=0, atol=1e-8)
+    np.testing.assert_allclose(ei.omegas_int, g['eiv_imp_omegas'], rtol=1e-6)
+    np.testing.assert_allclose(ei.evaluate(g['xs']), g['eiv_imp_loss'], rtol=0,
+                               atol=1e-8 * np.max(np.abs(g['eiv_imp_loss'])))
+    np.testing.assert_allclose(thi, g['eiv_imp_theta'], rtol=0, atol=5e-3)
+
+
+def test_finite_difference_objective_matches_scipy_without_jacobian():
+    import scipy.optimize as so
+    from elfi_amd import multistart
+    from elfi_amd.maxvar_acquisition import finite_difference_objective
+    f = lambda X: np.array([so.rosen(x) + 0.1 * np.sin(3 * x[0]) for x in X])
+    bounds = [(-1.5, 0.8)] * 4
+    starts = np.random.RandomState(0).uniform(-1.5, 0.8, (4, 4))
+    starts[0, 1] = 0.8   # on the upper bound: that coordinate's step turns backwards
+    res = multistart.minimize_lockstep(finite_difference_objective(f, bounds), starts, bounds)
+    for i, x0 in enumerate(starts):
+        r = so.minimize(lambda x: float(f(x[None])[0]), x0, method='L-BFGS-B', bounds=bounds, options={'maxiter': 1000})
+        assert np.max(np.abs(r.x - res['locs'][i])) <= 1e-5 and abs(r.fun - res['vals'][i]) <= 1e-9 * (1 + abs(r.fun))

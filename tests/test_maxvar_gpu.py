@@ -6,7 +6,7 @@ import pytest
 
 import posterior_oracle as PO
 from conftest import GOLDEN
-from test_maxvar import check_against_fixture
+from test_maxvar import check_against_fixture, check_expintvar
 
 pytestmark = pytest.mark.gpu
 
@@ -46,3 +46,24 @@ def test_randmaxvar_on_the_device_gp(hip_ctx):
         assert b.shape == (3, 2) and np.all(b >= lo) and np.all(b <= hi)
         again = elfi_amd.HipRandMaxVar(model, prior, quantile_eps=0.05, sampler=sampler, n_samples=40, seed=9).acquire(3)
         assert np.array_equal(b, again)
+
+
+def test_expintvar_on_the_device_gp(hip_ctx):
+    g, ev, ei, thi = check_expintvar(_device_model, 1e-7, 1e-4)
+    scale = np.max(np.abs(g['eiv_imp_loss']))
+    assert thi.shape == (1, 2) and np.all(np.abs(thi) <= 2)
+    assert ei.points_int.shape == g['eiv_imp_points'].shape
+    # posterior covariance against the point set: the device answer vs the NumPy formula of the oracle model
+    from test_maxvar import OracleModel
+    om = OracleModel(g)
+    om.set_integration_points(ev.points_int)
+    model = ev.model
+    model.set_integration_points(ev.points_int)
+    cov, var = model.cross_cov(g['xs'])
+    cov_ref, var_ref = om.cross_cov(g['xs'])
+    np.testing.assert_allclose(cov, cov_ref, rtol=0, atol=1e-10 * max(1.0, np.max(np.abs(cov_ref))))
+    np.testing.assert_allclose(var, var_ref, rtol=1e-8, atol=1e-12)
+    # the point set belongs to one factorisation: new evidence invalidates it loudly
+    model.update(np.array([[0.1, 0.2]]), np.array([[0.5]]))
+    with pytest.raises(RuntimeError):
+        model.cross_cov(g['xs'])
