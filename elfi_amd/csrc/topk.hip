@@ -11,24 +11,29 @@
 // are resolved towards the lower row index -- np.argsort's default quicksort leaves that order
 // unspecified.
 //
-// Method: MSD radix select on the order-preserving 64-bit image of the doubles, 8 bits per pass:
-// per pass one histogram kernel over the keys that still match the prefix (LDS bins, one global
-// atomic per bin per workgroup -- integer counts, so the result is deterministic) and one
-// single-workgroup kernel that picks the digit; then a stable two-pass compaction (per-block
-// counts, scan, write) of the keys below the k-th key plus as many equal ones as needed.
-// HBM-bound and tiny next to the distance kernel: 8 bytes per distance per pass.
+// Method: MSD radix select on the order-preserving 64-bit image of the doubles, 11 bits per pass (six
+// passes: 5 x 11 + 9): one kernel per pass builds the histogram of the keys that still match the prefix (LDS
+// bins, one global atomic per non-empty bin per workgroup -- integer counts, so the result is deterministic;
+// a wave whose lanes all carry the same digit, the normal case in the exponent bits, adds its count with a
+// single LDS atomic) and the LAST workgroup to finish picks the digit (parallel scan of the 2048 bins);
+// then a stable two-pass compaction (per-block counts, scan, write) of the keys below the k-th key plus as
+// many equal ones as needed.  Nine launches, 8 bytes per distance per pass.
 #include <algorithm>
+#include <cstdlib>
 #include <numeric>
 
 #include "common.hpp"
 
 namespace elfihip {
 
+constexpr int SEL_BITS = 11, SEL_BINS = 1 << SEL_BITS, SEL_PASSES = 6;
+
 struct SelState {
   unsigned long long prefix;   // bits decided so far (high bits), rest zero
   unsigned long long k_rem;    // rank still to find inside the prefix class (1-based)
   unsigned long long n_lt;     // keys strictly below the prefix class
-  unsigned int hist[256];
+  unsigned int done;           // workgroups of the current pass that have added their bins
+  unsigned int hist[SEL_BINS];
 };
 
 __device__ __forceinline__ unsigned long long key_of(double v) {
@@ -37,40 +42,100 @@ __device__ __forceinline__ unsigned long long key_of(double v) {
   return (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
 }
 
+// pass p looks at bits [shift, shift + width): 53/11, 42/11, 31/11, 20/11, 9/11, 0/9
+__device__ __forceinline__ int sel_shift(int pass) { return pass < 5 ? 53 - SEL_BITS * pass : 0; }
+__device__ __forceinline__ int sel_width(int pass) { return pass < 5 ? SEL_BITS : 9; }
+
 __global__ __launch_bounds__(256) void sel_hist_kernel(const double* d, int64_t n, int64_t stride, int pass,
                                                        SelState* st) {
-  __shared__ unsigned int h[256];
-  h[threadIdx.x] = 0;
+  __shared__ unsigned int h[SEL_BINS];
+  __shared__ unsigned int part[256];
+  __shared__ int last;
+  for (int b = threadIdx.x; b < SEL_BINS; b += 256) h[b] = 0;
   __syncthreads();
-  const int shift = 56 - 8 * pass;
+  const int shift = sel_shift(pass), width = sel_width(pass);
+  const unsigned int dmask = (1u << width) - 1u;
   const unsigned long long prefix = st->prefix;
-  const unsigned long long himask = pass == 0 ? 0ull : (~0ull << (shift + 8));
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const unsigned long long k = key_of(d[i * stride]);
-    if ((k & himask) == prefix) atomicAdd(&h[(k >> shift) & 255], 1u);
+  const unsigned long long himask = pass == 0 ? 0ull : (~0ull << (shift + width));
+  // eight rows per thread and trip, all eight loads in flight before the first is looked at (the scan is
+  // latency-bound otherwise: a wave would wait a full memory round trip per 512 bytes)
+  constexpr int U = 8;
+  for (int64_t i0 = (int64_t)blockIdx.x * 256 * U; i0 < n; i0 += (int64_t)gridDim.x * 256 * U) {
+    double v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = i0 + u * 256 + threadIdx.x;
+      v[u] = i < n ? d[i * stride] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = i0 + u * 256 + threadIdx.x;
+      const unsigned long long k = key_of(v[u]);
+      const bool in = i < n && (k & himask) == prefix;
+      const unsigned int digit = (unsigned int)(k >> shift) & dmask;
+      const unsigned long long members = __ballot(in);
+      if (members == 0) continue;
+      // the wave's first member's digit; one atomic for the whole wave when every member shares it
+      const int lead = __ffsll((long long)members) - 1;
+      const unsigned int d0 = (unsigned int)__builtin_amdgcn_readlane((int)digit, lead);
+      if (__ballot(in && digit == d0) == members) {
+        if ((int)(threadIdx.x & 63) == lead) atomicAdd(&h[d0], (unsigned int)__popcll(members));
+      } else if (in) {
+        atomicAdd(&h[digit], 1u);
+      }
+    }
   }
   __syncthreads();
-  if (h[threadIdx.x]) atomicAdd(&st->hist[threadIdx.x], h[threadIdx.x]);
-}
-
-__global__ void sel_pick_kernel(int pass, SelState* st) {
-  if (threadIdx.x != 0) return;
-  const int shift = 56 - 8 * pass;
-  unsigned long long rem = st->k_rem, below = 0;
-  int digit = 255;
-  for (int b = 0; b < 256; ++b) {
-    const unsigned long long c = st->hist[b];
-    if (rem <= c) {
-      digit = b;
-      break;
-    }
-    rem -= c;
-    below += c;
+  // one wave adds the workgroup's bins to the global histogram, orders them before its arrival mark (a single
+  // device-scope fence per workgroup: the fence is the expensive part) and learns whether it arrived last
+  if (threadIdx.x < 64) {
+    for (int b = threadIdx.x; b < SEL_BINS; b += 64)
+      if (h[b]) atomicAdd(&st->hist[b], h[b]);
+    __threadfence();
+    if (threadIdx.x == 0) last = (atomicAdd(&st->done, 1u) == gridDim.x - 1);
   }
-  st->prefix |= (unsigned long long)digit << shift;
-  st->k_rem = rem;
-  st->n_lt += below;
-  for (int b = 0; b < 256; ++b) st->hist[b] = 0;
+  __syncthreads();
+  if (!last) return;
+  // the last workgroup to arrive picks the digit of this pass
+  constexpr int PER = SEL_BINS / 256;  // bins per thread
+  unsigned int c[PER], sum = 0;
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    c[q] = atomicAdd(&st->hist[threadIdx.x * PER + q], 0u);  // coherent read of the other workgroups' adds
+    sum += c[q];
+  }
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) {  // exclusive scan of 256 partial sums: short and sequential
+    unsigned int run = 0;
+    for (int t = 0; t < 256; ++t) {
+      const unsigned int v = part[t];
+      part[t] = run;
+      run += v;
+    }
+  }
+  __syncthreads();
+  const unsigned long long rem = st->k_rem;
+  const unsigned long long below0 = part[threadIdx.x];
+  if (rem > below0 && rem <= below0 + sum) {  // exactly one thread owns the k-th key's bin range
+    unsigned long long below = below0;
+    int digit = threadIdx.x * PER;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      if (rem > below + c[q]) {
+        below += c[q];
+        digit = threadIdx.x * PER + q + 1;
+      } else {
+        break;
+      }
+    }
+    st->prefix = prefix | ((unsigned long long)digit << shift);
+    st->k_rem = rem - below;
+    st->n_lt += below;
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < SEL_BINS; b += 256) st->hist[b] = 0;
+  if (threadIdx.x == 0) st->done = 0;
 }
 
 // counts[b] = {#keys < kth, #keys == kth} of block b's contiguous slice
@@ -95,14 +160,35 @@ __global__ __launch_bounds__(256) void sel_count_kernel(const double* d, int64_t
 }
 
 // exclusive scan of the per-block counts (single workgroup, sequential over blocks per class)
-__global__ void sel_scan_kernel(unsigned int* counts, int nblocks) {
+__global__ __launch_bounds__(256) void sel_scan_kernel(unsigned int* counts, int nblocks) {
+  // both classes at once: thread t owns the contiguous run of blocks [t * per, t * per + per)
+  __shared__ unsigned int tot[2][256];
+  const int per = (nblocks + 255) / 256;
+  const int b0 = threadIdx.x * per, b1 = b0 + per < nblocks ? b0 + per : nblocks;
+  unsigned int s0 = 0, s1 = 0;
+  for (int b = b0; b < b1; ++b) {
+    s0 += counts[2 * b];
+    s1 += counts[2 * b + 1];
+  }
+  tot[0][threadIdx.x] = s0;
+  tot[1][threadIdx.x] = s1;
+  __syncthreads();
   if (threadIdx.x < 2) {
     unsigned int run = 0;
-    for (int b = 0; b < nblocks; ++b) {
-      const unsigned int c = counts[2 * b + threadIdx.x];
-      counts[2 * b + threadIdx.x] = run;
-      run += c;
+    for (int t = 0; t < 256; ++t) {
+      const unsigned int v = tot[threadIdx.x][t];
+      tot[threadIdx.x][t] = run;
+      run += v;
     }
+  }
+  __syncthreads();
+  unsigned int r0 = tot[0][threadIdx.x], r1 = tot[1][threadIdx.x];
+  for (int b = b0; b < b1; ++b) {
+    const unsigned int c0 = counts[2 * b], c1 = counts[2 * b + 1];
+    counts[2 * b] = r0;
+    counts[2 * b + 1] = r1;
+    r0 += c0;
+    r1 += c1;
   }
 }
 
@@ -181,13 +267,13 @@ static int topk_dev_impl(elfihip_ctx* ctx, const double* dD, int64_t n, int64_t 
   memset(&init, 0, sizeof init);
   init.k_rem = (unsigned long long)k;
   ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(ds, &init, sizeof init, hipMemcpyHostToDevice, st));
-  const int hist_blocks = (int)std::min<int64_t>((n + 255) / 256, (int64_t)ctx->cu_count * 8);
-  for (int pass = 0; pass < 8; ++pass) {
+  // one workgroup per CU at most: each pays a device-scope fence, and a launch of this size is latency-bound anyway
+  // (10^6 keys: 0.16 ms with 8 workgroups per CU, 0.10 ms with one)
+  const int hist_blocks = (int)std::min<int64_t>((n + 2047) / 2048, (int64_t)ctx->cu_count);
+  for (int pass = 0; pass < SEL_PASSES; ++pass)
     hipLaunchKernelGGL(sel_hist_kernel, dim3(hist_blocks), dim3(256), 0, st, dD, n, stride, pass, ds);
-    hipLaunchKernelGGL(sel_pick_kernel, dim3(1), dim3(64), 0, st, pass, ds);
-  }
   hipLaunchKernelGGL(sel_count_kernel, dim3(nblocks), dim3(256), 0, st, dD, n, stride, per_block, ds, counts);
-  hipLaunchKernelGGL(sel_scan_kernel, dim3(1), dim3(64), 0, st, counts, nblocks);
+  hipLaunchKernelGGL(sel_scan_kernel, dim3(1), dim3(256), 0, st, counts, nblocks);
   hipLaunchKernelGGL(sel_write_kernel, dim3(nblocks), dim3(256), 0, st, dD, n, stride, per_block, ds, counts, k, dvals,
                      didx);
   return launch_status(ctx, "top-k selection kernels");
