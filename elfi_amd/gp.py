@@ -41,6 +41,7 @@ class GPHandle:
         self._check(self.lib.elfihip_gp_size(self.h, C.byref(n), C.byref(cap), C.byref(dd)))
         self.capacity = cap.value
         self.n = 0
+        self._n_int = 0   # integration points held by the device object (set_integration_points)
 
     def _check(self, rc):
         if rc != _lib.OK:
@@ -121,6 +122,8 @@ class GPHandle:
 
     def cross_cov(self, x):
         """Posterior covariance (M, S) between the integration points and x (S, d), noiseless variance (S,) of x."""
+        if self._n_int == 0:
+            raise RuntimeError('no integration points: call set_integration_points first')
         x = self._xs(x)
         S = x.shape[0]
         cov = np.empty((self._n_int, S))
