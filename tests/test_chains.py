@@ -100,3 +100,33 @@ def test_against_the_live_reference_on_another_target():
     ours = chains.nuts(80, inits, ev, seeds=[5, 6])
     for c in range(2):
         assert np.array_equal(ours[c], mcmc.nuts(80, inits[c], t, g, seed=5 + c))
+
+
+# ---- the reference's own sampler tests (tests/unit/test_mcmc.py:1-46), on the lock-step chains ---------------------
+def _gaussian_problem():
+    rs = np.random.RandomState(42)
+    n = 5
+    true_cov = rs.rand(n, n) * 0.5
+    true_cov += true_cov.T
+    true_cov += n * np.eye(n)
+    prec = np.linalg.inv(true_cov)
+    evaluate_batch = lambda X: (-0.5 * np.einsum('si,ij,sj->s', X, prec, X), -X @ prec)
+    return n, true_cov, evaluate_batch, rs
+
+
+def test_metropolis_recovers_a_gaussian_covariance():
+    n, true_cov, ev, rs = _gaussian_problem()
+    n_samples = 30000          # the reference draws 200000 in one chain; here 8 chains of 30000 advance together
+    samples = chains.metropolis(n_samples, rs.rand(8, n), ev, np.ones(n), seeds=range(8))
+    assert samples.shape == (8, n_samples, n)
+    cov = np.cov(samples[:, n_samples // 2:, :].reshape(-1, n).T)
+    assert np.allclose(cov, true_cov, atol=0.3, rtol=0.1)
+
+
+def test_nuts_recovers_a_gaussian_covariance():
+    n, true_cov, ev, rs = _gaussian_problem()
+    n_samples, n_adapt = 2500, 500
+    samples = chains.nuts(n_samples, rs.rand(8, n), ev, seeds=range(8), n_adapt=n_adapt)
+    assert samples.shape == (8, n_samples, n)
+    cov = np.cov(samples[:, n_adapt:, :].reshape(-1, n).T)
+    assert np.allclose(cov, true_cov, atol=0.35, rtol=0.1)

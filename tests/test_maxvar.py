@@ -158,3 +158,26 @@ def test_finite_difference_objective_matches_scipy_without_jacobian():
     for i, x0 in enumerate(starts):
         r = so.minimize(lambda x: float(f(x[None])[0]), x0, method='L-BFGS-B', bounds=bounds, options={'maxiter': 1000})
         assert np.max(np.abs(r.x - res['locs'][i])) <= 1e-5 and abs(r.fun - res['vals'][i]) <= 1e-9 * (1 + abs(r.fun))
+
+
+def check_gradient_numerically(model):
+    """tests/unit/test_bo.py:162-181 (GPy's GradientChecker, ratio tolerance 1e-4) on value_and_gradient."""
+    import elfi_amd
+    prior = PO.BoxPrior(model.bounds)
+    mv = elfi_amd.HipMaxVar(model, prior, quantile_eps=0.05, seed=1)
+    mv.eps = float(np.percentile(model.Y, 5))
+    pts = np.random.RandomState(8).uniform(-1.8, 1.8, (20, model.input_dim))
+    v, g = mv.value_and_gradient(pts)
+    h = 1e-6
+    num = np.empty_like(g)
+    for i in range(model.input_dim):
+        e = np.zeros(model.input_dim)
+        e[i] = h
+        num[:, i] = (mv.evaluate(pts + e)[:, 0] - mv.evaluate(pts - e)[:, 0]) / (2 * h)
+    big = np.abs(num) > 1e-3 * np.max(np.abs(num))
+    assert np.allclose(g[big] / num[big], 1.0, atol=1e-4), np.max(np.abs(g[big] / num[big] - 1))
+
+
+def test_maxvar_gradient_is_the_derivative_of_the_value():
+    g = np.load(os.path.join(GOLDEN, 'maxvar.npz'))
+    check_gradient_numerically(OracleModel(g))

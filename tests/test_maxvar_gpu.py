@@ -6,7 +6,7 @@ import pytest
 
 import posterior_oracle as PO
 from conftest import GOLDEN
-from test_maxvar import check_against_fixture, check_expintvar
+from test_maxvar import check_against_fixture, check_expintvar, check_gradient_numerically
 
 pytestmark = pytest.mark.gpu
 
@@ -67,3 +67,8 @@ def test_expintvar_on_the_device_gp(hip_ctx):
     model.update(np.array([[0.1, 0.2]]), np.array([[0.5]]))
     with pytest.raises(RuntimeError):
         model.cross_cov(g['xs'])
+
+
+def test_maxvar_gradient_is_the_derivative_of_the_value_on_the_device(hip_ctx):
+    g = np.load(os.path.join(GOLDEN, 'maxvar.npz'))
+    check_gradient_numerically(_device_model(g))
