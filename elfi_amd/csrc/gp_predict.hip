@@ -37,12 +37,13 @@ constexpr int MAX_GROUP = 8;  // 16-point passes handled by one set of launches
 
 
 // Query points of a single-pass call travel in the kernel arguments (the argument block is written by the host and
-// read from device memory): [point][dimension, padded to 16] and the squared norms.
+// read from device memory): [point][dimension, padded to 24] and the squared norms -- 3.2 KiB of the 4 KiB an
+// argument block may hold, enough for the 20 parameters of BASELINE configs[4].
+constexpr int QUERY_ARGS_MAX_DP = 24;
 struct QueryArgs {
-  double x[PC][16];
+  double x[PC][QUERY_ARGS_MAX_DP];
   double x2[PC];
 };
-constexpr int QUERY_ARGS_MAX_DP = 16;
 
 // ---- kr[s][i], partial mu ----------------------------------------------------------
 __global__ __launch_bounds__(256) void kstar_kernel(const double* X, const double* x2, const double* alpha,
@@ -62,13 +63,13 @@ __global__ __launch_bounds__(256) void kstar_kernel(const double* X, const doubl
   if (from_args) {
     // single-pass call: the point comes with the arguments (uniform index: two wide scalar loads); workgroup
     // column 0 leaves a device copy of it for the gradient kernel
-    double row[16];
+    double row[QUERY_ARGS_MAX_DP];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) row[c] = q.x[s][c];
-    if (threadIdx.x < 16) {
+    for (int c = 0; c < QUERY_ARGS_MAX_DP; ++c) row[c] = q.x[s][c];
+    if (threadIdx.x < QUERY_ARGS_MAX_DP) {
       double x = 0.0;
 #pragma unroll
-      for (int c = 0; c < 16; ++c) x = (int)threadIdx.x == c ? row[c] : x;
+      for (int c = 0; c < QUERY_ARGS_MAX_DP; ++c) x = (int)threadIdx.x == c ? row[c] : x;
       sx[threadIdx.x] = x;
       if (blockIdx.x == 0 && (int)threadIdx.x < dp) xs_copy[s * dp + threadIdx.x] = x;
     }
@@ -516,7 +517,7 @@ int predict_prepare(elfihip_gp* gp, int64_t S, PredictPlan* P) {
   P->n_in = (size_t)P->npass * PC * dp + (size_t)P->npass * PC;
   P->n_out = (size_t)P->npass * P->outsz;
   // pinned, device-visible staging: [completion flag | query points | results].  Calls of one pass (S <= 16 points
-  // of <= 16 dimensions: every step of the acquisition search) skip both copies: the points ride in the kernel
+  // of <= 24 dimensions: every step of the acquisition search) skip both copies: the points ride in the kernel
   // arguments, the last kernel writes the results into this buffer and raises the flag the host polls.
   if (gp->h_cap < P->n_in + P->n_out + 16) {
     if (gp->h_stage) ELFIHIP_CHECK_HIP(ctx, hipHostFree(gp->h_stage));
@@ -576,7 +577,7 @@ int predict_enqueue(elfihip_gp* gp, const PredictPlan& P, int64_t S_active, int 
     double* out = W.out + (size_t)pass0 * P.outsz;
     if (P.direct) {
       for (int s = 0; s < PC; ++s) {
-        for (int c = 0; c < 16; ++c) qa.x[s][c] = c < dp ? P.hx[(size_t)s * dp + c] : 0.0;
+        for (int c = 0; c < QUERY_ARGS_MAX_DP; ++c) qa.x[s][c] = c < dp ? P.hx[(size_t)s * dp + c] : 0.0;
         qa.x2[s] = P.hx[(size_t)PC * dp + s];
       }
     }

@@ -50,7 +50,7 @@ def test_factorization_vs_oracle(hip_ctx, n, d):
 
 
 @pytest.mark.parametrize('n,d,S', [(50, 2, 1), (300, 2, 7), (1000, 10, 10), (1000, 10, 37), (700, 5, 16),
-                                   (600, 3, 129), (900, 4, 300)])
+                                   (600, 3, 129), (900, 4, 300), (500, 20, 10), (400, 23, 5), (400, 30, 7)])
 def test_predict_and_gradients_vs_oracle(hip_ctx, n, d, S):
     X, y, bounds = _problem(n, d, seed=7 * n + S)
     gp, _, ref = _fit(X, y, bounds)
