@@ -404,6 +404,14 @@ static int set_lds(elfihip_ctx* ctx, KernelT k, size_t lds) {
   return ELFIHIP_OK;
 }
 
+// 16-byte loads per thread of the pipelined row kernels.  Rows that cost a few flops per element (everything but
+// general Minkowski and the K-weight sums) stream best in tiles of 32 to 64 rows (8 to 16 KiB per workgroup); the
+// heavier per-row work wants all 128 lanes of the workgroup on rows (tiles of 128 rows).
+static int pipe_unroll(int m, bool light) {
+  if (!light) return m <= 16 ? 8 : 16;
+  return m <= 32 ? 4 : (m <= 64 ? 8 : 16);
+}
+
 template <int METRIC, bool W>
 static int launch_rows(elfihip_ctx* ctx, RowArgs A) {
   if (A.m > kMaxTileM) {
@@ -419,15 +427,19 @@ static int launch_rows(elfihip_ctx* ctx, RowArgs A) {
   const int64_t ntiles = (A.n + T - 1) / T;
   const int g = grid_for(ctx, ntiles, lds, T);
   if (A.vec2 && A.m <= 128) {
-    // pipelined form: 128 threads, 16 (m <= 16: 8) register pairs each = one whole tile of R rows
-    // (measured on 10^6 x 32: 256-thread tiles 5.1 TB/s vs 5.25; non-temporal loads +-1 %: not used)
-    const int Tp = 128, U = A.m <= 16 ? 8 : 16;
+    // pipelined form: 128 threads, U register pairs each = one whole tile of R rows.  Small tiles win: 8 KiB in
+    // flight per workgroup (32 rows of 32) with 8 workgroups per CU streams 10^6 x 32 in 47.5 us, the 32 KiB tile
+    // (U = 16) in 49.6 us, 4 KiB (U = 2) in 59 us; a pure read of the buffer takes 42.5 us
+    // (scripts/native/stream_probe.hip).  Also measured: 256-thread tiles and non-temporal loads, no gain.
+    const int Tp = 128, U = pipe_unroll(A.m, METRIC != ELFIHIP_MINKOWSKI);
     int R = 2 * Tp * U / A.m;
     if (R > Tp) R = Tp;
     A.R = R;
     const size_t ldsp = ((size_t)R * A.mp + 2 * (size_t)A.m) * sizeof(double);
     const int gp = grid_for(ctx, (A.n + R - 1) / R, ldsp, Tp);
-    if (U == 8)
+    if (U == 4)
+      hipLaunchKernelGGL((dist_rows_pipe_kernel<METRIC, W, 4>), dim3(gp), dim3(Tp), ldsp, ctx->stream, A);
+    else if (U == 8)
       hipLaunchKernelGGL((dist_rows_pipe_kernel<METRIC, W, 8>), dim3(gp), dim3(Tp), ldsp, ctx->stream, A);
     else
       hipLaunchKernelGGL((dist_rows_pipe_kernel<METRIC, W, 16>), dim3(gp), dim3(Tp), ldsp, ctx->stream, A);

