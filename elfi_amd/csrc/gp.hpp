@@ -65,7 +65,8 @@ struct PredictPlan {
   double* hout = nullptr;                 // pinned: results
   unsigned long long* flag = nullptr;     // pinned: completion flags, one per query column (single-pass calls)
   int n_flags = 0;                        // columns in use
-  bool direct = false;                    // kernels read hx / write hout themselves, no copies
+  bool direct = false;                    // no copies: the last kernel writes hout and the flags
+  bool by_args = false;                   // ... and the points travel in the kernel arguments (else read from hx)
 };
 int predict_prepare(elfihip_gp* gp, int64_t S, PredictPlan* P);
 void predict_fill(const elfihip_gp* gp, const PredictPlan& P, const double* Xs, int64_t S);

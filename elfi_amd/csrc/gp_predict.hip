@@ -75,7 +75,12 @@ __global__ __launch_bounds__(256) void kstar_kernel(const double* X, const doubl
     }
     if (threadIdx.x == 0) sx[256] = q.x2[s];
   } else {
-    if ((int)threadIdx.x < dp) sx[threadIdx.x] = xs[s * dp + threadIdx.x];
+    // xs may be pinned host memory here (multi-pass calls without an upload): one parallel read per workgroup
+    if ((int)threadIdx.x < dp) {
+      const double x = xs[s * dp + threadIdx.x];
+      sx[threadIdx.x] = x;
+      if (xs_copy && blockIdx.x == 0) xs_copy[(int64_t)blockIdx.z * PC * dp + s * dp + threadIdx.x] = x;
+    }
     if (threadIdx.x == 0) sx[256] = xs2[s];
   }
   __syncthreads();
@@ -390,8 +395,10 @@ __global__ __launch_bounds__(256) void finish_kernel(const double* mu_part, int 
     }
   }
   if (host_out) {
-    // single-pass call: one wave copies this column's results to pinned host memory, makes them visible to the
+    // copy-free call: one wave copies this column's results to pinned host memory, makes them visible to the
     // host and raises the column's flag (the host polls the flags of the columns it asked for)
+    host_out += (int64_t)blockIdx.y * (3 * PC + 3 * PC * dp);
+    done_flags += (int64_t)blockIdx.y * PC;
     __syncthreads();
     if (t < 64) {
       if (t < 3) host_out[t * PC + s] = out[t * PC + s];
@@ -519,7 +526,8 @@ int predict_prepare(elfihip_gp* gp, int64_t S, PredictPlan* P) {
   // pinned, device-visible staging: [completion flag | query points | results].  Calls of one pass (S <= 16 points
   // of <= 24 dimensions: every step of the acquisition search) skip both copies: the points ride in the kernel
   // arguments, the last kernel writes the results into this buffer and raises the flag the host polls.
-  if (gp->h_cap < P->n_in + P->n_out + 16) {
+  constexpr size_t HDR = (size_t)MAX_GROUP * PC;  // completion flags, one per query column of a group
+  if (gp->h_cap < P->n_in + P->n_out + HDR) {
     if (gp->h_stage) ELFIHIP_CHECK_HIP(ctx, hipHostFree(gp->h_stage));
     gp->h_stage = nullptr;
     gp->h_cap = 0;
@@ -527,13 +535,16 @@ int predict_prepare(elfihip_gp* gp, int64_t S, PredictPlan* P) {
     ELFIHIP_CHECK_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&gp->h_stage), want * sizeof(double),
                                          hipHostMallocMapped | hipHostMallocCoherent));
     gp->h_cap = want;
-    for (int f = 0; f < PC; ++f) reinterpret_cast<unsigned long long*>(gp->h_stage)[f] = 0;
+    for (size_t f = 0; f < HDR; ++f) reinterpret_cast<unsigned long long*>(gp->h_stage)[f] = 0;
     gp->done_seq = 0;
   }
-  P->direct = P->npass == 1 && gp->dp <= QUERY_ARGS_MAX_DP && !zero_copy_disabled();
+  // copy-free when the call is one group of passes: points from the kernel arguments (one pass, <= 24 dimensions) or
+  // read by the first kernel straight from this buffer, results and flags written by the last kernel
+  P->direct = P->npass <= W.group && !zero_copy_disabled();
+  P->by_args = P->direct && P->npass == 1 && gp->dp <= QUERY_ARGS_MAX_DP;
   P->flag = reinterpret_cast<unsigned long long*>(gp->h_stage);
-  P->n_flags = (int)(S < PC ? S : PC);
-  P->hx = gp->h_stage + 16;
+  P->n_flags = (int)S;
+  P->hx = gp->h_stage + HDR;
   P->hout = P->hx + P->n_in;
   return ELFIHIP_OK;
 }
@@ -575,15 +586,17 @@ int predict_enqueue(elfihip_gp* gp, const PredictPlan& P, int64_t S_active, int 
     const double* xs = W.xs + (size_t)pass0 * PC * dp;  // device copy (filled by the upload or by kstar_kernel)
     const double* xs2 = W.xs2 + (size_t)pass0 * PC;
     double* out = W.out + (size_t)pass0 * P.outsz;
-    if (P.direct) {
+    const bool from_host = P.direct && !P.by_args;  // direct calls are a single group: pass0 == 0
+    if (P.by_args) {
       for (int s = 0; s < PC; ++s) {
         for (int c = 0; c < QUERY_ARGS_MAX_DP; ++c) qa.x[s][c] = c < dp ? P.hx[(size_t)s * dp + c] : 0.0;
         qa.x2[s] = P.hx[(size_t)PC * dp + s];
       }
     }
-    hipLaunchKernelGGL(kstar_kernel, dim3(W.nblk_k, PC, g), dim3(256), 0, st, gp->X, gp->x2, gp->alpha, xs, xs2,
-                       W.kr, W.kb, W.mu_part, gp->n, np, dp, gp->var, -0.5 * inv_ls2, gp->bias, W.xs,
-                       P.direct ? 1 : 0, qa);
+    hipLaunchKernelGGL(kstar_kernel, dim3(W.nblk_k, PC, g), dim3(256), 0, st, gp->X, gp->x2, gp->alpha,
+                       from_host ? P.hx : xs, from_host ? P.hx + (size_t)P.npass * PC * dp : xs2, W.kr, W.kb,
+                       W.mu_part, gp->n, np, dp, gp->var, -0.5 * inv_ls2, gp->bias,
+                       P.direct ? W.xs : (double*)nullptr, P.by_args ? 1 : 0, qa);
     launch_tri(gp, W, false, W.kb, g);
     hipLaunchKernelGGL(tri_reduce_kernel, dim3(rblocks, g), dim3(256), 0, st, W.part, W.v, W.var_part, np, W.nkc, 0,
                        1);
