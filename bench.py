@@ -250,15 +250,15 @@ def main():
     # distances on the GPU (elfihip_topk_smallest_dev, what Rejection keeps of a batch) and rank 0
     # gathers those (value, row) pairs -- 16 KB per rank instead of the 8 MB distance shard.
     K_BEST = min(1000, n)
-    best_v = torch.empty(K_BEST, dtype=torch.float64, device=dev)
-    best_i = torch.empty(K_BEST, dtype=torch.int64, device=dev)
-    gath_v = [torch.empty_like(best_v) for _ in range(world)] if (world > 1 and rank == 0) else None
-    gath_i = [torch.empty_like(best_i) for _ in range(world)] if (world > 1 and rank == 0) else None
+    # values and row numbers travel together: one buffer (the int64 rows viewed through the second half), ONE gather
+    best = torch.empty(2 * K_BEST, dtype=torch.float64, device=dev)
+    best_v = best[:K_BEST]
+    best_i = best[K_BEST:].view(torch.int64)
+    gath = [torch.empty_like(best) for _ in range(world)] if (world > 1 and rank == 0) else None
 
     def exchange():
         ctx.call("elfihip_topk_smallest_dev", out.data_ptr(), n, 1, K_BEST, best_v.data_ptr(), best_i.data_ptr())
-        dist.gather(best_v, gath_v, dst=0)
-        dist.gather(best_i, gath_i, dst=0)
+        dist.gather(best, gath, dst=0)
 
     counter = [0]
 
@@ -336,7 +336,7 @@ def main():
                                    "GPU per step, elfi.Distance('euclidean'), inputs resident in HBM" % (n, m),
                        "samples_per_gpu": n, "summaries": m, "layout": "row-major (n,m) f64",
                        "batches_in_rotation": NBUF,
-                       "exchange": "per job: device top-%d of the last batch per rank + one RCCL gather of the "
+                       "exchange": "per job: device top-%d of the last batch per rank + ONE RCCL gather of the packed "
                                    "(distance, row) pairs to rank 0" % K_BEST if world > 1 else "none"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
