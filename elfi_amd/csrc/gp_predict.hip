@@ -707,9 +707,23 @@ __global__ __launch_bounds__(256) void extend_scalars_kernel(const double* v, co
 
 __global__ __launch_bounds__(256) void extend_write_kernel(const double* v, const double* u, const double* red,
                                                            double* A, double* WT, double* WL, double* alpha, int64_t lda,
-                                                           int64_t n, int64_t np) {
+                                                           int64_t n, int64_t np, const double* xs, double x2new,
+                                                           double ynew, double* X, double* x2, double* y, int dp,
+                                                           const int* info, double* host_report,
+                                                           unsigned long long* done_flag, unsigned long long done_value) {
   const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const double d = red[8], zn = red[9];
+  if (j == n) {
+    // the evidence arrays themselves (row n): padded x, |x|^2, y -- and the report the host waits for
+    for (int c = 0; c < dp; ++c) X[n * dp + c] = xs[c];
+    x2[n] = x2new;
+    y[n] = ynew;
+    host_report[0] = d;
+    host_report[1] = zn;
+    host_report[2] = (double)*info;
+    __threadfence_system();
+    __hip_atomic_store(done_flag, done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   if (j < n) {
     A[n * lda + j] = v[j * PC];              // new row of L
     const double w = -u[j * PC] / d;         // new column of L^-T
@@ -733,24 +747,28 @@ static int extend_one(elfihip_gp* gp, const double* x, double ynew) {
   const int dp = gp->dp, d = gp->d;
   const int64_t np = gp->np, n = gp->n;
   const double inv_ls2 = 1.0 / (gp->ls * gp->ls);
-  static thread_local std::vector<double> hx;
-  hx.assign((size_t)PC * dp + PC, 0.0);
+  // No copy in either direction for d <= 24: the point rides in the first kernel's arguments (which leaves the device
+  // copy the last kernel files into the evidence arrays), and the last kernel reports (d, z_new, info) into pinned
+  // memory and raises the flag the host polls.  Wider points are uploaded once.
+  PredictPlan P;
+  ELFIHIP_TRY(predict_prepare(gp, 1, &P));
   double q = 0.0;
-  for (int c = 0; c < d; ++c) {
-    hx[c] = x[c];
-    q += x[c] * x[c];
+  for (int c = 0; c < d; ++c) q += x[c] * x[c];
+  const bool by_args = dp <= QUERY_ARGS_MAX_DP;
+  static thread_local QueryArgs qa;
+  if (by_args) {
+    for (int s_ = 0; s_ < PC; ++s_) {
+      for (int c = 0; c < QUERY_ARGS_MAX_DP; ++c) qa.x[s_][c] = (s_ == 0 && c < d) ? x[c] : 0.0;
+      qa.x2[s_] = s_ == 0 ? q : 0.0;
+    }
+  } else {
+    predict_fill(gp, P, x, 1);
+    ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(W.xs, P.hx, P.n_in * sizeof(double), hipMemcpyHostToDevice, st));
   }
-  hx[(size_t)PC * dp] = q;
-  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(W.xs, hx.data(), (size_t)PC * dp * sizeof(double), hipMemcpyHostToDevice, st));
-  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(W.xs2, hx.data() + (size_t)PC * dp, PC * sizeof(double), hipMemcpyHostToDevice, st));
-  // the evidence arrays themselves (row n): padded x, |x|^2, y
-  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(gp->X + n * dp, hx.data(), (size_t)dp * sizeof(double), hipMemcpyHostToDevice, st));
-  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(gp->x2 + n, hx.data() + (size_t)PC * dp, sizeof(double), hipMemcpyHostToDevice, st));
-  hx[(size_t)PC * dp + 1] = ynew;
-  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(gp->y + n, hx.data() + (size_t)PC * dp + 1, sizeof(double), hipMemcpyHostToDevice, st));
   ELFIHIP_TRY(ensure_wl(gp));
   hipLaunchKernelGGL(kstar_kernel, dim3(W.nblk_k, PC), dim3(256), 0, st, gp->X, gp->x2, gp->alpha, W.xs, W.xs2, W.kr,
-                     W.kb, W.mu_part, n, np, dp, gp->var, -0.5 * inv_ls2, gp->bias, (double*)nullptr, 0, QueryArgs());
+                     W.kb, W.mu_part, n, np, dp, gp->var, -0.5 * inv_ls2, gp->bias, by_args ? W.xs : (double*)nullptr,
+                     by_args ? 1 : 0, qa);
   const int rblocks = (int)(np * PC / 256);
   launch_tri(gp, W, false, W.kb, 1);
   hipLaunchKernelGGL(tri_reduce_kernel, dim3(rblocks), dim3(256), 0, st, W.part, W.v, W.var_part, np, W.nkc, 0, 1);
@@ -760,13 +778,15 @@ static int extend_one(elfihip_gp* gp, const double* x, double ynew) {
   launch_tri(gp, W, true, W.v, 1);
   hipLaunchKernelGGL(tri_reduce_kernel, dim3(rblocks), dim3(256), 0, st, W.part, W.u, (double*)nullptr, np, W.nkc, 1, 0);
   hipLaunchKernelGGL(extend_write_kernel, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, st, W.v, W.u, gp->red,
-                     gp->A, gp->WT, gp->WL, gp->alpha, gp->lda, n, np);
+                     gp->A, gp->WT, gp->WL, gp->alpha, gp->lda, n, np, W.xs, q, ynew, gp->X, gp->x2, gp->y, dp,
+                     gp->info, P.hout, P.flag, (unsigned long long)(gp->done_seq + 1));
+  ++gp->done_seq;
   ELFIHIP_TRY(launch_status(ctx, "extend kernels"));
-  double sc[2];
-  int info = 0;
-  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(sc, gp->red + 8, sizeof sc, hipMemcpyDeviceToHost, st));
-  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(&info, gp->info, sizeof info, hipMemcpyDeviceToHost, st));
-  ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(st));
+  P.direct = true;
+  P.n_flags = 1;
+  ELFIHIP_TRY(predict_wait(gp, P));
+  const double sc[2] = {P.hout[0], P.hout[1]};
+  const int info = (int)P.hout[2];
   if (info != 0) {
     gp->factored = false;
     return fail(ctx, ELFIHIP_ERR_NOT_PD, "covariance matrix is not positive definite (pivot %d <= 0)", info);
