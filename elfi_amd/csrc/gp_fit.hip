@@ -141,7 +141,7 @@ __device__ __forceinline__ void sqrt_rsqrt(double p, double& s, double& y) {
 
 constexpr int SP = 129;   // pitch of the 128x128 working block S in LDS
 constexpr int PP = 18;    // pitch of the dense copy of the solved 16-wide panel
-constexpr int POTF2_LDS_DOUBLES = NB * SP + NB + NB * PP + 128;  // + per-lane trash slots
+constexpr int POTF2_LDS_DOUBLES = NB * SP + NB + NB * PP + 128 + 2;  // + per-lane trash slots + the look-ahead flag
 
 // S holds two triangles at once: entries (i, c <= i) are the block of Ky being turned into
 // L11; entries (r, c > r) are the rows of the appended identity being turned into L11^-T
@@ -156,50 +156,112 @@ constexpr int POTF2_LDS_DOUBLES = NB * SP + NB + NB * PP + 128;  // + per-lane t
 //            the tile, solves the panel below it and carries the identity rows along in one go.
 //   phase B  rank-16 update of everything right of the panel, 16x16 f64 MFMA tiles; a wave owns
 //            whole tile rows (A fragment loaded once) and runs two independent accumulators.
-__global__ __launch_bounds__(256) void potf2_aug_kernel(double* Akk, int64_t lda, double* Wkk, int64_t ldw,
+//   LA (look-ahead, 512 threads): phase B of panel p is split.  Its first tile column -- the 16 columns panel p+1
+//            eliminates -- is updated right after phase A by all eight waves; the rest is updated by waves 3-7 WHILE
+//            waves 0-2 (48 other rows each instead of 32) run phase A of panel p+1 (two waves per SIMD: the MFMA
+//            work of one overlaps the VALU chain of the other).  A panel step then costs max(A, rest of B) + one
+//            tile column instead of A + B.  The dense panel copy P2 is shared: phase A(p+1) files its panel only
+//            after the five update waves have all raised the flag that they are done reading panel p's.
+template <bool LA>
+__global__ __launch_bounds__(LA ? 512 : 256) void potf2_aug_kernel(double* Akk, int64_t lda, double* Wkk, int64_t ldw,
                                                         double* W11, int* info, int kblock, int skip) {
   extern __shared__ __align__(16) double sm[];
   double* S = sm;
   double* bd = S + NB * SP;
   double* P2 = bd + NB;        // 128 x PP: solved panel entries of the 128 non-tile rows, dense
+  int* la_flag = reinterpret_cast<int*>(P2 + NB * PP + 128);  // number of "rest of B" phases wave 3 has completed
   const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
   long long tc[6] = {0, 0, 0, 0, 0, 0};
   const long long t_begin = clock64();
 
   // block load, lower triangle only (plus the diagonal pair): 16-byte loads, all 32 per thread in
   // flight at once -- one memory latency for the whole 128 x 128 block instead of four
+  constexpr int NT = LA ? 512 : 256;  // threads of the workgroup
   {
     typedef double v2d __attribute__((ext_vector_type(2)));
-    v2d v[32];
+    constexpr int NL = NB * NB / 2 / NT;
+    v2d v[NL];
 #pragma unroll
-    for (int u = 0; u < 32; ++u) {
-      const int e2 = tid + 256 * u;
+    for (int u = 0; u < NL; ++u) {
+      const int e2 = tid + NT * u;
       const int i = e2 >> 6, c = 2 * (e2 & 63);
       v[u] = (v2d){0.0, 0.0};
       if (c <= i) v[u] = *reinterpret_cast<const v2d*>(Akk + (int64_t)i * lda + c);
     }
 #pragma unroll
-    for (int u = 0; u < 32; ++u) {
-      const int e2 = tid + 256 * u;
+    for (int u = 0; u < NL; ++u) {
+      const int e2 = tid + NT * u;
       const int i = e2 >> 6, c = 2 * (e2 & 63);
       S[i * SP + c] = (c <= i) ? v[u].x : 0.0;
       S[i * SP + c + 1] = (c + 1 <= i) ? v[u].y : 0.0;
     }
   }
   if (tid < NB) bd[tid] = 1.0;
+  if (tid == 0) *la_flag = 0;
   __syncthreads();
   int bad = 0;
+  // rank-16 update of tile row tr by panel q, tile columns [b_lo, b_hi): Cholesky rows (columns b <= tr, lower
+  // triangle) for tr < Tn, identity rows above
+  auto update_row_tile = [&](int q, int tr, int b_lo, int b_hi) {
+    const int c0q = 16 * q, ntopq = NB - 16 - c0q, Tnq = ntopq / 16;
+    const bool chol = tr < Tnq;
+    const int prow = chol ? 16 * tr : ntopq + 16 * (tr - Tnq);
+    const int srow = chol ? c0q + 16 + 16 * tr : 16 * (tr - Tnq);
+    const int ncol = chol ? tr + 1 : Tnq;
+    if (b_hi > ncol) b_hi = ncol;
+    if (b_lo >= b_hi) return;
+    double am[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) am[kk] = -P2[(prow + (l & 15)) * PP + 4 * kk + (l >> 4)];
+    for (int b = b_lo; b < b_hi; b += 2) {
+      const bool two = b + 1 < b_hi;
+      const int b1 = two ? b + 1 : b;
+      const int sc0 = c0q + 16 + 16 * b, sc1 = c0q + 16 + 16 * b1;
+      double bv0[4], bv1[4];
+      v4d x0, x1;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        bv0[kk] = P2[(16 * b + (l & 15)) * PP + 4 * kk + (l >> 4)];
+        bv1[kk] = P2[(16 * b1 + (l & 15)) * PP + 4 * kk + (l >> 4)];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        x0[r] = S[(srow + (l >> 4) + 4 * r) * SP + sc0 + (l & 15)];
+        x1[r] = S[(srow + (l >> 4) + 4 * r) * SP + sc1 + (l & 15)];
+      }
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(am[kk], bv0[kk], x0, 0, 0, 0);
+        x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(am[kk], bv1[kk], x1, 0, 0, 0);
+      }
+      const bool d0 = chol && b == tr, d1 = chol && b1 == tr;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rr = (l >> 4) + 4 * r, cc = l & 15;
+        if (!d0 || cc <= rr) S[(srow + rr) * SP + sc0 + cc] = x0[r];
+        if (two && (!d1 || cc <= rr)) S[(srow + rr) * SP + sc1 + cc] = x1[r];
+      }
+    }
+  };
 
   for (int p = 0; p < NB / 16; ++p) {
     const int c0 = 16 * p;
     const int ntop = NB - 16 - c0;  // rows below the tile
     // ---- phase A: one lane per row, column elimination in registers
     long long t0 = clock64();
-    if (!(skip & 1)) {
-      // role of this lane: tile row (l < 16), other row o = 32 w + (l - 16) (16 <= l < 48), or idle
+    if (LA && w >= 3) {
+      // look-ahead: these five waves apply the rest of panel p-1's update while waves 0-2 eliminate panel p
+      if (p > 0) {
+        for (int tr = w - 3; tr < 8; tr += 5) update_row_tile(p - 1, tr, 1, NB);  // panel p-1 has 8 tile rows
+        __builtin_amdgcn_s_waitcnt(0);          // this wave's LDS traffic has completed
+        if (l == 0) __hip_atomic_fetch_add(la_flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    } else if (!(skip & 1)) {
+      // role of this lane: tile row (l < 16), other row o = 32 w + (l - 16) (16 <= l < 48; look-ahead: 48 w +
+      // (l - 16), 16 <= l < 64, three waves), or idle
       const bool is_tile = l < 16;
-      const int o = 32 * w + (l - 16);
-      const bool is_other = l >= 16 && l < 48;
+      const int o = (LA ? 48 : 32) * w + (l - 16);
+      const bool is_other = LA ? (l >= 16 && o < NB) : (l >= 16 && l < 48);
       const bool below = is_other && o < ntop;
       const int srow = is_tile ? c0 + l : (below ? c0 + 16 + o : o - ntop);  // row of S (aug: identity row r)
       // branch-free loads: every lane reads 16 in-range words of its row; a 16-bit mask per lane
@@ -276,6 +338,10 @@ __global__ __launch_bounds__(256) void potf2_aug_kernel(double* Akk, int64_t lda
         }
         double* bdp = diag_m ? bd + rrow : trash + 1;
         *bdp = bdn;
+        if (LA) {  // the dense panel copy is still being read by wave 3 until it says otherwise
+          while (__hip_atomic_load(la_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < 5 * p)
+            __builtin_amdgcn_s_sleep(1);
+        }
         if (is_other) {
           double* pp = P2 + o * PP;
 #pragma unroll
@@ -291,44 +357,8 @@ __global__ __launch_bounds__(256) void potf2_aug_kernel(double* Akk, int64_t lda
     const int Tn = ntop / 16;
     if (!(skip & 4)) {
       const int R = Tn + p + 1;
-      for (int tr = w; tr < R; tr += 4) {
-        const bool chol = tr < Tn;
-        const int prow = chol ? 16 * tr : ntop + 16 * (tr - Tn);
-        const int srow = chol ? c0 + 16 + 16 * tr : 16 * (tr - Tn);
-        const int ncol = chol ? tr + 1 : Tn;
-        double am[4];
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) am[kk] = -P2[(prow + (l & 15)) * PP + 4 * kk + (l >> 4)];
-        for (int b = 0; b < ncol; b += 2) {
-          const bool two = b + 1 < ncol;
-          const int b1 = two ? b + 1 : b;
-          const int sc0 = c0 + 16 + 16 * b, sc1 = c0 + 16 + 16 * b1;
-          double bv0[4], bv1[4];
-          v4d x0, x1;
-#pragma unroll
-          for (int kk = 0; kk < 4; ++kk) {
-            bv0[kk] = P2[(16 * b + (l & 15)) * PP + 4 * kk + (l >> 4)];
-            bv1[kk] = P2[(16 * b1 + (l & 15)) * PP + 4 * kk + (l >> 4)];
-          }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            x0[r] = S[(srow + (l >> 4) + 4 * r) * SP + sc0 + (l & 15)];
-            x1[r] = S[(srow + (l >> 4) + 4 * r) * SP + sc1 + (l & 15)];
-          }
-#pragma unroll
-          for (int kk = 0; kk < 4; ++kk) {
-            x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(am[kk], bv0[kk], x0, 0, 0, 0);
-            x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(am[kk], bv1[kk], x1, 0, 0, 0);
-          }
-          const bool d0 = chol && b == tr, d1 = chol && b1 == tr;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int rr = (l >> 4) + 4 * r, cc = l & 15;
-            if (!d0 || cc <= rr) S[(srow + rr) * SP + sc0 + cc] = x0[r];
-            if (two && (!d1 || cc <= rr)) S[(srow + rr) * SP + sc1 + cc] = x1[r];
-          }
-        }
-      }
+      // look-ahead: only the tile column panel p+1 needs now (the rest follows on wave 3 during the next phase A)
+      for (int tr = w; tr < R; tr += NT / 64) update_row_tile(p, tr, 0, LA ? 1 : NB);
     }
     __syncthreads();
     tc[3] += clock64() - t0;
@@ -340,8 +370,8 @@ __global__ __launch_bounds__(256) void potf2_aug_kernel(double* Akk, int64_t lda
   // (lower incl. diagonal).  The other triangles of those two targets are zero from allocation and
   // are never written by anyone, so they are not rewritten here.
 #pragma unroll 4
-  for (int it = 0; it < 32; ++it) {
-    const int e2 = tid + 256 * it;
+  for (int it = 0; it < NB * NB / 2 / NT; ++it) {
+    const int e2 = tid + NT * it;
     const int i = e2 >> 6, c = 2 * (e2 & 63);
     const double s0 = S[i * SP + c], s1 = S[i * SP + c + 1];
     if (c + 1 <= i) {
@@ -585,7 +615,10 @@ int gp_factorize_impl(elfihip_gp* gp) {
   }
   const size_t potf2_lds = POTF2_LDS_DOUBLES * sizeof(double);
   const size_t gemm_lds = GEMM_LDS_DOUBLES * sizeof(double);
-  ELFIHIP_TRY(enable_lds(ctx, potf2_aug_kernel, potf2_lds));
+  ELFIHIP_TRY(enable_lds(ctx, potf2_aug_kernel<false>, potf2_lds));
+  ELFIHIP_TRY(enable_lds(ctx, potf2_aug_kernel<true>, potf2_lds));
+  bool potf2_la = true;  // look-ahead form of the diagonal-block kernel (ELFIHIP_POTF2_LA=0: plain form)
+  if (const char* e = getenv("ELFIHIP_POTF2_LA")) potf2_la = atoi(e) != 0;
   PanelArgs P;
   P.A = gp->A;
   P.WT = gp->WT;
@@ -631,8 +664,12 @@ int gp_factorize_impl(elfihip_gp* gp) {
     P.k = k;
     double* Akk = gp->A + ((int64_t)k * NB) * gp->lda + (int64_t)k * NB;
     double* Wkk = gp->WT + ((int64_t)k * NB) * gp->lda + (int64_t)k * NB;
-    hipLaunchKernelGGL(potf2_aug_kernel, dim3(1), dim3(256), potf2_lds, hi, Akk, gp->lda, Wkk, gp->lda, gp->W11,
-                       gp->info, k, 0);
+    if (potf2_la)
+      hipLaunchKernelGGL(potf2_aug_kernel<true>, dim3(1), dim3(512), potf2_lds, hi, Akk, gp->lda, Wkk, gp->lda,
+                         gp->W11, gp->info, k, 0);
+    else
+      hipLaunchKernelGGL(potf2_aug_kernel<false>, dim3(1), dim3(256), potf2_lds, hi, Akk, gp->lda, Wkk, gp->lda,
+                         gp->W11, gp->info, k, 0);
     const int nrows = (nb - 1 - k) + 1 + k;  // below + y block + L^-T rows above
     hipLaunchKernelGGL(trsm_gemm_kernel, dim3(4 * nrows), dim3(256), lds32, hi, P);
     const int m = nb - 1 - k;  // block columns right of k
@@ -824,11 +861,17 @@ int elfihip_debug_potf2(elfihip_gp* gp, int skip, int reps, float* ms) {
   elfihip_ctx* ctx = gp->ctx;
   DeviceGuard g(ctx->device);
   const size_t potf2_lds = POTF2_LDS_DOUBLES * sizeof(double);
-  ELFIHIP_TRY(enable_lds(ctx, potf2_aug_kernel, potf2_lds));
+  const bool la = getenv("ELFIHIP_POTF2_LA") ? atoi(getenv("ELFIHIP_POTF2_LA")) != 0 : true;
+  ELFIHIP_TRY(enable_lds(ctx, potf2_aug_kernel<false>, potf2_lds));
+  ELFIHIP_TRY(enable_lds(ctx, potf2_aug_kernel<true>, potf2_lds));
   ELFIHIP_CHECK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   for (int r = 0; r < reps; ++r)
-    hipLaunchKernelGGL(potf2_aug_kernel, dim3(1), dim3(256), potf2_lds, ctx->stream, gp->A, gp->lda, gp->WT, gp->lda,
-                       gp->W11, gp->info, 0, skip);
+    if (la)
+      hipLaunchKernelGGL(potf2_aug_kernel<true>, dim3(1), dim3(512), potf2_lds, ctx->stream, gp->A, gp->lda, gp->WT,
+                         gp->lda, gp->W11, gp->info, 0, skip);
+    else
+      hipLaunchKernelGGL(potf2_aug_kernel<false>, dim3(1), dim3(256), potf2_lds, ctx->stream, gp->A, gp->lda, gp->WT,
+                         gp->lda, gp->W11, gp->info, 0, skip);
   ELFIHIP_CHECK_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   ELFIHIP_CHECK_HIP(ctx, hipEventSynchronize(ctx->ev1));
   ELFIHIP_CHECK_HIP(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
