@@ -506,8 +506,10 @@ __global__ __launch_bounds__(256) void trailing_update_kernel(PanelArgs P, int c
 // times the workgroups at a quarter of the latency -- this launch sits on the critical path.
 __global__ __launch_bounds__(256) void trailing_update_col_kernel(PanelArgs P, int cblk) {
   extern __shared__ __align__(16) double lds[];
+  cblk += blockIdx.y;  // a launch with gridDim.y > 1 covers consecutive block columns (fine-grained bulk pass)
   const int rb = blockIdx.x >> 2, sub = blockIdx.x & 3;
   const int mrows = P.nb - cblk;
+  if (rb >= mrows + 1 + P.ku0 + P.kun) return;
   const double* Ap;
   double* C;
   bool beta0 = false;
@@ -654,6 +656,11 @@ int gp_factorize_impl(elfihip_gp* gp) {
     group = (g_ == 2 || g_ == 4) ? g_ : 1;
   }
   const size_t lds32 = GEMM32_LDS_DOUBLES * sizeof(double);
+  // the pass over the trailing matrix in 32-row workgroups (the look-ahead column kernel over all block columns)
+  // instead of 128 x 128 tiles: measured n=6144: 6.04 -> 5.77 ms, n=8192: 11.1 -> 10.3 ms, n=12288: 29.6 -> 27.0 ms
+  // (0.58 of peak); n=4096: 3.00 -> 3.08 ms, so only from 40 block columns on
+  bool fine_bulk = nb >= 40;
+  if (const char* e = getenv("ELFIHIP_FINE_BULK")) fine_bulk = atoi(e) != 0;
   auto col_update = [&](hipStream_t s_, int cblk) {  // every row block of block column cblk, 32-row workgroups
     const int rows = (nb - cblk) + 1 + (P.ku0 + P.kun);
     hipLaunchKernelGGL(trailing_update_col_kernel, dim3(4 * rows), dim3(256), lds32, s_, P, cblk);
@@ -698,7 +705,12 @@ int gp_factorize_impl(elfihip_gp* gp) {
     if (c0 < nb) {
       const int mc = nb - c0;
       const int tiles = mc * (mc + 1) / 2 + mc + (k + 1) * mc;
-      hipLaunchKernelGGL(trailing_update_kernel, dim3(tiles), dim3(256), gemm_lds, bulk, P, c0, 0);
+      if (fine_bulk) {
+        const int rows_max = (nb - c0) + 1 + (P.ku0 + P.kun);
+        hipLaunchKernelGGL(trailing_update_col_kernel, dim3(4 * rows_max, mc), dim3(256), lds32, bulk, P, c0);
+      } else {
+        hipLaunchKernelGGL(trailing_update_kernel, dim3(tiles), dim3(256), gemm_lds, bulk, P, c0, 0);
+      }
     }
     ELFIHIP_CHECK_HIP(ctx, hipEventRecord(ctx->ev_b, bulk));
     bulk_pending = true;
