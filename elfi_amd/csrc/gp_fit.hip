@@ -538,6 +538,93 @@ __global__ __launch_bounds__(256) void trailing_update_col_kernel(PanelArgs P, i
     acc32_foreach(acc, [&](int row, int col, double v) { C[(int64_t)row * P.lda + col] -= v; });
 }
 
+// The look-ahead column again, for the launches that sit on the critical path: ONE memory round trip per workgroup.
+// A workgroup owns a 32 x 32 tile of C (16 per 128-row block: blockIdx.x = (row block, 32-row sub block, 32-column
+// slice)); its four waves split the k range [0, 128 KUN) and each lane loads the MFMA operands of its wave's quarter
+// straight from global memory -- every load of the kernel is issued before the first wait (16 KUN doubles of A, as many
+// of B and the C words per lane) -- instead of walking k through LDS one 16-deep slice per round trip.  k is permuted so
+// that a 16-byte load feeds two MFMAs (lane group q of MFMA 2o / 2o+1 holds k = 8o + 2q / + 1, the same for both
+// operands).  The wave partials meet in LDS and are summed in wave order (deterministic).  Compared with the 32 x 128
+// form above the workgroup pulls 64 KUN KiB instead of 160 KUN KiB through its CU and four times as many CUs take part.
+template <int KUN>
+__global__ __launch_bounds__(256) void lookahead_tile_kernel(PanelArgs P, int cblk) {
+  extern __shared__ __align__(16) double lds[];
+  const int t = threadIdx.x, l = t & 63, w = t >> 6;
+  cblk += blockIdx.y;  // gridDim.y consecutive block columns in one launch
+  const int rb = blockIdx.x >> 4, sub = (blockIdx.x >> 2) & 3, cs = blockIdx.x & 3;
+  const int mrows = P.nb - cblk;
+  if (rb >= mrows + 1 + P.ku0 + P.kun) return;
+  const double* Ap;
+  double* C;
+  bool beta0 = false;
+  if (rb < mrows) {
+    const int ib = cblk + rb;
+    Ap = P.A + ((int64_t)ib * NB) * P.lda + (int64_t)P.ku0 * NB;
+    C = P.A + ((int64_t)ib * NB) * P.lda + (int64_t)cblk * NB;
+  } else if (rb == mrows) {
+    Ap = P.A + ((int64_t)P.nb * NB) * P.lda + (int64_t)P.ku0 * NB;
+    C = P.A + ((int64_t)P.nb * NB) * P.lda + (int64_t)cblk * NB;
+  } else {
+    const int r = rb - mrows - 1;
+    Ap = P.WT + ((int64_t)r * NB) * P.lda + (int64_t)P.ku0 * NB;
+    C = P.WT + ((int64_t)r * NB) * P.lda + (int64_t)cblk * NB;
+    beta0 = (r >= P.ku0);  // first group that touches this L^-T row: overwrite
+  }
+  Ap += (int64_t)sub * 32 * P.lda;
+  C += (int64_t)sub * 32 * P.lda + cs * 32;
+  const double* Bp = P.A + ((int64_t)cblk * NB + cs * 32) * P.lda + (int64_t)P.ku0 * NB;
+  constexpr int KW = 32 * KUN;  // k range of one wave
+  constexpr int NO = KW / 8;    // 8-wide k slices ("octets") of that range
+  const int kb = w * KW + 2 * (l >> 4);
+  const double* pa = Ap + (int64_t)(l & 15) * P.lda + kb;
+  const double* pb = Bp + (int64_t)(l & 15) * P.lda + kb;
+  double2 a[2][NO], b[2][NO];
+#pragma unroll
+  for (int o = 0; o < NO; ++o)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      a[i][o] = *reinterpret_cast<const double2*>(pa + (int64_t)i * 16 * P.lda + 8 * o);
+      b[i][o] = *reinterpret_cast<const double2*>(pb + (int64_t)i * 16 * P.lda + 8 * o);
+    }
+  double cv[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int e = t + 256 * u;
+    cv[u] = beta0 ? 0.0 : C[(int64_t)(e >> 5) * P.lda + (e & 31)];
+  }
+  v4d acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int o = 0; o < NO; ++o)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][o].x, b[j][o].x, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][o].y, b[j][o].y, acc[i][j], 0, 0, 0);
+      }
+  constexpr int TP = 33;  // pitch of a 32 x 32 partial in LDS
+  double* part = lds + w * 32 * TP;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part[(i * 16 + (l >> 4) + 4 * r) * TP + j * 16 + (l & 15)] = acc[i][j][r];
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int e = t + 256 * u;
+    const int o = (e >> 5) * TP + (e & 31);
+    const double s = ((lds[o] + lds[32 * TP + o]) + lds[2 * 32 * TP + o]) + lds[3 * 32 * TP + o];
+    C[(int64_t)(e >> 5) * P.lda + (e & 31)] = cv[u] - s;
+  }
+}
+constexpr size_t LOOKAHEAD_TILE_LDS = 4 * 32 * 33 * sizeof(double);
+
 // --------------------------------------------------------------- alpha, logdet, y^T K^-1 y
 // alpha_i = sum_{k >= i} WT[i][k] z_k : one wavefront per row, coalesced along k.
 __global__ void alpha_kernel(const double* WT, const double* z, double* alpha, int64_t n, int64_t np, int64_t lda) {
@@ -627,11 +714,11 @@ int gp_factorize_impl(elfihip_gp* gp) {
   P.W11 = gp->W11;
   P.lda = gp->lda;
   P.nb = nb;
-  // Two streams besides the caller's: `hi` carries the critical path  potf2(k) -> trsm(k) -> update of
-  // block column k+1  and is confined (CU mask) to a few reserved XCDs, `bulk` carries the rest of the
-  // trailing update (block columns >= k+2) on the other XCDs, overlapping the next panel
-  // factorisation.  Without the partition the bulk tiles fill every CU's registers and LDS and the
-  // short critical kernels queue behind them (rocprof: 41 us for a 5 us column update).
+  // Two streams besides the caller's: `hi` (high priority) carries the critical path  potf2(k) -> trsm(k) -> update
+  // of block column k+1, `bulk` carries the rest of the trailing update (block columns >= k+2), overlapping the next
+  // panel factorisation.  (CU masks are not honoured on this stack -- DESIGN.md section 7 -- so the streams differ in
+  // priority only: a critical kernel that meets a running bulk pass waits for its workgroups to retire, rocprof:
+  // trsm 8 us alone, 25-30 us inside a pass.)
   // Hazards: the column-(k+1) update must follow the previous bulk update (same tiles), the bulk
   // update must follow trsm(k) (reads its panels).
   ELFIHIP_TRY(ctx_aux(ctx));
@@ -661,9 +748,22 @@ int gp_factorize_impl(elfihip_gp* gp) {
   // (0.58 of peak); n=4096: 3.00 -> 3.08 ms, so only from 40 block columns on
   bool fine_bulk = nb >= 40;
   if (const char* e = getenv("ELFIHIP_FINE_BULK")) fine_bulk = atoi(e) != 0;
-  auto col_update = [&](hipStream_t s_, int cblk) {  // every row block of block column cblk, 32-row workgroups
+  // Up to 8 block columns (n <= 1024) the trailing matrix is so small that one launch per panel updates all of it in the
+  // time of a look-ahead column: everything stays on the critical stream, no hand-offs between streams (each costs
+  // about 6 us on the chain).  Measured: n=512: 0.364 -> 0.335 ms, n=1024: 0.633 -> 0.597 ms, n=2048: no change.
+  const bool one_stream = nb <= 8;
+  // every row block of block columns [cblk, cblk + ncol), 32-row workgroups
+  auto col_update = [&](hipStream_t s_, int cblk, int ncol = 1) {
     const int rows = (nb - cblk) + 1 + (P.ku0 + P.kun);
-    hipLaunchKernelGGL(trailing_update_col_kernel, dim3(4 * rows), dim3(256), lds32, s_, P, cblk);
+    if (P.kun > 2) {  // the one-round-trip form needs 64 kun registers per lane for its operands
+      hipLaunchKernelGGL(trailing_update_col_kernel, dim3(4 * rows, ncol), dim3(256), lds32, s_, P, cblk);
+      return;
+    }
+    const dim3 grid(16 * rows, ncol), block(256);
+    if (P.kun == 1)
+      hipLaunchKernelGGL(lookahead_tile_kernel<1>, grid, block, LOOKAHEAD_TILE_LDS, s_, P, cblk);
+    else
+      hipLaunchKernelGGL(lookahead_tile_kernel<2>, grid, block, LOOKAHEAD_TILE_LDS, s_, P, cblk);
   };
   int g0 = 0;              // first panel of the current group
   int urgent_pending = 0;  // window columns of this group still guarded by ev_u[0..)
@@ -681,6 +781,12 @@ int gp_factorize_impl(elfihip_gp* gp) {
     hipLaunchKernelGGL(trsm_gemm_kernel, dim3(4 * nrows), dim3(256), lds32, hi, P);
     const int m = nb - 1 - k;  // block columns right of k
     if (m == 0) break;
+    if (one_stream) {
+      P.ku0 = k;
+      P.kun = 1;
+      col_update(hi, k + 1, m);
+      continue;
+    }
     const int j = k - g0;      // position inside the group
     P.ku0 = g0;
     P.kun = j + 1;
