@@ -551,7 +551,10 @@ __global__ __launch_bounds__(256) void lookahead_tile_kernel(PanelArgs P, int cb
   extern __shared__ __align__(16) double lds[];
   const int t = threadIdx.x, l = t & 63, w = t >> 6;
   cblk += blockIdx.y;  // gridDim.y consecutive block columns in one launch
-  const int rb = blockIdx.x >> 4, sub = (blockIdx.x >> 2) & 3, cs = blockIdx.x & 3;
+  // workgroups go round-robin over the 8 XCDs: renumber so that the four column slices of one 32-row sub block (the
+  // same rows of A) run on the same XCD and share its L2 (gridDim.x is a multiple of 16)
+  const int lb = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int rb = lb >> 4, sub = (lb >> 2) & 3, cs = lb & 3;
   const int mrows = P.nb - cblk;
   if (rb >= mrows + 1 + P.ku0 + P.kun) return;
   const double* Ap;
