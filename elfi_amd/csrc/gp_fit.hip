@@ -400,6 +400,268 @@ __global__ __launch_bounds__(LA ? 512 : 256) void potf2_aug_kernel(double* Akk, 
   }
 }
 
+// ---- the same factorisation with the trailing tiles of the block held in REGISTERS ----
+// The 128 x 128 working block (both triangles, as above) is 8 x 8 tiles of 16 x 16.  In potf2_aug_kernel every rank-16
+// update reads and rewrites its tiles in LDS -- eight times per tile, with a 4-way bank conflict on the 129-double pitch
+// -- and that LDS traffic, not the elimination (0.6 us per panel), is what the 41 us of the kernel are made of.  Here:
+//   * waves 3.. ("update waves") own the 64 tiles, dealt round-robin along tile columns; a tile lives in the MFMA
+//     accumulator layout in 4 registers per lane from the first load to the moment its column is eliminated;
+//   * waves 0-2 run phase A of panel p exactly as above (one lane per row), reading the tile column from a small LDS
+//     panel PB (128 x 16) and writing the solved panel (i) densely into P2 (double-buffered) for the updates and
+//     (ii) straight to global memory -- L11, L11^-T and W11 = L11^-1 entries are final once their column is eliminated,
+//     so there is no write-out pass and no global store on the critical path (barriers wait for LDS traffic only);
+//   * after phase A(p) the owners of tile column p+1 apply panel p and publish their tiles into PB (U1, one tile per
+//     wave), then phase A(p+1) starts while the update waves apply panel p to the remaining tiles (U2).
+// LDS: PB 17 KiB + P2 37 KiB; per panel about 120 KiB of LDS traffic instead of about 370 KiB-equivalents.
+constexpr int PBP = 17;  // pitch of the tile-column panel PB
+constexpr int POTF2T_LDS_DOUBLES = NB * PBP + 2 * NB * PP + 2 * 16 * PBP;
+
+__device__ __forceinline__ void lds_barrier() {
+  // s_barrier that waits for this wave's LDS traffic only: global stores stay in flight (__syncthreads would drain them)
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void potf2_tiles_kernel(double* Akk, int64_t lda, double* Wkk, int64_t ldw, double* W11,
+                                                         int* info, int kblock) {
+  constexpr int NA = 3;              // phase-A waves
+  constexpr int NU = NT / 64 - NA;   // update waves
+  constexpr int NS = (64 + NU - 1) / NU;  // tile slots per update wave
+  extern __shared__ __align__(16) double sm[];
+  double* PB = sm;
+  double* P2 = PB + NB * PBP;
+  double* TB = P2 + 2 * NB * PP;  // 2 x (16 x PBP): the tile rows of the solved panel
+  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
+  const bool upd = w >= NA;
+  const int u = w - NA;
+  const int lr = l >> 4, lc = l & 15;
+  v4d x[NS];
+  // tile t = u + NU s of this wave: column C = t >> 3, row R = t & 7
+  auto publish = [&](const v4d& v, int R) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) PB[(16 * R + lr + 4 * r) * PBP + lc] = v[r];
+  };
+  // x(R, C) -= panel_q(R) panel_q(C)^T for an active tile: C > q and (R >= C (Cholesky part) or R <= q (L^-T part))
+  auto apply = [&](v4d& v, int R, int C, int q, const double* P2q) {
+    const int arow = (R >= C) ? 16 * (R - q - 1) : (NB - 16 - 16 * q) + 16 * R;
+    const int brow = 16 * (C - q - 1);
+    double am[4], bv[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      am[kk] = -P2q[(arow + lc) * PP + 4 * kk + lr];
+      bv[kk] = P2q[(brow + lc) * PP + 4 * kk + lr];
+    }
+    v4d n = v;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) n = __builtin_amdgcn_mfma_f64_16x16x4f64(am[kk], bv[kk], n, 0, 0, 0);
+    if (R == C) {  // diagonal tile: its strict upper part belongs to the L^-T rows of a later panel
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = (lc <= lr + 4 * r) ? n[r] : v[r];
+    } else {
+      v = n;
+    }
+  };
+  // Solved panel q -> global memory, by the update waves, off the critical path (coalesced: 8 rows x 128 bytes per
+  // instruction; a lane-per-row store from phase A costs 64 cache lines per instruction, 1.5 us per panel).
+  //   rows below the tile: L11 entries;  L^-T rows r < 16 q + 16: entries (r, j >= r) into WT's diagonal block and,
+  //   transposed, into W11 = L11^-1;  tile rows: lower triangle of the diagonal tile of L11.
+  auto write_out = [&](int q) {
+    const int c0 = 16 * q, ntop = NB - 16 - c0, naug = c0 + 16;
+    const double* P2q = P2 + (q & 1) * NB * PP;
+    const double* tb = TB + (q & 1) * 16 * PBP;
+    const int sub = l >> 3, pair = l & 7;
+    const int j0 = u, nj = NU;
+    // items are dealt round-robin and taken four at a time: four LDS reads in flight, then four stores
+    // (a) rows below the tile, 8 rows x 128 bytes per item
+    for (int b0 = j0; 8 * b0 < ntop; b0 += 4 * nj) {
+      double2 v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int o = 8 * (b0 + e * nj) + sub;
+        v[e] = *reinterpret_cast<const double2*>(P2q + (o < ntop ? o : 0) * PP + 2 * pair);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int o = 8 * (b0 + e * nj) + sub;
+        if (o < ntop) *reinterpret_cast<double2*>(Akk + ((int64_t)(c0 + 16 + o) * lda + c0 + 2 * pair)) = v[e];
+      }
+    }
+    // (b) L^-T rows r < naug: entries (r, j >= r) of WT's diagonal block
+    for (int b0 = j0; 8 * b0 < naug; b0 += 4 * nj) {
+      double2 v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 8 * (b0 + e * nj) + sub;
+        v[e] = *reinterpret_cast<const double2*>(P2q + (ntop + (r < naug ? r : 0)) * PP + 2 * pair);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 8 * (b0 + e * nj) + sub;
+        double* dst = Wkk + ((int64_t)r * ldw + c0 + 2 * pair);
+        const int j = c0 + 2 * pair;
+        if (r < naug) {
+          if (j >= r)
+            *reinterpret_cast<double2*>(dst) = v[e];
+          else if (j + 1 >= r)
+            dst[1] = v[e].y;
+        }
+      }
+    }
+    // (c) the same entries transposed into W11 = L11^-1: item = (column c, 64 rows)
+    const int nh = (naug + 63) >> 6;
+    for (int b0 = j0; b0 < 16 * nh; b0 += 4 * nj) {
+      double v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int idx = b0 + e * nj;
+        const int c = nh == 1 ? idx : idx >> 1, r = (nh == 1 ? 0 : 64 * (idx & 1)) + l;
+        v[e] = P2q[(ntop + (r < naug ? r : 0)) * PP + (c & 15)];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int idx = b0 + e * nj;
+        const int c = nh == 1 ? idx : idx >> 1, r = (nh == 1 ? 0 : 64 * (idx & 1)) + l;
+        if (idx < 16 * nh && r < naug && c0 + c >= r) W11[(c0 + c) * NB + r] = v[e];
+      }
+    }
+    // (d) the tile rows: lower triangle of the diagonal tile of L11
+    if (j0 == nj - 1) {
+      const int i = l >> 2;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = 4 * (l & 3) + e;
+        if (c <= i) Akk[(int64_t)(c0 + i) * lda + c0 + c] = tb[i * PBP + c];
+      }
+    }
+  };
+  int bad = 0;
+  // the two roles are separate loops (not one loop with a branch inside) so that the registers of one role are not
+  // live in the other: same number of barriers on both sides
+  if (upd) {
+#pragma unroll
+    for (int s_ = 0; s_ < NS; ++s_) {
+      const int t = u + NU * s_;
+      x[s_] = (v4d){0.0, 0.0, 0.0, 0.0};
+      if (t < 64) {
+        const int C = t >> 3, R = t & 7;
+        if (C <= R) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = lr + 4 * r;
+            const double v = Akk[(int64_t)(16 * R + row) * lda + 16 * C + lc];
+            x[s_][r] = (R != C || lc <= row) ? v : 0.0;
+          }
+        }
+        if (C == 0) publish(x[s_], R);
+      }
+    }
+    lds_barrier();
+    for (int p = 0; p < NB / 16; ++p) {
+      double* P2w = P2 + (p & 1) * NB * PP;
+      // U2 of the previous panel on the waves of the SIMD without a phase-A wave: every tile right of column p (column p
+      // itself was brought up to date in U1)
+      if (p > 0) {
+        const double* P2r = P2 + ((p - 1) & 1) * NB * PP;
+#pragma unroll
+        for (int s_ = 0; s_ < NS; ++s_) {
+          const int t = u + NU * s_;
+          const int C = t >> 3, R = t & 7;
+          if (t < 64 && C > p && (R >= C || R <= p - 1)) apply(x[s_], R, C, p - 1, P2r);
+        }
+        write_out(p - 1);
+      }
+      lds_barrier();
+      // U1: tile column p+1 receives panel p and goes to PB for the next phase A
+      if (p + 1 < NB / 16) {
+#pragma unroll
+        for (int s_ = 0; s_ < NS; ++s_) {
+          const int t = u + NU * s_;
+          const int C = t >> 3, R = t & 7;
+          if (t < 64 && C == p + 1) {
+            apply(x[s_], R, C, p, P2w);
+            publish(x[s_], R);
+          }
+        }
+      }
+      lds_barrier();
+    }
+    write_out(NB / 16 - 1);
+  } else {
+    lds_barrier();
+    for (int p = 0; p < NB / 16; ++p) {
+      const int c0 = 16 * p;
+      const int ntop = NB - 16 - c0;  // rows below the tile
+      double* P2w = P2 + (p & 1) * NB * PP;
+      // ---- phase A (see potf2_aug_kernel): one lane per row of the tile column, elimination in registers
+      const bool is_tile = l < 16;
+      const int o = 48 * w + (l - 16);
+      const bool is_other = l >= 16 && o < NB;
+      const bool below = is_other && o < ntop;
+      const int srow = is_tile ? c0 + l : (below ? c0 + 16 + o : o - ntop);
+      const bool is_aug = is_other && !below;
+      const bool live = is_tile || is_other;
+      const int rrow = live ? srow : 0;
+      const int t = srow - c0;
+      const unsigned upto_l = (2u << (l & 15)) - 1u;
+      const unsigned right_of_diag = t < 0 ? 0xFFFFu : (t >= 15 ? 0u : (0xFFFFu & ~((2u << (t & 15)) - 1u)));
+      const unsigned keep_r = is_tile ? upto_l : (below ? 0xFFFFu : (is_aug ? right_of_diag : 0u));
+      const unsigned diag_m = (is_aug && t >= 0 && t < 16) ? (1u << (t & 15)) : 0u;
+      const double* rp = PB + rrow * PBP;
+      double a[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) a[c] = rp[c];
+      asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
+                        "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]),
+                        "+v"(a[15]));
+#pragma unroll
+      for (int c = 0; c < 16; ++c) a[c] = ((keep_r >> c) & 1u) ? a[c] : (((diag_m >> c) & 1u) ? 1.0 : 0.0);
+      double sdiag = 0.0;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        double acc0 = a[c], acc1 = 0.0;
+#pragma unroll
+        for (int j = 0; j < c; ++j) {
+          const double lcj = readlane_f64(a[j], c);
+          if (j & 1)
+            acc1 = fma(-a[j], lcj, acc1);
+          else
+            acc0 = fma(-a[j], lcj, acc0);
+        }
+        a[c] = acc0 + acc1;
+        const double pc = readlane_f64(a[c], c);
+        double yc = __builtin_amdgcn_rsq(pc);
+        const double hc = -0.5 * pc;
+        yc = yc * fma(hc * yc, yc, 1.5);
+        yc = yc * fma(hc * yc, yc, 1.5);
+        if (!(pc > 0.0) && bad == 0) bad = kblock * NB + c0 + c + 1;
+        a[c] = a[c] * yc;
+        double sc = pc * yc;
+        sc = fma(0.5 * fma(-sc, sc, pc), yc, sc);
+        if (l == c) sdiag = sc;
+      }
+      if (is_tile) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+          if (c == l) a[c] = sdiag;
+      }
+      // the solved panel: densely into P2 for the updates ...
+      if (is_other) {
+        double* pp = P2w + o * PP;
+#pragma unroll
+        for (int c = 0; c < 16; c += 2) *reinterpret_cast<double2*>(pp + c) = make_double2(a[c], a[c + 1]);
+      }
+      if (is_tile && w == 0) {  // ... and the tile rows next to it (the update waves carry both to global memory)
+        double* tb = TB + (p & 1) * 16 * PBP + l * PBP;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) tb[c] = a[c];
+      }
+      lds_barrier();
+      lds_barrier();
+    }
+  }
+  if (bad != 0 && tid == 0) atomicCAS(info, 0, bad);
+}
+
 // --------------------------------------------------------------- panel solve on the matrix cores
 // Row block list for block column k: A row blocks k+1..nb-1, the y block, then WT row blocks 0..k-1.
 // Each workgroup: P <- P * W11^T, i.e. P[x][c] = sum_j P[x][j] W11[c][j]  (NT GEMM, K = 128, in place).
@@ -709,8 +971,12 @@ int gp_factorize_impl(elfihip_gp* gp) {
   const size_t gemm_lds = GEMM_LDS_DOUBLES * sizeof(double);
   ELFIHIP_TRY(enable_lds(ctx, potf2_aug_kernel<false>, potf2_lds));
   ELFIHIP_TRY(enable_lds(ctx, potf2_aug_kernel<true>, potf2_lds));
-  bool potf2_la = true;  // look-ahead form of the diagonal-block kernel (ELFIHIP_POTF2_LA=0: plain form)
+  // diagonal-block kernel: tiles in registers (default; measured 37 us per block), ELFIHIP_POTF2_TILES=0 selects the
+  // LDS-resident form (43 us; with ELFIHIP_POTF2_LA=0 its plain variant, 56 us)
+  bool potf2_la = true;
   if (const char* e = getenv("ELFIHIP_POTF2_LA")) potf2_la = atoi(e) != 0;
+  bool potf2_tiles = true;
+  if (const char* e = getenv("ELFIHIP_POTF2_TILES")) potf2_tiles = atoi(e) != 0;
   PanelArgs P;
   P.A = gp->A;
   P.WT = gp->WT;
@@ -774,7 +1040,10 @@ int gp_factorize_impl(elfihip_gp* gp) {
     P.k = k;
     double* Akk = gp->A + ((int64_t)k * NB) * gp->lda + (int64_t)k * NB;
     double* Wkk = gp->WT + ((int64_t)k * NB) * gp->lda + (int64_t)k * NB;
-    if (potf2_la)
+    if (potf2_tiles)
+      hipLaunchKernelGGL(potf2_tiles_kernel<1024>, dim3(1), dim3(1024), POTF2T_LDS_DOUBLES * sizeof(double), hi, Akk,
+                         gp->lda, Wkk, gp->lda, gp->W11, gp->info, k);
+    else if (potf2_la)
       hipLaunchKernelGGL(potf2_aug_kernel<true>, dim3(1), dim3(512), potf2_lds, hi, Akk, gp->lda, Wkk, gp->lda,
                          gp->W11, gp->info, k, 0);
     else
@@ -977,17 +1246,21 @@ int elfihip_gp_factorize(elfihip_gp* gp, double* log_marginal) {
   return ELFIHIP_OK;
 }
 
-// Developer probe: time `reps` launches of the diagonal-block kernel with phases masked out.
+// Developer probe: time `reps` launches of the diagonal-block kernel (the LDS-resident forms with phases masked out).
 int elfihip_debug_potf2(elfihip_gp* gp, int skip, int reps, float* ms) {
   elfihip_ctx* ctx = gp->ctx;
   DeviceGuard g(ctx->device);
   const size_t potf2_lds = POTF2_LDS_DOUBLES * sizeof(double);
   const bool la = getenv("ELFIHIP_POTF2_LA") ? atoi(getenv("ELFIHIP_POTF2_LA")) != 0 : true;
+  const bool tiles = getenv("ELFIHIP_POTF2_TILES") ? atoi(getenv("ELFIHIP_POTF2_TILES")) != 0 : true;
   ELFIHIP_TRY(enable_lds(ctx, potf2_aug_kernel<false>, potf2_lds));
   ELFIHIP_TRY(enable_lds(ctx, potf2_aug_kernel<true>, potf2_lds));
   ELFIHIP_CHECK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   for (int r = 0; r < reps; ++r)
-    if (la)
+    if (tiles)
+      hipLaunchKernelGGL(potf2_tiles_kernel<1024>, dim3(1), dim3(1024), POTF2T_LDS_DOUBLES * sizeof(double), ctx->stream,
+                         gp->A, gp->lda, gp->WT, gp->lda, gp->W11, gp->info, 0);
+    else if (la)
       hipLaunchKernelGGL(potf2_aug_kernel<true>, dim3(1), dim3(512), potf2_lds, ctx->stream, gp->A, gp->lda, gp->WT,
                          gp->lda, gp->W11, gp->info, 0, skip);
     else
@@ -997,7 +1270,7 @@ int elfihip_debug_potf2(elfihip_gp* gp, int skip, int reps, float* ms) {
   ELFIHIP_CHECK_HIP(ctx, hipEventSynchronize(ctx->ev1));
   ELFIHIP_CHECK_HIP(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
   *ms /= (float)reps;
-  if (skip & 8) {
+  if ((skip & 8) && !tiles) {
     double dbg[6];
     ELFIHIP_CHECK_HIP(ctx, hipMemcpy(dbg, gp->W11 + NB * NB, sizeof dbg, hipMemcpyDeviceToHost));
     fprintf(stderr, "potf2 cycles: A-load %.0f A-elim %.0f A-store+barrier %.0f B+barrier %.0f | loop-end %.0f total %.0f\n", dbg[0],
