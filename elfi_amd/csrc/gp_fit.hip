@@ -1006,7 +1006,11 @@ int gp_factorize_impl(elfihip_gp* gp) {
   // needs), then the rest.
   // measured rebuild times, G = 1 / 2 / 4:  n=4096: 3.38 / 3.30 / 3.36 ms;  n=8192: 15.3 / 12.2 / 11.7 ms;
   // n=12288: 48.1 / 35.1 / 30.0 ms (41 TFLOP/s)
-  int group = nb >= 48 ? 4 : (nb >= 24 ? 2 : 1);
+  // (after the register-resident diagonal-block kernel, fit in ms for G = 1 / 2 / 4 with the pass over C in 128 x 128
+  // tiles: n=2048: 1.29 / 1.16 / 1.21, n=3072: 2.01 / 1.77 / 1.88, n=4096: 3.07 / 2.68 / 2.67, n=4608: 4.02 / 3.41 / 3.23;
+  // with the pass in 32-row workgroups: n=2048: 1.07 / 1.09 / 1.18, n=3072: 1.67 / 1.74 / 1.86, n=4096: 2.72 / 2.70 /
+  // 2.83, n=4608: 3.25 / 3.27 / 3.30 -- below 30 block columns single panels with the fine pass win, from 30 on groups)
+  int group = nb >= 48 ? 4 : (nb >= 40 ? 2 : (nb >= 30 ? 4 : 1));
   if (const char* e = getenv("ELFIHIP_PANEL_GROUP")) {
     const int g_ = atoi(e);
     group = (g_ == 2 || g_ == 4) ? g_ : 1;
@@ -1014,8 +1018,9 @@ int gp_factorize_impl(elfihip_gp* gp) {
   const size_t lds32 = GEMM32_LDS_DOUBLES * sizeof(double);
   // the pass over the trailing matrix in 32-row workgroups (the look-ahead column kernel over all block columns)
   // instead of 128 x 128 tiles: measured n=6144: 6.04 -> 5.77 ms, n=8192: 11.1 -> 10.3 ms, n=12288: 29.6 -> 27.0 ms
-  // (0.58 of peak); n=4096: 3.00 -> 3.08 ms, so only from 40 block columns on
-  bool fine_bulk = nb >= 40;
+  // (0.58 of peak); also below 30 block columns, where short-lived workgroups let the critical kernels in sooner
+  // (n=2048: 1.29 -> 1.07 ms, n=3072: 1.77 -> 1.67 ms); in between the grouped pass in 128 x 128 tiles is ahead
+  bool fine_bulk = nb < 30 || nb >= 40;
   if (const char* e = getenv("ELFIHIP_FINE_BULK")) fine_bulk = atoi(e) != 0;
   // Up to 8 block columns (n <= 1024) the trailing matrix is so small that one launch per panel updates all of it in the
   // time of a look-ahead column: everything stays on the critical stream, no hand-offs between streams (each costs
