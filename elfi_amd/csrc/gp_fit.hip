@@ -615,7 +615,6 @@ __global__ __launch_bounds__(NT) void potf2_tiles_kernel(double* Akk, int64_t ld
                         "+v"(a[15]));
 #pragma unroll
       for (int c = 0; c < 16; ++c) a[c] = ((keep_r >> c) & 1u) ? a[c] : (((diag_m >> c) & 1u) ? 1.0 : 0.0);
-      double sdiag = 0.0;
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
         double acc0 = a[c], acc1 = 0.0;
@@ -628,21 +627,17 @@ __global__ __launch_bounds__(NT) void potf2_tiles_kernel(double* Akk, int64_t ld
             acc0 = fma(-a[j], lcj, acc0);
         }
         a[c] = acc0 + acc1;
+        // pivot: a[c] / sqrt(p) with ONE third-order step on the 24-bit v_rsq_f64 seed y0 (scripts/native/rsq_probe.hip:
+        // 1.25 ulp): e = 1 - p y0^2, 1/sqrt(p) = y0 (1 + e/2 + 3 e^2/8).  Four dependent operations from the seed to
+        // the scaled column instead of seven with two Newton steps -- this chain is what a panel's time is made of.
         const double pc = readlane_f64(a[c], c);
-        double yc = __builtin_amdgcn_rsq(pc);
-        const double hc = -0.5 * pc;
-        yc = yc * fma(hc * yc, yc, 1.5);
-        yc = yc * fma(hc * yc, yc, 1.5);
+        const double y0 = __builtin_amdgcn_rsq(pc);
+        const double ay0 = a[c] * y0;
+        const double tc_ = pc * y0;
+        const double ec = fma(-tc_, y0, 1.0);
+        const double sc_ = fma(0.375, ec, 0.5);
         if (!(pc > 0.0) && bad == 0) bad = kblock * NB + c0 + c + 1;
-        a[c] = a[c] * yc;
-        double sc = pc * yc;
-        sc = fma(0.5 * fma(-sc, sc, pc), yc, sc);
-        if (l == c) sdiag = sc;
-      }
-      if (is_tile) {
-#pragma unroll
-        for (int c = 0; c < 16; ++c)
-          if (c == l) a[c] = sdiag;
+        a[c] = fma(ay0 * ec, sc_, ay0);  // on tile row c this is p / sqrt(p): the diagonal of the factor
       }
       // the solved panel: densely into P2 for the updates ...
       if (is_other) {
