@@ -27,6 +27,9 @@ import os
 import sys
 import time
 
+# the host driver of these boxes supports dmabuf IPC only: without this RCCL fails in hipIpcGetMemHandle (N > 1)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for _p in (ROOT, os.path.join(ROOT, "oracle")):
     if _p not in sys.path:
