@@ -11,10 +11,12 @@ def _ref(d, k):
     return d[order], order
 
 
+@pytest.mark.parametrize('form', ['resident', 'nine-launch'])
 @pytest.mark.parametrize('n,k', [(1, 1), (10, 3), (1000, 1000), (1000, 5000), (4097, 100), (10**6, 1000),
-                                 (10**6, 1), (300000, 10000)])
-def test_smallest_k_matches_numpy(hip_ctx, n, k):
+                                 (10**6, 1), (300000, 10000), (2 * 10**6 + 17, 64)])
+def test_smallest_k_matches_numpy(hip_ctx, monkeypatch, form, n, k):
     import elfi_amd
+    monkeypatch.setenv('ELFIHIP_TOPK_MULTI', '1' if form == 'nine-launch' else '0')
     rs = np.random.RandomState(n + k)
     d = np.abs(rs.randn(n)) * rs.uniform(0.1, 10)
     vals, idx = elfi_amd.smallest_k(d, k)
@@ -22,8 +24,10 @@ def test_smallest_k_matches_numpy(hip_ctx, n, k):
     assert np.array_equal(vals, rv) and np.array_equal(idx, ri)
 
 
-def test_smallest_k_ties_negatives_nan_inf(hip_ctx):
+@pytest.mark.parametrize('form', ['resident', 'nine-launch'])
+def test_smallest_k_ties_negatives_nan_inf(hip_ctx, monkeypatch, form):
     import elfi_amd
+    monkeypatch.setenv('ELFIHIP_TOPK_MULTI', '1' if form == 'nine-launch' else '0')
     rs = np.random.RandomState(0)
     d = rs.randint(-5, 5, 20000).astype(float)            # massive ties, negative values
     d[::97] = np.nan
@@ -59,3 +63,15 @@ def test_merge_batch_equals_the_reference_merge(hip_ctx):
         for k_ in ref:
             assert np.array_equal(state[k_], ref[k_][:n_samples]), (b, k_)
     assert np.all(np.diff(state['d']) >= 0)
+
+
+def test_smallest_k_many_equal_keys_large(hip_ctx):
+    """10^6 keys with 7 distinct values: the prefix class stays large, so the resident kernel runs all its passes and
+    the cut falls inside a run of equal keys (lowest rows win)."""
+    import elfi_amd
+    rs = np.random.RandomState(5)
+    d = rs.randint(0, 7, 10**6).astype(float) * 0.25
+    for k in (1, 1000, 150000):
+        vals, idx = elfi_amd.smallest_k(d, k)
+        rv, ri = _ref(d, k)
+        assert np.array_equal(idx, ri) and np.array_equal(vals, rv)
