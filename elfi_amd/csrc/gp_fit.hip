@@ -803,6 +803,8 @@ __global__ __launch_bounds__(256) void trailing_update_col_kernel(PanelArgs P, i
 // that a 16-byte load feeds two MFMAs (lane group q of MFMA 2o / 2o+1 holds k = 8o + 2q / + 1, the same for both
 // operands).  The wave partials meet in LDS and are summed in wave order (deterministic).  Compared with the 32 x 128
 // form above the workgroup pulls 64 KUN KiB instead of 160 KUN KiB through its CU and four times as many CUs take part.
+// Updates deeper than 256 (panel groups of four) keep two 32-deep pieces per wave in flight and refill a buffer as soon
+// as its piece has been multiplied: two to three round trips instead of 24-32 (28-36 -> about 20 us per launch).
 template <int KUN>
 __global__ __launch_bounds__(256) void lookahead_tile_kernel(PanelArgs P, int cblk) {
   extern __shared__ __align__(16) double lds[];
@@ -834,18 +836,24 @@ __global__ __launch_bounds__(256) void lookahead_tile_kernel(PanelArgs P, int cb
   C += (int64_t)sub * 32 * P.lda + cs * 32;
   const double* Bp = P.A + ((int64_t)cblk * NB + cs * 32) * P.lda + (int64_t)P.ku0 * NB;
   constexpr int KW = 32 * KUN;  // k range of one wave
-  constexpr int NO = KW / 8;    // 8-wide k slices ("octets") of that range
+  // the wave's range in pieces of 32 (4 octets of 8 k): two pieces are in flight; for KUN <= 2 that is everything, loaded
+  // before the first wait; deeper updates refill a buffer as soon as its piece has been multiplied
+  constexpr int NO = 4;
   const int kb = w * KW + 2 * (l >> 4);
   const double* pa = Ap + (int64_t)(l & 15) * P.lda + kb;
   const double* pb = Bp + (int64_t)(l & 15) * P.lda + kb;
-  double2 a[2][NO], b[2][NO];
+  double2 a[2][2][NO], b[2][2][NO];  // [buffer][row tile][octet]
+  auto load_piece = [&](int buf, int piece) {
 #pragma unroll
-  for (int o = 0; o < NO; ++o)
+    for (int o = 0; o < NO; ++o)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      a[i][o] = *reinterpret_cast<const double2*>(pa + (int64_t)i * 16 * P.lda + 8 * o);
-      b[i][o] = *reinterpret_cast<const double2*>(pb + (int64_t)i * 16 * P.lda + 8 * o);
-    }
+      for (int i = 0; i < 2; ++i) {
+        a[buf][i][o] = *reinterpret_cast<const double2*>(pa + (int64_t)i * 16 * P.lda + 32 * piece + 8 * o);
+        b[buf][i][o] = *reinterpret_cast<const double2*>(pb + (int64_t)i * 16 * P.lda + 32 * piece + 8 * o);
+      }
+  };
+  load_piece(0, 0);
+  if (KUN > 1) load_piece(1, 1);
   double cv[4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
@@ -858,14 +866,19 @@ __global__ __launch_bounds__(256) void lookahead_tile_kernel(PanelArgs P, int cb
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-  for (int o = 0; o < NO; ++o)
+  for (int piece = 0; piece < KUN; ++piece) {
+    const int buf = piece & 1;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int o = 0; o < NO; ++o)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][o].x, b[j][o].x, acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][o].y, b[j][o].y, acc[i][j], 0, 0, 0);
-      }
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[buf][i][o].x, b[buf][j][o].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[buf][i][o].y, b[buf][j][o].y, acc[i][j], 0, 0, 0);
+        }
+    if (piece + 2 < KUN) load_piece(buf, piece + 2);
+  }
   constexpr int TP = 33;  // pitch of a 32 x 32 partial in LDS
   double* part = lds + w * 32 * TP;
 #pragma unroll
@@ -1024,15 +1037,13 @@ int gp_factorize_impl(elfihip_gp* gp) {
   // every row block of block columns [cblk, cblk + ncol), 32-row workgroups
   auto col_update = [&](hipStream_t s_, int cblk, int ncol = 1) {
     const int rows = (nb - cblk) + 1 + (P.ku0 + P.kun);
-    if (P.kun > 2) {  // the one-round-trip form needs 64 kun registers per lane for its operands
-      hipLaunchKernelGGL(trailing_update_col_kernel, dim3(4 * rows, ncol), dim3(256), lds32, s_, P, cblk);
-      return;
-    }
     const dim3 grid(16 * rows, ncol), block(256);
-    if (P.kun == 1)
-      hipLaunchKernelGGL(lookahead_tile_kernel<1>, grid, block, LOOKAHEAD_TILE_LDS, s_, P, cblk);
-    else
-      hipLaunchKernelGGL(lookahead_tile_kernel<2>, grid, block, LOOKAHEAD_TILE_LDS, s_, P, cblk);
+    switch (P.kun) {
+      case 1: hipLaunchKernelGGL(lookahead_tile_kernel<1>, grid, block, LOOKAHEAD_TILE_LDS, s_, P, cblk); break;
+      case 2: hipLaunchKernelGGL(lookahead_tile_kernel<2>, grid, block, LOOKAHEAD_TILE_LDS, s_, P, cblk); break;
+      case 3: hipLaunchKernelGGL(lookahead_tile_kernel<3>, grid, block, LOOKAHEAD_TILE_LDS, s_, P, cblk); break;
+      default: hipLaunchKernelGGL(lookahead_tile_kernel<4>, grid, block, LOOKAHEAD_TILE_LDS, s_, P, cblk); break;
+    }
   };
   int g0 = 0;              // first panel of the current group
   int urgent_pending = 0;  // window columns of this group still guarded by ev_u[0..)
