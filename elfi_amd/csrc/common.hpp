@@ -56,8 +56,8 @@ struct elfihip_ctx {
   hipStream_t stream = nullptr;  // own_stream or an adopted one
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // look-ahead machinery of the GP factorisation (created on first use)
-  hipStream_t hi_stream = nullptr;    // critical path, confined to the reserved XCDs
-  hipStream_t bulk_stream = nullptr;  // bulk trailing update, every other XCD
+  hipStream_t hi_stream = nullptr;    // critical path of the sweep (high priority)
+  hipStream_t bulk_stream = nullptr;  // passes over the trailing matrix
   hipEvent_t ev_a = nullptr, ev_b = nullptr;
   hipEvent_t ev_u[4] = {nullptr, nullptr, nullptr, nullptr};  // look-ahead window columns of the next panel group
   int cu_count = 0;
