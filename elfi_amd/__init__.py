@@ -17,6 +17,7 @@ from .distance import (AdaptiveDistanceState, HipDiscrepancy, HipDistance, cdist
                        cdist_rows, nested_weighted_euclidean, welford_update)
 
 from .gmix import GMDistribution  # noqa: F401
+from .weighted import weighted_sample_quantile, weighted_var  # noqa: F401
 from .gp import GPHandle, HipGPRegression  # noqa: F401
 from .selection import merge_batch, smallest_k  # noqa: F401
 from .summaries import autocov, ma2_distance, ss_mean, ss_var  # noqa: F401

@@ -68,6 +68,9 @@ PROTOTYPES = {
                                             C.c_void_p]),
     "elfihip_gm_pdf": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_void_p,
                                  C.c_void_p, C.c_double, C.c_void_p]),
+    "elfihip_weighted_var": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),
+    "elfihip_weighted_var_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_void_p,
+                                           C.c_void_p]),
     "elfihip_row_summary": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_int,
                                       C.c_void_p]),
     "elfihip_row_summary_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_int,

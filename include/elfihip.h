@@ -146,6 +146,15 @@ int elfihip_topk_smallest_dev(elfihip_ctx* ctx, const double* dD, int64_t n, int
 int elfihip_gm_pdf(elfihip_ctx* ctx, const double* x, int64_t M, int d, const double* means, int64_t N,
                    const double* weights, const double* U, double log_norm, double* out);
 
+/* ------------------------------------------------------------------ SMC population statistics
+ * weighted_var (elfi/methods/utils.py:108-139; caller samplers.py:521-534): unbiased weighted variance of every
+ * column of the accepted sample, s2[c] = sum_i w_i (x_ic - xbar_c)^2 / (V1 - V2 / V1), xbar_c = sum_i w_i x_ic / V1,
+ * V1 = sum w, V2 = sum w^2.  X (n, m) row-major with pitch ldx; w (n) or NULL for unit weights (the reference's
+ * default); s2 (m).  Deterministic (fixed summation order). */
+int elfihip_weighted_var(elfihip_ctx* ctx, const double* X, int64_t n, int m, int64_t ldx, const double* w, double* s2);
+int elfihip_weighted_var_dev(elfihip_ctx* ctx, const double* dX, int64_t n, int m, int64_t ldx, const double* dw,
+                             double* ds2);
+
 /* ------------------------------------------------------------------ summaries
  * Row-wise summary statistics that ELFI's example models install as elfi.Summary operations, with
  * NumPy's exact (pairwise) summation order, i.e. bit-identical results:

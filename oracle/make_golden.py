@@ -226,10 +226,46 @@ def make_gm(elfi):
     print('gm_pdf:', len(cases), 'cases')
 
 
+def make_weighted(elfi):
+    """weighted_var / weighted_sample_quantile of the real reference (elfi/methods/utils.py:108-139, 379-411)."""
+    from elfi.methods.utils import weighted_sample_quantile, weighted_var
+    rs = np.random.RandomState(4242)
+    out, cases = {}, []
+    for k, (n, m, have_w) in enumerate([(7, 1, True), (500, 2, True), (500, 2, False), (6000, 5, True), (800, 64, True),
+                                        (257, 300, True)]):
+        x = rs.randn(n, m) * rs.uniform(0.1, 30, m) + rs.uniform(-5, 5, m)
+        w = rs.uniform(0.0, 3.0, n) ** 2 if have_w else None
+        xin = x[:, 0] if m == 1 else x
+        out['x_%d' % k] = xin
+        if have_w:
+            out['w_%d' % k] = w
+        out['var_%d' % k] = np.asarray(weighted_var(xin, w))
+        cases.append(k)
+    out['var_cases'] = np.array(cases)
+    # quantiles: random weights, equal weights with alpha on the boundaries k / n, ties in x, alpha = 0 and 1
+    qcases = []
+    for k, (n, equal, ties) in enumerate([(1000, False, False), (64, True, False), (64, True, True), (5, False, True),
+                                           (20000, False, False)]):
+        x = rs.randn(n)
+        if ties:
+            x = np.round(x, 1)
+        w = None if equal else rs.uniform(0.01, 1.0, n)
+        alphas = np.array([0.0, 1e-9, 0.01, 0.25, 0.5, 0.75, 0.999, 1.0] + ([j / n for j in (1, 2, n // 2, n - 1)] if equal else []))
+        out['qx_%d' % k] = x
+        if w is not None:
+            out['qw_%d' % k] = w
+        out['qalpha_%d' % k] = alphas
+        out['q_%d' % k] = np.array([weighted_sample_quantile(x, a, weights=w) for a in alphas])
+        qcases.append(k)
+    out['q_cases'] = np.array(qcases)
+    np.savez_compressed(os.path.join(GOLDEN, 'weighted_stats.npz'), **out)
+    print('weighted_stats:', len(cases), 'variance cases,', len(qcases), 'quantile cases')
+
+
 def main(argv):
     os.makedirs(GOLDEN, exist_ok=True)
     elfi = ref_shim.install()
-    which = set(argv) or {'ma2', 'adaptive', 'metrics', 'gp', 'gm', 'posterior'}
+    which = set(argv) or {'ma2', 'adaptive', 'metrics', 'gp', 'gm', 'posterior', 'weighted'}
     if 'ma2' in which:
         make_ma2(elfi)
     if 'adaptive' in which:
@@ -238,6 +274,8 @@ def main(argv):
         make_metrics(elfi)
     if 'gm' in which:
         make_gm(elfi)
+    if 'weighted' in which:
+        make_weighted(elfi)
     if 'gp' in which:
         try:
             import make_golden_gp
