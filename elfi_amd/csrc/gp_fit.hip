@@ -422,12 +422,11 @@ __device__ __forceinline__ void lds_barrier() {
 }
 
 template <int NT>
-__global__ __launch_bounds__(NT) void potf2_tiles_kernel(double* Akk, int64_t lda, double* Wkk, int64_t ldw, double* W11,
-                                                         int* info, int kblock) {
+__device__ __forceinline__ void potf2_tiles_body(double* Akk, int64_t lda, double* Wkk, int64_t ldw, double* W11, int* info,
+                                                 int kblock, double* sm) {
   constexpr int NA = 3;              // phase-A waves
   constexpr int NU = NT / 64 - NA;   // update waves
   constexpr int NS = (64 + NU - 1) / NU;  // tile slots per update wave
-  extern __shared__ __align__(16) double sm[];
   double* PB = sm;
   double* P2 = PB + NB * PBP;
   double* TB = P2 + 2 * NB * PP;  // 2 x (16 x PBP): the tile rows of the solved panel
@@ -655,6 +654,13 @@ __global__ __launch_bounds__(NT) void potf2_tiles_kernel(double* Akk, int64_t ld
     }
   }
   if (bad != 0 && tid == 0) atomicCAS(info, 0, bad);
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void potf2_tiles_kernel(double* Akk, int64_t lda, double* Wkk, int64_t ldw, double* W11,
+                                                         int* info, int kblock) {
+  extern __shared__ __align__(16) double sm[];
+  potf2_tiles_body<NT>(Akk, lda, Wkk, ldw, W11, info, kblock, sm);
 }
 
 // --------------------------------------------------------------- panel solve on the matrix cores
@@ -898,6 +904,228 @@ __global__ __launch_bounds__(256) void lookahead_tile_kernel(PanelArgs P, int cb
 }
 constexpr size_t LOOKAHEAD_TILE_LDS = 4 * 32 * 33 * sizeof(double);
 
+// out-of-line instance for the resident sweep kernel: inlined there, the block's 128 live registers meet the task
+// loop's and spill (117 VGPRs)
+__device__ __noinline__ void potf2_tiles_call(double* Akk, int64_t lda, double* Wkk, int64_t ldw, double* W11, int* info,
+                                              int kblock, double* sm) {
+  potf2_tiles_body<1024>(Akk, lda, Wkk, ldw, W11, info, kblock, sm);
+}
+
+// --------------------------------------------------------------- the whole sweep in one resident kernel
+// EXPERIMENTAL (ELFIHIP_SWEEP=1).  One 1024-thread workgroup per CU draws tasks from a statically ordered list with an
+// atomic ticket and runs them when their inputs are there:
+//   potf2(k)        diagonal block k (potf2_tiles_body)                     needs  cnt[k][k] == k
+//   trsm(rb, k)     row block rb of panel k times W11_k^T, in place         needs  potf2(k), cnt[rb][k] == prior
+//   upd(rb, c, k)   C(rb, c) -= P(rb, k) P(c, k)^T                          needs  the two solves, cnt[rb][c] == prior
+// Row blocks: 0..nb-1 the rows of A, nb the y block, nb+1+r the L^-T row r (its tile (r, c) takes panels r..c-1, the
+// first of them overwrites).  `prior` = updates a tile must have received = k for A / y rows, k - r for L^-T row r.
+// The list is a topological order with the next panel's critical tasks first (block k: potf2(k), [solve of row k+1,
+// update of tile (k+1, k+1)], rest of panel k-1, [solves and the two next columns of panel k]); a workgroup that has
+// drawn a task spins on its inputs -- the earliest unfinished task can always run, so there is no deadlock while the
+// drawn tasks' workgroups are resident (grid <= CUs, one workgroup per CU).  Spins are bounded; a time-out raises
+// `err`, every workgroup leaves and the host repeats the factorisation with the multi-launch sweep.
+// Publishing: every thread fences its stores (device scope), the workgroup synchronises, one thread stores the counter;
+// a consumer fences after it has seen the counter, before its first load.
+struct SweepTask {
+  int type, rb, c, k;
+};
+
+struct SweepArgs {
+  double* A;
+  double* WT;
+  double* w11;   // nb x (NB x NB): the inverse diagonal blocks, one per panel
+  int64_t lda;
+  int nb;
+  const SweepTask* tasks;
+  int ntasks;
+  int* sync;     // [0] ticket, [1] err, [2] diagonal blocks done, [4 .. 4 + 2nb + 1) panels solved per row block, then cnt
+  int* info;
+};
+
+__device__ __forceinline__ int sweep_load(const int* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// thread 0 waits until *p >= want (counters only grow); false after a time-out or when another workgroup gave up
+__device__ __forceinline__ bool sweep_wait(const int* p, int want, int* err) {
+  unsigned int spins = 0;
+  while (sweep_load(p) < want) {
+    __builtin_amdgcn_s_sleep(1);
+    if ((++spins & 1023u) == 0 && (sweep_load(err) != 0 || spins > (1u << 20))) {
+      __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return false;
+    }
+  }
+  return true;
+}
+
+__global__ __launch_bounds__(1024) void sweep_kernel(SweepArgs S) {
+  extern __shared__ __align__(16) double sm[];
+  __shared__ int sh_task, sh_ok;
+  const int tid = threadIdx.x, nb = S.nb;
+  int* ticket = S.sync;
+  int* err = S.sync + 1;
+  int* pdone = S.sync + 2;
+  int* solved = S.sync + 4;
+  int* cnt = solved + (2 * nb + 1);
+  auto rowptr = [&](int rb, int col) -> double* {
+    return rb <= nb ? S.A + ((int64_t)rb * NB) * S.lda + (int64_t)col * NB
+                    : S.WT + ((int64_t)(rb - nb - 1) * NB) * S.lda + (int64_t)col * NB;
+  };
+  // ONE `if (tid == 0)` region per iteration, between two barriers: with the publication of the finished task at the
+  // tail of the loop and the ticket at its head, the compiler threads lane 0 from one region into the other across the
+  // back edge and the waves of a workgroup no longer execute the same number of barriers (the kernel never returns;
+  // scripts/native/scaffold_probe.hip reproduces it).
+  int prev_type = -1, prev_a = 0, prev_b = 0;  // what the previous task has to publish (thread 0)
+  for (;;) {
+    __syncthreads();
+    if (tid == 0) {
+      if (prev_type == 0)
+        __hip_atomic_store(pdone, prev_a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else if (prev_type == 1)
+        __hip_atomic_store(solved + prev_a, prev_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else if (prev_type == 2)
+        __hip_atomic_fetch_add(cnt + prev_a, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int t = atomicAdd(ticket, 1);
+      bool ok = true;
+      if (t < S.ntasks) {
+        const SweepTask Q = S.tasks[t];
+        const int q_wt = Q.rb - nb - 1;
+        const int prior = q_wt >= 0 ? Q.k - q_wt : Q.k;
+        if (Q.type == 0) {
+          ok = sweep_wait(cnt + (int64_t)Q.k * nb + Q.k, Q.k, err);
+        } else if (Q.type == 1) {
+          ok = sweep_wait(pdone, Q.k + 1, err) && sweep_wait(cnt + (int64_t)Q.rb * nb + Q.k, prior, err);
+        } else {
+          ok = (q_wt == Q.k ? sweep_wait(pdone, Q.k + 1, err) : sweep_wait(solved + Q.rb, Q.k + 1, err)) &&
+               sweep_wait(solved + Q.c, Q.k + 1, err) && sweep_wait(cnt + (int64_t)Q.rb * nb + Q.c, prior, err);
+        }
+      }
+      sh_task = t;
+      sh_ok = ok ? 1 : 0;
+    }
+    __syncthreads();
+    const int ti = sh_task;
+    if (ti >= S.ntasks || !sh_ok) return;
+    const SweepTask T = S.tasks[ti];
+    const int r_wt = T.rb - nb - 1;  // L^-T row index (>= 0) or negative
+    if (tid < 64) __threadfence();  // acquire (one wave: the caches it invalidates are shared by the CU)
+    __syncthreads();
+    if (T.type == 0) {
+      double* Akk = S.A + ((int64_t)T.k * NB) * S.lda + (int64_t)T.k * NB;
+      double* Wkk = S.WT + ((int64_t)T.k * NB) * S.lda + (int64_t)T.k * NB;
+      potf2_tiles_call(Akk, S.lda, Wkk, S.lda, S.w11 + (int64_t)T.k * NB * NB, S.info, T.k, sm);
+      prev_a = T.k + 1;
+    } else if (T.type == 1) {
+      double* P = rowptr(T.rb, T.k);
+      GemmAcc32 acc;
+      acc.zero();
+      gemm_tile_nt16(acc, P, S.lda, S.w11 + (int64_t)T.k * NB * NB, NB, 0, NB, sm);
+      acc16_foreach(acc, [&](int row, int col, double v) {
+        __hip_atomic_store(&P[(int64_t)row * S.lda + col], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through
+      });
+      prev_a = T.rb;
+      prev_b = T.k + 1;
+    } else {
+      const double* Ap = rowptr(T.rb, T.k);
+      const double* Bp = rowptr(T.c, T.k);
+      double* C = rowptr(T.rb, T.c);
+      GemmAcc32 acc;
+      acc.zero();
+      gemm_tile_nt16(acc, Ap, S.lda, Bp, S.lda, 0, NB, sm);
+      if (r_wt == T.k)
+        acc16_foreach(acc, [&](int row, int col, double v) {
+          __hip_atomic_store(&C[(int64_t)row * S.lda + col], -v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        });
+      else
+        acc16_foreach(acc, [&](int row, int col, double v) {
+          double* q = &C[(int64_t)row * S.lda + col];
+          __hip_atomic_store(q, *q - v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        });
+      prev_a = T.rb * nb + T.c;
+    }
+    prev_type = T.type;
+    __syncthreads();
+    if (tid < 64) __threadfence();  // release: after every wave's stores have been issued and waited for
+  }
+}
+
+// The task list for nb block columns (see the order above).
+static void sweep_build_tasks(int nb, std::vector<SweepTask>* out) {
+  std::vector<SweepTask>& L = *out;
+  L.clear();
+  const int Y = nb;
+  auto wt = [&](int r) { return nb + 1 + r; };
+  auto emit_B = [&](int k) {  // the other solves of panel k, then its updates of block columns k+1 and k+2
+    for (int i = k + 2; i < nb; ++i) L.push_back({1, i, 0, k});
+    L.push_back({1, Y, 0, k});
+    for (int r = 0; r < k; ++r) L.push_back({1, wt(r), 0, k});
+    for (int c = k + 1; c <= k + 2 && c < nb; ++c) {
+      for (int i = c; i < nb; ++i)
+        if (!(i == k + 1 && c == k + 1)) L.push_back({2, i, c, k});
+      L.push_back({2, Y, c, k});
+      for (int r = 0; r <= k; ++r) L.push_back({2, wt(r), c, k});
+    }
+  };
+  auto emit_C = [&](int k) {  // the rest of panel k: block columns >= k+3
+    for (int c = k + 3; c < nb; ++c) {
+      for (int i = c; i < nb; ++i) L.push_back({2, i, c, k});
+      L.push_back({2, Y, c, k});
+      for (int r = 0; r <= k; ++r) L.push_back({2, wt(r), c, k});
+    }
+  };
+  for (int k = 0; k < nb; ++k) {
+    L.push_back({0, k, k, k});
+    if (k + 1 < nb) {
+      L.push_back({1, k + 1, 0, k});
+      L.push_back({2, k + 1, k + 1, k});
+    }
+    if (k > 0) emit_C(k - 1);
+    emit_B(k);
+  }
+}
+
+static int sweep_run(elfihip_gp* gp, int nb, hipStream_t st, bool* timed_out) {
+  elfihip_ctx* ctx = gp->ctx;
+  if (gp->sweep_nb != nb) {
+    std::vector<SweepTask> tasks;
+    sweep_build_tasks(nb, &tasks);
+    ELFIHIP_CHECK_HIP(ctx, gp->sweep_tasks.reserve(tasks.size() * sizeof(SweepTask)));
+    ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(gp->sweep_tasks.p, tasks.data(), tasks.size() * sizeof(SweepTask),
+                                          hipMemcpyHostToDevice, st));
+    ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(st));  // `tasks` is about to go out of scope
+    gp->sweep_ntasks = (int)tasks.size();
+    const size_t w11_bytes = (size_t)nb * NB * NB * sizeof(double);
+    if (gp->sweep_w11.cap < w11_bytes) {
+      ELFIHIP_CHECK_HIP(ctx, gp->sweep_w11.reserve(w11_bytes));
+      ELFIHIP_CHECK_HIP(ctx, hipMemsetAsync(gp->sweep_w11.p, 0, gp->sweep_w11.cap, st));  // upper triangles stay zero
+    }
+    gp->sweep_nb = nb;
+  }
+  const size_t sync_ints = 4 + (size_t)(2 * nb + 1) + (size_t)(2 * nb + 1) * nb;
+  ELFIHIP_CHECK_HIP(ctx, gp->sweep_sync.reserve(sync_ints * sizeof(int)));
+  ELFIHIP_CHECK_HIP(ctx, hipMemsetAsync(gp->sweep_sync.p, 0, sync_ints * sizeof(int), st));
+  SweepArgs S;
+  S.A = gp->A;
+  S.WT = gp->WT;
+  S.w11 = gp->sweep_w11.as<double>();
+  S.lda = gp->lda;
+  S.nb = nb;
+  S.tasks = gp->sweep_tasks.as<SweepTask>();
+  S.ntasks = gp->sweep_ntasks;
+  S.sync = gp->sweep_sync.as<int>();
+  S.info = gp->info;
+  const size_t lds = std::max<size_t>(POTF2T_LDS_DOUBLES, GEMM_LDS_DOUBLES) * sizeof(double);
+  const int grid = std::min(ctx->cu_count, S.ntasks);
+  hipLaunchKernelGGL(sweep_kernel, dim3(grid), dim3(1024), lds, st, S);
+  ELFIHIP_TRY(launch_status(ctx, "sweep_kernel"));
+  int flags[2] = {0, 0};
+  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(flags, gp->sweep_sync.as<int>(), sizeof flags, hipMemcpyDeviceToHost, st));
+  ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(st));
+  *timed_out = flags[1] != 0;
+  return ELFIHIP_OK;
+}
+
 // --------------------------------------------------------------- alpha, logdet, y^T K^-1 y
 // alpha_i = sum_{k >= i} WT[i][k] z_k : one wavefront per row, coalesced along k.
 __global__ void alpha_kernel(const double* WT, const double* z, double* alpha, int64_t n, int64_t np, int64_t lda) {
@@ -946,7 +1174,9 @@ static int enable_lds(elfihip_ctx* ctx, K k, size_t bytes) {
   return ELFIHIP_OK;
 }
 
-int gp_factorize_impl(elfihip_gp* gp) {
+int gp_factorize_impl(elfihip_gp* gp, bool allow_sweep);
+
+int gp_factorize_impl(elfihip_gp* gp, bool allow_sweep) {
   elfihip_ctx* ctx = gp->ctx;
   ELFIHIP_REQUIRE(ctx, gp->n > 0, "GP has no evidence");
   hipStream_t st = ctx->stream;
@@ -975,6 +1205,14 @@ int gp_factorize_impl(elfihip_gp* gp) {
     hipLaunchKernelGGL(gram_kernel, dim3((unsigned)(nt * (nt + 1) / 2)), dim3(256), lds, st, G);
     ELFIHIP_TRY(launch_status(ctx, "gram_kernel"));
   }
+  bool swept = false;
+  if (allow_sweep && getenv("ELFIHIP_SWEEP") && atoi(getenv("ELFIHIP_SWEEP")) != 0) {  // EXPERIMENTAL resident sweep
+    bool timed_out = false;
+    ELFIHIP_TRY(sweep_run(gp, nb, st, &timed_out));
+    if (timed_out) return gp_factorize_impl(gp, false);  // from the Gram matrix again, multi-launch sweep
+    swept = true;
+  }
+  if (!swept) {
   const size_t potf2_lds = POTF2_LDS_DOUBLES * sizeof(double);
   const size_t gemm_lds = GEMM_LDS_DOUBLES * sizeof(double);
   ELFIHIP_TRY(enable_lds(ctx, potf2_aug_kernel<false>, potf2_lds));
@@ -1110,6 +1348,7 @@ int gp_factorize_impl(elfihip_gp* gp) {
   ELFIHIP_CHECK_HIP(ctx, hipEventRecord(ctx->ev_b, bulk));
   ELFIHIP_CHECK_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_b, 0));
   ELFIHIP_TRY(launch_status(ctx, "cholesky sweep"));
+  }  // !swept
   const double* z = gp->A + np * gp->lda;  // row np of A: z = L^-1 y
   hipLaunchKernelGGL(alpha_kernel, dim3((unsigned)((np * 64 + 255) / 256)), dim3(256), 0, st, gp->WT, z, gp->alpha,
                      gp->n, np, gp->lda);
@@ -1191,6 +1430,9 @@ int elfihip_gp_free(elfihip_gp* gp) {
   if (gp->Pint) (void)hipFree(gp->Pint);
   gp->ws.release();
   gp->ws2.release();
+  gp->sweep_tasks.release();
+  gp->sweep_sync.release();
+  gp->sweep_w11.release();
   delete gp;
   return ELFIHIP_OK;
 }
@@ -1251,7 +1493,7 @@ int elfihip_gp_append(elfihip_gp* gp, const double* X_new, const double* y_new, 
 int elfihip_gp_factorize(elfihip_gp* gp, double* log_marginal) {
   if (!gp) return fail(nullptr, ELFIHIP_ERR_ARG, "gp is NULL");
   DeviceGuard g(gp->ctx->device);
-  ELFIHIP_TRY(gp_factorize_impl(gp));
+  ELFIHIP_TRY(gp_factorize_impl(gp, true));
   if (log_marginal)
     *log_marginal = 0.5 * (-(double)gp->n * 1.8378770664093453 /* log(2 pi) */ - gp->logdet - gp->yKy);
   return ELFIHIP_OK;

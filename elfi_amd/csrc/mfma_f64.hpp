@@ -219,4 +219,64 @@ __device__ __forceinline__ void acc32_foreach(const GemmAcc32& acc, F f) {
       for (int r = 0; r < 4; ++r) f(i * 16 + (l >> 4) + 4 * r, w * 32 + j * 16 + (l & 15), acc.c[i][j][r]);
 }
 
+// ---- the 128 x 128 tile on SIXTEEN waves (1024 threads, 4 x 4 waves of 32 x 32): the form the resident sweep kernel
+// uses, where one workgroup per CU does every kind of task.  One 16-byte load of A and one of B per thread and k-tile.
+// `lds` holds GEMM_LDS_DOUBLES doubles.
+__device__ __forceinline__ void gemm_tile_nt16(GemmAcc32& acc, const double* __restrict__ A, int64_t lda,
+                                               const double* __restrict__ B, int64_t ldb, int kbeg, int kend,
+                                               double* lds) {
+  double* As = lds;
+  double* Bs = lds + GT * GLP;
+  const int t = threadIdx.x, l = t & 63, w = t >> 6;
+  const int wr = w >> 2, wc = w & 3;
+  const double* pa = A + (int64_t)(t >> 3) * lda + 2 * (t & 7) + kbeg;
+  const double* pb = B + (int64_t)(t >> 3) * ldb + 2 * (t & 7) + kbeg;
+  double* da = As + (t >> 3) * GLP + 2 * (t & 7);
+  double* db = Bs + (t >> 3) * GLP + 2 * (t & 7);
+  double2 a0 = *reinterpret_cast<const double2*>(pa);
+  double2 b0 = *reinterpret_cast<const double2*>(pb);
+  const double* fa = As + (wr * 32 + (l & 15)) * GLP + 2 * (l >> 4);
+  const double* fb = Bs + (wc * 32 + (l & 15)) * GLP + 2 * (l >> 4);
+  for (int k0 = kbeg; k0 < kend; k0 += GK) {
+    __syncthreads();
+    *reinterpret_cast<double2*>(da) = a0;
+    *reinterpret_cast<double2*>(db) = b0;
+    __syncthreads();
+    if (k0 + GK < kend) {
+      pa += GK;
+      pb += GK;
+      a0 = *reinterpret_cast<const double2*>(pa);
+      b0 = *reinterpret_cast<const double2*>(pb);
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      double2 a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        a[i] = *reinterpret_cast<const double2*>(fa + i * 16 * GLP + 8 * h);
+        b[i] = *reinterpret_cast<const double2*>(fb + i * 16 * GLP + 8 * h);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc.c[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].x, b[j].x, acc.c[i][j], 0, 0, 0);
+          acc.c[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].y, b[j].y, acc.c[i][j], 0, 0, 0);
+        }
+    }
+  }
+}
+
+template <class F>
+__device__ __forceinline__ void acc16_foreach(const GemmAcc32& acc, F f) {
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int wr = w >> 2, wc = w & 3;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) f(wr * 32 + i * 16 + (l >> 4) + 4 * r, wc * 32 + j * 16 + (l & 15), acc.c[i][j][r]);
+}
+
 }  // namespace elfihip

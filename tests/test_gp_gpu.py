@@ -240,3 +240,23 @@ def test_against_the_reference_closed_forms(hip_ctx):
             val, grad = gp.lcb(xs, float(g['beta_%s_%d' % (tag, t)]))
             _close(val, g['lcb_%s_%d' % (tag, t)], 1e-8, 'LCB vs reference LCBSC ' + tag)
             _close(grad, g['lcbg_%s_%d' % (tag, t)], 1e-7, 'LCB gradient vs reference LCBSC ' + tag)
+
+
+@pytest.mark.parametrize('n,d', [(100, 2), (129, 3), (700, 5), (1500, 10)])
+def test_resident_sweep_form_matches_the_default_sweep(hip_ctx, monkeypatch, n, d):
+    """ELFIHIP_SWEEP=1 (experimental: the whole sweep as one resident kernel, tasks + dependency counters) against the
+    multi-launch sweep and the oracle: same factor up to summation order (K = 128 per update instead of panel groups)."""
+    X, y, bounds = _problem(n, d, seed=3)
+    monkeypatch.setenv('ELFIHIP_SWEEP', '0')
+    gp0, logz0, post = _fit(X, y, bounds)
+    xs = np.random.RandomState(4).uniform(-2, 2, (7, d))
+    m0, v0 = gp0.predict(xs)
+    monkeypatch.setenv('ELFIHIP_SWEEP', '1')
+    gp1, logz1, _ = _fit(X, y, bounds)
+    m1, v1 = gp1.predict(xs)
+    assert abs(logz1 - logz0) <= 1e-9 * abs(logz0)
+    assert abs(logz1 - post.log_marginal) <= 1e-8 * abs(logz0)
+    _close(gp1.get(0), post.L, 1e-10, 'L, resident sweep')
+    _close(gp1.get(1), post.Linv.T, 1e-9, 'L^-T, resident sweep')
+    _close(m1, m0, 1e-9, 'mean, resident vs multi-launch sweep')
+    _close(v1, v0, 1e-8, 'variance, resident vs multi-launch sweep')
