@@ -20,6 +20,7 @@
 // Flops: n^3/3 (Cholesky) + n^3/3 (L^-T) on v_mfma_f64_16x16x4_f64.
 #include "gp.hpp"
 #include "mfma_f64.hpp"
+#include "sweep_tasks.hpp"
 
 namespace elfihip {
 
@@ -926,9 +927,6 @@ __device__ __noinline__ void potf2_tiles_call(double* Akk, int64_t lda, double* 
 // `err`, every workgroup leaves and the host repeats the factorisation with the multi-launch sweep.
 // Publishing: every thread fences its stores (device scope), the workgroup synchronises, one thread stores the counter;
 // a consumer fences after it has seen the counter, before its first load.
-struct SweepTask {
-  int type, rb, c, k;
-};
 
 struct SweepArgs {
   double* A;
@@ -1047,41 +1045,6 @@ __global__ __launch_bounds__(1024) void sweep_kernel(SweepArgs S) {
     prev_type = T.type;
     __syncthreads();
     if (tid < 64) __threadfence();  // release: after every wave's stores have been issued and waited for
-  }
-}
-
-// The task list for nb block columns (see the order above).
-static void sweep_build_tasks(int nb, std::vector<SweepTask>* out) {
-  std::vector<SweepTask>& L = *out;
-  L.clear();
-  const int Y = nb;
-  auto wt = [&](int r) { return nb + 1 + r; };
-  auto emit_B = [&](int k) {  // the other solves of panel k, then its updates of block columns k+1 and k+2
-    for (int i = k + 2; i < nb; ++i) L.push_back({1, i, 0, k});
-    L.push_back({1, Y, 0, k});
-    for (int r = 0; r < k; ++r) L.push_back({1, wt(r), 0, k});
-    for (int c = k + 1; c <= k + 2 && c < nb; ++c) {
-      for (int i = c; i < nb; ++i)
-        if (!(i == k + 1 && c == k + 1)) L.push_back({2, i, c, k});
-      L.push_back({2, Y, c, k});
-      for (int r = 0; r <= k; ++r) L.push_back({2, wt(r), c, k});
-    }
-  };
-  auto emit_C = [&](int k) {  // the rest of panel k: block columns >= k+3
-    for (int c = k + 3; c < nb; ++c) {
-      for (int i = c; i < nb; ++i) L.push_back({2, i, c, k});
-      L.push_back({2, Y, c, k});
-      for (int r = 0; r <= k; ++r) L.push_back({2, wt(r), c, k});
-    }
-  };
-  for (int k = 0; k < nb; ++k) {
-    L.push_back({0, k, k, k});
-    if (k + 1 < nb) {
-      L.push_back({1, k + 1, 0, k});
-      L.push_back({2, k + 1, k + 1, k});
-    }
-    if (k > 0) emit_C(k - 1);
-    emit_B(k);
   }
 }
 
