@@ -40,7 +40,7 @@ struct elfihip_gp {
   elfihip::DevBuf ws2;      // partials and result tile of the dense product V_P^T v
   // resident sweep kernel (gp_fit.hip): task list for `sweep_nb` block columns, dependency counters, one W11 per panel
   elfihip::DevBuf sweep_tasks, sweep_sync, sweep_w11;
-  int sweep_nb = 0, sweep_ntasks = 0;
+  int sweep_nb = 0, sweep_group = 0, sweep_ntasks = 0;
   // prediction workspace (grown on demand)
   elfihip::DevBuf ws;
   int64_t ws_S = 0;

@@ -988,16 +988,9 @@ __global__ __launch_bounds__(1024) void sweep_kernel(SweepArgs S) {
       bool ok = true;
       if (t < S.ntasks) {
         const SweepTask Q = S.tasks[t];
-        const int q_wt = Q.rb - nb - 1;
-        const int prior = q_wt >= 0 ? Q.k - q_wt : Q.k;
-        if (Q.type == 0) {
-          ok = sweep_wait(cnt + (int64_t)Q.k * nb + Q.k, Q.k, err);
-        } else if (Q.type == 1) {
-          ok = sweep_wait(pdone, Q.k + 1, err) && sweep_wait(cnt + (int64_t)Q.rb * nb + Q.k, prior, err);
-        } else {
-          ok = (q_wt == Q.k ? sweep_wait(pdone, Q.k + 1, err) : sweep_wait(solved + Q.rb, Q.k + 1, err)) &&
-               sweep_wait(solved + Q.c, Q.k + 1, err) && sweep_wait(cnt + (int64_t)Q.rb * nb + Q.c, prior, err);
-        }
+        ok = sweep_wait(pdone, Q.need_pdone, err) && sweep_wait(solved + Q.rb, Q.need_rb, err) &&
+             (Q.type != 2 || sweep_wait(solved + Q.c, Q.need_c, err)) &&
+             sweep_wait(cnt + (int64_t)Q.rb * nb + (Q.type == 2 ? Q.c : Q.k0), Q.prior, err);
       }
       sh_task = t;
       sh_ok = ok ? 1 : 0;
@@ -1006,32 +999,31 @@ __global__ __launch_bounds__(1024) void sweep_kernel(SweepArgs S) {
     const int ti = sh_task;
     if (ti >= S.ntasks || !sh_ok) return;
     const SweepTask T = S.tasks[ti];
-    const int r_wt = T.rb - nb - 1;  // L^-T row index (>= 0) or negative
     if (tid < 64) __threadfence();  // acquire (one wave: the caches it invalidates are shared by the CU)
     __syncthreads();
     if (T.type == 0) {
-      double* Akk = S.A + ((int64_t)T.k * NB) * S.lda + (int64_t)T.k * NB;
-      double* Wkk = S.WT + ((int64_t)T.k * NB) * S.lda + (int64_t)T.k * NB;
-      potf2_tiles_call(Akk, S.lda, Wkk, S.lda, S.w11 + (int64_t)T.k * NB * NB, S.info, T.k, sm);
-      prev_a = T.k + 1;
+      double* Akk = S.A + ((int64_t)T.k0 * NB) * S.lda + (int64_t)T.k0 * NB;
+      double* Wkk = S.WT + ((int64_t)T.k0 * NB) * S.lda + (int64_t)T.k0 * NB;
+      potf2_tiles_call(Akk, S.lda, Wkk, S.lda, S.w11 + (int64_t)T.k0 * NB * NB, S.info, T.k0, sm);
+      prev_a = T.k0 + 1;
     } else if (T.type == 1) {
-      double* P = rowptr(T.rb, T.k);
+      double* P = rowptr(T.rb, T.k0);
       GemmAcc32 acc;
       acc.zero();
-      gemm_tile_nt16(acc, P, S.lda, S.w11 + (int64_t)T.k * NB * NB, NB, 0, NB, sm);
+      gemm_tile_nt16(acc, P, S.lda, S.w11 + (int64_t)T.k0 * NB * NB, NB, 0, NB, sm);
       acc16_foreach(acc, [&](int row, int col, double v) {
         __hip_atomic_store(&P[(int64_t)row * S.lda + col], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through
       });
       prev_a = T.rb;
-      prev_b = T.k + 1;
+      prev_b = T.k0 + 1;
     } else {
-      const double* Ap = rowptr(T.rb, T.k);
-      const double* Bp = rowptr(T.c, T.k);
+      const double* Ap = rowptr(T.rb, T.k0);
+      const double* Bp = rowptr(T.c, T.k0);
       double* C = rowptr(T.rb, T.c);
       GemmAcc32 acc;
       acc.zero();
-      gemm_tile_nt16(acc, Ap, S.lda, Bp, S.lda, 0, NB, sm);
-      if (r_wt == T.k)
+      gemm_tile_nt16(acc, Ap, S.lda, Bp, S.lda, 0, T.kun * NB, sm);
+      if (T.beta0)
         acc16_foreach(acc, [&](int row, int col, double v) {
           __hip_atomic_store(&C[(int64_t)row * S.lda + col], -v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         });
@@ -1050,9 +1042,13 @@ __global__ __launch_bounds__(1024) void sweep_kernel(SweepArgs S) {
 
 static int sweep_run(elfihip_gp* gp, int nb, hipStream_t st, bool* timed_out) {
   elfihip_ctx* ctx = gp->ctx;
-  if (gp->sweep_nb != nb) {
+  // panels per update of a tile right of them (ELFIHIP_SWEEP_GROUP).  Measured, resident kernel, G = 1 / 2 / 4:
+  // n=1024: 0.75 / 0.79 / 0.88 ms, n=4096: 3.52 / 3.45 / 3.74 ms, n=8192: 15.7 / 12.4 / 12.6 ms
+  int group = nb >= 48 ? 2 : 1;
+  if (const char* e = getenv("ELFIHIP_SWEEP_GROUP")) group = std::max(1, atoi(e));
+  if (gp->sweep_nb != nb || gp->sweep_group != group) {
     std::vector<SweepTask> tasks;
-    sweep_build_tasks(nb, &tasks);
+    sweep_build_tasks(nb, group, &tasks);
     ELFIHIP_CHECK_HIP(ctx, gp->sweep_tasks.reserve(tasks.size() * sizeof(SweepTask)));
     ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(gp->sweep_tasks.p, tasks.data(), tasks.size() * sizeof(SweepTask),
                                           hipMemcpyHostToDevice, st));
@@ -1064,6 +1060,7 @@ static int sweep_run(elfihip_gp* gp, int nb, hipStream_t st, bool* timed_out) {
       ELFIHIP_CHECK_HIP(ctx, hipMemsetAsync(gp->sweep_w11.p, 0, gp->sweep_w11.cap, st));  // upper triangles stay zero
     }
     gp->sweep_nb = nb;
+    gp->sweep_group = group;
   }
   const size_t sync_ints = 4 + (size_t)(2 * nb + 1) + (size_t)(2 * nb + 1) * nb;
   ELFIHIP_CHECK_HIP(ctx, gp->sweep_sync.reserve(sync_ints * sizeof(int)));

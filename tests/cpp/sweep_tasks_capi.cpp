@@ -5,16 +5,15 @@
 
 extern "C" {
 
-// number of tasks for nb block columns; if `out` is not NULL it receives 4 ints per task (type, rb, c, k)
-int sweep_tasks(int nb, int* out) {
+// number of tasks for nb block columns in panel groups of G; if `out` is not NULL it receives 10 ints per task
+int sweep_tasks(int nb, int G, int* out) {
   std::vector<elfihip::SweepTask> v;
-  elfihip::sweep_build_tasks(nb, &v);
+  elfihip::sweep_build_tasks(nb, G, &v);
   if (out)
     for (std::size_t i = 0; i < v.size(); ++i) {
-      out[4 * i] = v[i].type;
-      out[4 * i + 1] = v[i].rb;
-      out[4 * i + 2] = v[i].c;
-      out[4 * i + 3] = v[i].k;
+      const elfihip::SweepTask& t = v[i];
+      const int f[10] = {t.type, t.rb, t.c, t.k0, t.kun, t.prior, t.need_pdone, t.need_rb, t.need_c, t.beta0};
+      for (int j = 0; j < 10; ++j) out[10 * i + j] = f[j];
     }
   return (int)v.size();
 }
