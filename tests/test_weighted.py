@@ -72,3 +72,32 @@ def test_device_weighted_var_large_and_strided(hip_ctx):
     np.testing.assert_allclose(out, np.var(wide[:, 2:6], axis=0, ddof=1), rtol=1e-12)
     with pytest.raises(ValueError):
         elfi_amd.weighted_var(x, w[:-1])
+
+
+def test_host_quantile_equals_oracle_on_random_cases():
+    """Property test (CPU): mirror == oracle for random samples with ties, zero weights and boundary alphas."""
+    from hypothesis import given, settings, strategies as st
+    import weighted_oracle as O
+    from elfi_amd.weighted import weighted_sample_quantile
+
+    @settings(max_examples=200, deadline=None)
+    @given(st.integers(1, 40), st.integers(0, 2 ** 31 - 1), st.booleans(), st.booleans(),
+           st.one_of(st.floats(0.0, 1.0), st.integers(0, 40)))
+    def check(n, seed, ties, equal, a):
+        rs = np.random.RandomState(seed)
+        x = rs.randn(n)
+        if ties:
+            x = np.round(x)
+        w = None if equal else rs.uniform(0, 1, n) * (rs.uniform(0, 1, n) > 0.2)
+        if w is not None and w.sum() == 0:
+            w[0] = 1.0
+        alpha = float(a) if isinstance(a, float) else min(a, n) / n        # k / n sits on a cumulative-weight boundary
+        try:
+            ref = O.weighted_sample_quantile(x, alpha, w)
+        except IndexError:
+            with pytest.raises(IndexError):
+                weighted_sample_quantile(x, alpha, weights=w)
+            return
+        assert weighted_sample_quantile(x, alpha, weights=w) == ref
+
+    check()
