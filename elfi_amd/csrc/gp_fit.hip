@@ -988,9 +988,15 @@ __global__ __launch_bounds__(1024) void sweep_kernel(SweepArgs S) {
       bool ok = true;
       if (t < S.ntasks) {
         const SweepTask Q = S.tasks[t];
-        ok = sweep_wait(pdone, Q.need_pdone, err) && sweep_wait(solved + Q.rb, Q.need_rb, err) &&
-             (Q.type != 2 || sweep_wait(solved + Q.c, Q.need_c, err)) &&
-             sweep_wait(cnt + (int64_t)Q.rb * nb + (Q.type == 2 ? Q.c : Q.k0), Q.prior, err);
+        const int* tile_cnt = cnt + (int64_t)Q.rb * nb + (Q.type == 2 ? Q.c : Q.k0);
+        const int* col_solved = solved + (Q.type == 2 ? Q.c : Q.rb);
+        const int need_col = Q.type == 2 ? Q.need_c : 0;
+        // the four counters in one round trip; only a miss goes to the spinning waits
+        const int v0 = sweep_load(pdone), v1 = sweep_load(solved + Q.rb), v2 = sweep_load(col_solved),
+                  v3 = sweep_load(tile_cnt);
+        if (!(v0 >= Q.need_pdone && v1 >= Q.need_rb && v2 >= need_col && v3 >= Q.prior))
+          ok = sweep_wait(pdone, Q.need_pdone, err) && sweep_wait(solved + Q.rb, Q.need_rb, err) &&
+               sweep_wait(col_solved, need_col, err) && sweep_wait(tile_cnt, Q.prior, err);
       }
       sh_task = t;
       sh_ok = ok ? 1 : 0;
