@@ -6,35 +6,17 @@
 namespace elfihip {
 thread_local std::string g_err;
 
-// Streams of the GP factorisation: `hi` (high priority) carries the critical chain, `bulk` the rest of the
-// trailing update.  A CU-mask partition of the two (hipExtStreamCreateWithCUMask, ELFIHIP_RESERVED_XCDS = R
-// reserves i % 8 >= 8 - R) is kept as an option but is OFF: on this stack a masked stream still runs on all
-// 256 CUs (scripts/native/cumask_probe.hip prints the XCC / CU ids the workgroups of each stream land on).
+// Streams of the GP factorisation's stream schedule: `hi` (high priority) carries the critical chain, `bulk` the
+// rest of the trailing update.  (A CU-mask partition of the two was tried and removed: on this stack a stream made with
+// hipExtStreamCreateWithCUMask still runs on all 256 CUs -- scripts/native/cumask_probe.hip prints the XCC / CU ids.)
 int ctx_aux(elfihip_ctx* ctx) {
   if (ctx->hi_stream) return ELFIHIP_OK;
-  int reserved = 0;
-  if (const char* e = getenv("ELFIHIP_RESERVED_XCDS")) reserved = atoi(e);
-  if (reserved < 0) reserved = 0;
-  if (reserved > 4) reserved = 4;
-  const int words = (ctx->cu_count + 31) / 32;
-  if (reserved > 0 && ctx->cu_count % 8 == 0) {
-    std::vector<uint32_t> crit((size_t)words, 0u), bulk((size_t)words, 0u);
-    for (int i = 0; i < ctx->cu_count; ++i) {
-      const bool r = (i % 8) >= 8 - reserved;
-      (r ? crit : bulk)[(size_t)(i / 32)] |= 1u << (i % 32);
-    }
-    ELFIHIP_CHECK_HIP(ctx, hipExtStreamCreateWithCUMask(&ctx->hi_stream, (uint32_t)words, crit.data()));
-    ELFIHIP_CHECK_HIP(ctx, hipExtStreamCreateWithCUMask(&ctx->bulk_stream, (uint32_t)words, bulk.data()));
-  } else {
-    int lo = 0, hi = 0;
-    ELFIHIP_CHECK_HIP(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));
-    ELFIHIP_CHECK_HIP(ctx, hipStreamCreateWithPriority(&ctx->hi_stream, hipStreamNonBlocking, hi));
-    ELFIHIP_CHECK_HIP(ctx, hipStreamCreateWithFlags(&ctx->bulk_stream, hipStreamNonBlocking));
-  }
+  int lo = 0, hi = 0;
+  ELFIHIP_CHECK_HIP(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));
+  ELFIHIP_CHECK_HIP(ctx, hipStreamCreateWithPriority(&ctx->hi_stream, hipStreamNonBlocking, hi));
+  ELFIHIP_CHECK_HIP(ctx, hipStreamCreateWithFlags(&ctx->bulk_stream, hipStreamNonBlocking));
   // device-scope release: these events only order kernels on this GPU, no host visibility needed
-  unsigned flags = hipEventDisableTiming | hipEventReleaseToDevice;
-  if (const char* e = getenv("ELFIHIP_EVENT_SYSTEM_SCOPE"))
-    if (atoi(e)) flags = hipEventDisableTiming;
+  const unsigned flags = hipEventDisableTiming | hipEventReleaseToDevice;
   ELFIHIP_CHECK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_a, flags));
   ELFIHIP_CHECK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_b, flags));
   for (auto& e : ctx->ev_u) ELFIHIP_CHECK_HIP(ctx, hipEventCreateWithFlags(&e, flags));

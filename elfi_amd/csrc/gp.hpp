@@ -5,6 +5,7 @@
 
 namespace elfihip {
 constexpr int NB = 128;          // block size of the factorisation (one MFMA GEMM tile)
+constexpr int FUSED_BELOW_NB = 40;  // block columns below which the fused-step schedule is the default (gp_fit.hip)
 constexpr double GP_JITTER = 1e-8;  // [GPy-upstream] ExactGaussianInference: Ky = K + (noise + 1e-8) I
 inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 }  // namespace elfihip
@@ -38,9 +39,9 @@ struct elfihip_gp {
   int64_t n_int = 0, m_pad = 0;
   unsigned long long fact_gen = 0, vp_gen = 0;  // factorisation counter / the one VP belongs to
   elfihip::DevBuf ws2;      // partials and result tile of the dense product V_P^T v
-  // resident sweep kernel (gp_fit.hip): task list for `sweep_nb` block columns, dependency counters, one W11 per panel
-  elfihip::DevBuf sweep_tasks, sweep_sync, sweep_w11;
-  int sweep_nb = 0, sweep_group = 0, sweep_ntasks = 0;
+  // schedule of the factorisation sweep (elfihip_gp_set_schedule): 0 = by size, 1 = streams, 2 = fused steps;
+  // panel_group 0 = by size, else 1 / 2 / 4 panels per pass over the trailing matrix (stream schedule)
+  int schedule = 0, panel_group = 0;
   // prediction workspace (grown on demand)
   elfihip::DevBuf ws;
   int64_t ws_S = 0;

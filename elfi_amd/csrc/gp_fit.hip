@@ -11,7 +11,7 @@
 //     identity turns into L^-T (upper triangular) -- no separate triangular inversion
 //     and no triangular solves, whose 32-step dependency chain is what makes the
 //     reference's per-point predict an O(n^2) BLAS-2 affair.
-//   * per block column: (1) potf2_aug: one workgroup factors the 128x128 diagonal block and
+//   * per block column: (1) potf2_tiles: one workgroup factors the 128x128 diagonal block and
 //     its inverse in LDS; (2) trsm: every row block below / above multiplies its panel by
 //     W11^T on the matrix cores (a 128x128x128 GEMM per workgroup); (3) update: one launch
 //     of 128x128 f64-MFMA tiles does the SYRK on the trailing lower triangle AND the GEMM
@@ -20,7 +20,6 @@
 // Flops: n^3/3 (Cholesky) + n^3/3 (L^-T) on v_mfma_f64_16x16x4_f64.
 #include "gp.hpp"
 #include "mfma_f64.hpp"
-#include "sweep_tasks.hpp"
 
 namespace elfihip {
 
@@ -140,271 +139,21 @@ __device__ __forceinline__ void sqrt_rsqrt(double p, double& s, double& y) {
   y = fma(e2, y, y);
 }
 
-constexpr int SP = 129;   // pitch of the 128x128 working block S in LDS
 constexpr int PP = 18;    // pitch of the dense copy of the solved 16-wide panel
-constexpr int POTF2_LDS_DOUBLES = NB * SP + NB + NB * PP + 128 + 2;  // + per-lane trash slots + the look-ahead flag
 
-// S holds two triangles at once: entries (i, c <= i) are the block of Ky being turned into
-// L11; entries (r, c > r) are the rows of the appended identity being turned into L11^-T
-// (its diagonal lives in bd[]).  Eliminating 16 columns at a time:
-//   phase A  every row that has entries in the panel -- the 16 rows of the diagonal tile, the rows
-//            below it and the identity rows above -- is held by ONE LANE (16 doubles in
-//            registers).  Eliminating column j is then the same three vector instructions for
-//            every row: scale entry j by 1/sqrt(pivot), subtract entry j times l_cj from entry c.
-//            The pivot and the l_cj come from the tile rows by v_readlane (SGPR broadcast); each
-//            wave keeps its own copy of the tile rows in lanes 0-15 (redundant, so no cross-wave
-//            traffic or barrier inside the panel) and 32 other rows in lanes 16-47.  This factors
-//            the tile, solves the panel below it and carries the identity rows along in one go.
-//   phase B  rank-16 update of everything right of the panel, 16x16 f64 MFMA tiles; a wave owns
-//            whole tile rows (A fragment loaded once) and runs two independent accumulators.
-//   LA (look-ahead, 512 threads): phase B of panel p is split.  Its first tile column -- the 16 columns panel p+1
-//            eliminates -- is updated right after phase A by all eight waves; the rest is updated by waves 3-7 WHILE
-//            waves 0-2 (48 other rows each instead of 32) run phase A of panel p+1 (two waves per SIMD: the MFMA
-//            work of one overlaps the VALU chain of the other).  A panel step then costs max(A, rest of B) + one
-//            tile column instead of A + B.  The dense panel copy P2 is shared: phase A(p+1) files its panel only
-//            after the five update waves have all raised the flag that they are done reading panel p's.
-template <bool LA>
-__global__ __launch_bounds__(LA ? 512 : 256) void potf2_aug_kernel(double* Akk, int64_t lda, double* Wkk, int64_t ldw,
-                                                        double* W11, int* info, int kblock, int skip) {
-  extern __shared__ __align__(16) double sm[];
-  double* S = sm;
-  double* bd = S + NB * SP;
-  double* P2 = bd + NB;        // 128 x PP: solved panel entries of the 128 non-tile rows, dense
-  int* la_flag = reinterpret_cast<int*>(P2 + NB * PP + 128);  // number of "rest of B" phases wave 3 has completed
-  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
-  long long tc[6] = {0, 0, 0, 0, 0, 0};
-  const long long t_begin = clock64();
+// The 128 x 128 working block holds two triangles at once: entries (i, c <= i) are the block of Ky being turned into
+// L11; entries (r, c > r) are the rows of the appended identity being turned into L11^-T.  Eliminating 16 columns at a
+// time ("phase A"): every row that has entries in the panel -- the 16 rows of the diagonal tile, the rows below it and
+// the identity rows above -- is held by ONE LANE (16 doubles in registers).  Eliminating column j is then the same
+// three vector instructions for every row: scale entry j by 1/sqrt(pivot), subtract entry j times l_cj from entry c.
+// The pivot and the l_cj come from the tile rows by v_readlane (SGPR broadcast); each wave keeps its own copy of the
+// tile rows in lanes 0-15 (redundant, so no cross-wave traffic or barrier inside the panel).  This factors the tile,
+// solves the panel below it and carries the identity rows along in one go.  The rank-16 update of everything right
+// of the panel runs on 16 x 16 f64 MFMA tiles.
 
-  // block load, lower triangle only (plus the diagonal pair): 16-byte loads, all 32 per thread in
-  // flight at once -- one memory latency for the whole 128 x 128 block instead of four
-  constexpr int NT = LA ? 512 : 256;  // threads of the workgroup
-  {
-    typedef double v2d __attribute__((ext_vector_type(2)));
-    constexpr int NL = NB * NB / 2 / NT;
-    v2d v[NL];
-#pragma unroll
-    for (int u = 0; u < NL; ++u) {
-      const int e2 = tid + NT * u;
-      const int i = e2 >> 6, c = 2 * (e2 & 63);
-      v[u] = (v2d){0.0, 0.0};
-      if (c <= i) v[u] = *reinterpret_cast<const v2d*>(Akk + (int64_t)i * lda + c);
-    }
-#pragma unroll
-    for (int u = 0; u < NL; ++u) {
-      const int e2 = tid + NT * u;
-      const int i = e2 >> 6, c = 2 * (e2 & 63);
-      S[i * SP + c] = (c <= i) ? v[u].x : 0.0;
-      S[i * SP + c + 1] = (c + 1 <= i) ? v[u].y : 0.0;
-    }
-  }
-  if (tid < NB) bd[tid] = 1.0;
-  if (tid == 0) *la_flag = 0;
-  __syncthreads();
-  int bad = 0;
-  // rank-16 update of tile row tr by panel q, tile columns [b_lo, b_hi): Cholesky rows (columns b <= tr, lower
-  // triangle) for tr < Tn, identity rows above
-  auto update_row_tile = [&](int q, int tr, int b_lo, int b_hi) {
-    const int c0q = 16 * q, ntopq = NB - 16 - c0q, Tnq = ntopq / 16;
-    const bool chol = tr < Tnq;
-    const int prow = chol ? 16 * tr : ntopq + 16 * (tr - Tnq);
-    const int srow = chol ? c0q + 16 + 16 * tr : 16 * (tr - Tnq);
-    const int ncol = chol ? tr + 1 : Tnq;
-    if (b_hi > ncol) b_hi = ncol;
-    if (b_lo >= b_hi) return;
-    double am[4];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) am[kk] = -P2[(prow + (l & 15)) * PP + 4 * kk + (l >> 4)];
-    for (int b = b_lo; b < b_hi; b += 2) {
-      const bool two = b + 1 < b_hi;
-      const int b1 = two ? b + 1 : b;
-      const int sc0 = c0q + 16 + 16 * b, sc1 = c0q + 16 + 16 * b1;
-      double bv0[4], bv1[4];
-      v4d x0, x1;
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        bv0[kk] = P2[(16 * b + (l & 15)) * PP + 4 * kk + (l >> 4)];
-        bv1[kk] = P2[(16 * b1 + (l & 15)) * PP + 4 * kk + (l >> 4)];
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        x0[r] = S[(srow + (l >> 4) + 4 * r) * SP + sc0 + (l & 15)];
-        x1[r] = S[(srow + (l >> 4) + 4 * r) * SP + sc1 + (l & 15)];
-      }
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(am[kk], bv0[kk], x0, 0, 0, 0);
-        x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(am[kk], bv1[kk], x1, 0, 0, 0);
-      }
-      const bool d0 = chol && b == tr, d1 = chol && b1 == tr;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int rr = (l >> 4) + 4 * r, cc = l & 15;
-        if (!d0 || cc <= rr) S[(srow + rr) * SP + sc0 + cc] = x0[r];
-        if (two && (!d1 || cc <= rr)) S[(srow + rr) * SP + sc1 + cc] = x1[r];
-      }
-    }
-  };
-
-  for (int p = 0; p < NB / 16; ++p) {
-    const int c0 = 16 * p;
-    const int ntop = NB - 16 - c0;  // rows below the tile
-    // ---- phase A: one lane per row, column elimination in registers
-    long long t0 = clock64();
-    if (LA && w >= 3) {
-      // look-ahead: these five waves apply the rest of panel p-1's update while waves 0-2 eliminate panel p
-      if (p > 0) {
-        for (int tr = w - 3; tr < 8; tr += 5) update_row_tile(p - 1, tr, 1, NB);  // panel p-1 has 8 tile rows
-        __builtin_amdgcn_s_waitcnt(0);          // this wave's LDS traffic has completed
-        if (l == 0) __hip_atomic_fetch_add(la_flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
-    } else if (!(skip & 1)) {
-      // role of this lane: tile row (l < 16), other row o = 32 w + (l - 16) (16 <= l < 48; look-ahead: 48 w +
-      // (l - 16), 16 <= l < 64, three waves), or idle
-      const bool is_tile = l < 16;
-      const int o = (LA ? 48 : 32) * w + (l - 16);
-      const bool is_other = LA ? (l >= 16 && o < NB) : (l >= 16 && l < 48);
-      const bool below = is_other && o < ntop;
-      const int srow = is_tile ? c0 + l : (below ? c0 + 16 + o : o - ntop);  // row of S (aug: identity row r)
-      // branch-free loads: every lane reads 16 in-range words of its row; a 16-bit mask per lane
-      // (bit c = entry c is a real entry of this row) drives the selects.  Bit tricks instead of
-      // boolean expressions: hipcc turns short-circuit logic on divergent values into branches.
-      const bool is_aug = is_other && !below;
-      const bool live = is_tile || is_other;
-      const int rrow = live ? srow : 0;
-      const int t = srow - c0;                       // aug rows: first panel column that is right of the diagonal is t + 1
-      const unsigned upto_l = (2u << (l & 15)) - 1u;  // bits 0..l
-      const unsigned right_of_diag = t < 0 ? 0xFFFFu : (t >= 15 ? 0u : (0xFFFFu & ~((2u << (t & 15)) - 1u)));
-      const unsigned keep_r = is_tile ? upto_l : (below ? 0xFFFFu : (is_aug ? right_of_diag : 0u));
-      const unsigned diag_m = (is_aug && t >= 0 && t < 16) ? (1u << (t & 15)) : 0u;
-      const double* rp = S + rrow * SP + c0;
-      const double bdv = bd[rrow];
-      double a[16];
-#pragma unroll
-      for (int c = 0; c < 16; ++c) a[c] = rp[c];
-      // pin the 16 loads (issued back to back, one wait): hipcc would otherwise sink each of them
-      // into its select as an exec-masked branch with its own s_waitcnt
-      asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
-                        "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]),
-                        "+v"(a[15]));
-#pragma unroll
-      for (int c = 0; c < 16; ++c) a[c] = ((keep_r >> c) & 1u) ? a[c] : (((diag_m >> c) & 1u) ? bdv : 0.0);
-      tc[0] += clock64() - t0;
-      t0 = clock64();
-      double sdiag = 0.0;  // tile lane l: L[l][l]
-#pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        // left-looking: bring entry c of every row up to date with row c of the tile factor
-        // (broadcast from lane c, consumed at once: short SGPR live ranges), two accumulators
-        double acc0 = a[c], acc1 = 0.0;
-#pragma unroll
-        for (int j = 0; j < c; ++j) {
-          const double lcj = readlane_f64(a[j], c);
-          if (j & 1)
-            acc1 = fma(-a[j], lcj, acc1);
-          else
-            acc0 = fma(-a[j], lcj, acc0);
-        }
-        a[c] = acc0 + acc1;
-        // pivot: rsq + two Newton steps, scale the column
-        const double pc = readlane_f64(a[c], c);
-        double yc = __builtin_amdgcn_rsq(pc);
-        const double hc = -0.5 * pc;
-        yc = yc * fma(hc * yc, yc, 1.5);
-        yc = yc * fma(hc * yc, yc, 1.5);
-        if (!(pc > 0.0) && bad == 0) bad = kblock * NB + c0 + c + 1;  // NaNs follow; the caller discards
-        a[c] = a[c] * yc;
-        double sc = pc * yc;                       // sqrt(p) with one correction step, off the chain
-        sc = fma(0.5 * fma(-sc, sc, pc), yc, sc);
-        if (l == c) sdiag = sc;
-      }
-      if (is_tile) {
-#pragma unroll
-        for (int c = 0; c < 16; ++c)
-          if (c == l) a[c] = sdiag;
-      }
-      tc[1] += clock64() - t0;
-      t0 = clock64();
-      // write back, branch-free: masked-off words go to a per-lane trash slot.  Tile rows (wave 0
-      // only, lower part) and other rows into S / bd; other rows also densely into P2.
-      {
-        double* wp = S + rrow * SP + c0;
-        double* trash = P2 + NB * PP + 2 * l;
-        const unsigned keep_w = is_tile ? (w == 0 ? upto_l : 0u) : keep_r;
-        double bdn = bdv;
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-          double* dst = ((keep_w >> c) & 1u) ? wp + c : trash;
-          *dst = a[c];
-          bdn = ((diag_m >> c) & 1u) ? a[c] : bdn;
-        }
-        double* bdp = diag_m ? bd + rrow : trash + 1;
-        *bdp = bdn;
-        if (LA) {  // the dense panel copy is still being read by wave 3 until it says otherwise
-          while (__hip_atomic_load(la_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < 5 * p)
-            __builtin_amdgcn_s_sleep(1);
-        }
-        if (is_other) {
-          double* pp = P2 + o * PP;
-#pragma unroll
-          for (int c = 0; c < 16; c += 2) *reinterpret_cast<double2*>(pp + c) = make_double2(a[c], a[c + 1]);
-        }
-      }
-    }
-    __syncthreads();
-    tc[2] += clock64() - t0;
-    t0 = clock64();
-    // ---- phase B: rank-16 update right of the panel.  Tile rows [0, Tn): Cholesky rows (columns
-    // b <= tr, lower triangle); [Tn, Tn + p + 1): identity rows rt = tr - Tn (all Tn columns).
-    const int Tn = ntop / 16;
-    if (!(skip & 4)) {
-      const int R = Tn + p + 1;
-      // look-ahead: only the tile column panel p+1 needs now (the rest follows on wave 3 during the next phase A)
-      for (int tr = w; tr < R; tr += NT / 64) update_row_tile(p, tr, 0, LA ? 1 : NB);
-    }
-    __syncthreads();
-    tc[3] += clock64() - t0;
-  }
-  if (bad != 0 && tid == 0) atomicCAS(info, 0, bad);
-  const long long t_mid = clock64();
-
-  // ---- write out: L11 (lower), L11^-T into WT's diagonal block (upper incl. diagonal), W11 = L11^-1
-  // (lower incl. diagonal).  The other triangles of those two targets are zero from allocation and
-  // are never written by anyone, so they are not rewritten here.
-#pragma unroll 4
-  for (int it = 0; it < NB * NB / 2 / NT; ++it) {
-    const int e2 = tid + NT * it;
-    const int i = e2 >> 6, c = 2 * (e2 & 63);
-    const double s0 = S[i * SP + c], s1 = S[i * SP + c + 1];
-    if (c + 1 <= i) {
-      *reinterpret_cast<double2*>(Akk + (int64_t)i * lda + c) = make_double2(s0, s1);
-    } else if (c <= i) {
-      Akk[(int64_t)i * lda + c] = s0;
-    }
-    if (c + 1 >= i) {  // pair touches the upper triangle (diagonal included)
-      double2 wv;
-      wv.x = c > i ? s0 : (c == i ? bd[i] : 0.0);
-      wv.y = c + 1 > i ? s1 : (c + 1 == i ? bd[i] : 0.0);
-      *reinterpret_cast<double2*>(Wkk + (int64_t)i * ldw + c) = wv;
-    }
-    if (c <= i) {  // W11[i][c] = L11^-1[i][c] = (L11^-T)[c][i]
-      double2 q;
-      q.x = c < i ? S[c * SP + i] : bd[i];
-      q.y = c + 1 < i ? S[(c + 1) * SP + i] : (c + 1 == i ? bd[i] : 0.0);
-      *reinterpret_cast<double2*>(W11 + i * NB + c) = q;
-    }
-  }
-  if ((skip & 8) && tid == 0) {  // developer probe: shader-clock cycle counts
-    double* dbg = W11 + NB * NB;
-    for (int q = 0; q < 4; ++q) dbg[q] = (double)tc[q];
-    dbg[4] = (double)(t_mid - t_begin);
-    dbg[5] = (double)(clock64() - t_begin);
-  }
-}
-
-// ---- the same factorisation with the trailing tiles of the block held in REGISTERS ----
-// The 128 x 128 working block (both triangles, as above) is 8 x 8 tiles of 16 x 16.  In potf2_aug_kernel every rank-16
-// update reads and rewrites its tiles in LDS -- eight times per tile, with a 4-way bank conflict on the 129-double pitch
-// -- and that LDS traffic, not the elimination (0.6 us per panel), is what the 41 us of the kernel are made of.  Here:
+// The trailing tiles of the block live in REGISTERS: the 128 x 128 working block (both triangles, as above) is 8 x 8
+// tiles of 16 x 16.  (With the block in LDS every rank-16 update reads and rewrites its tiles there -- eight times per
+// tile -- and that traffic, not the elimination, made up the 41-56 us of the LDS-resident predecessors of this kernel.)
 //   * waves 3.. ("update waves") own the 64 tiles, dealt round-robin along tile columns; a tile lives in the MFMA
 //     accumulator layout in 4 registers per lane from the first load to the moment its column is eliminated;
 //   * waves 0-2 run phase A of panel p exactly as above (one lane per row), reading the tile column from a small LDS
@@ -592,7 +341,7 @@ __device__ __forceinline__ void potf2_tiles_body(double* Akk, int64_t lda, doubl
       const int c0 = 16 * p;
       const int ntop = NB - 16 - c0;  // rows below the tile
       double* P2w = P2 + (p & 1) * NB * PP;
-      // ---- phase A (see potf2_aug_kernel): one lane per row of the tile column, elimination in registers
+      // ---- phase A (see above): one lane per row of the tile column, elimination in registers
       const bool is_tile = l < 16;
       const int o = 48 * w + (l - 16);
       const bool is_other = l >= 16 && o < NB;
@@ -905,192 +654,94 @@ __global__ __launch_bounds__(256) void lookahead_tile_kernel(PanelArgs P, int cb
 }
 constexpr size_t LOOKAHEAD_TILE_LDS = 4 * 32 * 33 * sizeof(double);
 
-// out-of-line instance for the resident sweep kernel: inlined there, the block's 128 live registers meet the task
-// loop's and spill (117 VGPRs)
+// out-of-line instance for the fused step kernel: inlined there, the block's 128 live registers would be allocated
+// next to the update tile's
 __device__ __noinline__ void potf2_tiles_call(double* Akk, int64_t lda, double* Wkk, int64_t ldw, double* W11, int* info,
                                               int kblock, double* sm) {
   potf2_tiles_body<1024>(Akk, lda, Wkk, ldw, W11, info, kblock, sm);
 }
 
-// --------------------------------------------------------------- the whole sweep in one resident kernel
-// EXPERIMENTAL (ELFIHIP_SWEEP=1).  One 1024-thread workgroup per CU draws tasks from a statically ordered list with an
-// atomic ticket and runs them when their inputs are there:
-//   potf2(k)        diagonal block k (potf2_tiles_body)                     needs  cnt[k][k] == k
-//   trsm(rb, k)     row block rb of panel k times W11_k^T, in place         needs  potf2(k), cnt[rb][k] == prior
-//   upd(rb, c, k)   C(rb, c) -= P(rb, k) P(c, k)^T                          needs  the two solves, cnt[rb][c] == prior
-// Row blocks: 0..nb-1 the rows of A, nb the y block, nb+1+r the L^-T row r (its tile (r, c) takes panels r..c-1, the
-// first of them overwrites).  `prior` = updates a tile must have received = k for A / y rows, k - r for L^-T row r.
-// The list is a topological order with the next panel's critical tasks first (block k: potf2(k), [solve of row k+1,
-// update of tile (k+1, k+1)], rest of panel k-1, [solves and the two next columns of panel k]); a workgroup that has
-// drawn a task spins on its inputs -- the earliest unfinished task can always run, so there is no deadlock while the
-// drawn tasks' workgroups are resident (grid <= CUs, one workgroup per CU).  Spins are bounded; a time-out raises
-// `err`, every workgroup leaves and the host repeats the factorisation with the multi-launch sweep.
-// Publishing: every thread fences its stores (device scope), the workgroup synchronises, one thread stores the counter;
-// a consumer fences after it has seen the counter, before its first load.
-
-struct SweepArgs {
-  double* A;
-  double* WT;
-  double* w11;   // nb x (NB x NB): the inverse diagonal blocks, one per panel
-  int64_t lda;
-  int nb;
-  const SweepTask* tasks;
-  int ntasks;
-  int* sync;     // [0] ticket, [1] err, [2] diagonal blocks done, [4 .. 4 + 2nb + 1) panels solved per row block, then cnt
-  int* info;
-};
-
-__device__ __forceinline__ int sweep_load(const int* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// thread 0 waits until *p >= want (counters only grow); false after a time-out or when another workgroup gave up
-__device__ __forceinline__ bool sweep_wait(const int* p, int want, int* err) {
-  unsigned int spins = 0;
-  while (sweep_load(p) < want) {
-    __builtin_amdgcn_s_sleep(1);
-    if ((++spins & 1023u) == 0 && (sweep_load(err) != 0 || spins > (1u << 20))) {
-      __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      return false;
-    }
-  }
-  return true;
-}
-
-__global__ __launch_bounds__(1024) void sweep_kernel(SweepArgs S) {
+// --------------------------------------------------------------- one step of the sweep as ONE launch
+// step_kernel(k): workgroup 0 factors diagonal block k+1 (potf2_tiles_body) WHILE the other workgroups apply panel k to
+// every other tile right of it -- the two halves of a step that do not depend on each other, in one launch on one
+// stream: no second stream, no event hand-offs (about 6 us each on the critical chain), and the diagonal block is the
+// launch's first workgroup, so it never waits for a compute unit to drain (as a separate one-workgroup kernel it
+// needs a whole CU and measured 34 us alone, 57 us beside a running pass over the trailing matrix).
+// Before it, per step: trsm_gemm_kernel (all row blocks of panel k) and the update of tile (k+1, k+1) alone
+// (lookahead_tile_kernel<1>, 16 workgroups) -- the only tile the next diagonal block needs.
+// Tiles of step k (m = nb-1-k block columns right of k), tile (k+1, k+1) excluded:
+//   [0, tA)        Cholesky rows: (i, c), k < c <= i < nb, tA = m (m+1) / 2 - 1     C -= P_i P_c^T   (SYRK)
+//   [tA, tA+m)     y block:       (y, c)                                          C -= P_y P_c^T
+//   [tA+m, ...)    L^-T rows:     (r, c), r <= k                                  C  = beta C - P_r P_c^T, beta = 0 for r == k
+// 1024 threads per workgroup (what the diagonal block needs): an update tile is 128 x 128 on 16 waves (gemm_tile_nt16).
+__global__ __launch_bounds__(1024) void step_kernel(PanelArgs P, double* W11, int* info) {
   extern __shared__ __align__(16) double sm[];
-  __shared__ int sh_task, sh_ok;
-  const int tid = threadIdx.x, nb = S.nb;
-  int* ticket = S.sync;
-  int* err = S.sync + 1;
-  int* pdone = S.sync + 2;
-  int* solved = S.sync + 4;
-  int* cnt = solved + (2 * nb + 1);
-  auto rowptr = [&](int rb, int col) -> double* {
-    return rb <= nb ? S.A + ((int64_t)rb * NB) * S.lda + (int64_t)col * NB
-                    : S.WT + ((int64_t)(rb - nb - 1) * NB) * S.lda + (int64_t)col * NB;
-  };
-  // ONE `if (tid == 0)` region per iteration, between two barriers: with the publication of the finished task at the
-  // tail of the loop and the ticket at its head, the compiler threads lane 0 from one region into the other across the
-  // back edge and the waves of a workgroup no longer execute the same number of barriers (the kernel never returns;
-  // scripts/native/scaffold_probe.hip reproduces it).
-  int prev_type = -1, prev_a = 0, prev_b = 0;  // what the previous task has to publish (thread 0)
-  for (;;) {
-    __syncthreads();
-    if (tid == 0) {
-      if (prev_type == 0)
-        __hip_atomic_store(pdone, prev_a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      else if (prev_type == 1)
-        __hip_atomic_store(solved + prev_a, prev_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      else if (prev_type == 2)
-        __hip_atomic_fetch_add(cnt + prev_a, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int t = atomicAdd(ticket, 1);
-      bool ok = true;
-      if (t < S.ntasks) {
-        const SweepTask Q = S.tasks[t];
-        const int* tile_cnt = cnt + (int64_t)Q.rb * nb + (Q.type == 2 ? Q.c : Q.k0);
-        const int* col_solved = solved + (Q.type == 2 ? Q.c : Q.rb);
-        const int need_col = Q.type == 2 ? Q.need_c : 0;
-        // the four counters in one round trip; only a miss goes to the spinning waits
-        const int v0 = sweep_load(pdone), v1 = sweep_load(solved + Q.rb), v2 = sweep_load(col_solved),
-                  v3 = sweep_load(tile_cnt);
-        if (!(v0 >= Q.need_pdone && v1 >= Q.need_rb && v2 >= need_col && v3 >= Q.prior))
-          ok = sweep_wait(pdone, Q.need_pdone, err) && sweep_wait(solved + Q.rb, Q.need_rb, err) &&
-               sweep_wait(col_solved, need_col, err) && sweep_wait(tile_cnt, Q.prior, err);
-      }
-      sh_task = t;
-      sh_ok = ok ? 1 : 0;
-    }
-    __syncthreads();
-    const int ti = sh_task;
-    if (ti >= S.ntasks || !sh_ok) return;
-    const SweepTask T = S.tasks[ti];
-    if (tid < 64) __threadfence();  // acquire (one wave: the caches it invalidates are shared by the CU)
-    __syncthreads();
-    if (T.type == 0) {
-      double* Akk = S.A + ((int64_t)T.k0 * NB) * S.lda + (int64_t)T.k0 * NB;
-      double* Wkk = S.WT + ((int64_t)T.k0 * NB) * S.lda + (int64_t)T.k0 * NB;
-      potf2_tiles_call(Akk, S.lda, Wkk, S.lda, S.w11 + (int64_t)T.k0 * NB * NB, S.info, T.k0, sm);
-      prev_a = T.k0 + 1;
-    } else if (T.type == 1) {
-      double* P = rowptr(T.rb, T.k0);
-      GemmAcc32 acc;
-      acc.zero();
-      gemm_tile_nt16(acc, P, S.lda, S.w11 + (int64_t)T.k0 * NB * NB, NB, 0, NB, sm);
-      acc16_foreach(acc, [&](int row, int col, double v) {
-        __hip_atomic_store(&P[(int64_t)row * S.lda + col], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through
-      });
-      prev_a = T.rb;
-      prev_b = T.k0 + 1;
-    } else {
-      const double* Ap = rowptr(T.rb, T.k0);
-      const double* Bp = rowptr(T.c, T.k0);
-      double* C = rowptr(T.rb, T.c);
-      GemmAcc32 acc;
-      acc.zero();
-      gemm_tile_nt16(acc, Ap, S.lda, Bp, S.lda, 0, T.kun * NB, sm);
-      if (T.beta0)
-        acc16_foreach(acc, [&](int row, int col, double v) {
-          __hip_atomic_store(&C[(int64_t)row * S.lda + col], -v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        });
-      else
-        acc16_foreach(acc, [&](int row, int col, double v) {
-          double* q = &C[(int64_t)row * S.lda + col];
-          __hip_atomic_store(q, *q - v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        });
-      prev_a = T.rb * nb + T.c;
-    }
-    prev_type = T.type;
-    __syncthreads();
-    if (tid < 64) __threadfence();  // release: after every wave's stores have been issued and waited for
+  const int k = P.k;
+  if (blockIdx.x == 0) {
+    const int kk = k + 1;
+    double* Akk = P.A + ((int64_t)kk * NB) * P.lda + (int64_t)kk * NB;
+    double* Wkk = P.WT + ((int64_t)kk * NB) * P.lda + (int64_t)kk * NB;
+    potf2_tiles_call(Akk, P.lda, Wkk, P.lda, W11, info, kk, sm);
+    return;
   }
-}
-
-static int sweep_run(elfihip_gp* gp, int nb, hipStream_t st, bool* timed_out) {
-  elfihip_ctx* ctx = gp->ctx;
-  // panels per update of a tile right of them (ELFIHIP_SWEEP_GROUP).  Measured, resident kernel, G = 1 / 2 / 4:
-  // n=1024: 0.75 / 0.79 / 0.88 ms, n=4096: 3.52 / 3.45 / 3.74 ms, n=8192: 15.7 / 12.4 / 12.6 ms
-  int group = nb >= 48 ? 2 : 1;
-  if (const char* e = getenv("ELFIHIP_SWEEP_GROUP")) group = std::max(1, atoi(e));
-  if (gp->sweep_nb != nb || gp->sweep_group != group) {
-    std::vector<SweepTask> tasks;
-    sweep_build_tasks(nb, group, &tasks);
-    ELFIHIP_CHECK_HIP(ctx, gp->sweep_tasks.reserve(tasks.size() * sizeof(SweepTask)));
-    ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(gp->sweep_tasks.p, tasks.data(), tasks.size() * sizeof(SweepTask),
-                                          hipMemcpyHostToDevice, st));
-    ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(st));  // `tasks` is about to go out of scope
-    gp->sweep_ntasks = (int)tasks.size();
-    const size_t w11_bytes = (size_t)nb * NB * NB * sizeof(double);
-    if (gp->sweep_w11.cap < w11_bytes) {
-      ELFIHIP_CHECK_HIP(ctx, gp->sweep_w11.reserve(w11_bytes));
-      ELFIHIP_CHECK_HIP(ctx, hipMemsetAsync(gp->sweep_w11.p, 0, gp->sweep_w11.cap, st));  // upper triangles stay zero
-    }
-    gp->sweep_nb = nb;
-    gp->sweep_group = group;
+  // workgroups go round-robin over the 8 XCDs: renumber so that an XCD works through a contiguous stretch of the tile
+  // list (consecutive tiles share their row block, i.e. the A operand, in that XCD's L2).  The grid is 1 + 8 `per`
+  // workgroups, per = ceil(tiles / 8): tile x * per + s goes to workgroup 1 + 8 s + x, surplus workgroups leave.
+  const int b = (int)blockIdx.x - 1;
+  const int per = ((int)gridDim.x - 1) >> 3;
+  const int idx = (b & 7) * per + (b >> 3);
+  const int m = P.nb - 1 - k;
+  const int c0 = k + 1;
+  const int tA = m * (m + 1) / 2 - 1;
+  if (idx >= tA + m + (k + 1) * m) return;
+  const double* Ap;
+  double* C;
+  int cblk;
+  bool beta0 = false;
+  if (idx < tA) {
+    const int e = idx + 1;  // triangular enumeration without its first element, tile (k+1, k+1)
+    int i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+    while (i * (i + 1) / 2 > e) --i;
+    while ((i + 1) * (i + 2) / 2 <= e) ++i;
+    const int c = e - i * (i + 1) / 2;
+    cblk = c0 + c;
+    Ap = P.A + ((int64_t)(c0 + i) * NB) * P.lda + (int64_t)k * NB;
+    C = P.A + ((int64_t)(c0 + i) * NB) * P.lda + (int64_t)cblk * NB;
+  } else if (idx < tA + m) {
+    cblk = c0 + (idx - tA);
+    Ap = P.A + ((int64_t)P.nb * NB) * P.lda + (int64_t)k * NB;
+    C = P.A + ((int64_t)P.nb * NB) * P.lda + (int64_t)cblk * NB;
+  } else {
+    const int e = idx - tA - m;
+    const int r = e / m;
+    cblk = c0 + (e - r * m);
+    Ap = P.WT + ((int64_t)r * NB) * P.lda + (int64_t)k * NB;
+    C = P.WT + ((int64_t)r * NB) * P.lda + (int64_t)cblk * NB;
+    beta0 = (r == k);  // the panel that creates this L^-T row: overwrite
   }
-  const size_t sync_ints = 4 + (size_t)(2 * nb + 1) + (size_t)(2 * nb + 1) * nb;
-  ELFIHIP_CHECK_HIP(ctx, gp->sweep_sync.reserve(sync_ints * sizeof(int)));
-  ELFIHIP_CHECK_HIP(ctx, hipMemsetAsync(gp->sweep_sync.p, 0, sync_ints * sizeof(int), st));
-  SweepArgs S;
-  S.A = gp->A;
-  S.WT = gp->WT;
-  S.w11 = gp->sweep_w11.as<double>();
-  S.lda = gp->lda;
-  S.nb = nb;
-  S.tasks = gp->sweep_tasks.as<SweepTask>();
-  S.ntasks = gp->sweep_ntasks;
-  S.sync = gp->sweep_sync.as<int>();
-  S.info = gp->info;
-  const size_t lds = std::max<size_t>(POTF2T_LDS_DOUBLES, GEMM_LDS_DOUBLES) * sizeof(double);
-  const int grid = std::min(ctx->cu_count, S.ntasks);
-  hipLaunchKernelGGL(sweep_kernel, dim3(grid), dim3(1024), lds, st, S);
-  ELFIHIP_TRY(launch_status(ctx, "sweep_kernel"));
-  int flags[2] = {0, 0};
-  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(flags, gp->sweep_sync.as<int>(), sizeof flags, hipMemcpyDeviceToHost, st));
-  ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(st));
-  *timed_out = flags[1] != 0;
-  return ELFIHIP_OK;
+  const double* Bp = P.A + ((int64_t)cblk * NB) * P.lda + (int64_t)k * NB;
+  // the tile's old values travel with the first operand loads
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  double* Cw = C + (int64_t)((w >> 2) * 32 + (l >> 4)) * P.lda + (w & 3) * 32 + (l & 15);
+  v4d cv[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cv[i][j][r] = beta0 ? 0.0 : Cw[(int64_t)(i * 16 + 4 * r) * P.lda + j * 16];
+  GemmAcc32 acc;
+  acc.zero();
+  gemm_tile_nt16(acc, Ap, P.lda, Bp, P.lda, 0, NB, sm);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Cw[(int64_t)(i * 16 + 4 * r) * P.lda + j * 16] = cv[i][j][r] - acc.c[i][j][r];
 }
+constexpr size_t STEP_LDS_BYTES =
+    (GEMM16_LDS_DOUBLES > POTF2T_LDS_DOUBLES ? GEMM16_LDS_DOUBLES : POTF2T_LDS_DOUBLES) * sizeof(double);
 
 // --------------------------------------------------------------- alpha, logdet, y^T K^-1 y
 // alpha_i = sum_{k >= i} WT[i][k] z_k : one wavefront per row, coalesced along k.
@@ -1140,55 +791,47 @@ static int enable_lds(elfihip_ctx* ctx, K k, size_t bytes) {
   return ELFIHIP_OK;
 }
 
-int gp_factorize_impl(elfihip_gp* gp, bool allow_sweep);
-
-int gp_factorize_impl(elfihip_gp* gp, bool allow_sweep) {
+// ---- the sweep, fused schedule: everything on the caller's stream, two small launches and one fused launch per step
+//   potf2(0);  for k = 0 .. nb-1:  trsm(k) | tile (k+1, k+1) -= P P^T | step_kernel(k) = potf2(k+1) beside the update by panel k
+// Chain per step: 8 + 5 + max(30, update) us + three same-stream kernel boundaries (1.5-2 us each), against
+// potf2 -> trsm -> look-ahead column -> two event hops (measured 82 us per step at n = 4096) of the stream schedule.
+static int sweep_fused(elfihip_gp* gp, int nb, hipStream_t st) {
   elfihip_ctx* ctx = gp->ctx;
-  ELFIHIP_REQUIRE(ctx, gp->n > 0, "GP has no evidence");
-  hipStream_t st = ctx->stream;
-  const int64_t np = gp->np;
-  const int nb = (int)(np / NB);
-  ELFIHIP_CHECK_HIP(ctx, hipMemsetAsync(gp->info, 0, sizeof(int), st));
-  {
-    const int T = 256;
-    hipLaunchKernelGGL(x2_kernel, dim3((unsigned)((gp->cap + T - 1) / T)), dim3(T), 0, st, gp->X, gp->x2, gp->n,
-                       gp->cap, gp->dp);
-    GramArgs G;
-    G.X = gp->X;
-    G.x2 = gp->x2;
-    G.y = gp->y;
-    G.A = gp->A;
-    G.lda = gp->lda;
-    G.n = gp->n;
-    G.np = np;
-    G.dp = gp->dp;
-    G.var = gp->var;
-    G.neg_half_inv_ls2 = -0.5 / (gp->ls * gp->ls);
-    G.bias = gp->bias;
-    G.diag_add = gp->noise + GP_JITTER;
-    const int64_t nt = np / 64;
-    const size_t lds = 2 * 64 * (size_t)(gp->dp + 1) * sizeof(double);
-    hipLaunchKernelGGL(gram_kernel, dim3((unsigned)(nt * (nt + 1) / 2)), dim3(256), lds, st, G);
-    ELFIHIP_TRY(launch_status(ctx, "gram_kernel"));
+  if (!ctx->step_lds_enabled) {
+    ELFIHIP_TRY(enable_lds(ctx, step_kernel, STEP_LDS_BYTES));
+    ctx->step_lds_enabled = true;
   }
-  bool swept = false;
-  if (allow_sweep && getenv("ELFIHIP_SWEEP") && atoi(getenv("ELFIHIP_SWEEP")) != 0) {  // EXPERIMENTAL resident sweep
-    bool timed_out = false;
-    ELFIHIP_TRY(sweep_run(gp, nb, st, &timed_out));
-    if (timed_out) return gp_factorize_impl(gp, false);  // from the Gram matrix again, multi-launch sweep
-    swept = true;
+  PanelArgs P;
+  P.A = gp->A;
+  P.WT = gp->WT;
+  P.W11 = gp->W11;
+  P.lda = gp->lda;
+  P.nb = nb;
+  P.kun = 1;
+  hipLaunchKernelGGL(potf2_tiles_kernel<1024>, dim3(1), dim3(1024), POTF2T_LDS_DOUBLES * sizeof(double), st, gp->A,
+                     gp->lda, gp->WT, gp->lda, gp->W11, gp->info, 0);
+  const size_t lds32 = GEMM32_LDS_DOUBLES * sizeof(double);
+  for (int k = 0; k < nb; ++k) {
+    P.k = k;
+    P.ku0 = k;
+    const int nrows = (nb - 1 - k) + 1 + k;  // below + y block + L^-T rows above
+    hipLaunchKernelGGL(trsm_gemm_kernel, dim3(4 * nrows), dim3(256), lds32, st, P);
+    const int m = nb - 1 - k;
+    if (m == 0) break;
+    hipLaunchKernelGGL(lookahead_tile_kernel<1>, dim3(16), dim3(256), LOOKAHEAD_TILE_LDS, st, P, k + 1);
+    const int ntile = m * (m + 1) / 2 - 1 + m + (k + 1) * m;
+    const int per = (ntile + 7) / 8;
+    hipLaunchKernelGGL(step_kernel, dim3(1 + 8 * per), dim3(1024), STEP_LDS_BYTES, st, P, gp->W11, gp->info);
   }
-  if (!swept) {
-  const size_t potf2_lds = POTF2_LDS_DOUBLES * sizeof(double);
+  return launch_status(ctx, "cholesky sweep (fused steps)");
+}
+
+// ---- the sweep, stream schedule: critical chain on a high-priority stream, passes over the trailing matrix on a
+// second one, panel groups (one pass with K = 128 G per G panels).  Ahead from about 40 block columns, where a
+// K = 128 pass over the trailing matrix is HBM-limited (8 flop per byte).
+static int sweep_streams(elfihip_gp* gp, int nb, hipStream_t st) {
+  elfihip_ctx* ctx = gp->ctx;
   const size_t gemm_lds = GEMM_LDS_DOUBLES * sizeof(double);
-  ELFIHIP_TRY(enable_lds(ctx, potf2_aug_kernel<false>, potf2_lds));
-  ELFIHIP_TRY(enable_lds(ctx, potf2_aug_kernel<true>, potf2_lds));
-  // diagonal-block kernel: tiles in registers (default; measured 37 us per block), ELFIHIP_POTF2_TILES=0 selects the
-  // LDS-resident form (43 us; with ELFIHIP_POTF2_LA=0 its plain variant, 56 us)
-  bool potf2_la = true;
-  if (const char* e = getenv("ELFIHIP_POTF2_LA")) potf2_la = atoi(e) != 0;
-  bool potf2_tiles = true;
-  if (const char* e = getenv("ELFIHIP_POTF2_TILES")) potf2_tiles = atoi(e) != 0;
   PanelArgs P;
   P.A = gp->A;
   P.WT = gp->WT;
@@ -1216,28 +859,15 @@ int gp_factorize_impl(elfihip_gp* gp, bool allow_sweep) {
   // Order on `bulk` after a group: first the G-1 block columns the next group touches before its
   // own end (one launch and one event each, so the critical stream never waits for more than it
   // needs), then the rest.
-  // measured rebuild times, G = 1 / 2 / 4:  n=4096: 3.38 / 3.30 / 3.36 ms;  n=8192: 15.3 / 12.2 / 11.7 ms;
-  // n=12288: 48.1 / 35.1 / 30.0 ms (41 TFLOP/s)
-  // (after the register-resident diagonal-block kernel, fit in ms for G = 1 / 2 / 4 with the pass over C in 128 x 128
-  // tiles: n=2048: 1.29 / 1.16 / 1.21, n=3072: 2.01 / 1.77 / 1.88, n=4096: 3.07 / 2.68 / 2.67, n=4608: 4.02 / 3.41 / 3.23;
-  // with the pass in 32-row workgroups: n=2048: 1.07 / 1.09 / 1.18, n=3072: 1.67 / 1.74 / 1.86, n=4096: 2.72 / 2.70 /
-  // 2.83, n=4608: 3.25 / 3.27 / 3.30 -- below 30 block columns single panels with the fine pass win, from 30 on groups)
-  int group = nb >= 48 ? 4 : (nb >= 40 ? 2 : (nb >= 30 ? 4 : 1));
-  if (const char* e = getenv("ELFIHIP_PANEL_GROUP")) {
-    const int g_ = atoi(e);
-    group = (g_ == 2 || g_ == 4) ? g_ : 1;
-  }
+  // measured rebuild times (round 1), G = 1 / 2 / 4:  n=8192: 15.3 / 12.2 / 11.7 ms; n=12288: 48.1 / 35.1 / 30.0 ms;
+  // with the pass over C in 32-row workgroups n=4096: 2.72 / 2.70 / 2.83, n=4608: 3.25 / 3.27 / 3.30
+  int group = gp->panel_group > 0 ? gp->panel_group : (nb >= 48 ? 4 : (nb >= 40 ? 2 : (nb >= 30 ? 4 : 1)));
+  if (group != 2 && group != 4) group = 1;
   const size_t lds32 = GEMM32_LDS_DOUBLES * sizeof(double);
   // the pass over the trailing matrix in 32-row workgroups (the look-ahead column kernel over all block columns)
-  // instead of 128 x 128 tiles: measured n=6144: 6.04 -> 5.77 ms, n=8192: 11.1 -> 10.3 ms, n=12288: 29.6 -> 27.0 ms
-  // (0.58 of peak); also below 30 block columns, where short-lived workgroups let the critical kernels in sooner
-  // (n=2048: 1.29 -> 1.07 ms, n=3072: 1.77 -> 1.67 ms); in between the grouped pass in 128 x 128 tiles is ahead
-  bool fine_bulk = nb < 30 || nb >= 40;
-  if (const char* e = getenv("ELFIHIP_FINE_BULK")) fine_bulk = atoi(e) != 0;
-  // Up to 8 block columns (n <= 1024) the trailing matrix is so small that one launch per panel updates all of it in the
-  // time of a look-ahead column: everything stays on the critical stream, no hand-offs between streams (each costs
-  // about 6 us on the chain).  Measured: n=512: 0.364 -> 0.335 ms, n=1024: 0.633 -> 0.597 ms, n=2048: no change.
-  const bool one_stream = nb <= 8;
+  // instead of 128 x 128 tiles: measured n=6144: 6.04 -> 5.77 ms, n=8192: 11.1 -> 10.3 ms, n=12288: 29.6 -> 27.0 ms;
+  // also below 30 block columns, where short-lived workgroups let the critical kernels in sooner
+  const bool fine_bulk = nb < 30 || nb >= 40;
   // every row block of block columns [cblk, cblk + ncol), 32-row workgroups
   auto col_update = [&](hipStream_t s_, int cblk, int ncol = 1) {
     const int rows = (nb - cblk) + 1 + (P.ku0 + P.kun);
@@ -1255,25 +885,12 @@ int gp_factorize_impl(elfihip_gp* gp, bool allow_sweep) {
     P.k = k;
     double* Akk = gp->A + ((int64_t)k * NB) * gp->lda + (int64_t)k * NB;
     double* Wkk = gp->WT + ((int64_t)k * NB) * gp->lda + (int64_t)k * NB;
-    if (potf2_tiles)
-      hipLaunchKernelGGL(potf2_tiles_kernel<1024>, dim3(1), dim3(1024), POTF2T_LDS_DOUBLES * sizeof(double), hi, Akk,
-                         gp->lda, Wkk, gp->lda, gp->W11, gp->info, k);
-    else if (potf2_la)
-      hipLaunchKernelGGL(potf2_aug_kernel<true>, dim3(1), dim3(512), potf2_lds, hi, Akk, gp->lda, Wkk, gp->lda,
-                         gp->W11, gp->info, k, 0);
-    else
-      hipLaunchKernelGGL(potf2_aug_kernel<false>, dim3(1), dim3(256), potf2_lds, hi, Akk, gp->lda, Wkk, gp->lda,
-                         gp->W11, gp->info, k, 0);
+    hipLaunchKernelGGL(potf2_tiles_kernel<1024>, dim3(1), dim3(1024), POTF2T_LDS_DOUBLES * sizeof(double), hi, Akk,
+                       gp->lda, Wkk, gp->lda, gp->W11, gp->info, k);
     const int nrows = (nb - 1 - k) + 1 + k;  // below + y block + L^-T rows above
     hipLaunchKernelGGL(trsm_gemm_kernel, dim3(4 * nrows), dim3(256), lds32, hi, P);
     const int m = nb - 1 - k;  // block columns right of k
     if (m == 0) break;
-    if (one_stream) {
-      P.ku0 = k;
-      P.kun = 1;
-      col_update(hi, k + 1, m);
-      continue;
-    }
     const int j = k - g0;      // position inside the group
     P.ku0 = g0;
     P.kun = j + 1;
@@ -1313,8 +930,46 @@ int gp_factorize_impl(elfihip_gp* gp, bool allow_sweep) {
   ELFIHIP_CHECK_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_a, 0));
   ELFIHIP_CHECK_HIP(ctx, hipEventRecord(ctx->ev_b, bulk));
   ELFIHIP_CHECK_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_b, 0));
-  ELFIHIP_TRY(launch_status(ctx, "cholesky sweep"));
-  }  // !swept
+  return launch_status(ctx, "cholesky sweep (streams)");
+}
+
+int gp_factorize_impl(elfihip_gp* gp);
+
+int gp_factorize_impl(elfihip_gp* gp) {
+  elfihip_ctx* ctx = gp->ctx;
+  ELFIHIP_REQUIRE(ctx, gp->n > 0, "GP has no evidence");
+  hipStream_t st = ctx->stream;
+  const int64_t np = gp->np;
+  const int nb = (int)(np / NB);
+  ELFIHIP_CHECK_HIP(ctx, hipMemsetAsync(gp->info, 0, sizeof(int), st));
+  {
+    const int T = 256;
+    hipLaunchKernelGGL(x2_kernel, dim3((unsigned)((gp->cap + T - 1) / T)), dim3(T), 0, st, gp->X, gp->x2, gp->n,
+                       gp->cap, gp->dp);
+    GramArgs G;
+    G.X = gp->X;
+    G.x2 = gp->x2;
+    G.y = gp->y;
+    G.A = gp->A;
+    G.lda = gp->lda;
+    G.n = gp->n;
+    G.np = np;
+    G.dp = gp->dp;
+    G.var = gp->var;
+    G.neg_half_inv_ls2 = -0.5 / (gp->ls * gp->ls);
+    G.bias = gp->bias;
+    G.diag_add = gp->noise + GP_JITTER;
+    const int64_t nt = np / 64;
+    const size_t lds = 2 * 64 * (size_t)(gp->dp + 1) * sizeof(double);
+    hipLaunchKernelGGL(gram_kernel, dim3((unsigned)(nt * (nt + 1) / 2)), dim3(256), lds, st, G);
+    ELFIHIP_TRY(launch_status(ctx, "gram_kernel"));
+  }
+  // schedule of the sweep: gp->schedule 1 = streams, 2 = fused steps, 0 = by size (elfihip_gp_set_schedule)
+  const bool fused = gp->schedule == 2 || (gp->schedule == 0 && nb < FUSED_BELOW_NB);
+  if (fused)
+    ELFIHIP_TRY(sweep_fused(gp, nb, st));
+  else
+    ELFIHIP_TRY(sweep_streams(gp, nb, st));
   const double* z = gp->A + np * gp->lda;  // row np of A: z = L^-1 y
   hipLaunchKernelGGL(alpha_kernel, dim3((unsigned)((np * 64 + 255) / 256)), dim3(256), 0, st, gp->WT, z, gp->alpha,
                      gp->n, np, gp->lda);
@@ -1396,9 +1051,6 @@ int elfihip_gp_free(elfihip_gp* gp) {
   if (gp->Pint) (void)hipFree(gp->Pint);
   gp->ws.release();
   gp->ws2.release();
-  gp->sweep_tasks.release();
-  gp->sweep_sync.release();
-  gp->sweep_w11.release();
   delete gp;
   return ELFIHIP_OK;
 }
@@ -1459,42 +1111,19 @@ int elfihip_gp_append(elfihip_gp* gp, const double* X_new, const double* y_new, 
 int elfihip_gp_factorize(elfihip_gp* gp, double* log_marginal) {
   if (!gp) return fail(nullptr, ELFIHIP_ERR_ARG, "gp is NULL");
   DeviceGuard g(gp->ctx->device);
-  ELFIHIP_TRY(gp_factorize_impl(gp, true));
+  ELFIHIP_TRY(gp_factorize_impl(gp));
   if (log_marginal)
     *log_marginal = 0.5 * (-(double)gp->n * 1.8378770664093453 /* log(2 pi) */ - gp->logdet - gp->yKy);
   return ELFIHIP_OK;
 }
 
-// Developer probe: time `reps` launches of the diagonal-block kernel (the LDS-resident forms with phases masked out).
-int elfihip_debug_potf2(elfihip_gp* gp, int skip, int reps, float* ms) {
-  elfihip_ctx* ctx = gp->ctx;
-  DeviceGuard g(ctx->device);
-  const size_t potf2_lds = POTF2_LDS_DOUBLES * sizeof(double);
-  const bool la = getenv("ELFIHIP_POTF2_LA") ? atoi(getenv("ELFIHIP_POTF2_LA")) != 0 : true;
-  const bool tiles = getenv("ELFIHIP_POTF2_TILES") ? atoi(getenv("ELFIHIP_POTF2_TILES")) != 0 : true;
-  ELFIHIP_TRY(enable_lds(ctx, potf2_aug_kernel<false>, potf2_lds));
-  ELFIHIP_TRY(enable_lds(ctx, potf2_aug_kernel<true>, potf2_lds));
-  ELFIHIP_CHECK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-  for (int r = 0; r < reps; ++r)
-    if (tiles)
-      hipLaunchKernelGGL(potf2_tiles_kernel<1024>, dim3(1), dim3(1024), POTF2T_LDS_DOUBLES * sizeof(double), ctx->stream,
-                         gp->A, gp->lda, gp->WT, gp->lda, gp->W11, gp->info, 0);
-    else if (la)
-      hipLaunchKernelGGL(potf2_aug_kernel<true>, dim3(1), dim3(512), potf2_lds, ctx->stream, gp->A, gp->lda, gp->WT,
-                         gp->lda, gp->W11, gp->info, 0, skip);
-    else
-      hipLaunchKernelGGL(potf2_aug_kernel<false>, dim3(1), dim3(256), potf2_lds, ctx->stream, gp->A, gp->lda, gp->WT,
-                         gp->lda, gp->W11, gp->info, 0, skip);
-  ELFIHIP_CHECK_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-  ELFIHIP_CHECK_HIP(ctx, hipEventSynchronize(ctx->ev1));
-  ELFIHIP_CHECK_HIP(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
-  *ms /= (float)reps;
-  if ((skip & 8) && !tiles) {
-    double dbg[6];
-    ELFIHIP_CHECK_HIP(ctx, hipMemcpy(dbg, gp->W11 + NB * NB, sizeof dbg, hipMemcpyDeviceToHost));
-    fprintf(stderr, "potf2 cycles: A-load %.0f A-elim %.0f A-store+barrier %.0f B+barrier %.0f | loop-end %.0f total %.0f\n", dbg[0],
-            dbg[1], dbg[2], dbg[3], dbg[4], dbg[5]);
-  }
+int elfihip_gp_set_schedule(elfihip_gp* gp, int schedule, int panel_group) {
+  if (!gp) return fail(nullptr, ELFIHIP_ERR_ARG, "gp is NULL");
+  ELFIHIP_REQUIRE(gp->ctx, schedule >= 0 && schedule <= 2, "schedule %d outside {0, 1, 2}", schedule);
+  ELFIHIP_REQUIRE(gp->ctx, panel_group == 0 || panel_group == 1 || panel_group == 2 || panel_group == 4,
+                  "panel_group %d outside {0, 1, 2, 4}", panel_group);
+  gp->schedule = schedule;
+  gp->panel_group = panel_group;
   return ELFIHIP_OK;
 }
 

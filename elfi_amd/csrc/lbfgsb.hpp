@@ -35,7 +35,9 @@ class Lbfgsb {
   static constexpr double PGTOL = 1e-5;
   static constexpr double LS_FTOL = 1e-3, LS_GTOL = 0.9, LS_XTOL = 0.1;
 
-  enum Status { RUNNING = 0, CONV_PGTOL = 1, CONV_FTOL = 2, MAXITER = 3, ABNORMAL = 4 };
+  enum Status { RUNNING = 0, CONV_PGTOL = 1, CONV_FTOL = 2, MAXITER = 3, ABNORMAL = 4, MAXFUN = 5 };
+  // scipy.optimize.minimize(method='L-BFGS-B') default maxfun: checked once per new iterate, after maxiter
+  static constexpr int MAXFUN_EVALS = 15000;
 
   // Start at x0 (projected into the box).  The first evaluation is requested at x().
   void init(int n, const double* lo, const double* hi, const double* x0, int maxiter) {
@@ -131,6 +133,10 @@ class Lbfgsb {
     }
     if (iter_ >= maxiter_) {
       status_ = MAXITER;
+      return;
+    }
+    if (nfev_ > MAXFUN_EVALS) {
+      status_ = MAXFUN;
       return;
     }
     if (dr > EPS * ddum) {

@@ -43,6 +43,7 @@ struct SelState {
 __device__ __forceinline__ unsigned long long key_of(double v) {
   unsigned long long b = (unsigned long long)__double_as_longlong(v);
   if (v != v) return ~0ull;                                   // NaN last
+  if (v == 0.0) b = 0ull;                                     // -0.0 and +0.0 are one key (NumPy compares them equal)
   return (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
 }
 

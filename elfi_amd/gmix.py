@@ -38,7 +38,8 @@ def _psd_factor(cov, d):
     if cov.shape != (d, d):
         raise ValueError("Array 'cov' must be square with the dimension of the means (%d)." % d)
     s, u = np.linalg.eigh(cov)
-    eps = 1e3 * np.finfo(np.float64).eps * np.max(np.abs(s)) * max(cov.shape) if s.size else 0.0
+    # scipy.stats._multivariate._eigvalsh_to_eps for float64: 1e6 * eps * max|s|, no dimension factor
+    eps = 1e6 * np.finfo(np.float64).eps * np.max(np.abs(s)) if s.size else 0.0
     eps = max(eps, 0.0)
     if np.min(s) < -eps:
         raise ValueError('the input matrix must be positive semidefinite')

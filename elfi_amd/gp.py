@@ -82,6 +82,10 @@ class GPHandle:
         self.n += X.shape[0]
         return lz.value
 
+    def set_schedule(self, schedule=0, panel_group=0):
+        """Sweep schedule of factorize(): 0 by size, 1 two-stream look-ahead, 2 fused steps (include/elfihip.h)."""
+        self._check(self.lib.elfihip_gp_set_schedule(self.h, int(schedule), int(panel_group)))
+
     def factorize(self):
         lz = C.c_double()
         self._check(self.lib.elfihip_gp_factorize(self.h, C.byref(lz)))

@@ -213,7 +213,11 @@ def optimize_hyperparameters(model, max_iters=50):
     phi0 = logexp_inv(np.array([h0[k] for k in NAMES]))
     try:
         phi, flog, nfev, status = scg(obj.f, obj.grad, phi0, maxiters=max_iters)
-    except np.linalg.LinAlgError:
+    except Exception:
+        # whatever ended the search (LinAlgError, or the ValueError / ZeroDivisionError the objective re-raises after
+        # ten failed evaluations in a row): the device GP holds the last TRIAL hyper-parameters, possibly
+        # unfactorised -- put the starting values back before the caller sees the error, so that the next update()
+        # does not extend a factorisation that belongs to other hyper-parameters
         model._hyper = h0
         model._refit()
         raise

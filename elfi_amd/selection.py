@@ -41,10 +41,17 @@ def merge_batch(samples, batch, discrepancy_name, n_samples, threshold=None, ctx
     first call; batch: dict name -> array with batch_size rows.  Returns the new dict (sorted by the
     discrepancy, last column if nested)."""
     d = np.asarray(batch[discrepancy_name])
-    vals, rows = smallest_k(d, n_samples, ctx=ctx)
-    if threshold is not None:   # acceptance condition of samplers.py:219-225: every nested column <= threshold
-        ok = np.all(np.atleast_2d(np.transpose(d[rows] <= threshold)), axis=0)
-        rows = rows[ok]
+    key = d[:, -1] if d.ndim == 2 else d
+    if threshold is not None:
+        # acceptance condition of samplers.py:219-225 over the WHOLE batch first (every nested column <= threshold),
+        # then the k smallest among the accepted rows: a rejected row's key becomes NaN, which the selection orders
+        # last, so it can never displace an accepted row that ranks beyond n_samples by the last column alone
+        accepted = np.all(np.atleast_2d(np.transpose(d <= threshold)), axis=0)
+        key = np.where(accepted, key, np.nan)
+        n_acc = int(np.count_nonzero(accepted))
+    else:
+        n_acc = key.shape[0]
+    vals, rows = smallest_k(key, min(n_samples, n_acc), ctx=ctx)
     if samples is None:
         samples = {}
         for name, v in batch.items():

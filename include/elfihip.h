@@ -199,6 +199,12 @@ int elfihip_gp_append(elfihip_gp* gp, const double* X_new, const double* y_new, 
  * gpy_regression.py:283-284 / :311-312 construct GPRegression).  log_marginal may be NULL.
  * ELFIHIP_ERR_NOT_PD if a pivot is not positive (GPy would raise LinAlgError). */
 int elfihip_gp_factorize(elfihip_gp* gp, double* log_marginal);
+/* How elfihip_gp_factorize schedules its sweep over the 128-wide block columns (no reference counterpart: GPy hands
+ * the factorisation to LAPACK).  schedule 0 = chosen by size (default), 1 = two-stream look-ahead with panel groups,
+ * 2 = fused steps on the caller's stream (the next diagonal block factored beside the trailing update, one launch);
+ * panel_group 0 = by size, else 1 / 2 / 4 panels per pass over the trailing matrix (schedule 1).  Results agree to
+ * rounding between schedules; each is deterministic. */
+int elfihip_gp_set_schedule(elfihip_gp* gp, int schedule, int panel_group);
 /* What GPy evaluates once per objective call of GPyRegression.optimize() (gpy_regression.py:317-323
  * -> [GPy-upstream] ExactGaussianInference + kern.update_gradients_full): the log marginal
  * likelihood and its gradient w.r.t. (rbf.variance, rbf.lengthscale, bias.variance,
@@ -268,7 +274,7 @@ int elfihip_lbfgsb_create(int d, int64_t S, const double* lower, const double* u
 /* idx (S) / x (S, d) receive the waiting searches' indices and points; returns their number, < 0 on error. */
 int64_t elfihip_lbfgsb_pending(elfihip_lbfgsb* h, int64_t* idx, double* x);
 int elfihip_lbfgsb_feed(elfihip_lbfgsb* h, int64_t n, const double* f, const double* g);
-/* x (S, d), f (S), iters (S), status (S: 1 projected gradient, 2 relative reduction, 3 maxiter, 4 abnormal);
+/* x (S, d), f (S), iters (S), status (S: 1 projected gradient, 2 relative reduction, 3 maxiter, 4 abnormal, 5 maxfun = 15000 evaluations);
  * any of f / iters / status may be NULL. */
 int elfihip_lbfgsb_result(const elfihip_lbfgsb* h, double* x, double* f, int* iters, int* status);
 int elfihip_lbfgsb_free(elfihip_lbfgsb* h);

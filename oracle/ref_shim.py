@@ -17,7 +17,22 @@ import types
 
 import numpy as np
 
-REFERENCE_ROOT = os.environ.get("ELFI_REFERENCE_ROOT", "/root/reference")
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _find_root():
+    """$ELFI_REFERENCE_ROOT, else /root/reference (build container), else oracle/_ref -- the copy oracle/make_ref.sh
+    makes so that the GPU box (where /root/reference does not exist) can run the real reference loops as a checker."""
+    env = os.environ.get("ELFI_REFERENCE_ROOT")
+    if env:
+        return env
+    for cand in ("/root/reference", os.path.join(_HERE, "_ref")):
+        if os.path.isdir(os.path.join(cand, "elfi")):
+            return cand
+    return "/root/reference"
+
+
+REFERENCE_ROOT = _find_root()
 
 
 def available():

@@ -61,6 +61,43 @@ def test_lockstep_minimiser_vs_scipy_on_the_oracle(hip_ctx, n, d, S, t):
     assert same >= 0.8 * S and same_it >= 0.7 * S, (same, same_it, S)
 
 
+def test_cfg5_shape_256_starts_n8192_d20(hip_ctx):
+    """BASELINE.json configs[4]: n_evidence = 8192, d = 20, 256 parallel acquisition starts (acquisition.py:129-172
+    with n_inits=256).  All starts in one lock-step call; every end point checked on the CPU oracle, a sample of the
+    starts against scipy's L-BFGS-B from the same start on the oracle (what the reference would run)."""
+    import scipy.optimize
+    n, d, S, t = 8192, 20, 256, 128
+    m, ref, bounds = _setup(n, d, seed=5)
+    beta = G.lcb_beta(t, d)
+    starts = np.random.RandomState(17).uniform(-2, 2, (S, d))
+    locs, vals, iters, n_eval = m._handle.lcb_minimize(starts, bounds, beta, maxiter=1000)
+    f0 = G.lcb_evaluate(ref, starts, t)[:, 0]
+    scale = np.max(np.abs(f0)) + 1.0
+    lo, hi = np.array(bounds).T
+    assert np.all(locs >= lo) and np.all(locs <= hi)
+    assert np.all(vals <= f0 + 1e-9 * scale)
+    np.testing.assert_allclose(vals, G.lcb_evaluate(ref, locs, t)[:, 0], rtol=0, atol=1e-8 * scale)
+    g = G.lcb_evaluate_gradient(ref, locs, t)
+    pg = locs - np.clip(locs - g, lo, hi)
+    assert np.max(np.abs(pg)) <= 1e-3, 'end points must be stationary in the box'
+    assert n_eval >= S and np.all(iters <= 1000)
+    fun = lambda x: float(G.lcb_evaluate(ref, x, t)[0, 0])
+    grad = lambda x: G.lcb_evaluate_gradient(ref, x, t)[0]
+    sample = [0, 31, 64, 100, 177, 255]
+    same, best = 0, np.inf
+    for i in sample:
+        r = scipy.optimize.minimize(fun, starts[i], method='L-BFGS-B', jac=grad, bounds=bounds,
+                                    options={'maxiter': 1000})
+        same += np.max(np.abs(r.x - locs[i])) <= 1e-4 and abs(int(r.nit) - int(iters[i])) <= 1
+        best = min(best, r.fun)
+    assert same >= len(sample) - 1, (same, len(sample))
+    assert vals.min() <= best + 1e-6 * scale
+    # the sharded form of the same call (32 starts per rank on 8 GPUs) is the same computation per start
+    part, pvals, piters, _ = m._handle.lcb_minimize(starts[3::8], bounds, beta, maxiter=1000)
+    agree = np.max(np.abs(part - locs[3::8]), axis=1) <= 1e-4
+    assert np.count_nonzero(agree) >= 30 and abs(pvals.min() - vals[3::8].min()) <= 1e-6 * scale
+
+
 def test_acquire_end_to_end_and_determinism(hip_ctx):
     from elfi_amd import HipLCBSC
     m, ref, bounds = _setup(400, 2, seed=1)

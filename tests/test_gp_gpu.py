@@ -242,21 +242,71 @@ def test_against_the_reference_closed_forms(hip_ctx):
             _close(grad, g['lcbg_%s_%d' % (tag, t)], 1e-7, 'LCB gradient vs reference LCBSC ' + tag)
 
 
-@pytest.mark.parametrize('n,d', [(100, 2), (129, 3), (700, 5), (1500, 10)])
-def test_resident_sweep_form_matches_the_default_sweep(hip_ctx, monkeypatch, n, d):
-    """ELFIHIP_SWEEP=1 (experimental: the whole sweep as one resident kernel, tasks + dependency counters) against the
-    multi-launch sweep and the oracle: same factor up to summation order (K = 128 per update instead of panel groups)."""
-    X, y, bounds = _problem(n, d, seed=3)
-    monkeypatch.setenv('ELFIHIP_SWEEP', '0')
-    gp0, logz0, post = _fit(X, y, bounds)
-    xs = np.random.RandomState(4).uniform(-2, 2, (7, d))
-    m0, v0 = gp0.predict(xs)
-    monkeypatch.setenv('ELFIHIP_SWEEP', '1')
-    gp1, logz1, _ = _fit(X, y, bounds)
-    m1, v1 = gp1.predict(xs)
-    assert abs(logz1 - logz0) <= 1e-9 * abs(logz0)
-    assert abs(logz1 - post.log_marginal) <= 1e-8 * abs(logz0)
-    _close(gp1.get(0), post.L, 1e-10, 'L, resident sweep')
-    _close(gp1.get(1), post.Linv.T, 1e-9, 'L^-T, resident sweep')
-    _close(m1, m0, 1e-9, 'mean, resident vs multi-launch sweep')
-    _close(v1, v0, 1e-8, 'variance, resident vs multi-launch sweep')
+_ORACLE_CACHE = {}
+
+
+def _oracle_for(n, d):
+    """One CPU posterior per shape (the O(n^3) LAPACK passes are the slow part of these tests)."""
+    key = (n, d)
+    if key not in _ORACLE_CACHE:
+        _ORACLE_CACHE.clear()            # at most one large posterior alive (8192^2 doubles = 0.5 GB per matrix)
+        X, y, bounds = G.synthetic_gp_problem(n, d, seed=n + d)
+        h = G.default_hyper(bounds, y)
+        _ORACLE_CACHE[key] = (X, y, bounds, h, G.Posterior(X, y, h['var'], h['ls'], h['bias'], h['noise']))
+    return _ORACLE_CACHE[key]
+
+
+def _fit_with_schedule(X, y, h, schedule, group=0):
+    from elfi_amd.gp import GPHandle
+    gp = GPHandle(X.shape[1], X.shape[0])
+    gp.set_schedule(schedule, group)
+    gp.set_hyper(h['var'], h['ls'], h['bias'], h['noise'])
+    gp.set_data(X, y)
+    return gp, gp.factorize()
+
+
+# schedule 1 = two-stream look-ahead with panel groups, 2 = fused steps (include/elfihip.h: elfihip_gp_set_schedule);
+# 0 = the size-dependent default.  Block columns nb = ceil(n / 128): every branch of the stream schedule's group / pass
+# selection (nb < 30: single panels, fine pass; 30..39: groups of 4, square tiles; 40..47: groups of 2, fine pass;
+# >= 48: groups of 4, fine pass) and the fused schedule on both sides of its default range are in the list.
+@pytest.mark.parametrize('n,d,schedule,group', [
+    (100, 2, 1, 0), (100, 2, 2, 0), (129, 3, 1, 0), (129, 3, 2, 0), (700, 5, 1, 2), (700, 5, 2, 0),
+    (1500, 10, 1, 4), (1500, 10, 2, 0), (2500, 4, 1, 0), (2500, 4, 2, 0)])
+def test_both_sweep_schedules_vs_oracle(hip_ctx, n, d, schedule, group):
+    X, y, bounds, h, post = _oracle_for(n, d)
+    gp, logz = _fit_with_schedule(X, y, h, schedule, group)
+    assert abs(logz - post.log_marginal) <= 1e-9 * abs(post.log_marginal)
+    _close(gp.get(0), post.L, 1e-10, 'L')
+    _close(gp.get(1), post.Linv.T, 1e-9, 'L^-T')
+    _close(gp.get(2), post.alpha, 1e-8, 'alpha')
+
+
+@pytest.mark.parametrize('n,d,schedule', [
+    (4096, 10, 0), (4096, 10, 1), (4096, 10, 2),      # cfg3 metric shape: nb = 32
+    (5120, 10, 0), (5120, 10, 1), (5120, 10, 2),      # nb = 40: stream schedule switches to groups of 2 + fine pass
+    (6144, 10, 1), (6144, 10, 2),                     # nb = 48: groups of 4 + fine pass
+    (8192, 20, 0), (8192, 20, 1), (8192, 20, 2)])     # cfg5 shape: nb = 64
+def test_large_n_full_matrix_parity(hip_ctx, n, d, schedule):
+    """Every entry of L, L^-T, alpha and the log marginal at the sizes of BASELINE.json configs[2] / configs[4], plus
+    mean / variance / gradients / LCB at 64 points, against the CPU posterior (LAPACK)."""
+    X, y, bounds, h, post = _oracle_for(n, d)
+    gp, logz = _fit_with_schedule(X, y, h, schedule)
+    assert abs(logz - post.log_marginal) <= 1e-9 * abs(post.log_marginal)
+    _close(gp.get(0), post.L, 1e-10, 'L')
+    _close(gp.get(1), post.Linv.T, 1e-9, 'L^-T')
+    _close(gp.get(2), post.alpha, 1e-8, 'alpha')
+    xs = np.random.RandomState(n).uniform(-2, 2, (64, d))
+    xs[0] = X[n // 2]
+    mu, var, dmu, dvar = gp.predict_grad(xs)
+    rmu, rvar = post.predict(xs, noiseless=True)
+    gmu, gvar = post.predictive_gradients(xs)
+    _close(mu, rmu, 1e-8, 'mu')
+    assert np.max(np.abs(var - rvar)) <= 1e-8 * (post.var + post.bias), 'var'
+    _close(dmu, gmu, 1e-8, 'grad mu')
+    _close(dvar, gvar, 1e-7, 'grad var')
+    for t in (0, 300):
+        val, grad = gp.lcb(xs, G.lcb_beta(t, d))
+        _close(val, G.lcb_evaluate(post, xs, t), 1e-8, 'lcb')
+        _close(grad, G.lcb_evaluate_gradient(post, xs, t), 1e-7, 'lcb grad')
+    _, g = gp.nlml_grad()
+    assert np.max(np.abs(g - post.log_marginal_grad())) <= 1e-7 * np.max(np.abs(g))

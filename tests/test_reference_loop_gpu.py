@@ -1,0 +1,162 @@
+"""GPU: the REAL reference loops driving the HIP objects.
+
+oracle/make_ref.sh copies the reference's Python package to the git-ignored oracle/_ref/ (it ships with the gpurun
+snapshot; /root/reference itself does not exist on the GPU box) and oracle/ref_shim.py makes it importable.  The
+reference is the checker and the host orchestration here, never the product: what executes the arithmetic of the hot
+path is libelfihip.so behind HipDistance / HipDiscrepancy / autocov / HipGPRegression / HipLCBSC.
+
+  * elfi.Rejection (samplers.py:24-299, _merge_batch :209-237) over an elfi.Distance node whose operation is
+    HipDistance, on the documented tutorial run (docs/usage/tutorial.rst:28-29,360,386,396):
+    Rejection(d, batch_size=10000, seed=20170530).sample(1000, quantile=0.01, bar=False) -> threshold 0.116859716394976;
+  * BASELINE.json configs[0] (MA2, batch_size=1000): the HIP-node run equals the reference-node run sample by sample;
+  * elfi.BOLFI (bolfi.py:201-254,289-292: update / prepare_new_batch / _should_optimize, the reference's own
+    acquisition index bookkeeping) with target_model=HipGPRegression, acquisition_method=HipLCBSC, initial_evidence=512,
+    next to the same call with the CPU oracle model and the reference's own LCBSC + scipy L-BFGS-B.
+
+Skipped (not failed) when neither /root/reference nor oracle/_ref is present.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ORACLE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle')
+sys.path.insert(0, ORACLE)
+import ref_shim  # noqa: E402
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(not ref_shim.available(), reason='no reference package (run oracle/make_ref.sh)')]
+
+
+@pytest.fixture(scope='module')
+def elfi():
+    e = ref_shim.install()
+    import elfi.clients.native as native
+    native.set_as_default()
+    return e
+
+
+def _tutorial_model(elfi, hip):
+    """The model of docs/usage/tutorial.rst; hip=True puts the HIP operations into its Summary / Distance nodes."""
+    import elfi_amd
+    from elfi.examples.ma2 import MA2, autocov
+    from elfi.examples.ma2 import CustomPrior1, CustomPrior2
+    np.random.seed(20170530)
+    y_obs = MA2(0.6, 0.2)
+    m = elfi.new_model()
+    t1 = elfi.Prior(CustomPrior1, 2, model=m, name='t1')
+    t2 = elfi.Prior(CustomPrior2, t1, 1, name='t2')
+    Y = elfi.Simulator(MA2, t1, t2, observed=y_obs, name='MA2')
+    ac = elfi_amd.autocov if hip else autocov
+    S1 = elfi.Summary(ac, Y, name='S1')
+    S2 = elfi.Summary(ac, Y, 2, name='S2')
+    d = elfi.Distance(elfi_amd.HipDistance('euclidean') if hip else 'euclidean', S1, S2, name='d')
+    return m, d
+
+
+def test_tutorial_rejection_known_answer_through_the_hip_nodes(hip_ctx, elfi):
+    m, d = _tutorial_model(elfi, hip=True)
+    res = elfi.Rejection(d, batch_size=10000, seed=20170530).sample(1000, quantile=0.01, bar=False)
+    assert repr(float(res.threshold)) == '0.116859716394976', repr(res.threshold)
+    assert res.n_sim == 100000
+    assert abs(res.sample_means['t1'] - 0.556) < 5e-4 and abs(res.sample_means['t2'] - 0.219) < 5e-4
+    # the same through HipDiscrepancy (skips the column_stack of utils.py:37-52) and with a threshold objective
+    d2 = elfi.Discrepancy(__import__('elfi_amd').HipDiscrepancy('euclidean'), m['S1'], m['S2'], name='d2')
+    res2 = elfi.Rejection(d2, batch_size=10000, seed=20170530).sample(1000, quantile=0.01, bar=False)
+    assert repr(float(res2.threshold)) == '0.116859716394976'
+    res3 = elfi.Rejection(d, batch_size=10000, seed=20170530).sample(1000, threshold=0.2, bar=False)
+    assert res3.n_sim == 40000 and abs(res3.threshold - 0.185) < 5e-4      # tutorial.rst:450,461-463
+
+
+def test_config0_ma2_batch_1000_equals_the_reference_nodes(hip_ctx, elfi):
+    """BASELINE.json configs[0]: elfi.Rejection, batch_size=1000, Euclidean distance on 2 summaries."""
+    import elfi_amd
+    from elfi.examples import ma2
+    ref_m = ma2.get_model(seed_obs=4)
+    ref = elfi.Rejection(ref_m['d'], batch_size=1000, seed=1).sample(1000, n_sim=100000, bar=False)
+    m = ma2.get_model(seed_obs=4)
+    m['S1'].become(elfi.Summary(elfi_amd.autocov, m['MA2'], model=m))
+    m['S2'].become(elfi.Summary(elfi_amd.autocov, m['MA2'], 2, model=m))
+    m['d'].become(elfi.Distance(elfi_amd.HipDistance('euclidean'), m['S1'], m['S2'], model=m))
+    got = elfi.Rejection(m['d'], batch_size=1000, seed=1).sample(1000, n_sim=100000, bar=False)
+    assert got.n_sim == ref.n_sim == 100000
+    assert got.threshold == ref.threshold
+    for k in ('t1', 't2'):
+        assert np.array_equal(got.samples[k], ref.samples[k])
+    assert np.array_equal(got.discrepancies, ref.discrepancies)
+
+
+def _bolfi(elfi, hip, n_initial, update_interval, seed=1):
+    import elfi_amd
+    from elfi.examples import ma2
+    from elfi.model.extensions import ModelPrior
+    m = ma2.get_model(seed_obs=4)
+    if hip:
+        m['d'].become(elfi.Distance(elfi_amd.HipDistance('euclidean'), m['S1'], m['S2'], model=m))
+    log_d = elfi.Operation(np.log, m['d'], name='log_d')
+    bounds = {'t1': (-2, 2), 't2': (-1, 1)}
+    if hip:
+        gp = elfi_amd.HipGPRegression(['t1', 't2'], bounds=bounds)
+        # what bolfi.py:103-107 builds by default, with the batched multi-start optimiser behind it
+        acq = elfi_amd.HipLCBSC(gp, prior=ModelPrior(m, parameter_names=['t1', 't2']), noise_var=0.1,
+                                exploration_rate=10, seed=seed)
+    else:
+        from oracle_gp_model import OracleGPRegression
+        gp, acq = OracleGPRegression(['t1', 't2'], bounds=bounds), None      # reference LCBSC + scipy L-BFGS-B
+    return elfi.BOLFI(log_d, batch_size=1, initial_evidence=n_initial, update_interval=update_interval,
+                      bounds=bounds, acq_noise_var=0.1, target_model=gp, acquisition_method=acq, seed=seed)
+
+
+@pytest.mark.timeout(900)
+def test_real_bolfi_loop_hip_model_next_to_the_oracle_model(hip_ctx, elfi):
+    n0, n1, interval = 512, 560, 16
+    hip = _bolfi(elfi, True, n0, interval)
+    hip.fit(n_evidence=n1, bar=False)
+    res_h = hip.extract_result()
+    cpu = _bolfi(elfi, False, n0, interval)
+    cpu.fit(n_evidence=n1, bar=False)
+    res_c = cpu.extract_result()
+    Xh, Xc = hip.target_model.X, cpu.target_model.X
+    assert Xh.shape == Xc.shape == (n1, 2)
+    # initial evidence: prior draws + the simulator + the distance -- bit for bit (HipDistance is exact on euclidean)
+    assert np.array_equal(Xh[:n0], Xc[:n0]) and np.array_equal(hip.target_model.Y[:n0], cpu.target_model.Y[:n0])
+    # the acquisitions before the first hyper-parameter optimisation (t = 0 .. interval-2): same start points, same
+    # GP up to rounding, same L-BFGS-B -> the same acquired points
+    first = slice(n0, n0 + interval - 1)
+    dev = np.max(np.abs(Xh[first] - Xc[first]), axis=1)
+    assert np.count_nonzero(dev <= 1e-6) >= interval - 2, dev        # at most one start tipped into another basin
+    assert dev[0] <= 1e-6
+    # both runs end near the data-generating parameters (tests/functional/test_inference.py:155-157)
+    for r in (res_h, res_c):
+        assert abs(r.x_min['t1'] - 0.6) < 0.2 and abs(r.x_min['t2'] - 0.2) < 0.2
+    # same seed, same result (tests/functional/test_consistency.py:83-128)
+    b2 = _bolfi(elfi, True, n0, interval)
+    b2.fit(n_evidence=n1, bar=False)
+    again = b2.extract_result()
+    assert np.allclose([again.x_min['t1'], again.x_min['t2']], [res_h.x_min['t1'], res_h.x_min['t2']], atol=1e-7)
+
+
+@pytest.mark.timeout(900)
+def test_real_bolfi_fit_1024_on_the_gpu(hip_ctx, elfi):
+    """elfi.BOLFI(..., target_model=HipGPRegression, acquisition_method=HipLCBSC, initial_evidence=512).fit(1024):
+    512 reference-driven acquisitions, a MAP search of the hyper-parameters every 64 of them."""
+    b = _bolfi(elfi, True, 512, 64)
+    b.fit(n_evidence=1024, bar=False)
+    res = b.extract_result()
+    gp = b.target_model
+    assert gp.n_evidence == 1024 and gp.X.shape == (1024, 2) and np.all(np.isfinite(gp.Y))
+    assert abs(res.x_min['t1'] - 0.6) < 0.2 and abs(res.x_min['t2'] - 0.2) < 0.2
+    lo, hi = np.array([(-2, 2), (-1, 1)]).T
+    assert np.all(gp.X >= lo) and np.all(gp.X <= hi)
+    # the surrogate the loop left behind is the GP of its evidence at its hyper-parameters (CPU posterior)
+    import gp_oracle as G
+    post = G.Posterior(gp.X, gp.Y, **gp._hyper)
+    xs = np.random.RandomState(0).uniform(lo, hi, (16, 2))
+    mu, var = gp.predict(xs, noiseless=True)
+    rmu, rvar = post.predict(xs, noiseless=True)
+    assert np.max(np.abs(mu - rmu)) <= 1e-7 * np.max(np.abs(rmu)) and np.max(np.abs(var - rvar)) <= 1e-7 * np.max(rvar + 1)
+    # extract_posterior / sample of the reference run on the HIP model (posteriors.py:20-212 reads predict / gradients)
+    post_ref = b.extract_posterior()
+    lp = post_ref.logpdf(np.array([[0.6, 0.2], [0.0, 0.0]]))
+    assert np.all(np.isfinite(lp)) and lp[0] > lp[1]

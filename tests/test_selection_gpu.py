@@ -65,6 +65,44 @@ def test_merge_batch_equals_the_reference_merge(hip_ctx):
     assert np.all(np.diff(state['d']) >= 0)
 
 
+@pytest.mark.parametrize('nested', [False, True])
+def test_merge_batch_with_threshold_equals_the_reference_merge(hip_ctx, nested):
+    """The acceptance condition (samplers.py:219-225: EVERY nested column <= threshold) is taken over the whole
+    batch before the k smallest are selected: accepted rows that rank beyond n_samples by the last column must
+    survive when higher-ranked rows fail the threshold in an earlier column."""
+    import elfi_amd
+    rs = np.random.RandomState(11)
+    n_samples, bs, thr = 50, 4000, 0.9
+    K = 3 if nested else 1
+    state = None
+    dshape = (n_samples + bs, K) if nested else (n_samples + bs,)
+    ref = {'d': np.full(dshape, np.inf), 't1': np.empty(n_samples + bs)}
+    kept = 0
+    for b in range(5):
+        d = np.abs(rs.randn(bs, K)) * np.array([3.0, 2.0, 1.0][:K])   # early columns fail the threshold most often
+        if not nested:
+            d = d[:, 0] * 0.3
+        batch = {'d': d, 't1': rs.rand(bs)}
+        state = elfi_amd.merge_batch(state, batch, 'd', n_samples, threshold=thr)
+        accepted = np.all(np.atleast_2d(np.transpose(batch['d'] <= thr)), axis=0)   # the reference's steps
+        num = int(np.sum(accepted))
+        kept += num
+        if num > 0:
+            for k_, v in ref.items():
+                v[-num:] = batch[k_][accepted]
+        order = np.argsort(np.atleast_2d(np.transpose(ref['d']))[-1], kind='stable')
+        for k_, v in ref.items():
+            v[:] = v[order]
+        for k_ in ref:
+            assert np.array_equal(state[k_], ref[k_][:n_samples]), (b, k_)
+    assert kept > n_samples and np.all(np.isfinite(state['d']))
+    # nothing accepted: the state is unchanged
+    same = elfi_amd.merge_batch(state, {'d': np.full_like(batch['d'], 5.0), 't1': batch['t1']}, 'd', n_samples,
+                                threshold=thr)
+    for k_ in ref:
+        assert np.array_equal(same[k_], state[k_])
+
+
 def test_smallest_k_many_equal_keys_large(hip_ctx):
     """10^6 keys with 7 distinct values: the prefix class stays large, so the resident kernel runs all its passes and
     the cut falls inside a run of equal keys (lowest rows win)."""
