@@ -673,7 +673,59 @@ __device__ __noinline__ void potf2_tiles_call(double* Akk, int64_t lda, double* 
 //   [0, tA)        Cholesky rows: (i, c), k < c <= i < nb, tA = m (m+1) / 2 - 1     C -= P_i P_c^T   (SYRK)
 //   [tA, tA+m)     y block:       (y, c)                                          C -= P_y P_c^T
 //   [tA+m, ...)    L^-T rows:     (r, c), r <= k                                  C  = beta C - P_r P_c^T, beta = 0 for r == k
-// 1024 threads per workgroup (what the diagonal block needs): an update tile is 128 x 128 on 16 waves (gemm_tile_nt16).
+// 1024 threads per workgroup (what the diagonal block needs), so one workgroup per CU: the update workgroups are
+// PERSISTENT -- 8 x 31 of them, one per CU beside workgroup 0 -- and walk their share of the tile list with the next
+// unit's first operand loads and old C values in flight while the current unit is multiplied (a one-tile-per-workgroup
+// form of the same launch spent 24.6 us per 128 x 128 x 128 tile against 13.6 us of matrix-pipe time: with one
+// workgroup per CU nothing overlaps a tile's first loads and its stores).  A unit is a whole tile (RT = 2) or its
+// upper / lower 64 rows (RT = 1), whichever leaves the shorter tail for this step's tile count (host's choice).
+// XCD-aware: workgroups go round-robin over the 8 XCDs, so XCD x works through the contiguous stretch
+// [x per, (x+1) per) of the unit list (consecutive units share their row block, the A operand, in that XCD's L2).
+struct StepUnit {
+  const double* Ap;   // unit's rows of the panel (64 RT x 128)
+  const double* Bp;   // the block column's rows of the panel (128 x 128)
+  double* C;          // unit's rows of the tile
+  double keep;        // 1: C -= P P^T, 0: C = -P P^T (the panel that creates an L^-T row)
+};
+
+template <int RT>
+__device__ __forceinline__ StepUnit step_decode(const PanelArgs& P, int unit) {
+  constexpr int UPT = 2 / RT;
+  const int k = P.k, m = P.nb - 1 - k, c0 = k + 1;
+  const int tA = m * (m + 1) / 2 - 1;
+  const int idx = unit / UPT;
+  const int half = unit - idx * UPT;
+  StepUnit U;
+  U.keep = 1.0;
+  int cblk;
+  if (idx < tA) {
+    const int e = idx + 1;  // triangular enumeration without its first element, tile (k+1, k+1)
+    int i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+    i -= (i * (i + 1) / 2 > e);
+    i += ((i + 1) * (i + 2) / 2 <= e);
+    const int c = e - i * (i + 1) / 2;
+    cblk = c0 + c;
+    U.Ap = P.A + ((int64_t)(c0 + i) * NB) * P.lda + (int64_t)k * NB;
+    U.C = P.A + ((int64_t)(c0 + i) * NB) * P.lda + (int64_t)cblk * NB;
+  } else if (idx < tA + m) {
+    cblk = c0 + (idx - tA);
+    U.Ap = P.A + ((int64_t)P.nb * NB) * P.lda + (int64_t)k * NB;
+    U.C = P.A + ((int64_t)P.nb * NB) * P.lda + (int64_t)cblk * NB;
+  } else {
+    const int e = idx - tA - m;
+    const int r = e / m;
+    cblk = c0 + (e - r * m);
+    U.Ap = P.WT + ((int64_t)r * NB) * P.lda + (int64_t)k * NB;
+    U.C = P.WT + ((int64_t)r * NB) * P.lda + (int64_t)cblk * NB;
+    U.keep = (r == k) ? 0.0 : 1.0;
+  }
+  U.Bp = P.A + ((int64_t)cblk * NB) * P.lda + (int64_t)k * NB;
+  U.Ap += (int64_t)half * (64 * RT) * P.lda;
+  U.C += (int64_t)half * (64 * RT) * P.lda;
+  return U;
+}
+
+template <int RT>
 __global__ __launch_bounds__(1024) void step_kernel(PanelArgs P, double* W11, int* info) {
   extern __shared__ __align__(16) double sm[];
   const int k = P.k;
@@ -684,61 +736,108 @@ __global__ __launch_bounds__(1024) void step_kernel(PanelArgs P, double* W11, in
     potf2_tiles_call(Akk, P.lda, Wkk, P.lda, W11, info, kk, sm);
     return;
   }
-  // workgroups go round-robin over the 8 XCDs: renumber so that an XCD works through a contiguous stretch of the tile
-  // list (consecutive tiles share their row block, i.e. the A operand, in that XCD's L2).  The grid is 1 + 8 `per`
-  // workgroups, per = ceil(tiles / 8): tile x * per + s goes to workgroup 1 + 8 s + x, surplus workgroups leave.
-  const int b = (int)blockIdx.x - 1;
-  const int per = ((int)gridDim.x - 1) >> 3;
-  const int idx = (b & 7) * per + (b >> 3);
+  constexpr int ROWS = 64 * RT;         // rows of a unit
+  constexpr int UPT = 2 / RT;           // units per tile
   const int m = P.nb - 1 - k;
-  const int c0 = k + 1;
-  const int tA = m * (m + 1) / 2 - 1;
-  if (idx >= tA + m + (k + 1) * m) return;
-  const double* Ap;
-  double* C;
-  int cblk;
-  bool beta0 = false;
-  if (idx < tA) {
-    const int e = idx + 1;  // triangular enumeration without its first element, tile (k+1, k+1)
-    int i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
-    while (i * (i + 1) / 2 > e) --i;
-    while ((i + 1) * (i + 2) / 2 <= e) ++i;
-    const int c = e - i * (i + 1) / 2;
-    cblk = c0 + c;
-    Ap = P.A + ((int64_t)(c0 + i) * NB) * P.lda + (int64_t)k * NB;
-    C = P.A + ((int64_t)(c0 + i) * NB) * P.lda + (int64_t)cblk * NB;
-  } else if (idx < tA + m) {
-    cblk = c0 + (idx - tA);
-    Ap = P.A + ((int64_t)P.nb * NB) * P.lda + (int64_t)k * NB;
-    C = P.A + ((int64_t)P.nb * NB) * P.lda + (int64_t)cblk * NB;
-  } else {
-    const int e = idx - tA - m;
-    const int r = e / m;
-    cblk = c0 + (e - r * m);
-    Ap = P.WT + ((int64_t)r * NB) * P.lda + (int64_t)k * NB;
-    C = P.WT + ((int64_t)r * NB) * P.lda + (int64_t)cblk * NB;
-    beta0 = (r == k);  // the panel that creates this L^-T row: overwrite
+  const int nunit = (m * (m + 1) / 2 - 1 + m + (k + 1) * m) * UPT;
+  const int b = (int)blockIdx.x - 1;
+  const int gx = ((int)gridDim.x - 1) >> 3;            // update workgroups per XCD
+  const int per = (nunit + 7) >> 3;                    // units per XCD
+  const int x = b & 7;
+  int u = x * per + (b >> 3);
+  const int uend = min((x + 1) * per, nunit);
+  if (u >= uend) return;
+  const int t = threadIdx.x, l = t & 63, w = t >> 6;
+  const int wr = w >> 2, wc = w & 3;
+  const int64_t lda = P.lda;
+  double* As = sm;
+  double* Bs = sm + ROWS * GLP2;
+  // global -> LDS: thread t carries k pair 2 (t & 15) of rows (t >> 4) and (t >> 4) + 64
+  const int64_t goff = (int64_t)(t >> 4) * lda + 2 * (t & 15);
+  double* da = As + (t >> 4) * GLP2 + 2 * (t & 15);
+  double* db = Bs + (t >> 4) * GLP2 + 2 * (t & 15);
+  // LDS -> MFMA operands: wave (wr, wc) owns rows [16 RT wr, +16 RT) x columns [32 wc, +32)
+  const double* fa = As + (wr * 16 * RT + (l & 15)) * GLP2 + 2 * (l >> 4);
+  const double* fb = Bs + (wc * 32 + (l & 15)) * GLP2 + 2 * (l >> 4);
+  const int64_t coff = (int64_t)(wr * 16 * RT + (l >> 4)) * lda + wc * 32 + (l & 15);
+
+  StepUnit cur = step_decode<RT>(P, u);
+  double2 pa0, pa1, pb0, pb1;
+  pa0 = *reinterpret_cast<const double2*>(cur.Ap + goff);
+  pa1 = pa0;
+  if (RT == 2) pa1 = *reinterpret_cast<const double2*>(cur.Ap + goff + 64 * lda);
+  pb0 = *reinterpret_cast<const double2*>(cur.Bp + goff);
+  pb1 = *reinterpret_cast<const double2*>(cur.Bp + goff + 64 * lda);
+  v4d cv[RT][2];
+#pragma unroll
+  for (int i = 0; i < RT; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cv[i][j][r] = cur.C[coff + (int64_t)(i * 16 + 4 * r) * lda + j * 16];
+  for (;;) {
+    const int un = u + gx;
+    const bool more = un < uend;
+    const StepUnit nxt = more ? step_decode<RT>(P, un) : cur;
+    v4d acc[RT][2];
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kt = 0; kt < NB / GK2; ++kt) {
+      __syncthreads();  // previous k-tile fully consumed
+      *reinterpret_cast<double2*>(da) = pa0;
+      if (RT == 2) *reinterpret_cast<double2*>(da + 64 * GLP2) = pa1;
+      *reinterpret_cast<double2*>(db) = pb0;
+      *reinterpret_cast<double2*>(db + 64 * GLP2) = pb1;
+      __syncthreads();
+      {
+        // the next k-tile lands while this one is multiplied; behind the last one, the next unit's first
+        const bool last = kt == NB / GK2 - 1;
+        const double* na = (last ? nxt.Ap : cur.Ap + (kt + 1) * GK2) + goff;
+        const double* nb_ = (last ? nxt.Bp : cur.Bp + (kt + 1) * GK2) + goff;
+        pa0 = *reinterpret_cast<const double2*>(na);
+        if (RT == 2) pa1 = *reinterpret_cast<const double2*>(na + 64 * lda);
+        pb0 = *reinterpret_cast<const double2*>(nb_);
+        pb1 = *reinterpret_cast<const double2*>(nb_ + 64 * lda);
+      }
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        double2 a[RT], bb[2];
+#pragma unroll
+        for (int i = 0; i < RT; ++i) a[i] = *reinterpret_cast<const double2*>(fa + i * 16 * GLP2 + 8 * h);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bb[j] = *reinterpret_cast<const double2*>(fb + j * 16 * GLP2 + 8 * h);
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].x, bb[j].x, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].y, bb[j].y, acc[i][j], 0, 0, 0);
+          }
+      }
+    }
+    double* cp = cur.C + coff;
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          cp[(int64_t)(i * 16 + 4 * r) * lda + j * 16] = cur.keep * cv[i][j][r] - acc[i][j][r];
+    if (!more) break;
+    // the next unit's old values: in flight during its k loop
+    const double* cn = nxt.C + coff;
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cv[i][j][r] = cn[(int64_t)(i * 16 + 4 * r) * lda + j * 16];
+    cur = nxt;
+    u = un;
   }
-  const double* Bp = P.A + ((int64_t)cblk * NB) * P.lda + (int64_t)k * NB;
-  // the tile's old values travel with the first operand loads
-  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
-  double* Cw = C + (int64_t)((w >> 2) * 32 + (l >> 4)) * P.lda + (w & 3) * 32 + (l & 15);
-  v4d cv[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) cv[i][j][r] = beta0 ? 0.0 : Cw[(int64_t)(i * 16 + 4 * r) * P.lda + j * 16];
-  GemmAcc32 acc;
-  acc.zero();
-  gemm_tile_nt16(acc, Ap, P.lda, Bp, P.lda, 0, NB, sm);
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) Cw[(int64_t)(i * 16 + 4 * r) * P.lda + j * 16] = cv[i][j][r] - acc.c[i][j][r];
 }
 constexpr size_t STEP_LDS_BYTES =
     (GEMM16_LDS_DOUBLES > POTF2T_LDS_DOUBLES ? GEMM16_LDS_DOUBLES : POTF2T_LDS_DOUBLES) * sizeof(double);
@@ -798,7 +897,8 @@ static int enable_lds(elfihip_ctx* ctx, K k, size_t bytes) {
 static int sweep_fused(elfihip_gp* gp, int nb, hipStream_t st) {
   elfihip_ctx* ctx = gp->ctx;
   if (!ctx->step_lds_enabled) {
-    ELFIHIP_TRY(enable_lds(ctx, step_kernel, STEP_LDS_BYTES));
+    ELFIHIP_TRY(enable_lds(ctx, step_kernel<1>, STEP_LDS_BYTES));
+    ELFIHIP_TRY(enable_lds(ctx, step_kernel<2>, STEP_LDS_BYTES));
     ctx->step_lds_enabled = true;
   }
   PanelArgs P;
@@ -819,9 +919,20 @@ static int sweep_fused(elfihip_gp* gp, int nb, hipStream_t st) {
     const int m = nb - 1 - k;
     if (m == 0) break;
     hipLaunchKernelGGL(lookahead_tile_kernel<1>, dim3(16), dim3(256), LOOKAHEAD_TILE_LDS, st, P, k + 1);
+    // unit of work: whole tiles or half tiles, whichever leaves the shorter tail on 8 x 31 workgroups (a half tile costs
+    // slightly more than half a tile: same B operand traffic for half the flops)
     const int ntile = m * (m + 1) / 2 - 1 + m + (k + 1) * m;
-    const int per = (ntile + 7) / 8;
-    hipLaunchKernelGGL(step_kernel, dim3(1 + 8 * per), dim3(1024), STEP_LDS_BYTES, st, P, gp->W11, gp->info);
+    const int gx = std::max(1, (ctx->cu_count - 1) / 8);   // update workgroups per XCD: one per CU beside workgroup 0
+    const int per_full = (ntile + 7) / 8, per_half = (2 * ntile + 7) / 8;
+    const double cost_full = (double)((per_full + gx - 1) / gx);
+    const double cost_half = 0.53 * (double)((per_half + gx - 1) / gx);
+    if (cost_half < cost_full) {
+      const int grid = 1 + 8 * std::min(gx, per_half);
+      hipLaunchKernelGGL(step_kernel<1>, dim3(grid), dim3(1024), STEP_LDS_BYTES, st, P, gp->W11, gp->info);
+    } else {
+      const int grid = 1 + 8 * std::min(gx, per_full);
+      hipLaunchKernelGGL(step_kernel<2>, dim3(grid), dim3(1024), STEP_LDS_BYTES, st, P, gp->W11, gp->info);
+    }
   }
   return launch_status(ctx, "cholesky sweep (fused steps)");
 }

@@ -122,10 +122,12 @@ def test_real_bolfi_loop_hip_model_next_to_the_oracle_model(hip_ctx, elfi):
     # initial evidence: prior draws + the simulator + the distance -- bit for bit (HipDistance is exact on euclidean)
     assert np.array_equal(Xh[:n0], Xc[:n0]) and np.array_equal(hip.target_model.Y[:n0], cpu.target_model.Y[:n0])
     # the acquisitions before the first hyper-parameter optimisation (t = 0 .. interval-2): same start points, same
-    # GP up to rounding, same L-BFGS-B -> the same acquired points
+    # GP up to rounding, same L-BFGS-B -> the same acquired points, to the accuracy L-BFGS-B locates a minimiser with
+    # (it stops at a projected gradient of 1e-5: scipy on the CPU posterior and the device state machines end
+    # 1e-7 .. 1e-5 apart; measured here: exact at box corners, <= 8e-6 inside)
     first = slice(n0, n0 + interval - 1)
     dev = np.max(np.abs(Xh[first] - Xc[first]), axis=1)
-    assert np.count_nonzero(dev <= 1e-6) >= interval - 2, dev        # at most one start tipped into another basin
+    assert np.count_nonzero(dev <= 2e-5) >= interval - 2, dev        # at most one start tipped into another basin
     assert dev[0] <= 1e-6
     # both runs end near the data-generating parameters (tests/functional/test_inference.py:155-157)
     for r in (res_h, res_c):
