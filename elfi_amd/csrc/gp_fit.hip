@@ -171,9 +171,16 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+typedef __attribute__((address_space(1))) double gdouble;    // global memory, said explicitly: inside the out-of-line
+typedef double v2d_t __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(1))) v2d_t gdouble2;   // instance below generic pointers would become FLAT accesses
+
 template <int NT>
-__device__ __forceinline__ void potf2_tiles_body(double* Akk, int64_t lda, double* Wkk, int64_t ldw, double* W11, int* info,
+__device__ __forceinline__ void potf2_tiles_body(double* Akk_, int64_t lda, double* Wkk_, int64_t ldw, double* W11_, int* info,
                                                  int kblock, double* sm) {
+  gdouble* Akk = (gdouble*)Akk_;
+  gdouble* Wkk = (gdouble*)Wkk_;
+  gdouble* W11 = (gdouble*)W11_;
   constexpr int NA = 3;              // phase-A waves
   constexpr int NU = NT / 64 - NA;   // update waves
   constexpr int NS = (64 + NU - 1) / NU;  // tile slots per update wave
@@ -232,7 +239,7 @@ __device__ __forceinline__ void potf2_tiles_body(double* Akk, int64_t lda, doubl
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int o = 8 * (b0 + e * nj) + sub;
-        if (o < ntop) *reinterpret_cast<double2*>(Akk + ((int64_t)(c0 + 16 + o) * lda + c0 + 2 * pair)) = v[e];
+        if (o < ntop) *reinterpret_cast<gdouble2*>(Akk + ((int64_t)(c0 + 16 + o) * lda + c0 + 2 * pair)) = (v2d_t){v[e].x, v[e].y};
       }
     }
     // (b) L^-T rows r < naug: entries (r, j >= r) of WT's diagonal block
@@ -246,11 +253,11 @@ __device__ __forceinline__ void potf2_tiles_body(double* Akk, int64_t lda, doubl
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int r = 8 * (b0 + e * nj) + sub;
-        double* dst = Wkk + ((int64_t)r * ldw + c0 + 2 * pair);
+        gdouble* dst = Wkk + ((int64_t)r * ldw + c0 + 2 * pair);
         const int j = c0 + 2 * pair;
         if (r < naug) {
           if (j >= r)
-            *reinterpret_cast<double2*>(dst) = v[e];
+            *reinterpret_cast<gdouble2*>(dst) = (v2d_t){v[e].x, v[e].y};
           else if (j + 1 >= r)
             dst[1] = v[e].y;
         }
@@ -662,84 +669,98 @@ __device__ __noinline__ void potf2_tiles_call(double* Akk, int64_t lda, double* 
 }
 
 // --------------------------------------------------------------- one step of the sweep as ONE launch
-// step_kernel(k): workgroup 0 factors diagonal block k+1 (potf2_tiles_body) WHILE the other workgroups apply panel k to
-// every other tile right of it -- the two halves of a step that do not depend on each other, in one launch on one
-// stream: no second stream, no event hand-offs (about 6 us each on the critical chain), and the diagonal block is the
-// launch's first workgroup, so it never waits for a compute unit to drain (as a separate one-workgroup kernel it
-// needs a whole CU and measured 34 us alone, 57 us beside a running pass over the trailing matrix).
+// step_kernel(k): workgroup 0 factors diagonal block k+1 (potf2_tiles_body) WHILE the other workgroups update the
+// trailing matrix -- the two halves of a step that do not depend on each other, in one launch on one stream: no second
+// stream, no event hand-offs (about 6 us each on the critical chain), and the diagonal block is the launch's first
+// workgroup, so it never waits for a compute unit to drain (as a separate one-workgroup kernel it needs a whole CU
+// and measured 34 us alone, 57 us beside a running pass over the trailing matrix).
 // Before it, per step: trsm_gemm_kernel (all row blocks of panel k) and the update of tile (k+1, k+1) alone
 // (lookahead_tile_kernel<1>, 16 workgroups) -- the only tile the next diagonal block needs.
-// Tiles of step k (m = nb-1-k block columns right of k), tile (k+1, k+1) excluded:
-//   [0, tA)        Cholesky rows: (i, c), k < c <= i < nb, tA = m (m+1) / 2 - 1     C -= P_i P_c^T   (SYRK)
-//   [tA, tA+m)     y block:       (y, c)                                          C -= P_y P_c^T
-//   [tA+m, ...)    L^-T rows:     (r, c), r <= k                                  C  = beta C - P_r P_c^T, beta = 0 for r == k
+//
+// Which tiles receive which panels.  A K = 128 update of a 128 x 128 tile moves 512 KB (its old and new values and both
+// operand blocks) for 4.2 MFLOP: 8 flop per byte.  With every tile right of panel k updated in every step the launch
+// ran at the fabric's 5 TB/s, 25 us per tile against 13.6 us of matrix-pipe time (measured, n = 4096).  So a block
+// column is updated every OTHER step with the last TWO panels (K = 256: the tile's values move once per two panels):
+//   near   block column k+1 (needed by the next panel solve) receives panel k:                  K = 128
+//   far    block columns c = k+2, k+4, ... (the parity of k) receive panels k-1 and k:         K = 256 (K = 128 at k = 0)
+// Column c was last updated at step c-2-2j ... and becomes the near column at step c-1, having received every panel
+// up to c-2 by then.  Row kinds of a column's tiles: Cholesky rows i >= c (C -= P_i P_c^T), the y block, L^-T rows
+// r <= k (created -- overwritten, not accumulated -- by the first panels that reach them: r >= k-1 far, r == k near;
+// the strictly lower blocks WT(r, j < r) an operand row may span are zero from allocation).
 // 1024 threads per workgroup (what the diagonal block needs), so one workgroup per CU: the update workgroups are
-// PERSISTENT -- 8 x 31 of them, one per CU beside workgroup 0 -- and walk their share of the tile list with the next
-// unit's first operand loads and old C values in flight while the current unit is multiplied (a one-tile-per-workgroup
-// form of the same launch spent 24.6 us per 128 x 128 x 128 tile against 13.6 us of matrix-pipe time: with one
-// workgroup per CU nothing overlaps a tile's first loads and its stores).  A unit is a whole tile (RT = 2) or its
-// upper / lower 64 rows (RT = 1), whichever leaves the shorter tail for this step's tile count (host's choice).
+// PERSISTENT -- 8 x 31 of them, one per CU beside workgroup 0 -- and walk their share of the unit list with the next
+// unit's first operand loads and old C values in flight while the current unit is multiplied.  A unit is a whole tile
+// (RT = 2) or its upper / lower 64 rows (RT = 1), whichever leaves the shorter tail for this step (host's choice).
 // XCD-aware: workgroups go round-robin over the 8 XCDs, so XCD x works through the contiguous stretch
-// [x per, (x+1) per) of the unit list (consecutive units share their row block, the A operand, in that XCD's L2).
+// [x per, (x+1) per) of the unit list; the list runs column by column (consecutive units share their B operand,
+// the column's own panel rows, in that XCD's L2), far columns first, the cheaper near units last.
+struct StepArgs {
+  PanelArgs P;
+  double* W11;
+  int* info;
+  int kbeg;    // first panel of the far updates: max(k - 1, 0)
+  int nfar;    // far tiles
+  int nnear;   // near tiles (block column k+1 without its diagonal tile)
+};
+
 struct StepUnit {
-  const double* Ap;   // unit's rows of the panel (64 RT x 128)
-  const double* Bp;   // the block column's rows of the panel (128 x 128)
+  const double* Ap;   // unit's rows of the panel(s) (64 RT x K)
+  const double* Bp;   // the block column's rows of the panel(s) (128 x K)
   double* C;          // unit's rows of the tile
-  double keep;        // 1: C -= P P^T, 0: C = -P P^T (the panel that creates an L^-T row)
+  double keep;        // 1: C -= P P^T, 0: C = -P P^T (the panels that create an L^-T row)
+  int nkt;            // 32-deep k-tiles: K / 32
 };
 
 template <int RT>
-__device__ __forceinline__ StepUnit step_decode(const PanelArgs& P, int unit) {
+__device__ __forceinline__ StepUnit step_decode(const StepArgs& S, int unit) {
   constexpr int UPT = 2 / RT;
-  const int k = P.k, m = P.nb - 1 - k, c0 = k + 1;
-  const int tA = m * (m + 1) / 2 - 1;
-  const int idx = unit / UPT;
+  const PanelArgs& P = S.P;
+  const int k = P.k, nb = P.nb;
+  int idx = unit / UPT;
   const int half = unit - idx * UPT;
   StepUnit U;
   U.keep = 1.0;
-  int cblk;
-  if (idx < tA) {
-    const int e = idx + 1;  // triangular enumeration without its first element, tile (k+1, k+1)
-    int i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
-    i -= (i * (i + 1) / 2 > e);
-    i += ((i + 1) * (i + 2) / 2 <= e);
-    const int c = e - i * (i + 1) / 2;
-    cblk = c0 + c;
-    U.Ap = P.A + ((int64_t)(c0 + i) * NB) * P.lda + (int64_t)k * NB;
-    U.C = P.A + ((int64_t)(c0 + i) * NB) * P.lda + (int64_t)cblk * NB;
-  } else if (idx < tA + m) {
-    cblk = c0 + (idx - tA);
-    U.Ap = P.A + ((int64_t)P.nb * NB) * P.lda + (int64_t)k * NB;
-    U.C = P.A + ((int64_t)P.nb * NB) * P.lda + (int64_t)cblk * NB;
+  int c, kb, row;        // block column, first panel, row block (0..nb-1: A rows, nb: y block, nb+1+r: L^-T row r)
+  if (idx < S.nfar) {
+    c = k + 2;
+    kb = S.kbeg;
+    for (int t = (nb - c) + k + 2; idx >= t; t -= 2) {  // the column's tiles: nb-c Cholesky rows, y, k+1 L^-T rows
+      idx -= t;
+      c += 2;
+    }
+    row = idx <= nb - c ? c + idx : idx + c;  // idx < nb-c: row c+idx; == nb-c: y (row nb); beyond: nb+1+r, r = idx-(nb-c)-1
+    if (row > nb && row - nb - 1 >= k - 1) U.keep = 0.0;
   } else {
-    const int e = idx - tA - m;
-    const int r = e / m;
-    cblk = c0 + (e - r * m);
-    U.Ap = P.WT + ((int64_t)r * NB) * P.lda + (int64_t)k * NB;
-    U.C = P.WT + ((int64_t)r * NB) * P.lda + (int64_t)cblk * NB;
-    U.keep = (r == k) ? 0.0 : 1.0;
+    idx -= S.nfar;
+    c = k + 1;
+    kb = k;
+    const int mm = nb - 1 - c;   // Cholesky rows below the column's diagonal tile
+    row = idx < mm ? c + 1 + idx : nb + (idx - mm);
+    if (row == nb + 1 + k) U.keep = 0.0;
   }
-  U.Bp = P.A + ((int64_t)cblk * NB) * P.lda + (int64_t)k * NB;
-  U.Ap += (int64_t)half * (64 * RT) * P.lda;
-  U.C += (int64_t)half * (64 * RT) * P.lda;
+  const double* base = row <= nb ? P.A + ((int64_t)row * NB) * P.lda : P.WT + ((int64_t)(row - nb - 1) * NB) * P.lda;
+  U.Ap = base + (int64_t)kb * NB + (int64_t)half * (64 * RT) * P.lda;
+  U.C = const_cast<double*>(base) + (int64_t)c * NB + (int64_t)half * (64 * RT) * P.lda;
+  U.Bp = P.A + ((int64_t)c * NB) * P.lda + (int64_t)kb * NB;
+  U.nkt = (k - kb + 1) * (NB / GK2);
   return U;
 }
 
 template <int RT>
-__global__ __launch_bounds__(1024) void step_kernel(PanelArgs P, double* W11, int* info) {
+__global__ __launch_bounds__(1024) void step_kernel(StepArgs S) {
   extern __shared__ __align__(16) double sm[];
-  const int k = P.k;
+  const PanelArgs& P = S.P;
   if (blockIdx.x == 0) {
-    const int kk = k + 1;
+    const int kk = P.k + 1;
     double* Akk = P.A + ((int64_t)kk * NB) * P.lda + (int64_t)kk * NB;
     double* Wkk = P.WT + ((int64_t)kk * NB) * P.lda + (int64_t)kk * NB;
-    potf2_tiles_call(Akk, P.lda, Wkk, P.lda, W11, info, kk, sm);
+    potf2_tiles_call(Akk, P.lda, Wkk, P.lda, S.W11, S.info, kk, sm);
     return;
   }
   constexpr int ROWS = 64 * RT;         // rows of a unit
   constexpr int UPT = 2 / RT;           // units per tile
-  const int m = P.nb - 1 - k;
-  const int nunit = (m * (m + 1) / 2 - 1 + m + (k + 1) * m) * UPT;
+  constexpr int BUF = (ROWS + 128) * GLP2;  // doubles of one LDS stage: A rows, then B rows
+  const int nunit = (S.nfar + S.nnear) * UPT;
   const int b = (int)blockIdx.x - 1;
   const int gx = ((int)gridDim.x - 1) >> 3;            // update workgroups per XCD
   const int per = (nunit + 7) >> 3;                    // units per XCD
@@ -750,24 +771,34 @@ __global__ __launch_bounds__(1024) void step_kernel(PanelArgs P, double* W11, in
   const int t = threadIdx.x, l = t & 63, w = t >> 6;
   const int wr = w >> 2, wc = w & 3;
   const int64_t lda = P.lda;
-  double* As = sm;
-  double* Bs = sm + ROWS * GLP2;
   // global -> LDS: thread t carries k pair 2 (t & 15) of rows (t >> 4) and (t >> 4) + 64
   const int64_t goff = (int64_t)(t >> 4) * lda + 2 * (t & 15);
-  double* da = As + (t >> 4) * GLP2 + 2 * (t & 15);
-  double* db = Bs + (t >> 4) * GLP2 + 2 * (t & 15);
+  const int doff = (t >> 4) * GLP2 + 2 * (t & 15);
   // LDS -> MFMA operands: wave (wr, wc) owns rows [16 RT wr, +16 RT) x columns [32 wc, +32)
-  const double* fa = As + (wr * 16 * RT + (l & 15)) * GLP2 + 2 * (l >> 4);
-  const double* fb = Bs + (wc * 32 + (l & 15)) * GLP2 + 2 * (l >> 4);
+  const int faoff = (wr * 16 * RT + (l & 15)) * GLP2 + 2 * (l >> 4);
+  const int fboff = (ROWS + wc * 32 + (l & 15)) * GLP2 + 2 * (l >> 4);
   const int64_t coff = (int64_t)(wr * 16 * RT + (l >> 4)) * lda + wc * 32 + (l & 15);
 
-  StepUnit cur = step_decode<RT>(P, u);
+  // The k-tiles of a workgroup's units form ONE stream e = (unit, kt) through two LDS stages: while stage p is
+  // multiplied, the next element (in registers since the previous step) is written to stage p^1 and the loads of the
+  // element after it are issued -- one barrier per k-tile, and the LDS stores overlap other waves' MFMAs.
+  StepUnit cur = step_decode<RT>(S, u);
   double2 pa0, pa1, pb0, pb1;
-  pa0 = *reinterpret_cast<const double2*>(cur.Ap + goff);
-  pa1 = pa0;
-  if (RT == 2) pa1 = *reinterpret_cast<const double2*>(cur.Ap + goff + 64 * lda);
-  pb0 = *reinterpret_cast<const double2*>(cur.Bp + goff);
-  pb1 = *reinterpret_cast<const double2*>(cur.Bp + goff + 64 * lda);
+  auto issue = [&](const double* A_, const double* B_) {
+    pa0 = *reinterpret_cast<const double2*>(A_ + goff);
+    if (RT == 2) pa1 = *reinterpret_cast<const double2*>(A_ + goff + 64 * lda);
+    pb0 = *reinterpret_cast<const double2*>(B_ + goff);
+    pb1 = *reinterpret_cast<const double2*>(B_ + goff + 64 * lda);
+  };
+  auto stage = [&](double* buf) {
+    double* da = buf + doff;
+    *reinterpret_cast<double2*>(da) = pa0;
+    if (RT == 2) *reinterpret_cast<double2*>(da + 64 * GLP2) = pa1;
+    *reinterpret_cast<double2*>(da + ROWS * GLP2) = pb0;
+    *reinterpret_cast<double2*>(da + (ROWS + 64) * GLP2) = pb1;
+  };
+  pa1 = (double2){0.0, 0.0};
+  issue(cur.Ap, cur.Bp);
   v4d cv[RT][2];
 #pragma unroll
   for (int i = 0; i < RT; ++i)
@@ -775,33 +806,32 @@ __global__ __launch_bounds__(1024) void step_kernel(PanelArgs P, double* W11, in
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) cv[i][j][r] = cur.C[coff + (int64_t)(i * 16 + 4 * r) * lda + j * 16];
+  int p = 0;
+  stage(sm);
+  issue(cur.Ap + GK2, cur.Bp + GK2);
+  __syncthreads();
   for (;;) {
     const int un = u + gx;
     const bool more = un < uend;
-    const StepUnit nxt = more ? step_decode<RT>(P, un) : cur;
+    const StepUnit nxt = more ? step_decode<RT>(S, un) : cur;
     v4d acc[RT][2];
 #pragma unroll
     for (int i = 0; i < RT; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int kt = 0; kt < NB / GK2; ++kt) {
-      __syncthreads();  // previous k-tile fully consumed
-      *reinterpret_cast<double2*>(da) = pa0;
-      if (RT == 2) *reinterpret_cast<double2*>(da + 64 * GLP2) = pa1;
-      *reinterpret_cast<double2*>(db) = pb0;
-      *reinterpret_cast<double2*>(db + 64 * GLP2) = pb1;
-      __syncthreads();
-      {
-        // the next k-tile lands while this one is multiplied; behind the last one, the next unit's first
-        const bool last = kt == NB / GK2 - 1;
-        const double* na = (last ? nxt.Ap : cur.Ap + (kt + 1) * GK2) + goff;
-        const double* nb_ = (last ? nxt.Bp : cur.Bp + (kt + 1) * GK2) + goff;
-        pa0 = *reinterpret_cast<const double2*>(na);
-        if (RT == 2) pa1 = *reinterpret_cast<const double2*>(na + 64 * lda);
-        pb0 = *reinterpret_cast<const double2*>(nb_);
-        pb1 = *reinterpret_cast<const double2*>(nb_ + 64 * lda);
+#pragma unroll 1
+    for (int kt = 0; kt < cur.nkt; ++kt) {
+      const double* buf = sm + p * BUF;
+      if (kt + 1 < cur.nkt || more) {
+        stage(sm + (p ^ 1) * BUF);                       // element e+1: this unit's next k-tile or the next unit's first
+        const int k2 = kt + 2 - cur.nkt;                 // element e+2
+        if (k2 < 0)
+          issue(cur.Ap + (kt + 2) * GK2, cur.Bp + (kt + 2) * GK2);
+        else if (more)
+          issue(nxt.Ap + k2 * GK2, nxt.Bp + k2 * GK2);
       }
+      const double* fa = buf + faoff;
+      const double* fb = buf + fboff;
 #pragma unroll
       for (int h = 0; h < 4; ++h) {
         double2 a[RT], bb[2];
@@ -817,6 +847,8 @@ __global__ __launch_bounds__(1024) void step_kernel(PanelArgs P, double* W11, in
             acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].y, bb[j].y, acc[i][j], 0, 0, 0);
           }
       }
+      __syncthreads();
+      p ^= 1;
     }
     double* cp = cur.C + coff;
 #pragma unroll
@@ -839,8 +871,26 @@ __global__ __launch_bounds__(1024) void step_kernel(PanelArgs P, double* W11, in
     u = un;
   }
 }
-constexpr size_t STEP_LDS_BYTES =
-    (GEMM16_LDS_DOUBLES > POTF2T_LDS_DOUBLES ? GEMM16_LDS_DOUBLES : POTF2T_LDS_DOUBLES) * sizeof(double);
+
+// Longest workgroup of a step under the static deal (far units cost 2, near units 1; x 0.53 for half-tile units, which
+// carry the whole B operand for half the flops): the host picks whole or half tiles per step by this.
+static double step_tail_cost(int nfar, int nnear, int upt, int gx) {
+  const int nfu = nfar * upt, nunit = (nfar + nnear) * upt;
+  const int per = (nunit + 7) / 8;
+  const double w_far = (upt == 2 ? 0.53 : 1.0) * 2.0, w_near = (upt == 2 ? 0.53 : 1.0);
+  double worst = 0.0;
+  for (int x = 0; x < 8; ++x) {
+    const int lo = x * per, hi = std::min((x + 1) * per, nunit);
+    for (int s_ = 0; s_ < gx && lo + s_ < hi; ++s_) {
+      double c = 0.0;
+      for (int u = lo + s_; u < hi; u += gx) c += u < nfu ? w_far : w_near;
+      worst = std::max(worst, c);
+    }
+  }
+  return worst;
+}
+constexpr size_t STEP_LDS_BYTES = 2 * (128 + 128) * GLP2 * sizeof(double);  // two stages of a whole-tile unit (> potf2's)
+static_assert(STEP_LDS_BYTES >= POTF2T_LDS_DOUBLES * sizeof(double) && STEP_LDS_BYTES <= 160 * 1024, "LDS budget");
 
 // --------------------------------------------------------------- alpha, logdet, y^T K^-1 y
 // alpha_i = sum_{k >= i} WT[i][k] z_k : one wavefront per row, coalesced along k.
@@ -891,7 +941,7 @@ static int enable_lds(elfihip_ctx* ctx, K k, size_t bytes) {
 }
 
 // ---- the sweep, fused schedule: everything on the caller's stream, two small launches and one fused launch per step
-//   potf2(0);  for k = 0 .. nb-1:  trsm(k) | tile (k+1, k+1) -= P P^T | step_kernel(k) = potf2(k+1) beside the update by panel k
+//   potf2(0);  for k = 0 .. nb-1:  trsm(k) | tile (k+1, k+1) -= P P^T | step_kernel(k) = potf2(k+1) beside the trailing update
 // Chain per step: 8 + 5 + max(30, update) us + three same-stream kernel boundaries (1.5-2 us each), against
 // potf2 -> trsm -> look-ahead column -> two event hops (measured 82 us per step at n = 4096) of the stream schedule.
 static int sweep_fused(elfihip_gp* gp, int nb, hipStream_t st) {
@@ -919,20 +969,23 @@ static int sweep_fused(elfihip_gp* gp, int nb, hipStream_t st) {
     const int m = nb - 1 - k;
     if (m == 0) break;
     hipLaunchKernelGGL(lookahead_tile_kernel<1>, dim3(16), dim3(256), LOOKAHEAD_TILE_LDS, st, P, k + 1);
-    // unit of work: whole tiles or half tiles, whichever leaves the shorter tail on 8 x 31 workgroups (a half tile costs
-    // slightly more than half a tile: same B operand traffic for half the flops)
-    const int ntile = m * (m + 1) / 2 - 1 + m + (k + 1) * m;
+    // far block columns c = k+2, k+4, ...: panels k-1 and k; near column k+1: panel k (see step_kernel)
+    StepArgs S;
+    S.P = P;
+    S.W11 = gp->W11;
+    S.info = gp->info;
+    S.kbeg = std::max(k - 1, 0);
+    S.nfar = 0;
+    for (int c = k + 2; c < nb; c += 2) S.nfar += (nb - c) + k + 2;
+    S.nnear = (m - 1) + 1 + (k + 1);
     const int gx = std::max(1, (ctx->cu_count - 1) / 8);   // update workgroups per XCD: one per CU beside workgroup 0
-    const int per_full = (ntile + 7) / 8, per_half = (2 * ntile + 7) / 8;
-    const double cost_full = (double)((per_full + gx - 1) / gx);
-    const double cost_half = 0.53 * (double)((per_half + gx - 1) / gx);
-    if (cost_half < cost_full) {
-      const int grid = 1 + 8 * std::min(gx, per_half);
-      hipLaunchKernelGGL(step_kernel<1>, dim3(grid), dim3(1024), STEP_LDS_BYTES, st, P, gp->W11, gp->info);
-    } else {
-      const int grid = 1 + 8 * std::min(gx, per_full);
-      hipLaunchKernelGGL(step_kernel<2>, dim3(grid), dim3(1024), STEP_LDS_BYTES, st, P, gp->W11, gp->info);
-    }
+    const bool halves = step_tail_cost(S.nfar, S.nnear, 2, gx) < step_tail_cost(S.nfar, S.nnear, 1, gx);
+    const int per = ((S.nfar + S.nnear) * (halves ? 2 : 1) + 7) / 8;
+    const int grid = 1 + 8 * std::min(gx, per);
+    if (halves)
+      hipLaunchKernelGGL(step_kernel<1>, dim3(grid), dim3(1024), STEP_LDS_BYTES, st, S);
+    else
+      hipLaunchKernelGGL(step_kernel<2>, dim3(grid), dim3(1024), STEP_LDS_BYTES, st, S);
   }
   return launch_status(ctx, "cholesky sweep (fused steps)");
 }
