@@ -5,21 +5,28 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Headline line (one JSON object on stdout, rank 0): BASELINE.json's metric
-"ABC distances/sec" on configs[1] -- a synthetic Gaussian summary matrix of 10^6
-samples x 32 summaries per GPU, euclidean distance to the observed summaries
-(elfi.Distance('euclidean'), elfi/model/elfi_model.py:1037).  A step is one pass of
-the distance path over the rank's batch, inputs already resident in HBM.  Weak
-scaling: every rank owns an independent batch (independent ABC batches,
-elfi/methods/parameter_inference.py:283-292); the only exchange, inside the timed
-region, is a device top-k per rank and one RCCL gather of the k best (distance, row) pairs to rank 0.
+Headline line (one JSON object on stdout, rank 0): BASELINE.json's scaling metric "ABC distances/sec".
+
+Default workload (every N): configs[1] per GPU -- a synthetic Gaussian summary matrix of 10^6 samples x 32 summaries,
+euclidean distance to the observed summaries (elfi.Distance('euclidean'), elfi/model/elfi_model.py:1037), inputs
+resident in HBM.  A step is one ABC batch of the rank: the distance kernel on the main stream and, overlapped on a second
+stream, what Rejection keeps of the previous batch (samplers.py:209-237): the device top-1000 (distance, row) pairs --
+and, for N > 1, ONE RCCL gather of those 16 KB per rank to rank 0.  The exchange happens EVERY step, inside the timed
+region.  Weak scaling: every rank owns independent batches (elfi/methods/parameter_inference.py:283-292); the work
+per GPU is the same at every N, so value(N) / (N value(1)) is the cost of the per-step exchange.
+
+--workload adaptive --scaling strong --total 10000000 --m 64 is BASELINE.json's configs[3] (SMC-ABC adaptive distance,
+10^7 samples x 64 summaries sharded over the ranks; N = 1 holds all of it): per step the shard's Welford statistics,
+an all-gather of the (1 + 2m)-double states, the fixed-order merge ON THE DEVICE, K = 3 nested weighted distances of every
+row, the device top-1000 by the last column and one gather of those to rank 0.
 
 The same line carries
-  "roofline"      HBM roofline of the distance kernel (HIP events on the library's stream)
-  "cpu_baseline"  the oracle (column_stack + SciPy cdist, what the reference executes)
-                  timed on this box's host cores for the same batch shape
-  "bolfi"         BASELINE.json's second metric, BOLFI iters/sec (GP fit + acquisition,
-                  n=4096, d=10) with its own MFMA-fp64 roofline (rank 0, N=1 only)
+  "roofline"      HBM roofline of the distance kernel (HIP events on the library's stream) and, under "phases", the
+                  BOLFI phases (Gram, sweep, K^-1 gradient: FP64-matrix; prediction step: HBM) from the library's
+                  own event timers, each against the bound that applies to it
+  "cpu_baseline"  the oracle (column_stack + SciPy cdist, what the reference executes) on this box's host cores: one
+                  core (the reference's native client) and all cores (its multiprocessing client), plus the BOLFI port
+  "bolfi"         BASELINE.json's first metric, BOLFI iters/sec (GP fit + acquisition, n=4096, d=10) (rank 0, N=1)
 """
 import argparse
 import json
@@ -36,7 +43,8 @@ for _p in (ROOT, os.path.join(ROOT, "oracle")):
         sys.path.insert(0, _p)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 measured)
-FP64_MFMA_PEAK_TFLOPS = 78.6  # AMD public spec, FP64 matrix (not in the local guide)
+FP64_MFMA_PEAK_TFLOPS = 78.6  # AMD public spec, FP64 matrix; measured 77.1 (scripts/native/mfma_probe.hip)
+K_BEST = 1000
 
 
 def parse():
@@ -44,20 +52,45 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--n", type=int, default=10 ** 6, help="samples per GPU per step")
-    ap.add_argument("--m", type=int, default=32, help="summaries per sample")
     ap.add_argument("--workload", choices=["distance", "adaptive"], default="distance",
-                    help="distance: configs[1] (default, the headline); adaptive: configs[3] shape per GPU "
-                         "(1.25e6 x 64, AdaptiveDistance with K=3 nested weights, Welford merge + gather)")
+                    help="distance: configs[1] per GPU (default, the headline); adaptive: configs[3] "
+                         "(AdaptiveDistance round with K=3 nested weights)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
+                    help="weak: --n rows per GPU; strong: --total rows shared by the ranks "
+                         "(default: weak for distance, strong for adaptive)")
+    ap.add_argument("--n", type=int, default=None, help="samples per GPU per step (weak scaling)")
+    ap.add_argument("--total", type=int, default=10 ** 7, help="samples per step over all GPUs (strong scaling)")
+    ap.add_argument("--m", type=int, default=None, help="summaries per sample (32 distance / 64 adaptive)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bolfi", action="store_true")
-    ap.add_argument("--bolfi-iters", type=int, default=5)
+    ap.add_argument("--bolfi-iters", type=int, default=50)
     return ap.parse_args()
 
 
-def cpu_baseline_distance(n, m, budget_s=12.0):
-    """Reference path on the host: 32 separate summary columns -> np.column_stack -> cdist
-    (elfi/model/utils.py:37-52).  Single thread (SciPy's cdist is not threaded)."""
+# ----------------------------------------------------------------------------- CPU baselines (rank 0, N = 1)
+def _oracle_batch(args):
+    """One worker of the all-core baseline: `reps` batches of n rows x m summaries through the oracle's
+    distance_as_discrepancy (np.column_stack + cdist), as a pool worker of the reference's multiprocessing client
+    executes a batch (elfi/clients/multiprocessing.py:50)."""
+    import numpy as np
+    import distance_oracle as O
+    seed, n, m, reps = args
+    rs = np.random.RandomState(seed)
+    cols = [rs.randn(n) for _ in range(m)]
+    obs = tuple(np.random.RandomState(1).randn(1, m)[:, j] for j in range(m))
+    op = O.make_distance('euclidean')
+    op(*cols, observed=obs)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        op(*cols, observed=obs)
+    return time.perf_counter() - t0
+
+
+def cpu_baseline_distance(n, m, budget_s=10.0):
+    """Reference path on the host: m separate summary columns -> np.column_stack -> cdist
+    (elfi/model/utils.py:37-52).  One core: SciPy's cdist is not threaded and the reference's native client runs
+    batches one after the other; all cores: one batch stream per worker process, as its multiprocessing client."""
+    import multiprocessing as mp
     import numpy as np
     import distance_oracle as O
     rs = np.random.RandomState(0)
@@ -75,9 +108,23 @@ def cpu_baseline_distance(n, m, budget_s=12.0):
     t0 = time.perf_counter()
     O.cdist_rows(X, np.array(obs).reshape(1, -1), 'euclidean')
     kern = time.perf_counter() - t0
-    return dict(value=n / best, unit="distances/s", cores=1, kind="port",
-                sample="%d x %d batch through oracle distance_as_discrepancy (np.column_stack + "
-                       "scipy cdist), best of %d; cdist alone %.0f Mdist/s" % (n, m, reps, n / kern / 1e6))
+    res = dict(value=n / best, unit="distances/s", cores=1, kind="port",
+               sample="%d x %d batch through oracle distance_as_discrepancy (np.column_stack + "
+                      "scipy cdist), best of %d; cdist alone %.0f Mdist/s" % (n, m, reps, n / kern / 1e6))
+    # all cores: batches of 10^5 rows (a usual ELFI batch size) in C worker processes
+    try:
+        C_ = max(1, min(os.cpu_count() or 1, 128))
+        nb, r = 100000, 3
+        t0 = time.perf_counter()
+        with mp.get_context("fork").Pool(C_) as pool:
+            busy = pool.map(_oracle_batch, [(100 + i, nb, m, r) for i in range(C_)])
+        wall = time.perf_counter() - t0
+        res["all_cores"] = dict(value=C_ * r * nb / max(busy), unit="distances/s", cores=C_, kind="port",
+                                sample="%d worker processes x %d batches of %d x %d (multiprocessing-client style); "
+                                       "slowest worker %.2f s, pool wall %.2f s" % (C_, r, nb, m, max(busy), wall))
+    except Exception as e:  # pragma: no cover - a baseline must never take the benchmark down
+        res["all_cores"] = dict(error=repr(e))
+    return res
 
 
 def cpu_baseline_bolfi(n, d, S, budget_s=25.0):
@@ -95,9 +142,12 @@ def cpu_baseline_bolfi(n, d, S, budget_s=25.0):
         threads = os.cpu_count() or 1
     X, y, bounds = problem(n, d)
     h = heuristic_hyper(bounds, y)
-    t0 = time.perf_counter()
-    post = G.Posterior(X, y, h['var'], h['ls'], h['bias'], h['noise'])
-    t_fit = time.perf_counter() - t0
+    G.Posterior(X[:512], y[:512], h['var'], h['ls'], h['bias'], h['noise'])   # BLAS warm-up
+    t_fit = float("inf")
+    for _ in range(2):
+        t0 = time.perf_counter()
+        post = G.Posterior(X, y, h['var'], h['ls'], h['bias'], h['noise'])
+        t_fit = min(t_fit, time.perf_counter() - t0)
     starts = np.random.RandomState(2).uniform(-2, 2, (S, d))
     t = n
     fun = lambda x: float(G.lcb_evaluate(post, x, t)[0, 0])
@@ -112,106 +162,247 @@ def cpu_baseline_bolfi(n, d, S, budget_s=25.0):
             break
     t_acq_full = t_acq * S / done
     return dict(value=1.0 / (t_fit + t_acq_full), unit="iters/s", cores=int(threads), kind="port",
-                sample="1 GP rebuild at n=%d (%.2f s) + L-BFGS-B from %d of %d starts (%.2f s, scaled to %d)"
+                sample="GP rebuild at n=%d (best of 2: %.2f s) + L-BFGS-B from %d of %d starts (%.2f s, scaled to %d)"
                        % (n, t_fit, done, S, t_acq, S),
                 ms_fit=1e3 * t_fit, ms_acquire=1e3 * t_acq_full)
 
 
-def run_adaptive(args, ctx, dev, world, rank):
-    """configs[3] per GPU: one SMC-ABC adaptive-distance round on this rank's shard
-    (elfi/model/elfi_model.py:1104-1151): Welford column statistics of the shard, all-gather +
-    fixed-order Chan merge of the (count, mean, M2) triples, K = 3 nested weighted distances of
-    every row, one gather of the (n, 3) distance shard to rank 0.  A step = that whole round."""
+# ----------------------------------------------------------------------------- the two workloads
+class Job:
+    """Streams, contexts and the per-step exchange shared by both workloads."""
+
+    def __init__(self, dev, local_rank, world, rank):
+        import torch
+        import elfi_amd
+        self.torch, self.dev, self.world, self.rank = torch, dev, world, rank
+        # one explicit (non-null) stream shared by torch / RCCL and the library for the kernels of a step, a second one
+        # (its own library context) for the selection + gather of the previous step's distances
+        self.main = torch.cuda.Stream(dev)
+        self.side = torch.cuda.Stream(dev)
+        torch.cuda.set_stream(self.main)
+        self.ctx = elfi_amd.Context(local_rank)
+        self.ctx.set_stream(self.main.cuda_stream)
+        self.ctx_side = elfi_amd.Context(local_rank)
+        self.ctx_side.set_stream(self.side.cuda_stream)
+        # values and row numbers travel together: one buffer (the int64 rows viewed through the second half), ONE gather
+        self.best = [torch.empty(2 * K_BEST, dtype=torch.float64, device=dev) for _ in range(2)]
+        self.gath = [torch.empty(2 * K_BEST, dtype=torch.float64, device=dev) for _ in range(world)] \
+            if (world > 1 and rank == 0) else None
+        self.ev_done = [torch.cuda.Event() for _ in range(2)]   # distances of buffer b are complete (main)
+        self.ev_free = [torch.cuda.Event() for _ in range(2)]   # selection has finished reading buffer b (side)
+        for e in self.ev_free:
+            e.record(self.side)
+
+    def select_and_gather(self, b, dptr, n, stride, k):
+        """On the side stream: top-k of the n distances at dptr (stride doubles apart), then the gather."""
+        torch = self.torch
+        import torch.distributed as dist
+        self.ev_done[b].record(self.main)
+        self.side.wait_event(self.ev_done[b])
+        best = self.best[b]
+        self.ctx_side.call("elfihip_topk_smallest_dev", dptr, n, stride, k, best.data_ptr(),
+                           best.data_ptr() + 8 * K_BEST)
+        if self.world > 1:
+            with torch.cuda.stream(self.side):
+                dist.gather(best, self.gath, dst=0)
+        self.ev_free[b].record(self.side)
+
+    def barrier(self):
+        import torch.distributed as dist
+        if self.world > 1:
+            dist.barrier()
+        self.torch.cuda.synchronize(self.dev)
+
+    def timed(self, step, steps, warmup):
+        for i in range(warmup):
+            step(i)
+        self.barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(warmup + i)
+        self.barrier()
+        elapsed = time.perf_counter() - t0
+        if self.world > 1:
+            import torch.distributed as dist
+            t = self.torch.tensor([elapsed], dtype=self.torch.float64, device=self.dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed
+
+
+def run_distance(args, job):
+    """configs[1] per GPU (see the module docstring)."""
     import numpy as np
-    import torch
+    torch, dev, world, rank, ctx = job.torch, job.dev, job.world, job.rank, job.ctx
+    m = args.m or 32
+    scaling = args.scaling or "weak"
+    n = (args.n or 10 ** 6) if scaling == "weak" else -(-args.total // world)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+    # NBUF independent batches, visited round-robin: the working set (NBUF x 8nm bytes) exceeds the
+    # 256 MiB Infinity Cache, so every step streams its batch from HBM instead of re-hitting the MALL
+    NBUF = max(3, int(-(-(400 << 20) // (8 * n * m))))
+    NBUF = min(NBUF, 8)
+    Xs = [torch.randn(n, m, dtype=torch.float64, device=dev, generator=gen) for _ in range(NBUF)]
+    y = torch.from_numpy(np.random.RandomState(1).randn(1, m)).to(dev)
+    outs = [torch.empty(n, dtype=torch.float64, device=dev) for _ in range(2)]
+    out_t = torch.empty(n, dtype=torch.float64, device=dev)   # target of the kernel-only timing loop
+    k = min(K_BEST, n)
+
+    def step(i):
+        b = i & 1
+        job.main.wait_event(job.ev_free[b])          # the selection two steps ago has released this buffer
+        ctx.call("elfihip_dist_rows_dev", 0, Xs[i % NBUF].data_ptr(), n, m, m, y.data_ptr(), None, 2.0,
+                 outs[b].data_ptr())
+        job.select_and_gather(b, outs[b].data_ptr(), n, 1, k)
+
+    elapsed = job.timed(step, args.steps, args.warmup)
+    # Kernel-only timing for the roofline: HIP events on the SAME stream the kernel runs on, nothing beside it
+    torch.cuda.synchronize(dev)
+    ctx.timer_start()
+    for i in range(args.steps):
+        ctx.call("elfihip_dist_rows_dev", 0, Xs[i % NBUF].data_ptr(), n, m, m, y.data_ptr(), None, 2.0,
+                 out_t.data_ptr())
+    kernel_ms = ctx.timer_stop() / args.steps
+    last = (args.steps - 1) % NBUF
+    alg_bytes = (8.0 * m + 8.0) * n          # SURVEY.md 8(d): 8m + 8 bytes per distance
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    if rank != 0:
+        return None
+    # parity guard on what was just timed (checker only)
+    import distance_oracle as O
+    idx = np.arange(0, n, max(1, n // 4096))[:4096]
+    ref = O.cdist_rows(Xs[last][idx].cpu().numpy(), y.cpu().numpy(), 'euclidean')
+    dh = out_t.cpu().numpy()
+    assert np.array_equal(dh[idx], ref), "bench output differs from the oracle"
+    bsel = (args.warmup + args.steps - 1) & 1       # the selection of the last timed step
+    bv = job.best[bsel][:k].cpu().numpy()
+    bi = job.best[bsel][K_BEST:K_BEST + k].view(torch.int64).cpu().numpy()
+    dl = outs[bsel].cpu().numpy()
+    assert np.array_equal(np.sort(bv), np.sort(dl)[:k]) and np.array_equal(dl[bi], bv), "top-k differs from numpy"
+    if world > 1:   # rank 0's own slice of the gather is what it selected
+        assert torch.equal(job.gath[0], job.best[bsel])
+    traffic, source = None, None
+    try:   # HBM traffic per launch from this round's rocprofv3 PMC passes of this very command (profiles/)
+        with open(os.path.join(ROOT, "profiles", "distance_pmc.json")) as f:
+            pmc = json.load(f)
+        if pmc["n"] == n and pmc["m"] == m:
+            traffic, source = pmc["traffic_bytes_per_launch"], pmc.get("source")
+    except (OSError, ValueError, KeyError):
+        pass
+    return {
+        "metric": "ABC distances/sec", "value": world * n * args.steps / elapsed, "unit": "distances/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+        "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "configs[1]: synthetic Gaussian summaries, %d samples x %d summaries per GPU per step, "
+                               "elfi.Distance('euclidean'), inputs resident in HBM" % (n, m),
+                   "samples_per_gpu": n, "summaries": m, "layout": "row-major (n,m) f64", "batches_in_rotation": NBUF,
+                   "step": "distance kernel (main stream) + device top-%d of the previous batch (second stream)" % k,
+                   "exchange": ("every step: ONE RCCL gather of the packed top-%d (distance, row) pairs per rank "
+                                "(16 KB) to rank 0, on the second stream" % k) if world > 1 else "none (N = 1)"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": source,
+                     "kernel": "dist_rows_pipe_kernel<euclidean>", "kernel_ms": kernel_ms,
+                     "algorithmic_bytes_per_launch": alg_bytes,
+                     "frac_of_measured_copy_peak_6290": achieved / 6290.0,
+                     "step_rate_frac": (alg_bytes * args.steps / elapsed / 1e9) / HBM_PEAK_GBS},
+    }
+
+
+def run_adaptive(args, job):
+    """configs[3]: one SMC-ABC adaptive-distance round on this rank's shard per step
+    (elfi/model/elfi_model.py:1104-1151); nothing leaves the device inside a step."""
+    import numpy as np
     import torch.distributed as dist
-    from elfi_amd import sharding
-    n, m, K = (args.n if args.n != 10 ** 6 else 1250000), (args.m if args.m != 32 else 64), 3
+    torch, dev, world, rank, ctx = job.torch, job.dev, job.world, job.rank, job.ctx
+    m, K = args.m or 64, 3
+    scaling = args.scaling or "strong"
+    n = (args.n or 1250000) if scaling == "weak" else -(-args.total // world)
     gen = torch.Generator(device=dev)
     gen.manual_seed(100 + rank)
     X = torch.randn(n, m, dtype=torch.float64, device=dev, generator=gen) * torch.linspace(0.5, 20, m, device=dev,
                                                                                             dtype=torch.float64)
     y = torch.from_numpy(np.random.RandomState(1).randn(1, m)).to(dev)
-    out = torch.empty(n, K, dtype=torch.float64, device=dev)
-    state = torch.zeros(1 + 2 * m, dtype=torch.float64, device=dev)
+    outs = [torch.empty(n, K, dtype=torch.float64, device=dev) for _ in range(2)]
+    out_t = torch.empty(n, K, dtype=torch.float64, device=dev)
+    ns = 1 + 2 * m
+    state = torch.zeros(ns, dtype=torch.float64, device=dev)
+    states = torch.zeros(world, ns, dtype=torch.float64, device=dev)
+    merged = torch.zeros(ns, dtype=torch.float64, device=dev)
     W = torch.ones(K, m, dtype=torch.float64, device=dev)
-    gathered = [torch.empty(n, K, dtype=torch.float64, device=dev) for _ in range(world)] \
-        if (world > 1 and rank == 0) else None
-    states = [torch.empty_like(state) for _ in range(world)]
+    k = min(K_BEST, n)
 
-    def step():
+    def step(i):
+        b = i & 1
         state.zero_()
         ctx.call("elfihip_welford_update_dev", X.data_ptr(), n, m, m, state.data_ptr())
         if world > 1:
-            dist.all_gather(states, state)
-            st = [s.cpu().numpy() for s in states]
+            dist.all_gather_into_tensor(states, state)       # (1 + 2m) doubles per rank, stays on the device
         else:
-            st = [state.cpu().numpy()]
-        N, mean, M2 = sharding.merge_welford([(v[0], v[1:1 + m], v[1 + m:]) for v in st])
-        w2 = 1.0 / (M2 / N)                      # (1/scale)^2, elfi_model.py:1129-1132
-        W[1].copy_(torch.from_numpy(w2))
-        W[2].copy_(torch.from_numpy(w2 * 0.5))   # a third, different weight vector (K = 3)
-        ctx.call("elfihip_dist_multiw_dev", X.data_ptr(), n, m, m, y.data_ptr(), W.data_ptr(), K, out.data_ptr())
-        if world > 1:
-            dist.gather(out, gathered, dst=0)
+            states[0].copy_(state)
+        # fixed-order Chan merge + weights 1/scale^2 on the device: row 1 of W; row 2 = a second adaptation round
+        ctx.call("elfihip_welford_merge_dev", states.data_ptr(), world, m, merged.data_ptr(), W[1].data_ptr())
+        torch.mul(W[1], 0.5, out=W[2])
+        job.main.wait_event(job.ev_free[b])
+        ctx.call("elfihip_dist_multiw_dev", X.data_ptr(), n, m, m, y.data_ptr(), W.data_ptr(), K, outs[b].data_ptr())
+        # Rejection ranks nested distances by the LAST column (samplers.py:233): top-k over column K-1, stride K
+        job.select_and_gather(b, outs[b].data_ptr() + 8 * (K - 1), n, K, k)
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = job.timed(step, args.steps, args.warmup)
     torch.cuda.synchronize(dev)
     ctx.timer_start()
     for _ in range(args.steps):
-        ctx.call("elfihip_dist_multiw_dev", X.data_ptr(), n, m, m, y.data_ptr(), W.data_ptr(), K, out.data_ptr())
+        ctx.call("elfihip_dist_multiw_dev", X.data_ptr(), n, m, m, y.data_ptr(), W.data_ptr(), K, out_t.data_ptr())
     kernel_ms = ctx.timer_stop() / args.steps
     alg_bytes = (8.0 * m + 8.0 * K) * n
     if rank != 0:
         return None
     import distance_oracle as O
+    from elfi_amd import sharding
     idx = np.arange(0, n, max(1, n // 2048))[:2048]
     Wh = W.cpu().numpy()
-    ref = np.column_stack([O.cdist_rows(X[idx].cpu().numpy(), y.cpu().numpy(), 'euclidean', w=Wh[k]) for k in range(K)])
-    assert np.array_equal(out[idx].cpu().numpy(), ref), "adaptive bench output differs from the oracle"
+    ref = np.column_stack([O.cdist_rows(X[idx].cpu().numpy(), y.cpu().numpy(), 'euclidean', w=Wh[kk]) for kk in range(K)])
+    assert np.array_equal(out_t[idx].cpu().numpy(), ref), "adaptive bench output differs from the oracle"
+    bsel = (args.warmup + args.steps - 1) & 1       # the selection of the last timed step
+    bv = job.best[bsel][:k].cpu().numpy()
+    bi = job.best[bsel][K_BEST:K_BEST + k].view(torch.int64).cpu().numpy()
+    dl = outs[bsel][:, K - 1].cpu().numpy()
+    assert np.array_equal(np.sort(bv), np.sort(dl)[:k]) and np.array_equal(dl[bi], bv), "top-k differs from numpy"
+    sh = states.cpu().numpy()
+    N_, mean_, M2_ = sharding.merge_welford([(v[0], v[1:1 + m], v[1 + m:]) for v in sh])
+    assert N_ == world * n and np.array_equal(Wh[1], 1.0 / (M2_ / N_)), "device merge differs from the host merge"
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
     return {
-        "metric": "ABC distances/sec", "value": world * n * args.steps / elapsed, "unit": "distances/s (rows; K=3 nested each)",
+        "metric": "ABC distances/sec", "value": world * n * args.steps / elapsed,
+        "unit": "distances/s (rows; K=3 nested each)",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "configs[3] shape per GPU: AdaptiveDistance round, %d samples x %d summaries, K=%d nested "
-                               "weights, Welford + all-gather/merge + gather" % (n, m, K),
+        "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "configs[3]: AdaptiveDistance round, %d samples x %d summaries %s, K=%d nested weights"
+                               % (n * world if scaling == "strong" else n, m,
+                                  "in total" if scaling == "strong" else "per GPU", K),
                    "samples_per_gpu": n, "summaries": m, "K": K,
-                   "exchange": "all_gather of (1+2m) doubles + gather of the (n,K) shard" if world > 1 else "none"},
+                   "step": "Welford statistics of the shard + merge of the rank states on the device + K nested "
+                           "distances of every row + device top-%d by the last column" % k,
+                   "exchange": ("every step: all_gather of %d doubles per rank + gather of the packed top-%d pairs "
+                                "(16 KB per rank) to rank 0" % (ns, k)) if world > 1 else "none (N = 1)"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "dist_multiw_pipe_kernel",
-                     "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes},
+                     "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                     "step_rate_frac": ((8.0 * m * 2 + 8.0 * K) * n * args.steps / elapsed / 1e9) / HBM_PEAK_GBS},
     }
 
 
 def main():
     args = parse()
-    import numpy as np
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if rank == 0:
-            print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    if world != args.gpus and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
@@ -219,144 +410,39 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
+        world = dist.get_world_size()
 
-    import elfi_amd
-    from elfi_amd import _lib
-    ctx = elfi_amd.Context(local_rank)
-    # one explicit (non-null) stream shared by torch/RCCL and the library, so the gather is
-    # ordered after the last kernel without a host sync
-    stream = torch.cuda.Stream(dev)
-    torch.cuda.set_stream(stream)
-    ctx.set_stream(stream.cuda_stream)
-
-    if args.workload == "adaptive":
-        result = run_adaptive(args, ctx, dev, world, rank)
-        if rank == 0:
-            print(json.dumps(result), flush=True)
-        if world > 1:
-            dist.barrier()
-            dist.destroy_process_group()
-        return
-
-    n, m = args.n, args.m
-    # Synthetic Gaussian simulator outputs: N(0,1) summaries,
-    # one independent batch per rank (seeded by rank), observed row from a fixed seed.
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(1234 + rank)
-    # NBUF independent batches, visited round-robin: the working set (NBUF x 8nm bytes) exceeds the
-    # 256 MiB Infinity Cache, so every step streams its batch from HBM instead of re-hitting the MALL
-    NBUF = 3
-    Xs = [torch.randn(n, m, dtype=torch.float64, device=dev, generator=gen) for _ in range(NBUF)]
-    y = torch.from_numpy(np.random.RandomState(1).randn(1, m)).to(dev)
-    out = torch.empty(n, dtype=torch.float64, device=dev)
-    # The one exchange of a multi-GPU job: every rank selects its K_BEST smallest
-    # distances on the GPU (elfihip_topk_smallest_dev, what Rejection keeps of a batch) and rank 0
-    # gathers those (value, row) pairs -- 16 KB per rank instead of the 8 MB distance shard.
-    K_BEST = min(1000, n)
-    # values and row numbers travel together: one buffer (the int64 rows viewed through the second half), ONE gather
-    best = torch.empty(2 * K_BEST, dtype=torch.float64, device=dev)
-    best_v = best[:K_BEST]
-    best_i = best[K_BEST:].view(torch.int64)
-    gath = [torch.empty_like(best) for _ in range(world)] if (world > 1 and rank == 0) else None
-
-    def exchange():
-        ctx.call("elfihip_topk_smallest_dev", out.data_ptr(), n, 1, K_BEST, best_v.data_ptr(), best_i.data_ptr())
-        dist.gather(best, gath, dst=0)
-
-    counter = [0]
-
-    def step():
-        X = Xs[counter[0] % NBUF]
-        counter[0] += 1
-        ctx.call("elfihip_dist_rows_dev", 0, X.data_ptr(), n, m, m, y.data_ptr(), None,
-                 2.0, out.data_ptr())
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    for _ in range(args.warmup):
-        step()
-    if world > 1:  # warm the exchange path too
-        exchange()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    if world > 1:
-        exchange()  # the one exchange: each rank's best K_BEST (distance, row) pairs -> rank 0
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # Kernel-only timing for the roofline: HIP events on the SAME stream the kernel runs on.
-    torch.cuda.synchronize(dev)
-    ctx.timer_start()
-    for _ in range(args.steps):
-        step()
-    kernel_ms = ctx.timer_stop() / args.steps
-    alg_bytes = (8.0 * m + 8.0) * n          # 8m + 8 bytes per distance
-    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-
-    # parity guard on what was just timed (checker only)
+    job = Job(dev, local_rank, world, rank)
+    result = (run_adaptive if args.workload == "adaptive" else run_distance)(args, job)
     if rank == 0:
-        import distance_oracle as O
-        idx = np.arange(0, n, max(1, n // 4096))[:4096]
-        X = Xs[(counter[0] - 1) % NBUF]   # the batch of the last step
-        ref = O.cdist_rows(X[idx].cpu().numpy(), y.cpu().numpy(), 'euclidean')
-        assert np.array_equal(out[idx].cpu().numpy(), ref), "bench output differs from the oracle"
-        # ... and on the selection used by the multi-GPU exchange (exercised here at every N)
-        ctx.call("elfihip_topk_smallest_dev", out.data_ptr(), n, 1, K_BEST, best_v.data_ptr(), best_i.data_ptr())
-        torch.cuda.synchronize(dev)
-        dh = out.cpu().numpy()
-        assert np.array_equal(np.sort(best_v.cpu().numpy()), np.sort(dh)[:K_BEST]), "top-k differs from numpy"
-        assert np.array_equal(dh[best_i.cpu().numpy()], best_v.cpu().numpy())
-
-    # HBM traffic per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 +
-    # WRITE_SIZE, profiles/r01_distance_pmc.md); PMC cannot be sampled from inside this process
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "distance_pmc.json")) as f:
-            pmc = json.load(f)
-        if pmc["n"] == n and pmc["m"] == m:
-            traffic = pmc["traffic_bytes_per_launch"]
-    except (OSError, ValueError, KeyError):
-        pass
-
-    result = None
-    if rank == 0:
-        value = world * n * args.steps / elapsed
-        result = {
-            "metric": "ABC distances/sec", "value": value, "unit": "distances/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "configs[1]: synthetic Gaussian summaries, %d samples x %d summaries per "
-                                   "GPU per step, elfi.Distance('euclidean'), inputs resident in HBM" % (n, m),
-                       "samples_per_gpu": n, "summaries": m, "layout": "row-major (n,m) f64",
-                       "batches_in_rotation": NBUF,
-                       "exchange": "per job: device top-%d of the last batch per rank + ONE RCCL gather of the packed "
-                                   "(distance, row) pairs to rank 0" % K_BEST if world > 1 else "none"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "dist_rows_pipe_kernel<euclidean>", "kernel_ms": kernel_ms,
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "frac_of_measured_copy_peak_6290": achieved / 6290.0},
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline_distance(n, m)
+        env = {"world_size_seen": world, "device": torch.cuda.get_device_name(dev)}
+        try:
+            env["rccl"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            pass
+        result["env"] = env
+        if world == 1 and not args.no_cpu_baseline and args.workload == "distance":
+            result["cpu_baseline"] = cpu_baseline_distance(result["config"]["samples_per_gpu"],
+                                                           result["config"]["summaries"])
             result["cpu_baseline"]["host_cores_available"] = os.cpu_count()
-        if world == 1 and not args.no_bolfi:
+        if world == 1 and not args.no_bolfi and args.workload == "distance":
             from elfi_amd import bolfi_bench
+            torch.cuda.synchronize(dev)
             b = bolfi_bench.run(iters=args.bolfi_iters)
             if not args.no_cpu_baseline:
                 b["cpu_baseline"] = cpu_baseline_bolfi(4096, 10, 10)
                 b["speedup_vs_cpu"] = b["value"] / b["cpu_baseline"]["value"]
+                result["cpu_baseline"]["bolfi"] = b["cpu_baseline"]
             result["bolfi"] = b
+            # the driver's parsed record keeps `roofline` and `cpu_baseline`: BASELINE.json's first metric and its
+            # per-phase rooflines ride in them as well
+            result["roofline"]["phases"] = b["roofline_phases"]
+            result["roofline"]["bolfi"] = {"metric": b["metric"], "value": b["value"], "unit": b["unit"],
+                                           "ms_fit": b["ms_fit"], "ms_acquire": b["ms_acquire"],
+                                           "fit_only_frac": b["roofline"]["fit_only_frac"],
+                                           "iter_frac_executed": b["roofline"]["frac"],
+                                           "iterations_timed": b["iterations_timed"],
+                                           "fit_large": b["fit_large"]}
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

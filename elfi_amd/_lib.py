@@ -62,6 +62,7 @@ PROTOTYPES = {
                                          C.POINTER(C.c_int64), C.c_void_p, C.c_void_p]),
     "elfihip_welford_update_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int64,
                                              C.c_void_p]),
+    "elfihip_welford_merge_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "elfihip_topk_smallest": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p,
                                         C.c_void_p]),
     "elfihip_topk_smallest_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p,
@@ -85,6 +86,7 @@ PROTOTYPES = {
     "elfihip_gp_set_data": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
     "elfihip_gp_append": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
     "elfihip_gp_factorize": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "elfihip_gp_profile": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "elfihip_gp_set_schedule": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "elfihip_gp_nlml_grad": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_void_p]),
     "elfihip_gp_form_kinv": (C.c_int, [C.c_void_p]),
@@ -100,6 +102,10 @@ PROTOTYPES = {
                                           C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
     "elfihip_gp_set_integration_points": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "elfihip_gp_cross_cov": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "elfihip_gp_maxvar": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p]),
+    "elfihip_gp_expintvar": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p]),
     "elfihip_lbfgsb_create": (C.c_int, [C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                         C.POINTER(C.c_void_p)]),
     "elfihip_lbfgsb_pending": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p]),

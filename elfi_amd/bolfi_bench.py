@@ -56,7 +56,56 @@ def _loop(gp, acq, X, y, n0, iters, warm):
     return float(np.mean(t_fit)), float(np.mean(t_acq)), float(np.mean(evals)), int(np.max(steps))
 
 
-def run(n=4096, d=10, S=10, iters=5, warm=2):
+HBM_PEAK_GBS = 8000.0
+
+
+def _phase_rooflines(prof, n, d):
+    """Per-phase rooflines from the library's own HIP-event phase timers
+    (elfihip_gp_profile): each phase against the bound that applies to it."""
+    out = {}
+
+    def per_call(k):
+        ms, calls = prof[k]
+        return ms / calls if calls else None
+    g, sw, al = per_call('gram'), per_call('sweep'), per_call('alpha')
+    if g:
+        fl = 2.0 * n * n * d
+        out['gram'] = {"bound": "mfma", "ms": g, "flops": fl, "achieved": fl / g / 1e9, "unit": "TFLOP/s",
+                       "peak": FP64_MFMA_PEAK_TFLOPS, "frac": fl / g / 1e9 / FP64_MFMA_PEAK_TFLOPS,
+                       "note": "2 n^2 d on the matrix cores + n^2/2 exp on the vector ALUs (the exp bounds it)"}
+    if sw:
+        fl = 2.0 * n ** 3 / 3.0
+        out['sweep'] = {"bound": "mfma", "ms": sw, "flops": fl, "achieved": fl / sw / 1e9, "unit": "TFLOP/s",
+                        "peak": FP64_MFMA_PEAK_TFLOPS, "frac": fl / sw / 1e9 / FP64_MFMA_PEAK_TFLOPS,
+                        "note": "Cholesky n^3/3 + L^-T n^3/3 in one sweep"}
+    if al:
+        by = 8.0 * n * n / 2
+        out['alpha_logdet'] = {"bound": "hbm", "ms": al, "bytes": by, "achieved": by / al / 1e6, "unit": "GB/s",
+                               "peak": HBM_PEAK_GBS, "frac": by / al / 1e6 / HBM_PEAK_GBS}
+    t1, t2 = per_call('tri_first'), per_call('tri_second')
+    ks, gf = per_call('kstar'), per_call('grad_finish')
+    if t1 and t2:
+        by = 8.0 * n * n / 2     # one triangle of n^2/2 doubles streamed once per product
+        out['predict'] = {"bound": "hbm", "bytes_per_step": 2 * by, "ms_first_product": t1, "ms_second_product": t2,
+                          "ms_kernel_row": ks, "ms_gradient_and_assembly": gf,
+                          "ms_per_step_device": t1 + t2 + (ks or 0) + (gf or 0),
+                          "achieved": 2 * by / (t1 + t2) / 1e6, "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                          "frac": 2 * by / (t1 + t2) / 1e6 / HBM_PEAK_GBS,
+                          "frac_whole_step": 2 * by / (t1 + t2 + (ks or 0) + (gf or 0)) / 1e6 / HBM_PEAK_GBS,
+                          "steps_timed": prof['tri_second'][1],
+                          "note": "two triangular products with 16 right-hand sides: 8 n^2 bytes per lock-step of the "
+                                  "acquisition search (S <= 16 points: HBM/L2-bound, SURVEY.md 8d)"}
+    kg = per_call('kinv_grad')
+    if kg:
+        fl = n ** 3 / 3.0
+        out['kinv_grad'] = {"bound": "mfma", "ms": kg, "flops": fl, "achieved": fl / kg / 1e9, "unit": "TFLOP/s",
+                            "peak": FP64_MFMA_PEAK_TFLOPS, "frac": fl / kg / 1e9 / FP64_MFMA_PEAK_TFLOPS,
+                            "note": "K^-1 = L^-T L^-1 tiles with the dlogZ/dtheta contractions fused (one objective "
+                                    "gradient of GPyRegression.optimize)"}
+    return out
+
+
+def run(n=4096, d=10, S=10, iters=50, warm=3):
     """Both update modes on the same workload: 'refactor' = full GP rebuild per update (what
     GPyRegression.update does), 'incremental' = bordering (elfihip_gp_extend), the product default
     between hyper-parameter changes.  The headline `value` is the refactor mode: it is the
@@ -75,21 +124,35 @@ def run(n=4096, d=10, S=10, iters=5, warm=2):
         gp._refit()
         acq = HipLCBSC(gp, n_inits=S, exploration_rate=10, seed=2)
         res[mode] = _loop(gp, acq, X, y, n0, iters, warm)
+        if mode == 'refactor':
+            # a second, short pass with the library's phase timers on (events cost a little, so not in the timed loop)
+            gp._handle.profile(1)
+            for i in range(6):
+                gp._refit()
+                acq.acquire(1, t=n0 + i)
+            gp._handle.nlml_grad()
+            gp._handle.nlml_grad()
+            phases = _phase_rooflines(gp._handle.profile(0), gp.n_evidence, d)
         del gp, acq
     fit, ac, E, steps = res['refactor']
     it_s = 1.0 / (fit + ac)
-    fl_gram = 2.0 * n * n * d
-    fl_chol = n ** 3 / 3.0
-    fl_eval = E * (2.0 * n * n + 6.0 * n * d + 4.0 * n)
+    # evidence counts of the timed iterations: n - iters + 1 .. n (one point is appended per iteration); flops are
+    # the means over exactly these sizes
+    sizes = np.arange(n - iters + 1, n + 1, dtype=np.float64)
+    fl_gram = float(np.mean(2.0 * sizes * sizes * d))
+    fl_chol = float(np.mean(sizes ** 3 / 3.0))
+    fl_eval = float(np.mean(E * (2.0 * sizes * sizes + 6.0 * sizes * d + 4.0 * sizes)))
     exec_flops = fl_gram + 2 * fl_chol + fl_eval
     model_flops = fl_gram + fl_chol + fl_eval
     ifit, iac, iE, isteps = res['incremental']
     out = {
         "metric": "BOLFI iters/sec (GP fit+acq, n=%d d=%d)" % (n, d), "value": it_s, "unit": "iters/s",
+        "evidence_sizes_timed": [int(sizes[0]), int(sizes[-1])],
         "mode": "refactor (full GP rebuild per update, as GPyRegression.update)",
         "ms_fit": 1e3 * fit, "ms_acquire": 1e3 * ac, "starts": S,
         "point_evaluations_per_acquire": E, "max_lbfgs_iterations": steps,
-        "flops_per_iter_executed": exec_flops, "flops_per_iter_model": model_flops,
+        "flops_per_iter_executed": exec_flops, "flops_per_iter_model": model_flops, "iterations_timed": iters,
+        "roofline_phases": phases,
         "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": FP64_MFMA_PEAK_TFLOPS,
                      "achieved": exec_flops * it_s / 1e12, "frac": exec_flops * it_s / 1e12 / FP64_MFMA_PEAK_TFLOPS,
                      "achieved_model": model_flops * it_s / 1e12,

@@ -43,6 +43,12 @@ struct elfihip_gp {
   // schedule of the factorisation sweep (elfihip_gp_set_schedule): 0 = by size, 1 = streams, 2 = fused steps;
   // panel_group 0 = by size, else 1 / 2 / 4 panels per pass over the trailing matrix (stream schedule)
   int schedule = 0, panel_group = 0;
+  // per-phase device timing (elfihip_gp_profile): HIP events around the phases of a fit / prediction / gradient call
+  // while enabled; sums in milliseconds and call counts per phase (indices: ELFIHIP_PHASE_* in include/elfihip.h)
+  bool profile = false;
+  hipEvent_t pev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  double phase_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int64_t phase_calls[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   // prediction workspace (grown on demand)
   elfihip::DevBuf ws;
   int64_t ws_S = 0;
@@ -53,6 +59,18 @@ struct elfihip_gp {
 };
 
 namespace elfihip {
+// profile helpers: record event `i` on the GP's stream when profiling; after a synchronisation add the time between
+// two recorded events to a phase
+inline void prof_mark(elfihip_gp* gp, int i) {
+  if (gp->profile) (void)hipEventRecord(gp->pev[i], gp->ctx->stream);
+}
+inline void prof_add(elfihip_gp* gp, int phase, int from, int to) {
+  float ms = 0.0f;
+  if (gp->profile && hipEventElapsedTime(&ms, gp->pev[from], gp->pev[to]) == hipSuccess) {
+    gp->phase_ms[phase] += (double)ms;
+    gp->phase_calls[phase] += 1;
+  }
+}
 struct PredictWs {
   double *xs, *xs2, *kr, *kb, *part, *v, *u, *mu_part, *var_part, *g_part, *out;
   int nblk_k;   // blocks of the kstar kernel along i
@@ -75,7 +93,21 @@ struct PredictPlan {
 };
 int predict_prepare(elfihip_gp* gp, int64_t S, PredictPlan* P);
 void predict_fill(const elfihip_gp* gp, const PredictPlan& P, const double* Xs, int64_t S);
-int predict_enqueue(elfihip_gp* gp, const PredictPlan& P, int64_t S_active, int mode, int noiseless, double beta);
+// optional epilogues: MaxVar surface from the assembled prediction (device pointers), ExpIntVar loss from the posterior
+// covariances against the integration points (host pointers, M entries each)
+struct MaxVarEpilogue {
+  double eps;
+  const double* prior_pdf;    // (S)
+  const double* prior_glog;   // (S, d): gradient of the log prior density
+};
+struct ExpIntVarArgs {
+  double eps;
+  const double* w_int;      // omega_i * prior(p_i)^2
+  const double* mean_int;   // GP mean at the integration points
+  const double* var_int;    // noiseless GP variance at the integration points
+};
+int predict_enqueue(elfihip_gp* gp, const PredictPlan& P, int64_t S_active, int mode, int noiseless, double beta,
+                    const MaxVarEpilogue* mv);
 int predict_wait(elfihip_gp* gp, const PredictPlan& P);
 void predict_read(const elfihip_gp* gp, const PredictPlan& P, int64_t S, double* mu, double* var, double* dmu,
                   double* dvar, double* val, double* grad);

@@ -1106,6 +1106,7 @@ int gp_factorize_impl(elfihip_gp* gp) {
   const int64_t np = gp->np;
   const int nb = (int)(np / NB);
   ELFIHIP_CHECK_HIP(ctx, hipMemsetAsync(gp->info, 0, sizeof(int), st));
+  prof_mark(gp, 0);
   {
     const int T = 256;
     hipLaunchKernelGGL(x2_kernel, dim3((unsigned)((gp->cap + T - 1) / T)), dim3(T), 0, st, gp->X, gp->x2, gp->n,
@@ -1128,22 +1129,28 @@ int gp_factorize_impl(elfihip_gp* gp) {
     hipLaunchKernelGGL(gram_kernel, dim3((unsigned)(nt * (nt + 1) / 2)), dim3(256), lds, st, G);
     ELFIHIP_TRY(launch_status(ctx, "gram_kernel"));
   }
+  prof_mark(gp, 1);
   // schedule of the sweep: gp->schedule 1 = streams, 2 = fused steps, 0 = by size (elfihip_gp_set_schedule)
   const bool fused = gp->schedule == 2 || (gp->schedule == 0 && nb < FUSED_BELOW_NB);
   if (fused)
     ELFIHIP_TRY(sweep_fused(gp, nb, st));
   else
     ELFIHIP_TRY(sweep_streams(gp, nb, st));
+  prof_mark(gp, 2);
   const double* z = gp->A + np * gp->lda;  // row np of A: z = L^-1 y
   hipLaunchKernelGGL(alpha_kernel, dim3((unsigned)((np * 64 + 255) / 256)), dim3(256), 0, st, gp->WT, z, gp->alpha,
                      gp->n, np, gp->lda);
   hipLaunchKernelGGL(logdet_kernel, dim3(1), dim3(256), 0, st, gp->A, z, gp->red, gp->n, gp->lda);
   ELFIHIP_TRY(launch_status(ctx, "alpha/logdet"));
+  prof_mark(gp, 3);
   double red[2];
   int info = 0;
   ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(red, gp->red, sizeof red, hipMemcpyDeviceToHost, st));
   ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(&info, gp->info, sizeof info, hipMemcpyDeviceToHost, st));
   ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(st));
+  prof_add(gp, ELFIHIP_PHASE_GRAM, 0, 1);
+  prof_add(gp, ELFIHIP_PHASE_SWEEP, 1, 2);
+  prof_add(gp, ELFIHIP_PHASE_ALPHA, 2, 3);
   if (info != 0) {
     gp->factored = false;
     return fail(ctx, ELFIHIP_ERR_NOT_PD, "covariance matrix is not positive definite (pivot %d <= 0)", info);
@@ -1211,6 +1218,8 @@ int elfihip_gp_free(elfihip_gp* gp) {
     if (p) (void)hipFree(p);
   if (gp->info) (void)hipFree(gp->info);
   if (gp->h_stage) (void)hipHostFree(gp->h_stage);
+  for (auto e : gp->pev)
+    if (e) (void)hipEventDestroy(e);
   if (gp->VP) (void)hipFree(gp->VP);
   if (gp->Pint) (void)hipFree(gp->Pint);
   gp->ws.release();
@@ -1278,6 +1287,28 @@ int elfihip_gp_factorize(elfihip_gp* gp, double* log_marginal) {
   ELFIHIP_TRY(gp_factorize_impl(gp));
   if (log_marginal)
     *log_marginal = 0.5 * (-(double)gp->n * 1.8378770664093453 /* log(2 pi) */ - gp->logdet - gp->yKy);
+  return ELFIHIP_OK;
+}
+
+int elfihip_gp_profile(elfihip_gp* gp, int enable, double* phase_ms, int64_t* phase_calls) {
+  if (!gp) return fail(nullptr, ELFIHIP_ERR_ARG, "gp is NULL");
+  elfihip_ctx* ctx = gp->ctx;
+  DeviceGuard g(ctx->device);
+  if (phase_ms)
+    for (int i = 0; i < ELFIHIP_PHASE_COUNT; ++i) phase_ms[i] = gp->phase_ms[i];
+  if (phase_calls)
+    for (int i = 0; i < ELFIHIP_PHASE_COUNT; ++i) phase_calls[i] = gp->phase_calls[i];
+  if (enable > 0) {
+    for (auto& e : gp->pev)
+      if (!e) ELFIHIP_CHECK_HIP(ctx, hipEventCreate(&e));
+    for (int i = 0; i < ELFIHIP_PHASE_COUNT; ++i) {
+      gp->phase_ms[i] = 0.0;
+      gp->phase_calls[i] = 0;
+    }
+    gp->profile = true;
+  } else if (enable == 0) {
+    gp->profile = false;
+  }
   return ELFIHIP_OK;
 }
 

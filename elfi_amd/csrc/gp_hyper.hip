@@ -218,12 +218,15 @@ static int hyper_grad_impl(elfihip_gp* gp, bool store_kinv, double* grad) {
   if (H.x_in_lds && xlds > lds) lds = xlds;
   ELFIHIP_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kinv_grad_kernel),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  prof_mark(gp, 0);
   hipLaunchKernelGGL(kinv_grad_kernel, dim3((unsigned)nitems), dim3(256), lds, st, H);
   hipLaunchKernelGGL(hyper_reduce_kernel, dim3(1), dim3(256), 0, st, H.part, nitems, gp->red);
+  prof_mark(gp, 1);
   ELFIHIP_TRY(launch_status(ctx, "kinv_grad_kernel"));
   double s[4];
   ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(s, gp->red + 2, sizeof s, hipMemcpyDeviceToHost, st));
   ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(st));
+  prof_add(gp, ELFIHIP_PHASE_KINV_GRAD, 0, 1);
   if (store_kinv) gp->has_kinv = true;
   if (grad) {
     grad[0] = s[0] / gp->var;

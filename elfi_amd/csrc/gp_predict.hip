@@ -26,6 +26,7 @@
 
 #include "gp.hpp"
 #include "mfma_f64.hpp"
+#include "special.hpp"
 
 namespace elfihip {
 
@@ -414,6 +415,71 @@ __global__ __launch_bounds__(256) void finish_kernel(const double* mu_part, int 
   }
 }
 
+// ---- MaxVar surface from the assembled prediction (elfi/methods/bo/acquisition.py:392-463) ----
+// Variance of the unnormalised approximate posterior at a point with GP mean m, noiseless variance v:
+//   value = p^2 W,   W = Phi(z) - Phi(z)^2 - 2 T(z, b),   z = (eps - m) / sqrt(s_n + v),   b = sqrt(s_n / (s_n + 2 v))
+// (Phi(z) - 2 T(z, b) is the skew-normal cdf the reference takes from SciPy), p the prior density; and its gradient by
+// the chain rule through z and b with dT/dh = -phi(h) (Phi(a h) - 1/2), dT/da = exp(-h^2 (1 + a^2) / 2) / (2 pi (1 + a^2)).
+// One thread per query point; reads mu / var / dmu / dvar of the pass from `out`, writes its val / grad slots.
+__global__ void maxvar_kernel(double* out, const double* prior_pdf, const double* prior_glog, int64_t S, int d, int dp,
+                              double eps, double s2n, int64_t s0) {
+  const int q = threadIdx.x;
+  out += (int64_t)blockIdx.x * (3 * PC + 3 * PC * dp);
+  const int64_t s = s0 + (int64_t)blockIdx.x * PC + q;
+  if (q >= PC || s >= S) return;
+  const double m = out[q], v = out[PC + q];
+  const double* dmu = out + 3 * PC + q * dp;
+  const double* dvar = dmu + PC * dp;
+  double* grad = out + 3 * PC + 2 * PC * dp + q * dp;
+  const double sv = s2n + v, sdev = sqrt(sv), z = (eps - m) / sdev;
+  const double sb = s2n + 2.0 * v, b = sqrt(s2n) / sqrt(sb);
+  const double Pz = norm_cdf(z), pz = norm_pdf(z);
+  const double W = (Pz - Pz * Pz) - 2.0 * owens_t(z, b);
+  const double p = prior_pdf[s];
+  out[2 * PC + q] = p * p * W;
+  const double dT_dh = -pz * (norm_cdf(z * b) - 0.5);
+  const double dT_da = exp(-0.5 * z * z * (1.0 + b * b)) / (6.28318530717958647692 * (1.0 + b * b));
+  const double dW_dz = (1.0 - 2.0 * Pz) * pz - 2.0 * dT_dh;
+  const double dz_dm = -1.0 / sdev, dz_dv = -(eps - m) / (2.0 * sv * sdev), db_dv = -sqrt(s2n) / (sb * sqrt(sb));
+  for (int a = 0; a < d; ++a) {
+    const double dz = dz_dm * dmu[a] + dz_dv * dvar[a];
+    const double dW = dW_dz * dz - 2.0 * dT_da * (db_dv * dvar[a]);
+    grad[a] = 2.0 * p * W * (p * prior_glog[s * d + a]) + p * p * dW;
+  }
+}
+
+// ---- ExpIntVar loss from the posterior covariances (elfi/methods/bo/acquisition.py:795-821) ----
+// For candidate s with noiseless variance v_s and covariances c_is to the M integration points (GP mean m_i, noiseless
+// variance v_i, weight w_i = omega_i prior_i^2):
+//   loss_s = 2 sum_i w_i T(z_i, a_is),   z_i = (eps - m_i) / sqrt(A_i),  A_i = s_n + v_i,  d_is = c_is^2 / (s_n + v_s),
+//   a_is = sqrt((A_i - d_is) / (A_i + d_is))
+// ((Phi(z_i) - skew-normal cdf) / 2 of the reference is T(z_i, a_is) itself).  One workgroup per candidate, fixed-order sum.
+__global__ __launch_bounds__(256) void expintvar_kernel(const double* cov, const double* outs, int64_t outsz,
+                                                        const double* w_int, const double* mean_int,
+                                                        const double* var_int, int64_t M, int64_t S, double eps,
+                                                        double s2n, double* loss) {
+  __shared__ double red[256];
+  const int64_t s = blockIdx.x;
+  const double v_s = outs[(s / PC) * outsz + PC + (s % PC)];   // noiseless variance of the candidate
+  const double den = s2n + v_s;
+  double acc = 0.0;
+  for (int64_t i = threadIdx.x; i < M; i += 256) {
+    const double c = cov[i * S + s];
+    const double A = s2n + var_int[i];
+    const double dl = c * c / den;
+    double r = (A - dl) / (A + dl);
+    r = r > 0.0 ? r : 0.0;
+    acc += w_int[i] * owens_t((eps - mean_int[i]) / sqrt(A), sqrt(r));
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss[s] = 2.0 * red[0];
+}
+
 // WL = WT^T in 64 x 64 tiles through LDS (upper tiles of WT -> lower tiles of WL).
 __global__ __launch_bounds__(256) void mirror_kernel(const double* WT, double* WL, int64_t lda) {
   __shared__ double tile[64][65];
@@ -567,7 +633,8 @@ void predict_fill(const elfihip_gp* gp, const PredictPlan& P, const double* Xs, 
 // All points go up in one copy; the 16-point passes run `group` at a time inside each launch (the
 // group scratch is reused in stream order); all results come down in one copy; no synchronisation here.
 // S_active: number of real points (columns beyond it are computed on zero inputs and ignored).
-int predict_enqueue(elfihip_gp* gp, const PredictPlan& P, int64_t S_active, int mode, int noiseless, double beta) {
+int predict_enqueue(elfihip_gp* gp, const PredictPlan& P, int64_t S_active, int mode, int noiseless, double beta,
+                    const MaxVarEpilogue* mv) {
   elfihip_ctx* ctx = gp->ctx;
   hipStream_t st = ctx->stream;
   const PredictWs& W = P.ws;
@@ -593,21 +660,30 @@ int predict_enqueue(elfihip_gp* gp, const PredictPlan& P, int64_t S_active, int 
         qa.x2[s] = P.hx[(size_t)PC * dp + s];
       }
     }
+    const bool prof = gp->profile && P.npass <= W.group;   // phase timing of single-group calls
+    if (prof) prof_mark(gp, 0);
     hipLaunchKernelGGL(kstar_kernel, dim3(W.nblk_k, PC, g), dim3(256), 0, st, gp->X, gp->x2, gp->alpha,
                        from_host ? P.hx : xs, from_host ? P.hx + (size_t)P.npass * PC * dp : xs2, W.kr, W.kb,
                        W.mu_part, gp->n, np, dp, gp->var, -0.5 * inv_ls2, gp->bias,
                        P.direct ? W.xs : (double*)nullptr, P.by_args ? 1 : 0, qa);
+    if (prof) prof_mark(gp, 1);
     launch_tri(gp, W, false, W.kb, g);
     hipLaunchKernelGGL(tri_reduce_kernel, dim3(rblocks, g), dim3(256), 0, st, W.part, W.v, W.var_part, np, W.nkc, 0,
                        1);
+    if (prof) prof_mark(gp, 2);
     if (mode == 1) {
       launch_tri(gp, W, true, W.v, g);
+      if (prof) prof_mark(gp, 3);
       hipLaunchKernelGGL(grad_kernel, dim3(W.ngc, g), dim3(256), 0, st, gp->X, gp->alpha, xs, W.kr, W.part, W.nkc,
                          W.g_part, gp->n, np, dp);
     }
     hipLaunchKernelGGL(finish_kernel, dim3(PC, g), dim3(256), 0, st, W.mu_part, W.nblk_k, W.var_part, rblocks, W.g_part,
                        W.ngc, out, dp, s_left, gp->var + gp->bias, noiseless ? 0.0 : gp->noise, inv_ls2, beta, mode,
                        P.direct ? P.hout : (double*)nullptr, P.flag, (unsigned long long)(gp->done_seq + 1));
+    if (prof) prof_mark(gp, mode == 1 ? 4 : 3);
+    if (mv)
+      hipLaunchKernelGGL(maxvar_kernel, dim3(g), dim3(64), 0, st, out, mv->prior_pdf, mv->prior_glog, S_active, gp->d, dp,
+                         mv->eps, gp->noise, pass0 * PC);
   }
   if (P.direct)
     ++gp->done_seq;
@@ -664,9 +740,22 @@ int predict_impl(elfihip_gp* gp, const double* Xs, int64_t S, int mode, int nois
   PredictPlan P;
   ELFIHIP_TRY(predict_prepare(gp, S, &P));
   predict_fill(gp, P, Xs, S);
-  ELFIHIP_TRY(predict_enqueue(gp, P, S, mode, noiseless, beta));
+  ELFIHIP_TRY(predict_enqueue(gp, P, S, mode, noiseless, beta, nullptr));
   ELFIHIP_TRY(launch_status(ctx, "predict kernels"));
   ELFIHIP_TRY(predict_wait(gp, P));
+  if (gp->profile && P.npass <= P.ws.group) {
+    // the polled flags precede the last event: wait for it, then file the four phases of this call
+    const int last = mode == 1 ? 4 : 3;
+    ELFIHIP_CHECK_HIP(ctx, hipEventSynchronize(gp->pev[last]));
+    prof_add(gp, ELFIHIP_PHASE_KSTAR, 0, 1);
+    prof_add(gp, ELFIHIP_PHASE_TRI_FIRST, 1, 2);
+    if (mode == 1) {
+      prof_add(gp, ELFIHIP_PHASE_TRI_SECOND, 2, 3);
+      prof_add(gp, ELFIHIP_PHASE_GRAD_FINISH, 3, 4);
+    } else {
+      prof_add(gp, ELFIHIP_PHASE_GRAD_FINISH, 2, 3);
+    }
+  }
   predict_read(gp, P, S, mu, var, dmu, dvar, val, grad);
   return ELFIHIP_OK;
 }
@@ -890,7 +979,8 @@ static int set_integration_points_impl(elfihip_gp* gp, const double* Pts, int64_
   return ELFIHIP_OK;
 }
 
-static int cross_cov_impl(elfihip_gp* gp, const double* Q, int64_t S, double* cov, double* var_q) {
+static int cross_cov_impl(elfihip_gp* gp, const double* Q, int64_t S, double* cov, double* var_q,
+                          const ExpIntVarArgs* ei = nullptr, double* loss = nullptr) {
   elfihip_ctx* ctx = gp->ctx;
   hipStream_t st = ctx->stream;
   ELFIHIP_REQUIRE(ctx, S >= 1 && Q && cov, "bad arguments");
@@ -936,7 +1026,23 @@ static int cross_cov_impl(elfihip_gp* gp, const double* Q, int64_t S, double* co
                        -0.5 * inv_ls2, gp->bias);
   }
   ELFIHIP_TRY(launch_status(ctx, "cross covariance"));
-  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(cov, cov_dev, (size_t)M * S * sizeof(double), hipMemcpyDeviceToHost, st));
+  std::vector<double> stage;
+  if (ei) {
+    // weights / means / variances of the integration points go up in one copy, the S losses come down
+    stage.resize((size_t)3 * M);
+    std::copy(ei->w_int, ei->w_int + M, stage.begin());
+    std::copy(ei->mean_int, ei->mean_int + M, stage.begin() + M);
+    std::copy(ei->var_int, ei->var_int + M, stage.begin() + 2 * M);
+    ELFIHIP_CHECK_HIP(ctx, ctx->par.reserve(((size_t)3 * M + (size_t)S) * sizeof(double)));
+    double* dpar = ctx->par.as<double>();
+    ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(dpar, stage.data(), (size_t)3 * M * sizeof(double), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(expintvar_kernel, dim3((unsigned)S), dim3(256), 0, st, cov_dev, W.out, (int64_t)P.outsz, dpar,
+                       dpar + M, dpar + 2 * M, M, S, ei->eps, gp->noise, dpar + 3 * M);
+    ELFIHIP_TRY(launch_status(ctx, "expintvar_kernel"));
+    ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(loss, dpar + 3 * M, (size_t)S * sizeof(double), hipMemcpyDeviceToHost, st));
+  }
+  if (cov)
+    ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(cov, cov_dev, (size_t)M * S * sizeof(double), hipMemcpyDeviceToHost, st));
   ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(P.hout, W.out, P.n_out * sizeof(double), hipMemcpyDeviceToHost, st));
   ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(st));
   if (var_q) predict_read(gp, P, S, nullptr, var_q, nullptr, nullptr, nullptr, nullptr);
@@ -967,6 +1073,50 @@ int elfihip_gp_lcb(elfihip_gp* gp, const double* Xs, int64_t S, double beta, dou
   ELFIHIP_REQUIRE(gp->ctx, beta >= 0, "beta must be non-negative");
   DeviceGuard g(gp->ctx->device);
   return predict_impl(gp, Xs, S, grad ? 1 : 0, 1, beta, nullptr, nullptr, nullptr, nullptr, val, grad);
+}
+
+int elfihip_gp_maxvar(elfihip_gp* gp, const double* Xs, int64_t S, double eps, const double* prior_pdf,
+                      const double* prior_grad_logpdf, double* val, double* grad) {
+  if (!gp) return fail(nullptr, ELFIHIP_ERR_ARG, "gp is NULL");
+  elfihip_ctx* ctx = gp->ctx;
+  ELFIHIP_REQUIRE(ctx, S >= 0 && (S == 0 || (Xs && prior_pdf && prior_grad_logpdf && val && grad)), "bad arguments");
+  if (S == 0) return ELFIHIP_OK;
+  DeviceGuard g(ctx->device);
+  PredictPlan P;
+  ELFIHIP_TRY(predict_prepare(gp, S, &P));
+  P.direct = false;   // staged call: the epilogue kernel runs between the assembly and the download
+  P.by_args = false;
+  predict_fill(gp, P, Xs, S);
+  const size_t npr = (size_t)S * (1 + (size_t)gp->d);
+  ELFIHIP_CHECK_HIP(ctx, ctx->par.reserve(npr * sizeof(double)));
+  double* dpr = ctx->par.as<double>();
+  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(dpr, prior_pdf, (size_t)S * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(dpr + S, prior_grad_logpdf, (size_t)S * gp->d * sizeof(double),
+                                        hipMemcpyHostToDevice, ctx->stream));
+  MaxVarEpilogue mv;
+  mv.eps = eps;
+  mv.prior_pdf = dpr;
+  mv.prior_glog = dpr + S;
+  ELFIHIP_TRY(predict_enqueue(gp, P, S, 1, 1, 0.0, &mv));
+  ELFIHIP_TRY(launch_status(ctx, "maxvar kernels"));
+  ELFIHIP_TRY(predict_wait(gp, P));
+  predict_read(gp, P, S, nullptr, nullptr, nullptr, nullptr, val, grad);
+  return ELFIHIP_OK;
+}
+
+int elfihip_gp_expintvar(elfihip_gp* gp, const double* Q, int64_t S, double eps, const double* w_int,
+                         const double* mean_int, const double* var_int, double* loss) {
+  if (!gp) return fail(nullptr, ELFIHIP_ERR_ARG, "gp is NULL");
+  if (!gp->factored)
+    return fail(gp->ctx, ELFIHIP_ERR_STATE, "GP is not factorised (call elfihip_gp_factorize first)");
+  ELFIHIP_REQUIRE(gp->ctx, S >= 1 && Q && w_int && mean_int && var_int && loss, "bad arguments");
+  DeviceGuard g(gp->ctx->device);
+  ExpIntVarArgs ei;
+  ei.eps = eps;
+  ei.w_int = w_int;
+  ei.mean_int = mean_int;
+  ei.var_int = var_int;
+  return cross_cov_impl(gp, Q, S, nullptr, nullptr, &ei, loss);
 }
 
 int elfihip_gp_extend(elfihip_gp* gp, const double* X_new, const double* y_new, int64_t k, double* log_marginal) {

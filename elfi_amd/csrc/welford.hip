@@ -151,7 +151,49 @@ static int welford_dev_impl(elfihip_ctx* ctx, const double* dX, int64_t n, int m
 
 using namespace elfihip;
 
+namespace elfihip {
+// Chan merge of `world` (count, mean[m], M2[m]) states in rank order, one thread per column: the device twin of the
+// host merge in elfi_amd/sharding.py (same operations in the same order, so both give the same bits), for the multi-GPU
+// adaptive distance: all-gather of the rank states -> this kernel -> the merged state and, optionally, the cdist
+// weights 1 / scale^2 = N / M2 (elfi/model/elfi_model.py:1124,1129-1132) without a host round trip.
+__global__ void welford_merge_kernel(const double* states, int world, int m, double* merged, double* w2) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= m) return;
+  const int ns = 1 + 2 * m;
+  double N = 0.0, mean = 0.0, M2 = 0.0;
+  for (int r = 0; r < world; ++r) {
+    const double* st = states + (size_t)r * ns;
+    const double nb = st[0];
+    if (nb == 0.0) continue;
+    if (N == 0.0) {
+      N = nb;
+      mean = st[1 + j];
+      M2 = st[1 + m + j];
+      continue;
+    }
+    const double tot = N + nb;
+    const double delta = st[1 + j] - mean;
+    M2 = M2 + st[1 + m + j] + delta * delta * (N * (nb / tot));
+    mean = mean + delta * (nb / tot);
+    N = tot;
+  }
+  if (j == 0) merged[0] = N;
+  merged[1 + j] = mean;
+  merged[1 + m + j] = M2;
+  if (w2) w2[j] = 1.0 / (M2 / N);
+}
+}  // namespace elfihip
+
 extern "C" {
+
+int elfihip_welford_merge_dev(elfihip_ctx* ctx, const double* dstates, int world, int m, double* dmerged, double* dw2) {
+  if (!ctx) return fail(nullptr, ELFIHIP_ERR_ARG, "ctx is NULL");
+  ELFIHIP_REQUIRE(ctx, world >= 1 && m >= 1 && dstates && dmerged, "bad arguments (world=%d m=%d)", world, m);
+  DeviceGuard g(ctx->device);
+  hipLaunchKernelGGL(welford_merge_kernel, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, ctx->stream, dstates, world, m,
+                     dmerged, dw2);
+  return launch_status(ctx, "welford_merge_kernel");
+}
 
 int elfihip_welford_update_dev(elfihip_ctx* ctx, const double* dX, int64_t n, int m, int64_t ldx,
                                double* dstate) {

@@ -86,6 +86,16 @@ class GPHandle:
         """Sweep schedule of factorize(): 0 by size, 1 two-stream look-ahead, 2 fused steps (include/elfihip.h)."""
         self._check(self.lib.elfihip_gp_set_schedule(self.h, int(schedule), int(panel_group)))
 
+    PHASES = ('gram', 'sweep', 'alpha', 'kstar', 'tri_first', 'tri_second', 'grad_finish', 'kinv_grad')
+
+    def profile(self, enable=-1):
+        """Device time per phase (include/elfihip.h: elfihip_gp_profile): enable 1 starts a fresh measurement, 0 stops,
+        -1 only reads.  Returns {phase: (milliseconds summed, calls)} collected so far."""
+        ms = np.zeros(len(self.PHASES))
+        calls = np.zeros(len(self.PHASES), dtype=np.int64)
+        self._check(self.lib.elfihip_gp_profile(self.h, int(enable), _lib.ptr(ms), _lib.ptr(calls)))
+        return {k: (float(ms[i]), int(calls[i])) for i, k in enumerate(self.PHASES)}
+
     def factorize(self):
         lz = C.c_double()
         self._check(self.lib.elfihip_gp_factorize(self.h, C.byref(lz)))
@@ -134,6 +144,29 @@ class GPHandle:
         var = np.empty(S)
         self._check(self.lib.elfihip_gp_cross_cov(self.h, _lib.ptr(x), S, _lib.ptr(cov), _lib.ptr(var)))
         return cov, var
+
+    def maxvar(self, x, eps, prior_pdf, prior_grad_logpdf):
+        """MaxVar surface and gradient at x (S, d): one batched prediction + the device epilogue (elfihip_gp_maxvar)."""
+        x = self._xs(x)
+        S = x.shape[0]
+        pdf = np.ascontiguousarray(prior_pdf, dtype=np.float64).reshape(S)
+        glog = np.ascontiguousarray(prior_grad_logpdf, dtype=np.float64).reshape(S, self.d)
+        val, grad = np.empty((S, 1)), np.empty((S, self.d))
+        self._check(self.lib.elfihip_gp_maxvar(self.h, _lib.ptr(x), S, float(eps), _lib.ptr(pdf), _lib.ptr(glog),
+                                               _lib.ptr(val), _lib.ptr(grad)))
+        return val, grad
+
+    def expintvar(self, x, eps, w_int, mean_int, var_int):
+        """ExpIntVar loss of the candidates x (S, d) against the current integration points (elfihip_gp_expintvar)."""
+        if self._n_int == 0:
+            raise RuntimeError('no integration points: call set_integration_points first')
+        x = self._xs(x)
+        S, M = x.shape[0], self._n_int
+        arrs = [np.ascontiguousarray(a, dtype=np.float64).reshape(M) for a in (w_int, mean_int, var_int)]
+        loss = np.empty(S)
+        self._check(self.lib.elfihip_gp_expintvar(self.h, _lib.ptr(x), S, float(eps), _lib.ptr(arrs[0]),
+                                                  _lib.ptr(arrs[1]), _lib.ptr(arrs[2]), _lib.ptr(loss)))
+        return loss
 
     def lcb(self, x, beta, with_grad=True):
         x = self._xs(x)
@@ -346,6 +379,15 @@ class HipGPRegression:
         """(cov (M, S), var (S,)): covariance of the GP between the integration points and the rows of x, and the
         noiseless predictive variance of the rows of x."""
         return self._handle.cross_cov(np.asanyarray(x).reshape((-1, self.input_dim)))
+
+    # -- surfaces of the MaxVar family (acquisition.py:392-463, 795-821), epilogues on the device ------
+    def maxvar_surface(self, theta, eps, prior_pdf, prior_grad_logpdf):
+        """(value (S, 1), gradient (S, d)) of the variance of the unnormalised approximate posterior at theta."""
+        return self._handle.maxvar(np.asanyarray(theta).reshape((-1, self.input_dim)), eps, prior_pdf, prior_grad_logpdf)
+
+    def expintvar_loss(self, theta, eps, w_int, mean_int, var_int):
+        """Expected integrated variance (S,) for the candidates theta against the points of set_integration_points."""
+        return self._handle.expintvar(np.asanyarray(theta).reshape((-1, self.input_dim)), eps, w_int, mean_int, var_int)
 
     # -- batched LCB used by elfi_amd.acquisition (one device pass for all start points) -------
     def lcb(self, x, beta, with_grad=True):

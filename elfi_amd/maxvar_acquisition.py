@@ -1,204 +1,168 @@
-"""MaxVar and RandMaxVar acquisition rules on the device GP.
+"""MaxVar, RandMaxVar and ExpIntVar acquisition rules over the device GP.
 
-Mirrors elfi.methods.bo.acquisition.MaxVar / RandMaxVar (elfi/methods/bo/acquisition.py:304-626;
-Jarvenpaa et al. 2019).  The acquisition surface is the variance of the unnormalised approximate posterior
+Drop-ins for elfi.methods.bo.acquisition.MaxVar / RandMaxVar / ExpIntVar (elfi/methods/bo/acquisition.py:304-821;
+Jarvenpaa et al. 2019): same constructor arguments, attributes (`eps`, `quantile_eps`, `points_int`, `omegas_int`,
+`name`, `label_fn` ...), random streams and error behaviour, `acquire(n, t)` / `evaluate` / `evaluate_gradient`.
 
-    Var(theta) = prior(theta)^2 [ Phi_skew(eps; mu, s, a) - Phi(eps; mu, s)^2 ],
-    s^2 = sigma_n^2 + v(theta),   a = sigma_n / sqrt(sigma_n^2 + 2 v(theta)),
+What this module holds is orchestration only.  The arithmetic of the three rules lives behind the model:
 
-mu, v the GP mean and noiseless variance.  The reference evaluates value and gradient separately, one
-point per call, three GP predictions per pair (acquisition.py:403-405,430-432), and MaxVar.acquire runs
-scipy's L-BFGS-B from each start in turn.  Here ONE batched device call (elfihip_gp_predict_grad) per
-round serves value AND gradient of all points of the round, the skew-normal / normal formulas run
-vectorised on the host with the SciPy functions the reference uses, the starts of MaxVar.acquire advance in
-lock-step (elfi_amd/multistart.py) and the chain of RandMaxVar.acquire spends one device call per
-leapfrog step (elfi_amd/chains.py).  Same arguments, attributes, random streams and error texts.
+    model.maxvar_surface(theta, eps, prior_pdf, prior_grad_logpdf)   -> value (S, 1), gradient (S, d)
+    model.expintvar_loss(theta, eps, w_int, mean_int, var_int)       -> loss (S,)
+    model.set_integration_points(points)
+
+which HipGPRegression answers with ONE batched device call each (elfihip_gp_maxvar / elfihip_gp_expintvar: prediction,
+gradients and the skew-normal / Owen's-T epilogue on the GPU; the reference spends three single-point GP predictions
+and SciPy's skewnorm per value / gradient pair, and a Cholesky of the n x n matrix per ExpIntVar evaluation).  The prior
+is the caller's object (elfi ModelPrior): its density and log-gradient at a round's points are evaluated here, on the
+host, and handed to the device call.  The searches run in lock-step (elfi_amd/multistart.py), the sampling chain of
+RandMaxVar as a coroutine with one device call per leapfrog step (elfi_amd/chains.py).
 """
 import logging
 
 import numpy as np
-import scipy.stats as ss
 
-from . import chains as _chains
-from . import multistart as _multistart
+from . import chains, multistart
 
 logger = logging.getLogger(__name__)
 
 
-class HipMaxVar:
-    """elfi.methods.bo.acquisition.MaxVar (acquisition.py:304-470) for a HipGPRegression."""
+def _as_points(model, theta):
+    return np.asanyarray(theta, dtype=float).reshape((-1, model.input_dim))
+
+
+def _clipped(point, bounds):
+    lo, hi = np.array(bounds, dtype=float).T
+    return np.minimum(np.maximum(point, lo), hi)
+
+
+class _SurfaceRule:
+    """What the three rules share: argument handling, the threshold eps (a quantile of the evidence) and the
+    variance-of-the-unnormalised-posterior surface with its gradient, both from one model call."""
+
+    name, label_fn = None, None
 
     def __init__(self, model, prior, quantile_eps=.01, n_inits=10, max_opt_iters=1000, noise_var=None,
                  exploration_rate=10, seed=None, constraints=None):
-        if getattr(model, 'predictive_gradients', None) is None:
-            raise TypeError('model must be a GP regression object (elfi_amd.HipGPRegression)')
+        for needed in ('maxvar_surface', 'expintvar_loss', 'set_integration_points'):
+            if not callable(getattr(model, needed, None)):
+                raise TypeError('model must evaluate the acquisition surfaces itself (elfi_amd.HipGPRegression); '
+                                'missing: %s' % needed)
         if constraints is not None:
-            raise NotImplementedError('constraints need the reference MaxVar (SLSQP on the host); it accepts '
+            raise NotImplementedError('constraints need the reference rule (SLSQP on the host); it accepts '
                                       'HipGPRegression as model')
-        self.model = model
-        self.prior = prior
-        self.n_inits = int(n_inits)
-        self.max_opt_iters = int(max_opt_iters)
+        self.model, self.prior = model, prior
+        self.n_inits, self.max_opt_iters = int(n_inits), int(max_opt_iters)
         self.constraints = None
-        self.noise_var = noise_var          # unused by this family (acquire() is overridden), kept as attribute
-        self.exploration_rate = exploration_rate
-        self.random_state = np.random if seed is None else np.random.RandomState(seed)
-        self.seed = 0 if seed is None else seed
-        self.name = 'max_var'
-        self.label_fn = 'Variance of the Unnormalised Approximate Posterior'
-        self.quantile_eps = quantile_eps
-        self.eps = .1  # pre-set until the first acquire() (acquisition.py:346-347)
+        # kept as attributes; this family never jitters its acquisitions
+        self.noise_var, self.exploration_rate = noise_var, exploration_rate
+        self.seed, self.random_state = (0, np.random) if seed is None else (seed, np.random.RandomState(seed))
+        self.quantile_eps, self.eps = quantile_eps, .1     # eps: until the first acquire() (acquisition.py:346-347)
         self.last_opt = None
 
-    # ---- value and gradient from one prediction ------------------------------------------------
-    def _predict(self, theta):
-        theta = np.asanyarray(theta, dtype=float).reshape((-1, self.model.input_dim))
-        handle = getattr(self.model, '_handle', None)
-        if handle is None or self.model.n_evidence == 0:
-            mean, var = self.model.predict(theta, noiseless=True)
-            grad_mean, grad_var = self.model.predictive_gradients(theta)
-        else:
-            mean, var, grad_mean, grad_var = handle.predict_grad(theta)  # noiseless variance
-        return theta, mean, var, grad_mean, grad_var
-
-    def _value(self, theta, mean, var):
-        # acquisition.py:403-417 (the skew-normal cdf stands in for Owen's T function)
-        sigma2_n = self.model.noise
-        a = np.sqrt(sigma2_n) / np.sqrt(sigma2_n + 2. * var)
-        scale = np.sqrt(sigma2_n + var)
-        phi_skew = ss.skewnorm.cdf(self.eps, a, loc=mean, scale=scale)
-        phi_norm = ss.norm.cdf(self.eps, loc=mean, scale=scale)
-        var_p_a = phi_skew - phi_norm ** 2
-        val_prior = self.prior.pdf(theta).ravel()[:, np.newaxis]
-        return val_prior ** 2 * var_p_a
-
-    def _gradient(self, theta, mean, var, grad_mean, grad_var):
-        # acquisition.py:434-463
-        phi = ss.norm.cdf
-        sigma2_n = self.model.noise
-        scale = np.sqrt(sigma2_n + var)
-        a = (self.eps - mean) / scale
-        b = np.sqrt(sigma2_n) / np.sqrt(sigma2_n + 2 * var)
-        grad_a = (-1. / scale) * grad_mean - ((self.eps - mean) / (2. * (sigma2_n + var) ** (1.5))) * grad_var
-        grad_b = (-np.sqrt(sigma2_n) / (sigma2_n + 2 * var) ** (1.5)) * grad_var
-        _phi_a = phi(a)
-        int_1 = _phi_a - _phi_a ** 2
-        int_2 = phi(self.eps, loc=mean, scale=scale) - ss.skewnorm.cdf(self.eps, b, loc=mean, scale=scale)
-        grad_int_1 = (1. - 2 * _phi_a) * (np.exp(-.5 * (a ** 2)) / np.sqrt(2. * np.pi)) * grad_a
-        grad_int_2 = (1. / np.pi) * (((np.exp(-.5 * (a ** 2) * (1. + b ** 2))) / (1. + b ** 2)) * grad_b
-                                     + (np.sqrt(np.pi / 2.) * np.exp(-.5 * (a ** 2)) * (1. - 2. * phi(a * b)) * grad_a))
-        term_prior = self.prior.pdf(theta).ravel()[:, np.newaxis]
-        grad_prior_log = self.prior.gradient_logpdf(theta)
-        term_grad_prior = term_prior * grad_prior_log
-        return 2. * term_prior * (int_1 - int_2) * term_grad_prior + term_prior ** 2 * (grad_int_1 - grad_int_2)
-
-    def evaluate(self, theta_new, t=None):
-        theta, mean, var = self._predict_value_only(theta_new)
-        return self._value(theta, mean, var)
-
-    def _predict_value_only(self, theta):
-        theta = np.asanyarray(theta, dtype=float).reshape((-1, self.model.input_dim))
-        mean, var = self.model.predict(theta, noiseless=True)
-        return theta, mean, var
-
-    def evaluate_gradient(self, theta_new, t=None):
-        theta, mean, var, gm, gv = self._predict(theta_new)
-        return self._gradient(theta, mean, var, gm, gv)
+    def _refresh_eps(self):
+        self.eps = np.percentile(self.model.Y, self.quantile_eps * 100)
 
     def value_and_gradient(self, theta):
-        """Both at theta (S, d) from one device prediction: (S, 1), (S, d)."""
-        theta, mean, var, gm, gv = self._predict(theta)
-        return self._value(theta, mean, var), self._gradient(theta, mean, var, gm, gv)
+        """Surface and gradient at the rows of theta: (S, 1), (S, d) -- one device call."""
+        theta = _as_points(self.model, theta)
+        pdf = np.ravel(self.prior.pdf(theta))
+        return self.model.maxvar_surface(theta, self.eps, pdf, self.prior.gradient_logpdf(theta))
 
-    # ---- acquisition.py:349-384 ----------------------------------------------------------------------
+    def evaluate(self, theta_new, t=None):
+        return self.value_and_gradient(theta_new)[0]
+
+    def evaluate_gradient(self, theta_new, t=None):
+        return self.value_and_gradient(theta_new)[1]
+
+    def _search(self, objective):
+        """Lock-step multi-start minimisation from the reference's start points; the arg-min, clipped."""
+        bounds = self.model.bounds
+        starts = multistart.draw_start_points(bounds, self.n_inits, self.prior, self.random_state)
+        res = multistart.minimize_lockstep(objective, starts, bounds, maxiter=self.max_opt_iters)
+        best = int(np.argmin(res['vals']))
+        self.last_opt = dict(starts=starts, ind_min=best, **res)
+        return _clipped(res['locs'][best], bounds)
+
+
+class HipMaxVar(_SurfaceRule):
+    """elfi.methods.bo.acquisition.MaxVar (acquisition.py:304-470): the next point maximises the surface."""
+
+    name = 'max_var'
+    label_fn = 'Variance of the Unnormalised Approximate Posterior'
+
     def acquire(self, n, t=None):
-        logger.debug('Acquiring the next batch of %d values', n)
-        gp = self.model
-        self.eps = np.percentile(gp.Y, self.quantile_eps * 100)
+        logger.debug('MaxVar: acquiring %d point(s)', n)
+        self._refresh_eps()
 
         def negated(theta):
-            v, g = self.value_and_gradient(theta)
-            return -v.ravel(), -g
+            value, grad = self.value_and_gradient(theta)
+            return -value.ravel(), -grad
 
-        starts = _multistart.draw_start_points(gp.bounds, self.n_inits, self.prior, self.random_state)
-        res = _multistart.minimize_lockstep(negated, starts, gp.bounds, maxiter=self.max_opt_iters)
-        k = int(np.argmin(res['vals']))
-        theta_max = res['locs'][k].copy()
-        for i in range(len(gp.bounds)):
-            theta_max[i] = np.clip(theta_max[i], *gp.bounds[i])
-        self.last_opt = dict(starts=starts, ind_min=k, **res)
-        return np.tile(theta_max, (n, 1))
+        return np.tile(self._search(negated), (n, 1))
 
 
-class HipRandMaxVar(HipMaxVar):
-    """elfi.methods.bo.acquisition.RandMaxVar (acquisition.py:472-626): the next point is a sample of the
-    density proportional to the MaxVar surface, drawn with one NUTS / Metropolis chain."""
+class HipRandMaxVar(_SurfaceRule):
+    """elfi.methods.bo.acquisition.RandMaxVar (acquisition.py:472-626): the next point is a draw from the density
+    proportional to the surface, taken from one NUTS or Metropolis chain."""
+
+    name = 'rand_max_var'
+    label_fn = HipMaxVar.label_fn
 
     def __init__(self, model, prior, quantile_eps=.01, sampler='nuts', n_samples=50, warmup=None,
                  limit_faulty_init=1000, init_from_prior=False, sigma_proposals=None, **opts):
-        super(HipRandMaxVar, self).__init__(model, prior, quantile_eps, **opts)
-        self.name = 'rand_max_var'
-        self.name_sampler = sampler
-        self._n_samples = n_samples
-        self._warmup = warmup or n_samples // 2
-        self._limit_faulty_init = limit_faulty_init
-        self._init_from_prior = init_from_prior
-        if self.name_sampler == 'metropolis':
-            # resolve_sigmas (elfi/methods/utils.py:460-500)
-            if sigma_proposals is None:
-                self._sigma_proposals = [(b[1] - b[0]) / 10 for b in self.model.bounds]
-            elif isinstance(sigma_proposals, dict):
-                if len(sigma_proposals) != len(self.model.parameter_names):
-                    raise ValueError("sigma_proposals' keys have to be identical to target_model.parameter_names.")
-                self._sigma_proposals = [sigma_proposals[x] for x in self.model.parameter_names]
-            else:
-                raise ValueError("If provided, sigma_proposals need to be input as a dict.")
+        super().__init__(model, prior, quantile_eps, **opts)
+        self.name_sampler, self._n_samples, self._warmup = sampler, n_samples, warmup or n_samples // 2
+        self._limit_faulty_init, self._init_from_prior = limit_faulty_init, init_from_prior
+        if sampler == 'metropolis':
+            self._sigma_proposals = self._proposal_widths(sigma_proposals)
 
-    def _log_density_and_gradient(self, theta):
-        """log Var(theta) and its gradient for rows theta (acquisition.py:563-575): -inf where the surface is 0."""
-        v, g = self.value_and_gradient(theta)
-        v = v.ravel()
+    def _proposal_widths(self, given):
+        # what resolve_sigmas does for this caller (elfi/methods/utils.py:460-500): a tenth of each bound by default
+        if given is None:
+            return [(hi - lo) / 10 for lo, hi in self.model.bounds]
+        if not isinstance(given, dict):
+            raise ValueError("If provided, sigma_proposals need to be input as a dict.")
+        names = self.model.parameter_names
+        if len(given) != len(names):
+            raise ValueError("sigma_proposals' keys have to be identical to target_model.parameter_names.")
+        return [given[k] for k in names]
+
+    def _log_density(self, theta):
+        """(log surface, its gradient) per row; -inf where the surface vanishes (acquisition.py:563-575)."""
+        value, grad = self.value_and_gradient(theta)
+        value = value.ravel()
+        dead = value == 0
         with np.errstate(divide='ignore', invalid='ignore'):
-            logp = np.where(v == 0, -np.inf, np.log(v))
-            grad = np.where((v == 0)[:, None], -np.inf, g / v[:, None])
-        return logp, grad
+            return np.where(dead, -np.inf, np.log(value)), np.where(dead[:, None], -np.inf, grad / value[:, None])
+
+    def _initial_point(self):
+        bounds = self.model.bounds
+        if self._init_from_prior:
+            return _clipped(np.asarray(self.prior.rvs(random_state=self.random_state), dtype=float), bounds)
+        return np.array([self.random_state.uniform(lo, hi) for lo, hi in bounds])
+
+    def _chain(self, start):
+        if self.name_sampler == 'metropolis':
+            return chains.metropolis_chain(self._n_samples, start, np.asarray(self._sigma_proposals), seed=self.seed)
+        if self.name_sampler == 'nuts':
+            return chains.nuts_chain(self._n_samples, start, seed=self.seed)
+        raise ValueError("Incompatible sampler. Please check the options in the documentation.")
 
     def acquire(self, n, t=None):
         if n > self._n_samples:
             raise ValueError(("The number of acquisitions ({0}) has to be lower than the number "
                               "of the samples ({1}).").format(n, self._n_samples - self._warmup))
-        logger.debug('Acquiring the next batch of %d values', n)
-        gp = self.model
-        self.eps = np.percentile(gp.Y, self.quantile_eps * 100)
-        batch_theta = np.zeros(shape=len(gp.bounds))
-        for i in range(self._limit_faulty_init + 1):
-            if i == self._limit_faulty_init:
-                raise SystemExit("Unable to find a suitable initial point.")
-            if self._init_from_prior:
-                theta_init = self.prior.rvs(random_state=self.random_state)
-                for idx_param, bound in enumerate(gp.bounds):
-                    theta_init[idx_param] = np.clip(theta_init[idx_param], bound[0], bound[1])
-            else:
-                theta_init = np.zeros(shape=len(gp.bounds))
-                for idx_param, bound in enumerate(gp.bounds):
-                    theta_init[idx_param] = self.random_state.uniform(bound[0], bound[1])
-            if np.isinf(self._log_density_and_gradient(theta_init[None, :])[0][0]):
-                continue  # a faulty initial point
-            if self.name_sampler == 'metropolis':
-                chain = _chains.metropolis_chain(self._n_samples, theta_init, np.asarray(self._sigma_proposals),
-                                                 seed=self.seed)
-            elif self.name_sampler == 'nuts':
-                chain = _chains.nuts_chain(self._n_samples, theta_init, seed=self.seed)
-            else:
-                raise ValueError("Incompatible sampler. Please check the options in the documentation.")
-            samples = _chains.run_lockstep([chain], self._log_density_and_gradient)[0]
-            if n > 1:
-                samples = samples[self._warmup:]
-                batch_theta = self.random_state.permutation(samples)[:n]
-            else:
-                batch_theta = samples[-1:]
-            break
-        return batch_theta
+        logger.debug('RandMaxVar: acquiring %d point(s) from one %s chain', n, self.name_sampler)
+        self._refresh_eps()
+        for _ in range(self._limit_faulty_init):
+            start = self._initial_point()
+            if np.isinf(self._log_density(start[None, :])[0][0]):
+                continue                                   # the surface vanishes there: draw another start
+            samples = chains.run_lockstep([self._chain(start)], self._log_density)[0]
+            if n == 1:
+                return samples[-1:]
+            return self.random_state.permutation(samples[self._warmup:])[:n]
+        raise SystemExit("Unable to find a suitable initial point.")
 
 
 def finite_difference_objective(fun_batch, bounds, step=1e-8):
@@ -222,72 +186,58 @@ def finite_difference_objective(fun_batch, bounds, step=1e-8):
     return value_and_gradient
 
 
-class HipExpIntVar(HipMaxVar):
+class HipExpIntVar(_SurfaceRule):
     """elfi.methods.bo.acquisition.ExpIntVar (acquisition.py:629-821): the next point minimises the expected
-    integrated variance of the unnormalised posterior over a set of integration points (a grid, or importance
-    samples of the MaxVar surface).
+    integrated variance of the unnormalised posterior over a set of integration points -- a grid, or importance
+    samples of the MaxVar surface refreshed every `iter_imp` acquisitions.
 
-    The reference's evaluate() factorises the n x n covariance matrix and solves with it on EVERY call
-    (cho_factor + cho_solve, :806-808) to get the GP covariance between the integration points and the candidate.
-    Here that covariance comes from the device factorisation already in place: the model keeps
-    V_P = L^-1 k(X, P) for the point set (set_integration_points, once per acquire) and cross_cov streams it once
-    per batch of candidates (elfihip_gp_cross_cov); all starts of the minimisation and the d + 1 points of each
-    finite-difference gradient are one batch per round."""
+    Per acquire(): the point set goes to the model once (set_integration_points: V_P = L^-1 k(X, P) on the device),
+    with the GP mean / variance there and the weights omega_i prior_i^2; every evaluation of the loss -- all starts of
+    the minimisation and the d + 1 points of each finite-difference gradient in one batch -- is one expintvar_loss
+    call (the reference factorises the n x n matrix and solves with it inside every evaluate(), :806-808)."""
+
+    name = 'exp_int_var'
+    label_fn = 'Expected Loss'
 
     def __init__(self, model, prior, quantile_eps=.01, integration='grid', d_grid=.2, n_samples_imp=100, iter_imp=2,
                  sampler='nuts', n_samples=2000, sigma_proposals=None, **opts):
-        super(HipExpIntVar, self).__init__(model, prior, quantile_eps, **opts)
-        if getattr(model, 'cross_cov', None) is None:
-            raise TypeError('model must provide set_integration_points / cross_cov (elfi_amd.HipGPRegression)')
-        self.name = 'exp_int_var'
-        self.label_fn = 'Expected Loss'
-        self._integration = integration
-        self._n_samples_imp = n_samples_imp
-        self._iter_imp = iter_imp
-        if self._integration == 'importance':
-            self.density_is = HipRandMaxVar(model=self.model, prior=self.prior, n_inits=self.n_inits, seed=self.seed,
-                                            quantile_eps=self.quantile_eps, sampler=sampler, n_samples=n_samples,
+        super().__init__(model, prior, quantile_eps, **opts)
+        self._integration, self._n_samples_imp, self._iter_imp = integration, n_samples_imp, iter_imp
+        if integration == 'importance':
+            self.density_is = HipRandMaxVar(model=model, prior=prior, n_inits=self.n_inits, seed=self.seed,
+                                            quantile_eps=quantile_eps, sampler=sampler, n_samples=n_samples,
                                             sigma_proposals=sigma_proposals)
+        elif integration == 'grid':
+            axes = [slice(lo, hi, d_grid) for lo, hi in model.bounds]
+            self.points_int = np.mgrid[axes].reshape(len(model.bounds), -1).T
+
+    def _prepare_integration(self, t):
+        resample = self._integration == 'importance' and t % self._iter_imp == 0
+        if resample:
+            self.points_int = self.density_is.acquire(self._n_samples_imp)
+        pts = self.points_int
+        self.mean_int, self.var_int = self.model.predict(pts, noiseless=True)
+        self.priors_int = (self.prior.pdf(pts) ** 2)[np.newaxis, :]
+        if resample:
+            inverse = (1 / self.value_and_gradient(pts)[0]).T
+            self.omegas_int = inverse / np.sum(inverse, axis=1)[:, np.newaxis]
         elif self._integration == 'grid':
-            grid_param = [slice(b[0], b[1], d_grid) for b in self.model.bounds]
-            self.points_int = np.mgrid[grid_param].reshape(len(self.model.bounds), -1).T
+            self.omegas_int = np.full(len(pts), 1 / len(pts))
+        self.model.set_integration_points(pts)
+        self._w_int = np.ravel(self.omegas_int * self.priors_int)
 
     def acquire(self, n, t):
-        logger.debug('Acquiring the next batch of %d values', n)
-        gp = self.model
-        self.sigma2_n = gp.noise
-        self.eps = np.percentile(gp.Y, self.quantile_eps * 100)
-        if self._integration == 'importance' and t % self._iter_imp == 0:
-            self.points_int = self.density_is.acquire(self._n_samples_imp)
-        self.mean_int, self.var_int = gp.predict(self.points_int, noiseless=True)
-        self.priors_int = (self.prior.pdf(self.points_int) ** 2)[np.newaxis, :]
-        if self._integration == 'importance' and t % self._iter_imp == 0:
-            omegas_int_unnormalised = (1 / HipMaxVar.evaluate(self, self.points_int)).T
-            self.omegas_int = omegas_int_unnormalised / np.sum(omegas_int_unnormalised, axis=1)[:, np.newaxis]
-        elif self._integration == 'grid':
-            self.omegas_int = np.empty(len(self.points_int))
-            self.omegas_int.fill(1 / len(self.points_int))
-        gp.set_integration_points(self.points_int)  # in place of K, k_int_old and the per-call Cholesky (:788-793)
-        self.phi_int = ss.norm.cdf(self.eps, loc=self.mean_int.T, scale=np.sqrt(self.sigma2_n + self.var_int.T))
-        starts = _multistart.draw_start_points(gp.bounds, self.n_inits, self.prior, self.random_state)
-        res = _multistart.minimize_lockstep(finite_difference_objective(self.evaluate, gp.bounds), starts, gp.bounds,
-                                            maxiter=self.max_opt_iters)
-        k = int(np.argmin(res['vals']))
-        theta_min = res['locs'][k].copy()
-        for i in range(len(gp.bounds)):
-            theta_min[i] = np.clip(theta_min[i], *gp.bounds[i])
-        self.last_opt = dict(starts=starts, ind_min=k, **res)
-        return np.tile(theta_min, (n, 1))
+        logger.debug('ExpIntVar: acquiring %d point(s), t = %s', n, t)
+        self.sigma2_n = self.model.noise
+        self._refresh_eps()
+        self._prepare_integration(t)
+        return np.tile(self._search(finite_difference_objective(self.evaluate, self.model.bounds)), (n, 1))
 
     def evaluate(self, theta_new, t=None):
-        theta_new = np.asanyarray(theta_new, dtype=float).reshape((-1, self.model.input_dim))
-        cov, var_new = self.model.cross_cov(theta_new)           # (M, S), (S,)
-        cov_int = cov.T
-        var_new = np.asarray(var_new).reshape(-1, 1)
-        # acquisition.py:809-819
-        delta_var_int = cov_int ** 2 / (self.sigma2_n + var_new)
-        a = np.sqrt((self.sigma2_n + self.var_int.T - delta_var_int) / (self.sigma2_n + self.var_int.T + delta_var_int))
-        phi_skew_imp = ss.skewnorm.cdf(self.eps, a, loc=self.mean_int.T, scale=np.sqrt(self.sigma2_n + self.var_int.T))
-        w = ((self.phi_int - phi_skew_imp) / 2)
-        loss_theta_new = 2 * np.sum(self.omegas_int * self.priors_int * w, axis=1)
-        return np.where(self.prior.pdf(theta_new) == 0, np.finfo(float).max, loss_theta_new)
+        theta_new = _as_points(self.model, theta_new)
+        loss = self.model.expintvar_loss(theta_new, self.eps, self._w_int, self.mean_int, self.var_int)
+        return np.where(self.prior.pdf(theta_new) == 0, np.finfo(float).max, loss)
+
+    def evaluate_gradient(self, theta_new, t=None):
+        raise NotImplementedError('ExpIntVar is minimised on finite differences, as in the reference '
+                                  '(acquisition.py:766-775 passes no gradient)')

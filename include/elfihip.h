@@ -125,6 +125,12 @@ int elfihip_welford_update(elfihip_ctx* ctx, const double* X, int64_t n, int m, 
                            int64_t* count, double* mean, double* M2);
 int elfihip_welford_update_dev(elfihip_ctx* ctx, const double* dX, int64_t n, int m, int64_t ldx,
                                double* dstate);
+/* Multi-GPU adaptive distance: merge the `world` rank states (each 1 + 2m doubles: count, mean, M2 -- what
+ * elfihip_welford_update_dev maintains) that an all-gather left in device memory, in rank order, with Chan's pairwise
+ * formula -- the merge the reference gets for free from seeing all batches in one process (elfi_model.py:1104-1125).
+ * dmerged (1 + 2m) receives the global state, dw2 (m, may be NULL) the cdist weights 1 / scale^2 = N / M2
+ * (elfi_model.py:1124,1129-1132).  Asynchronous on the context's stream. */
+int elfihip_welford_merge_dev(elfihip_ctx* ctx, const double* dstates, int world, int m, double* dmerged, double* dw2);
 
 /* ------------------------------------------------------------------ selection
  * The selection inside Rejection._merge_batch (elfi/methods/inference/samplers.py:209-237): the
@@ -205,6 +211,25 @@ int elfihip_gp_factorize(elfihip_gp* gp, double* log_marginal);
  * panel_group 0 = by size, else 1 / 2 / 4 panels per pass over the trailing matrix (schedule 1).  Results agree to
  * rounding between schedules; each is deterministic. */
 int elfihip_gp_set_schedule(elfihip_gp* gp, int schedule, int panel_group);
+/* Device time per phase, for roofline accounting (bench.py; no reference counterpart).  While enabled, HIP events on the
+ * GP's stream bracket the phases of elfihip_gp_factorize (Gram matrix | sweep | alpha + log-determinant), of single-group
+ * prediction calls -- elfihip_gp_predict / _predict_grad / _lcb and every step of elfihip_gp_lcb_minimize -- (kernel row |
+ * first triangular product + its reduction | second triangular product | gradient sums + final assembly) and of
+ * elfihip_gp_nlml_grad (K^-1 tiles with the fused gradient contractions).  enable > 0 starts a fresh measurement,
+ * 0 stops it, < 0 only reads; phase_ms / phase_calls (ELFIHIP_PHASE_COUNT entries each, may be NULL) receive the sums of
+ * milliseconds and the number of timed calls per phase collected so far. */
+enum {
+  ELFIHIP_PHASE_GRAM = 0,
+  ELFIHIP_PHASE_SWEEP = 1,
+  ELFIHIP_PHASE_ALPHA = 2,
+  ELFIHIP_PHASE_KSTAR = 3,
+  ELFIHIP_PHASE_TRI_FIRST = 4,
+  ELFIHIP_PHASE_TRI_SECOND = 5,
+  ELFIHIP_PHASE_GRAD_FINISH = 6,
+  ELFIHIP_PHASE_KINV_GRAD = 7,
+  ELFIHIP_PHASE_COUNT = 8
+};
+int elfihip_gp_profile(elfihip_gp* gp, int enable, double* phase_ms, int64_t* phase_calls);
 /* What GPy evaluates once per objective call of GPyRegression.optimize() (gpy_regression.py:317-323
  * -> [GPy-upstream] ExactGaussianInference + kern.update_gradients_full): the log marginal
  * likelihood and its gradient w.r.t. (rbf.variance, rbf.lengthscale, bias.variance,
@@ -258,6 +283,19 @@ int elfihip_gp_lcb_minimize(elfihip_gp* gp, const double* starts, int64_t S, con
  * predictive variance var_q (S) of the S candidates Q (S, d): one streaming pass over V_P per 128 candidates. */
 int elfihip_gp_set_integration_points(elfihip_gp* gp, const double* P, int64_t M);
 int elfihip_gp_cross_cov(elfihip_gp* gp, const double* Q, int64_t S, double* cov, double* var_q);
+/* MaxVar / RandMaxVar surface (elfi/methods/bo/acquisition.py:392-463): the variance of the unnormalised approximate
+ * posterior prior(x)^2 [Phi_skew(eps) - Phi(eps)^2] at S points and its gradient, from ONE batched prediction with the
+ * skew-normal / Owen's-T epilogue on the device (the reference: three single-point GP predictions and SciPy's skewnorm
+ * per value/gradient pair).  prior_pdf (S) and prior_grad_logpdf (S, d) are the prior's density and the gradient of its
+ * logarithm at the points (host callables of the caller's prior object); val (S), grad (S, d). */
+int elfihip_gp_maxvar(elfihip_gp* gp, const double* Xs, int64_t S, double eps, const double* prior_pdf,
+                      const double* prior_grad_logpdf, double* val, double* grad);
+/* ExpIntVar loss (acquisition.py:795-821) of S candidates against the integration points fixed by
+ * elfihip_gp_set_integration_points: 2 sum_i w_i T(z_i, a_is) with the posterior covariances taken from the device
+ * factorisation (the reference: cho_factor + cho_solve of the n x n matrix per call).  w_int = omega_i prior(p_i)^2,
+ * mean_int / var_int = GP mean and noiseless variance at the integration points (M each); loss (S). */
+int elfihip_gp_expintvar(elfihip_gp* gp, const double* Q, int64_t S, double eps, const double* w_int,
+                         const double* mean_int, const double* var_int, double* loss);
 
 /* ---- the same multi-start search for objectives the HOST assembles -----------------------
  * scipy.optimize.minimize(method='L-BFGS-B') as the reference calls it from minimize()

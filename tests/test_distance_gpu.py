@@ -246,48 +246,90 @@ def test_welford_reference_unit_test(hip_ctx):
     assert np.allclose(nd[:, 1], np.sqrt(np.sum(((d1 - obs) / a.state['scale']) ** 2, axis=1)))
 
 
-@pytest.mark.parametrize('n,m', [(1, 1), (7, 3), (10000, 2), (100003, 64), (5000, 300)])
-def test_welford_vs_oracle(hip_ctx, n, m):
+def _fold_and_check(batches, m):
+    """Fold the batches into the running (count, mean, M2) on the GPU and in the oracle, checking after every batch
+    with tolerances that are fixed IN ADVANCE by the data (no observed error is ever carried forward):
+
+      mean   mean_new = mean_old + sum(x - mean_old) / N: the two sides sum in different (fixed) orders, allowed
+             2e-13 of the mean absolute term + 8 ulp; a difference left by earlier batches enters the new mean scaled
+             by N_old / N, so the allowance is the running sum  A <- A N_old / N + allowance_b  (it does not grow).
+      M2     given OUR mean_new, our increment equals sum d1 d2 evaluated in extended precision to 1e-13 of the sum of
+             absolute terms (formula check, no reference involved).  Against the reference: the increment has
+             derivative -sum(d1) with respect to mean_new, so the means' allowance A is amplified by |sum d1| (up to
+             N |mean| for the first batch, where mean_old = 0: the reference's formula is that ill-conditioned itself);
+             increments add, so the allowance is the sum of the per-batch allowances -- linear in the number of
+             batches, as the rounding of any running sum is.
+    """
     import elfi_amd
-    rs = np.random.RandomState(n + m)
     ref = O.AdaptiveDistanceOracle()
     cnt, mean, M2 = 0, np.zeros(m), np.zeros(m)
-    M2_old, carry, carry_mean = np.zeros(m), np.zeros(m), np.zeros(m)
-    for b in range(3):
-        X = rs.randn(n, m) * rs.uniform(0.1, 100, m) + rs.uniform(-1000, 1000, m)
-        mean_old = mean.copy()           # OUR previous mean: what the kernel subtracts in d1
+    M2_old = np.zeros(m)
+    allow_mean, allow_m2 = np.zeros(m), np.zeros(m)
+    for b, X in enumerate(batches):
+        mean_old, n_old = mean.copy(), cnt          # OUR previous mean: what the kernel subtracts in d1
         ref.add_data(X)
         cnt, mean, M2 = elfi_amd.welford_update(X, cnt, mean, M2)
         assert cnt == ref.store[0]
-        # mean = mean_old + sum(x - mean_old)/N: error relative to the size of the summed terms
-        tol_mean = 1e-13 * np.mean(np.abs(X - mean_old), axis=0) + 4 * np.spacing(np.abs(ref.store[1])) + carry_mean
-        worst = np.argmax(np.abs(mean - ref.store[1]) / tol_mean)
-        assert np.all(np.abs(mean - ref.store[1]) <= tol_mean), (
-            b, worst, mean[worst], ref.store[1][worst], tol_mean[worst])
-        # M2 += sum(d1 * (x - mean_new)) has derivative -sum(d1) = -N (mean_new - mean_old) w.r.t.
-        # mean_new, so the few-ulp difference between the two sides' means (different but fixed
-        # summation orders, checked above) is amplified by up to N |mean| when mean_old = 0 -- for
-        # the reference exactly as for us.  The honest statement is therefore: given OUR mean_new,
-        # our M2 increment equals the update formula evaluated in extended precision, to 1e-13 of
-        # the sum of absolute terms; and it agrees with the reference's to that plus the
-        # first-order effect of the observed mean difference.
+        allow_mean = allow_mean * (n_old / cnt) + 2e-13 * np.mean(np.abs(X - mean_old), axis=0) \
+            + 8 * np.spacing(np.abs(ref.store[1]))
+        err = np.abs(mean - ref.store[1])
+        worst = np.argmax(err / allow_mean)
+        assert np.all(err <= allow_mean), ('mean', b, worst, mean[worst], ref.store[1][worst], allow_mean[worst])
         Xl = X.astype(np.longdouble)
         d1 = Xl - mean_old.astype(np.longdouble)
-        exact_inc = np.sum(d1 * (Xl - mean.astype(np.longdouble)), axis=0)
-        scale = np.sum(np.abs(d1 * (Xl - mean.astype(np.longdouble))), axis=0).astype(float)
+        terms = d1 * (Xl - mean.astype(np.longdouble))
+        exact_inc = np.sum(terms, axis=0)
+        scale = np.sum(np.abs(terms), axis=0).astype(float)
         inc = M2.astype(np.longdouble) - M2_old.astype(np.longdouble)
         e1 = np.abs((inc - exact_inc).astype(float))
         t1 = 1e-13 * scale + 4 * np.spacing(np.abs(M2))
         w1 = np.argmax(e1 / t1)
         assert np.all(e1 <= t1), ('formula', b, w1, e1[w1], t1[w1], scale[w1], M2[w1])
-        amplified = np.abs(np.sum(d1, axis=0).astype(float)) * np.abs(mean - ref.store[1])
+        allow_m2 = allow_m2 + 2e-13 * (scale + np.abs(M2)) + 2 * np.abs(np.sum(d1, axis=0).astype(float)) * allow_mean
         e2 = np.abs(M2 - ref.store[2])
-        t2 = 2e-13 * (scale + np.abs(M2)) + 2 * amplified + carry
-        w2 = np.argmax(e2 / t2)
-        assert np.all(e2 <= t2), ('vs reference', b, w2, e2[w2], t2[w2], amplified[w2], carry[w2])
-        carry = np.abs(M2 - ref.store[2])   # differences of earlier batches carry over additively
-        carry_mean = np.abs(mean - ref.store[1])
+        w2 = np.argmax(e2 / allow_m2)
+        assert np.all(e2 <= allow_m2), ('vs reference', b, w2, e2[w2], allow_m2[w2])
         M2_old = M2.copy()
+    return cnt, mean, M2
+
+
+@pytest.mark.parametrize('n,m', [(1, 1), (7, 3), (10000, 2), (100003, 64), (5000, 300)])
+def test_welford_vs_oracle(hip_ctx, n, m):
+    rs = np.random.RandomState(n + m)
+    _fold_and_check([rs.randn(n, m) * rs.uniform(0.1, 100, m) + rs.uniform(-1000, 1000, m) for _ in range(3)], m)
+
+
+@pytest.mark.parametrize('nbatch,n,m', [(40, 700, 9), (200, 97, 3), (1000, 33, 2)])
+def test_welford_many_batches(hip_ctx, nbatch, n, m):
+    """elfi_model.py:1104-1125 over many batches (an SMC round folds in every batch of the round), same a-priori
+    tolerances; at the end the scale is the population standard deviation of the union (test_elfi_model.py:197-218)."""
+    rs = np.random.RandomState(nbatch + n)
+    scale, shift = rs.uniform(0.1, 100, m), rs.uniform(-10, 10, m)
+    batches = [rs.randn(n + b % 7, m) * scale + shift for b in range(nbatch)]
+    cnt, mean, M2 = _fold_and_check(batches, m)
+    np.testing.assert_allclose(np.sqrt(M2 / cnt), np.std(np.vstack(batches), axis=0), rtol=1e-11)
+
+
+def test_welford_device_merge_equals_the_host_merge(hip_ctx):
+    """elfihip_welford_merge_dev (multi-GPU adaptive distance: merge of the all-gathered rank states on the device)
+    == elfi_amd.sharding.merge_welford bit for bit, weights N / M2 included."""
+    import torch
+    from elfi_amd import sharding as S
+    rs = np.random.RandomState(4)
+    world, m = 8, 64
+    states = []
+    for r in range(world):
+        nb = 0 if r == 3 else int(rs.randint(1000, 200000))      # one rank without rows
+        states.append(np.concatenate([[float(nb)], rs.randn(m) * 10, rs.uniform(1, 1e6, m) * (nb > 0)]))
+    st = torch.from_numpy(np.vstack(states)).cuda()
+    merged = torch.empty(1 + 2 * m, dtype=torch.float64, device='cuda')
+    w2 = torch.empty(m, dtype=torch.float64, device='cuda')
+    hip_ctx.call("elfihip_welford_merge_dev", st.data_ptr(), world, m, merged.data_ptr(), w2.data_ptr())
+    hip_ctx.synchronize()
+    N, mean, M2 = S.merge_welford([(v[0], v[1:1 + m], v[1 + m:]) for v in states])
+    got = merged.cpu().numpy()
+    assert got[0] == N and np.array_equal(got[1:1 + m], mean) and np.array_equal(got[1 + m:], M2)
+    assert np.array_equal(w2.cpu().numpy(), 1.0 / (M2 / N))
 
 
 def test_determinism(hip_ctx):

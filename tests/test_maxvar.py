@@ -10,6 +10,7 @@ import os
 import numpy as np
 import pytest
 
+import acquisition_oracle as AO
 import gp_oracle as G
 import posterior_oracle as PO
 from conftest import GOLDEN
@@ -43,6 +44,18 @@ class OracleModel:
         K = lambda a, b: G.kern_K(a, b, p.var, p.ls, p.bias)
         cov = K(self._pts, x) - K(self._pts, self.X) @ p.Kinv @ K(self.X, x)
         return cov, p.predict(x, noiseless=True)[1][:, 0]
+
+    # the two surfaces the acquisition classes ask their model for (HipGPRegression: one device call each), here by
+    # the CPU restatement of the reference's formulas (oracle/acquisition_oracle.py)
+    def maxvar_surface(self, theta, eps, prior_pdf, prior_grad_logpdf):
+        mean, var = self.predict(theta, noiseless=True)
+        gm, gv = self.predictive_gradients(theta)
+        return (AO.maxvar_value(mean, var, self.noise, eps, prior_pdf),
+                AO.maxvar_gradient(mean, var, gm, gv, self.noise, eps, prior_pdf, prior_grad_logpdf))
+
+    def expintvar_loss(self, theta, eps, w_int, mean_int, var_int):
+        cov, var_new = self.cross_cov(theta)
+        return AO.expintvar_loss(cov.T, var_new, self.noise, eps, w_int, mean_int, var_int)
 
 
 def check_against_fixture(make_model, value_tol, loc_tol):
