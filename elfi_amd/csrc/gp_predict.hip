@@ -983,7 +983,7 @@ static int cross_cov_impl(elfihip_gp* gp, const double* Q, int64_t S, double* co
                           const ExpIntVarArgs* ei = nullptr, double* loss = nullptr) {
   elfihip_ctx* ctx = gp->ctx;
   hipStream_t st = ctx->stream;
-  ELFIHIP_REQUIRE(ctx, S >= 1 && Q && cov, "bad arguments");
+  ELFIHIP_REQUIRE(ctx, S >= 1 && Q && (cov || loss), "bad arguments");
   if (!(gp->n_int > 0 && gp->vp_gen == gp->fact_gen))
     return fail(ctx, ELFIHIP_ERR_STATE,
                 "no integration points for the current factorisation (call elfihip_gp_set_integration_points)");
