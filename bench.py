@@ -176,36 +176,50 @@ class Job:
         import elfi_amd
         self.torch, self.dev, self.world, self.rank = torch, dev, world, rank
         # one explicit (non-null) stream shared by torch / RCCL and the library for the kernels of a step, a second one
-        # (its own library context) for the selection + gather of the previous step's distances
+        # for the per-step gather (N > 1)
         self.main = torch.cuda.Stream(dev)
         self.side = torch.cuda.Stream(dev)
         torch.cuda.set_stream(self.main)
         self.ctx = elfi_amd.Context(local_rank)
         self.ctx.set_stream(self.main.cuda_stream)
-        self.ctx_side = elfi_amd.Context(local_rank)
-        self.ctx_side.set_stream(self.side.cuda_stream)
         # values and row numbers travel together: one buffer (the int64 rows viewed through the second half), ONE gather
         self.best = [torch.empty(2 * K_BEST, dtype=torch.float64, device=dev) for _ in range(2)]
         self.gath = [torch.empty(2 * K_BEST, dtype=torch.float64, device=dev) for _ in range(world)] \
             if (world > 1 and rank == 0) else None
-        self.ev_done = [torch.cuda.Event() for _ in range(2)]   # distances of buffer b are complete (main)
-        self.ev_free = [torch.cuda.Event() for _ in range(2)]   # selection has finished reading buffer b (side)
+        self.ev_done = [torch.cuda.Event() for _ in range(2)]   # the step that fills send buffer b is queued (main)
+        self.ev_free = [torch.cuda.Event() for _ in range(2)]   # the gather has finished reading send buffer b (side)
         for e in self.ev_free:
             e.record(self.side)
 
-    def select_and_gather(self, b, dptr, n, stride, k):
-        """On the side stream: top-k of the n distances at dptr (stride doubles apart), then the gather."""
-        torch = self.torch
-        import torch.distributed as dist
-        self.ev_done[b].record(self.main)
-        self.side.wait_event(self.ev_done[b])
-        best = self.best[b]
-        self.ctx_side.call("elfihip_topk_smallest_dev", dptr, n, stride, k, best.data_ptr(),
-                           best.data_ptr() + 8 * K_BEST)
+    def new_state(self, k):
+        """The sampler state of this rank: the k best (distance, global row) pairs so far, on the device."""
+        import ctypes as C
+        h = C.c_void_p()
+        self.ctx.call("elfihip_reject_create", k, C.byref(h))
+        self.state = h
+        return h
+
+    def check(self, rc):
+        from elfi_amd import _lib
+        _lib.check(self.ctx.handle, rc)
+
+    def claim(self, b):
+        """Before a push: merges from now on leave the packed state in send buffer b (once the gather that last read
+        the buffer has released it)."""
         if self.world > 1:
-            with torch.cuda.stream(self.side):
-                dist.gather(best, self.gath, dst=0)
-        self.ev_free[b].record(self.side)
+            self.main.wait_event(self.ev_free[b])
+        self.check(self.ctx.lib.elfihip_reject_export_dev(self.state, self.best[b].data_ptr()))
+
+    def publish(self, b):
+        """After a push, N > 1: the rank's state as of its last merge (the library merges every 8th push; the final
+        result is exact) goes to rank 0 -- ONE gather of the 16 KB send buffer on the second stream, every step."""
+        if self.world > 1:
+            import torch.distributed as dist
+            self.ev_done[b].record(self.main)
+            self.side.wait_event(self.ev_done[b])
+            with self.torch.cuda.stream(self.side):
+                dist.gather(self.best[b], self.gath, dst=0)
+            self.ev_free[b].record(self.side)
 
     def barrier(self):
         import torch.distributed as dist
@@ -248,13 +262,17 @@ def run_distance(args, job):
     outs = [torch.empty(n, dtype=torch.float64, device=dev) for _ in range(2)]
     out_t = torch.empty(n, dtype=torch.float64, device=dev)   # target of the kernel-only timing loop
     k = min(K_BEST, n)
+    state = job.new_state(k)
+    lib = ctx.lib
 
     def step(i):
+        # one ABC batch: distances + the sampler's running best-k in the same pass (rows numbered globally:
+        # rank, batch, row), then the state's hand-over
         b = i & 1
-        job.main.wait_event(job.ev_free[b])          # the selection two steps ago has released this buffer
-        ctx.call("elfihip_dist_rows_dev", 0, Xs[i % NBUF].data_ptr(), n, m, m, y.data_ptr(), None, 2.0,
-                 outs[b].data_ptr())
-        job.select_and_gather(b, outs[b].data_ptr(), n, 1, k)
+        job.claim(b)
+        job.check(lib.elfihip_reject_push_rows_dev(state, 0, Xs[i % NBUF].data_ptr(), n, m, m, y.data_ptr(), None, 2.0,
+                                                   outs[b].data_ptr(), (rank * 1000003 + i) * n))
+        job.publish(b)
 
     elapsed = job.timed(step, args.steps, args.warmup)
     # Kernel-only timing for the roofline: HIP events on the SAME stream the kernel runs on, nothing beside it
@@ -275,13 +293,26 @@ def run_distance(args, job):
     ref = O.cdist_rows(Xs[last][idx].cpu().numpy(), y.cpu().numpy(), 'euclidean')
     dh = out_t.cpu().numpy()
     assert np.array_equal(dh[idx], ref), "bench output differs from the oracle"
-    bsel = (args.warmup + args.steps - 1) & 1       # the selection of the last timed step
+    # the sampler state after the run: the k best of everything this rank pushed (warm-up included) -- recomputed here
+    # from the NBUF distinct batches, each of which was pushed several times under different global row numbers
+    bsel = (args.warmup + args.steps - 1) & 1
+    job.check(lib.elfihip_reject_flush(state))
+    torch.cuda.synchronize(dev)
     bv = job.best[bsel][:k].cpu().numpy()
-    bi = job.best[bsel][K_BEST:K_BEST + k].view(torch.int64).cpu().numpy()
-    dl = outs[bsel].cpu().numpy()
-    assert np.array_equal(np.sort(bv), np.sort(dl)[:k]) and np.array_equal(dl[bi], bv), "top-k differs from numpy"
-    if world > 1:   # rank 0's own slice of the gather is what it selected
-        assert torch.equal(job.gath[0], job.best[bsel])
+    bi = job.best[bsel][k:2 * k].view(torch.int64).cpu().numpy()
+    total = args.warmup + args.steps
+    dist_of, pool = [], []
+    for j in range(min(NBUF, total)):
+        ctx.call("elfihip_dist_rows_dev", 0, Xs[j].data_ptr(), n, m, m, y.data_ptr(), None, 2.0, out_t.data_ptr())
+        dist_of.append(out_t.cpu().numpy().copy())
+        pool.append(np.tile(np.sort(dist_of[j])[:k], len(range(j, total, NBUF))))
+    assert np.array_equal(bv, np.sort(np.concatenate(pool))[:k]), "running best-k differs from numpy"
+    step_of, row_of = np.divmod(bi - rank * 1000003 * n, n)
+    assert np.all((step_of >= 0) & (step_of < total)) and len(set(bi.tolist())) == k
+    assert np.array_equal(np.array([dist_of[s_ % NBUF][r_] for s_, r_ in zip(step_of, row_of)]), bv)
+    order = np.lexsort((bi, bv))
+    assert np.array_equal(order, np.arange(k)), "state must be ascending by (distance, row)"
+    # (for N > 1 rank 0's slice of the last gather is its state as of the last merge before that gather)
     traffic, source = None, None
     try:   # HBM traffic per launch from this round's rocprofv3 PMC passes of this very command (profiles/)
         with open(os.path.join(ROOT, "profiles", "distance_pmc.json")) as f:
@@ -298,9 +329,11 @@ def run_distance(args, job):
         "config": {"workload": "configs[1]: synthetic Gaussian summaries, %d samples x %d summaries per GPU per step, "
                                "elfi.Distance('euclidean'), inputs resident in HBM" % (n, m),
                    "samples_per_gpu": n, "summaries": m, "layout": "row-major (n,m) f64", "batches_in_rotation": NBUF,
-                   "step": "distance kernel (main stream) + device top-%d of the previous batch (second stream)" % k,
-                   "exchange": ("every step: ONE RCCL gather of the packed top-%d (distance, row) pairs per rank "
-                                "(16 KB) to rank 0, on the second stream" % k) if world > 1 else "none (N = 1)"},
+                   "step": "ONE pass: distance kernel with the sampler's running top-%d fused in (rows below the "
+                           "state's k-th distance are listed by the kernel itself; a one-workgroup merge every "
+                           "8th step)" % k,
+                   "exchange": ("every step: ONE RCCL gather of the rank's packed state (top-%d (distance, row) pairs as of "
+                                "its last merge, 16 KB per rank) to rank 0, on a second stream" % k) if world > 1 else "none (N = 1)"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": source,
                      "kernel": "dist_rows_pipe_kernel<euclidean>", "kernel_ms": kernel_ms,
@@ -332,6 +365,8 @@ def run_adaptive(args, job):
     merged = torch.zeros(ns, dtype=torch.float64, device=dev)
     W = torch.ones(K, m, dtype=torch.float64, device=dev)
     k = min(K_BEST, n)
+    rstate = job.new_state(k)
+    lib = ctx.lib
 
     def step(i):
         b = i & 1
@@ -344,10 +379,13 @@ def run_adaptive(args, job):
         # fixed-order Chan merge + weights 1/scale^2 on the device: row 1 of W; row 2 = a second adaptation round
         ctx.call("elfihip_welford_merge_dev", states.data_ptr(), world, m, merged.data_ptr(), W[1].data_ptr())
         torch.mul(W[1], 0.5, out=W[2])
-        job.main.wait_event(job.ev_free[b])
-        ctx.call("elfihip_dist_multiw_dev", X.data_ptr(), n, m, m, y.data_ptr(), W.data_ptr(), K, outs[b].data_ptr())
-        # Rejection ranks nested distances by the LAST column (samplers.py:233): top-k over column K-1, stride K
-        job.select_and_gather(b, outs[b].data_ptr() + 8 * (K - 1), n, K, k)
+        # an SMC round re-ranks from scratch (samplers.py:279-299): fresh state, then distances + running best-k (by the
+        # LAST nested column, samplers.py:233) in one pass
+        job.check(lib.elfihip_reject_reset(rstate))
+        job.claim(b)
+        job.check(lib.elfihip_reject_push_multiw_dev(rstate, X.data_ptr(), n, m, m, y.data_ptr(), W.data_ptr(), K,
+                                                     outs[b].data_ptr(), rank * n))
+        job.publish(b)
 
     elapsed = job.timed(step, args.steps, args.warmup)
     torch.cuda.synchronize(dev)
@@ -364,11 +402,13 @@ def run_adaptive(args, job):
     Wh = W.cpu().numpy()
     ref = np.column_stack([O.cdist_rows(X[idx].cpu().numpy(), y.cpu().numpy(), 'euclidean', w=Wh[kk]) for kk in range(K)])
     assert np.array_equal(out_t[idx].cpu().numpy(), ref), "adaptive bench output differs from the oracle"
-    bsel = (args.warmup + args.steps - 1) & 1       # the selection of the last timed step
+    bsel = (args.warmup + args.steps - 1) & 1       # the state after the last timed step
+    job.check(lib.elfihip_reject_flush(rstate))
+    torch.cuda.synchronize(dev)
     bv = job.best[bsel][:k].cpu().numpy()
-    bi = job.best[bsel][K_BEST:K_BEST + k].view(torch.int64).cpu().numpy()
+    bi = job.best[bsel][k:2 * k].view(torch.int64).cpu().numpy() - rank * n
     dl = outs[bsel][:, K - 1].cpu().numpy()
-    assert np.array_equal(np.sort(bv), np.sort(dl)[:k]) and np.array_equal(dl[bi], bv), "top-k differs from numpy"
+    assert np.array_equal(bv, np.sort(dl)[:k]) and np.array_equal(dl[bi], bv), "running best-k differs from numpy"
     sh = states.cpu().numpy()
     N_, mean_, M2_ = sharding.merge_welford([(v[0], v[1:1 + m], v[1 + m:]) for v in sh])
     assert N_ == world * n and np.array_equal(Wh[1], 1.0 / (M2_ / N_)), "device merge differs from the host merge"
@@ -383,7 +423,7 @@ def run_adaptive(args, job):
                                   "in total" if scaling == "strong" else "per GPU", K),
                    "samples_per_gpu": n, "summaries": m, "K": K,
                    "step": "Welford statistics of the shard + merge of the rank states on the device + K nested "
-                           "distances of every row + device top-%d by the last column" % k,
+                           "distances of every row with the top-%d by the last column fused in" % k,
                    "exchange": ("every step: all_gather of %d doubles per rank + gather of the packed top-%d pairs "
                                 "(16 KB per rank) to rank 0" % (ns, k)) if world > 1 else "none (N = 1)"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -19,7 +19,7 @@ from .distance import (AdaptiveDistanceState, HipDiscrepancy, HipDistance, cdist
 from .gmix import GMDistribution  # noqa: F401
 from .weighted import weighted_sample_quantile, weighted_var  # noqa: F401
 from .gp import GPHandle, HipGPRegression  # noqa: F401
-from .selection import merge_batch, smallest_k  # noqa: F401
+from .selection import RunningBest, merge_batch, smallest_k  # noqa: F401
 from .summaries import autocov, ma2_distance, ss_mean, ss_var  # noqa: F401
 from .lcb_acquisition import HipLCBSC  # noqa: F401
 from .posterior import HipBolfiPosterior, sample_posterior  # noqa: F401

@@ -67,6 +67,20 @@ PROTOTYPES = {
                                         C.c_void_p]),
     "elfihip_topk_smallest_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p,
                                             C.c_void_p]),
+    "elfihip_reject_create": (C.c_int, [C.c_void_p, C.c_int64, c_void_pp]),
+    "elfihip_reject_free": (C.c_int, [C.c_void_p]),
+    "elfihip_reject_reset": (C.c_int, [C.c_void_p]),
+    "elfihip_reject_push_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_void_p,
+                                          C.c_void_p, C.c_double, C.c_void_p, C.c_int64]),
+    "elfihip_reject_push_rows_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_void_p,
+                                              C.c_void_p, C.c_double, C.c_void_p, C.c_int64]),
+    "elfihip_reject_push_multiw_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_void_p,
+                                                C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
+    "elfihip_reject_push_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64]),
+    "elfihip_reject_state_dev": (C.c_int, [C.c_void_p, c_void_pp, c_void_pp]),
+    "elfihip_reject_export_dev": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "elfihip_reject_flush": (C.c_int, [C.c_void_p]),
+    "elfihip_reject_result": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "elfihip_gm_pdf": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_void_p,
                                  C.c_void_p, C.c_double, C.c_void_p]),
     "elfihip_weighted_var": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),

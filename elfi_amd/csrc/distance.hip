@@ -21,6 +21,7 @@
 // reference's separate multiply and add.
 #include "common.hpp"
 #include "tile_stream.hpp"
+#include "internal.hpp"
 
 #pragma clang fp contract(off)
 
@@ -97,6 +98,7 @@ __global__ __launch_bounds__(256) void dist_rows_pipe_kernel(RowArgs A) {
     if constexpr (W) as[j] = A.aux[j];
   }
   const int64_t ntiles = (A.n + R - 1) / R;
+  const double thr = A.F.thr ? *A.F.thr : 0.0;   // fused selection: the sampler state's current k-th best distance
   double2 v[U];
   int64_t t = blockIdx.x;
   if (t < ntiles) tile_fetch<U>(A, t * R, (int)((A.n - t * R) < R ? (A.n - t * R) : R), v);
@@ -108,13 +110,16 @@ __global__ __launch_bounds__(256) void dist_rows_pipe_kernel(RowArgs A) {
     const int64_t tn = t + gridDim.x;
     if (tn < ntiles) tile_fetch<U>(A, tn * R, (int)((A.n - tn * R) < R ? (A.n - tn * R) : R), v);
     __syncthreads();
+    double dist = 0.0;
     if (tid < rows) {
       const double* row = tile + (size_t)tid * A.mp;
       double s = Op<METRIC, W>::init();
 #pragma unroll 8
       for (int j = 0; j < m; ++j) s = Op<METRIC, W>::step(s, row[j], ys[j], W ? as[j] : 1.0, A.p);
-      A.out[row0 + tid] = Op<METRIC, W>::finish(s, A.inv_p);
+      dist = Op<METRIC, W>::finish(s, A.inv_p);
+      A.out[row0 + tid] = dist;
     }
+    if (A.F.thr) reject_offer(A.F, tid < rows && dist < thr, dist, A.F.row_base + row0 + tid);
   }
 }
 
@@ -130,6 +135,7 @@ __global__ __launch_bounds__(256) void dist_multiw_pipe_kernel(RowArgs A) {
   for (int j = tid; j < m; j += T) ys[j] = A.y[j];
   for (int j = tid; j < K * m; j += T) ws[j] = A.aux[j];
   const int64_t ntiles = (A.n + R - 1) / R;
+  const double thr = A.F.thr ? *A.F.thr : 0.0;   // fused selection, by the LAST nested distance (samplers.py:233)
   double2 v[U];
   int64_t t = blockIdx.x;
   if (t < ntiles) tile_fetch<U>(A, t * R, (int)((A.n - t * R) < R ? (A.n - t * R) : R), v);
@@ -141,6 +147,7 @@ __global__ __launch_bounds__(256) void dist_multiw_pipe_kernel(RowArgs A) {
     const int64_t tn = t + gridDim.x;
     if (tn < ntiles) tile_fetch<U>(A, tn * R, (int)((A.n - tn * R) < R ? (A.n - tn * R) : R), v);
     __syncthreads();
+    double dlast = 0.0;
     if (tid < rows) {
       const double* row = tile + (size_t)tid * A.mp;
       // four weight vectors per sweep over the row: (x-y)^2 is formed once per element and feeds four
@@ -162,12 +169,15 @@ __global__ __launch_bounds__(256) void dist_multiw_pipe_kernel(RowArgs A) {
           s3 = s3 + w3[j] * d2;
         }
         double* o = A.out + (row0 + tid) * K + k0;
-        o[0] = sqrt(s0);
-        if (kn > 1) o[1] = sqrt(s1);
-        if (kn > 2) o[2] = sqrt(s2);
-        if (kn > 3) o[3] = sqrt(s3);
+        const double r0 = sqrt(s0), r1 = sqrt(s1), r2 = sqrt(s2), r3 = sqrt(s3);
+        o[0] = r0;
+        if (kn > 1) o[1] = r1;
+        if (kn > 2) o[2] = r2;
+        if (kn > 3) o[3] = r3;
+        dlast = kn > 3 ? r3 : (kn > 2 ? r2 : (kn > 1 ? r1 : r0));
       }
     }
+    if (A.F.thr) reject_offer(A.F, tid < rows && dlast < thr, dlast, A.F.row_base + row0 + tid);
   }
 }
 
@@ -413,7 +423,7 @@ static int pipe_unroll(int m, bool light) {
 }
 
 template <int METRIC, bool W>
-static int launch_rows(elfihip_ctx* ctx, RowArgs A) {
+static int launch_rows(elfihip_ctx* ctx, RowArgs A, bool* filtered) {
   if (A.m > kMaxTileM) {
     int64_t rows_per_block = 4;
     int64_t g = (A.n + rows_per_block - 1) / rows_per_block;
@@ -443,6 +453,7 @@ static int launch_rows(elfihip_ctx* ctx, RowArgs A) {
       hipLaunchKernelGGL((dist_rows_pipe_kernel<METRIC, W, 8>), dim3(gp), dim3(Tp), ldsp, ctx->stream, A);
     else
       hipLaunchKernelGGL((dist_rows_pipe_kernel<METRIC, W, 16>), dim3(gp), dim3(Tp), ldsp, ctx->stream, A);
+    if (filtered) *filtered = A.F.thr != nullptr;   // the pipelined form offers its candidates itself
     return launch_status(ctx, "dist_rows_pipe_kernel");
   }
   if (T == 64) {
@@ -518,13 +529,17 @@ static RowArgs make_row_args(const double* dX, int64_t n, int m, int64_t ldx, co
   A.K = 0;
   A.R = 0;
   A.nt = 0;
+  A.F = RejectFilter{nullptr, nullptr, nullptr, nullptr, 0u, 0ll};
   A.vec2 = (m % 2 == 0) && (ldx % 2 == 0) && aligned16(dX);
   A.div_h = make_fastdiv((uint32_t)(A.vec2 ? m / 2 : m));
   return A;
 }
 
-static int dist_rows_dev_impl(elfihip_ctx* ctx, int metric, const double* dX, int64_t n, int m,
-                              int64_t ldx, const double* dy, const double* daux, double p, double* dout) {
+// F / filtered: fused selection (reject.hip).  *filtered tells the caller whether the kernel that ran offered the
+// candidates itself; otherwise the caller filters dout in a separate pass.
+int dist_rows_dev_impl(elfihip_ctx* ctx, int metric, const double* dX, int64_t n, int m, int64_t ldx, const double* dy,
+                       const double* daux, double p, double* dout, const RejectFilter* F, bool* filtered) {
+  if (filtered) *filtered = false;
   ELFIHIP_REQUIRE(ctx, n >= 0 && m >= 1, "bad shape n=%lld m=%d", (long long)n, m);
   ELFIHIP_REQUIRE(ctx, ldx >= m, "ldx (%lld) < m (%d)", (long long)ldx, m);
   ELFIHIP_REQUIRE(ctx, n == 0 || (dX && dy && dout), "NULL data pointer");
@@ -532,6 +547,7 @@ static int dist_rows_dev_impl(elfihip_ctx* ctx, int metric, const double* dX, in
   ELFIHIP_TRY(canonical_metric(ctx, metric, p, daux, &cm));
   if (n == 0) return ELFIHIP_OK;
   RowArgs A = make_row_args(dX, n, m, ldx, dy, daux, p, dout);
+  if (F) A.F = *F;
   const bool w = daux != nullptr;
   if (cm == ELFIHIP_MAHALANOBIS) {
     ELFIHIP_REQUIRE(ctx, m <= kMaxTileM, "mahalanobis supports m <= %d", kMaxTileM);
@@ -544,7 +560,7 @@ static int dist_rows_dev_impl(elfihip_ctx* ctx, int metric, const double* dX, in
   }
 #define ELFIHIP_DISPATCH_ROWS(M)                                                  \
   case M:                                                                         \
-    return w ? launch_rows<M, true>(ctx, A) : launch_rows<M, false>(ctx, A);
+    return w ? launch_rows<M, true>(ctx, A, filtered) : launch_rows<M, false>(ctx, A, filtered);
   switch (cm) {
     ELFIHIP_DISPATCH_ROWS(ELFIHIP_EUCLIDEAN)
     ELFIHIP_DISPATCH_ROWS(ELFIHIP_SQEUCLIDEAN)
@@ -552,7 +568,7 @@ static int dist_rows_dev_impl(elfihip_ctx* ctx, int metric, const double* dX, in
     ELFIHIP_DISPATCH_ROWS(ELFIHIP_CHEBYSHEV)
     ELFIHIP_DISPATCH_ROWS(ELFIHIP_MINKOWSKI)
     case ELFIHIP_SEUCLIDEAN:
-      return launch_rows<ELFIHIP_SEUCLIDEAN, true>(ctx, A);
+      return launch_rows<ELFIHIP_SEUCLIDEAN, true>(ctx, A, filtered);
   }
 #undef ELFIHIP_DISPATCH_ROWS
   return fail(ctx, ELFIHIP_ERR_ARG, "unhandled metric %d", cm);
@@ -595,8 +611,9 @@ static int dist_cols_dev_impl(elfihip_ctx* ctx, int metric, const double* dC, in
   return fail(ctx, ELFIHIP_ERR_ARG, "unhandled metric %d", cm);
 }
 
-static int dist_multiw_dev_impl(elfihip_ctx* ctx, const double* dX, int64_t n, int m, int64_t ldx,
-                                const double* dy, const double* dW, int K, double* dout) {
+int dist_multiw_dev_impl(elfihip_ctx* ctx, const double* dX, int64_t n, int m, int64_t ldx, const double* dy,
+                         const double* dW, int K, double* dout, const RejectFilter* F, bool* filtered) {
+  if (filtered) *filtered = false;
   ELFIHIP_REQUIRE(ctx, n >= 0 && m >= 1, "bad shape n=%lld m=%d", (long long)n, m);
   ELFIHIP_REQUIRE(ctx, K >= 1 && K <= kMaxK, "K=%d outside [1,%d]", K, kMaxK);
   ELFIHIP_REQUIRE(ctx, ldx >= m, "ldx (%lld) < m (%d)", (long long)ldx, m);
@@ -604,6 +621,7 @@ static int dist_multiw_dev_impl(elfihip_ctx* ctx, const double* dX, int64_t n, i
   if (n == 0) return ELFIHIP_OK;
   RowArgs A = make_row_args(dX, n, m, ldx, dy, dW, 2.0, dout);
   A.K = K;
+  if (F) A.F = *F;
   size_t lds;
   int T = pick_block(m, (size_t)m + (size_t)K * m, &lds);
   ELFIHIP_REQUIRE(ctx, lds <= 160 * 1024, "m=%d with K=%d weight vectors does not fit LDS", m, K);
@@ -617,6 +635,7 @@ static int dist_multiw_dev_impl(elfihip_ctx* ctx, const double* dX, int64_t n, i
     if (ldsp <= 64 * 1024) {
       const int gp = grid_for(ctx, (n + R - 1) / R, ldsp, Tp);
       hipLaunchKernelGGL((dist_multiw_pipe_kernel<16>), dim3(gp), dim3(Tp), ldsp, ctx->stream, A);
+      if (filtered) *filtered = A.F.thr != nullptr;
       return launch_status(ctx, "dist_multiw_pipe_kernel");
     }
   }
@@ -639,7 +658,7 @@ int elfihip_dist_rows_dev(elfihip_ctx* ctx, int metric, const double* dX, int64_
                           const double* dy, const double* daux, double p, double* dout) {
   if (!ctx) return fail(nullptr, ELFIHIP_ERR_ARG, "ctx is NULL");
   DeviceGuard g(ctx->device);
-  return dist_rows_dev_impl(ctx, metric, dX, n, m, ldx, dy, daux, p, dout);
+  return dist_rows_dev_impl(ctx, metric, dX, n, m, ldx, dy, daux, p, dout, nullptr, nullptr);
 }
 
 int elfihip_dist_cols_dev(elfihip_ctx* ctx, int metric, const double* dC, int64_t n, int m, int64_t ldc,
@@ -653,7 +672,7 @@ int elfihip_dist_multiw_dev(elfihip_ctx* ctx, const double* dX, int64_t n, int m
                             const double* dy, const double* dW, int K, double* dout) {
   if (!ctx) return fail(nullptr, ELFIHIP_ERR_ARG, "ctx is NULL");
   DeviceGuard g(ctx->device);
-  return dist_multiw_dev_impl(ctx, dX, n, m, ldx, dy, dW, K, dout);
+  return dist_multiw_dev_impl(ctx, dX, n, m, ldx, dy, dW, K, dout, nullptr, nullptr);
 }
 
 // ---- host-pointer entry points: stage, launch, copy back, synchronise ---------------
@@ -694,7 +713,28 @@ int elfihip_dist_rows(elfihip_ctx* ctx, int metric, const double* X, int64_t n, 
   ELFIHIP_TRY(stage_params(ctx, y, aux, m, aux ? aux_len(metric, m) : 0, &dy, &daux));
   ELFIHIP_TRY(stage_rows(ctx, X, n, m, ldx, &dX));
   ELFIHIP_CHECK_HIP(ctx, ctx->out.reserve((size_t)(n ? n : 1) * sizeof(double)));
-  ELFIHIP_TRY(dist_rows_dev_impl(ctx, metric, dX, n, m, m, dy, daux, p, ctx->out.as<double>()));
+  ELFIHIP_TRY(dist_rows_dev_impl(ctx, metric, dX, n, m, m, dy, daux, p, ctx->out.as<double>(), nullptr, nullptr));
+  if (n)
+    ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(out, ctx->out.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ELFIHIP_OK;
+}
+
+// Host-pointer form of the fused distance + selection step (reject.hip): one ABC batch in, its distances out, the
+// sampler state updated on the way.
+int elfihip_reject_push_rows(elfihip_reject* h, int metric, const double* X, int64_t n, int m, int64_t ldx,
+                             const double* y, const double* aux, double p, double* out, int64_t row_base) {
+  if (!h) return fail(nullptr, ELFIHIP_ERR_ARG, "state is NULL");
+  elfihip_ctx* ctx = reject_ctx(h);
+  ELFIHIP_REQUIRE(ctx, n >= 0 && m >= 1 && ldx >= m, "bad shape n=%lld m=%d ldx=%lld", (long long)n, m,
+                  (long long)ldx);
+  ELFIHIP_REQUIRE(ctx, y && (n == 0 || (X && out)), "NULL data pointer");
+  DeviceGuard g(ctx->device);
+  double *dX, *dy, *daux;
+  ELFIHIP_TRY(stage_params(ctx, y, aux, m, aux ? aux_len(metric, m) : 0, &dy, &daux));
+  ELFIHIP_TRY(stage_rows(ctx, X, n, m, ldx, &dX));
+  ELFIHIP_CHECK_HIP(ctx, ctx->out.reserve((size_t)(n ? n : 1) * sizeof(double)));
+  ELFIHIP_TRY(reject_push_rows_impl(h, metric, dX, n, m, m, dy, daux, p, ctx->out.as<double>(), row_base));
   if (n)
     ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(out, ctx->out.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -738,7 +778,7 @@ int elfihip_dist_multiw(elfihip_ctx* ctx, const double* X, int64_t n, int m, int
   ELFIHIP_TRY(stage_params(ctx, y, W, m, (size_t)K * m, &dy, &dW));
   ELFIHIP_TRY(stage_rows(ctx, X, n, m, ldx, &dX));
   ELFIHIP_CHECK_HIP(ctx, ctx->out.reserve((size_t)(n ? n : 1) * K * sizeof(double)));
-  ELFIHIP_TRY(dist_multiw_dev_impl(ctx, dX, n, m, m, dy, dW, K, ctx->out.as<double>()));
+  ELFIHIP_TRY(dist_multiw_dev_impl(ctx, dX, n, m, m, dy, dW, K, ctx->out.as<double>(), nullptr, nullptr));
   if (n)
     ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(out, ctx->out.p, (size_t)n * K * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));

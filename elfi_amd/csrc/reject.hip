@@ -1,0 +1,394 @@
+// The rejection sampler's running best-k on the GPU, fused with the distance pass.
+//
+// Replaces Rejection._merge_batch (elfi/methods/inference/samplers.py:209-237): the reference copies every batch
+// behind its n_samples best rows and argsorts n_samples + batch_size distances on the host, batch after batch.  What
+// that merge keeps is the n_samples smallest distances seen so far.  Here that state lives in device memory -- k
+// (distance, row) pairs, ascending, ties to the earlier row -- and a batch is folded in by ONE distance pass:
+//   * once the state holds k finite distances its k-th is a threshold, and the distance kernel itself appends the rows
+//     below it to a candidate list (RejectFilter, distance.hip: one wave-aggregated atomic per wave that has a hit --
+//     after j batches of the same distribution about k / j rows per batch qualify);
+//   * a single-workgroup kernel merges state and candidates by ranks and keeps the first k -- not after every batch
+//     but, once the threshold has settled, after every REJ_MERGE_EVERY-th (the list simply keeps growing in between, against a threshold that is then a
+//     few batches old: still an upper bound of the current k-th distance, so nothing is missed), because a 15 us
+//     one-workgroup launch between two 48 us distance passes is a third of their time, and running it on a second
+//     stream costs a 10 us event hand-over per batch on this stack (both measured); result / reset / state_dev /
+//     flush merge what is pending first;
+//   * only while the state is still filling up (the first batch) the batch goes through the radix selection of topk.hip.
+// Only the k best rows ever leave the GPU; row numbers are global (row_base + row in the batch), so the host fetches the
+// parameters / summaries of the accepted rows from its own batch store (as ELFI's OutputPool keeps them).
+#include "internal.hpp"
+
+#include <cmath>
+#include <limits>
+
+struct elfihip_reject {
+  elfihip_ctx* ctx = nullptr;
+  int64_t k = 0;
+  int64_t filled = 0;        // rows offered so far, capped at k: the filter is armed once this reaches k
+  elfihip::DevBuf mem;       // everything below lives here
+  double* best_val = nullptr;      // (k) ascending
+  long long* best_row = nullptr;   // (k)
+  double* thr = nullptr;           // device scalar: best_val[k-1]
+  double* cand_val = nullptr;      // (cap) candidates offered since the last merge
+  long long* cand_row = nullptr;   // (cap)
+  unsigned int* count = nullptr;   // how many
+  unsigned int* status = nullptr;  // bit 0: more candidates were offered than the list holds
+  unsigned int cap = 0;
+  int unmerged = 0;                // pushes since the last merge
+  int64_t armed_pushes = 0;        // pushes since the state became full (sets the merge interval)
+  void* export_dst = nullptr;      // optional: every merge also leaves the packed state (k values, k rows) here
+};
+
+namespace elfihip {
+
+constexpr int64_t REJ_MAX_K = 2048;       // state entries (LDS-resident during a merge)
+constexpr int REJ_CHUNK = 1024;           // candidates merged per round
+constexpr int REJ_MERGE_EVERY = 8;        // pushes per merge
+constexpr unsigned int REJ_CAP = 1u << 16;
+
+__device__ __forceinline__ bool rej_less(double av, long long ar, double bv, long long br) {
+  return av < bv || (av == bv && ar < br);
+}
+
+// state <- the k smallest of state U candidates.  ncand < 0: read the count from S.count (and clear it); row_offset is
+// added to the candidates' row numbers (the radix selection of the first batch reports batch-local rows).
+struct RejArgs {
+  double* best_val;
+  long long* best_row;
+  double* thr;
+  const double* cand_val;
+  const long long* cand_row;
+  unsigned int* count;
+  unsigned int* status;
+  unsigned int cap;
+  int k;
+  int ncand;
+  long long row_offset;
+  double* export_val;   // packed copy of the new state for the caller (may be NULL)
+};
+
+__global__ __launch_bounds__(1024) void reject_merge_kernel(RejArgs S) {
+  // Merge by ranks, REJ_CHUNK candidates at a time: an element's place in the merged order is the number of elements
+  // before it -- for a state entry its index plus the candidates below it, for a candidate the state entries below it
+  // (binary search: the state is sorted) plus the candidates below it (a scan: a chunk is small).  Row numbers are
+  // unique, so (distance, row) is a strict order and every place is taken once.  Three barriers per chunk instead of
+  // the seventy-eight of a 4096-pair bitonic sort (measured: 50 us per merge that way).
+  __shared__ double bv[REJ_MAX_K];
+  __shared__ long long br[REJ_MAX_K];
+  __shared__ double cv[REJ_CHUNK];
+  __shared__ long long cr[REJ_CHUNK];
+  const int t = threadIdx.x, k = S.k;
+  unsigned int c = S.ncand >= 0 ? (unsigned int)S.ncand : *S.count;
+  if (c > S.cap) {
+    if (t == 0) atomicOr(S.status, 1u);   // the list is incomplete: the state can no longer be trusted (reported by result)
+    c = S.cap;
+  }
+  for (int e = t; e < k; e += 1024) {
+    bv[e] = S.best_val[e];
+    br[e] = S.best_row[e];
+  }
+  for (unsigned int c0 = 0; c0 < c; c0 += REJ_CHUNK) {
+    const int nc = (int)min((unsigned int)REJ_CHUNK, c - c0);
+    if (t < nc) {
+      cv[t] = S.cand_val[c0 + t];
+      cr[t] = S.cand_row[c0 + t] + S.row_offset;
+    }
+    __syncthreads();
+    double xv[3];
+    long long xr[3];
+    int pos[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int e = t + 1024 * u;
+      pos[u] = k;  // "no place"
+      xv[u] = 0.0;
+      xr[u] = 0;
+      if (e < k + nc) {
+        const bool is_state = e < k;
+        xv[u] = is_state ? bv[e] : cv[e - k];
+        xr[u] = is_state ? br[e] : cr[e - k];
+        int below = 0;
+        for (int j2 = 0; j2 < nc; ++j2) below += rej_less(cv[j2], cr[j2], xv[u], xr[u]) ? 1 : 0;
+        if (is_state) {
+          pos[u] = e + below;
+        } else {
+          int lo = 0, hi = k;   // first state entry that is not below x
+          while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (rej_less(bv[mid], br[mid], xv[u], xr[u]))
+              lo = mid + 1;
+            else
+              hi = mid;
+          }
+          pos[u] = lo + below;
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+      if (pos[u] < k) {
+        bv[pos[u]] = xv[u];
+        br[pos[u]] = xr[u];
+      }
+    __syncthreads();
+  }
+  long long* export_row = reinterpret_cast<long long*>(S.export_val + k);
+  for (int e = t; e < k; e += 1024) {
+    S.best_val[e] = bv[e];
+    S.best_row[e] = br[e];
+    if (S.export_val) {
+      S.export_val[e] = bv[e];
+      export_row[e] = br[e];
+    }
+  }
+  if (t == 0) {
+    *S.thr = bv[k - 1];
+    if (S.ncand < 0) *S.count = 0u;
+  }
+}
+
+// The candidate pass for distance kernels without the fused filter: d (n, stride apart) against the threshold.
+__global__ __launch_bounds__(256) void reject_filter_kernel(const double* d, int64_t n, int64_t stride, RejectFilter F) {
+  const double thr = *F.thr;
+  const int64_t nround = (n + (int64_t)gridDim.x * 256 - 1) / ((int64_t)gridDim.x * 256);
+  for (int64_t r = 0; r < nround; ++r) {
+    const int64_t i = (r * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
+    const double v = i < n ? d[i * stride] : 0.0;
+    reject_offer(F, i < n && v < thr, v, F.row_base + i);
+  }
+}
+
+__global__ void reject_init_kernel(double* best_val, long long* best_row, double* thr, unsigned int* count,
+                                   unsigned int* status, int k) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const double inf = __longlong_as_double(0x7ff0000000000000ll);
+  if (e < k) {
+    best_val[e] = inf;
+    best_row[e] = 0x7fffffffffffffffll;
+  }
+  if (e == 0) {
+    *thr = inf;
+    *count = 0u;
+    *status = 0u;
+  }
+}
+
+static RejArgs merge_args(elfihip_reject* h, int ncand, long long row_offset) {
+  RejArgs S;
+  S.best_val = h->best_val;
+  S.best_row = h->best_row;
+  S.thr = h->thr;
+  S.cand_val = h->cand_val;
+  S.cand_row = h->cand_row;
+  S.count = h->count;
+  S.status = h->status;
+  S.cap = h->cap;
+  S.k = (int)h->k;
+  S.ncand = ncand;
+  S.row_offset = row_offset;
+  S.export_val = reinterpret_cast<double*>(h->export_dst);
+  return S;
+}
+
+// merge whatever the list holds (asynchronous, context's stream)
+static int reject_flush(elfihip_reject* h) {
+  if (h->unmerged == 0) return ELFIHIP_OK;
+  hipLaunchKernelGGL(reject_merge_kernel, dim3(1), dim3(1024), 0, h->ctx->stream, merge_args(h, -1, 0));
+  h->unmerged = 0;
+  return launch_status(h->ctx, "reject_merge_kernel");
+}
+
+static int reject_reset_impl(elfihip_reject* h) {
+  hipLaunchKernelGGL(reject_init_kernel, dim3((unsigned)((h->k + 255) / 256)), dim3(256), 0, h->ctx->stream, h->best_val,
+                     h->best_row, h->thr, h->count, h->status, (int)h->k);
+  h->filled = 0;
+  h->unmerged = 0;
+  h->armed_pushes = 0;
+  return launch_status(h->ctx, "reject_init_kernel");
+}
+
+// Fold a batch into the state.  run(F, &filtered) launches the distance pass with the filter F (or without: F == nullptr)
+// on the context's stream; dsel / stride address the batch's ranking distances for the passes that need them.
+template <class Run>
+static int reject_push(elfihip_reject* h, int64_t n, const double* dsel, int64_t stride, long long row_base, Run run) {
+  elfihip_ctx* ctx = h->ctx;
+  hipStream_t st = ctx->stream;
+  if (h->filled < h->k) {
+    // state still filling up: every row could enter.  Plain distance pass, radix selection of the batch's k best
+    // (batch-local rows), merge.
+    bool dummy = false;
+    ELFIHIP_TRY(run(nullptr, &dummy));
+    const int64_t kb = n < h->k ? n : h->k;
+    if (kb > 0) {
+      ELFIHIP_TRY(topk_dev_impl(ctx, dsel, n, stride, kb, h->cand_val, reinterpret_cast<int64_t*>(h->cand_row), true));
+      hipLaunchKernelGGL(reject_merge_kernel, dim3(1), dim3(1024), 0, st, merge_args(h, (int)kb, row_base));
+    }
+    h->filled = h->filled + n < h->k ? h->filled + n : h->k;
+    return launch_status(ctx, "reject_merge_kernel");
+  }
+  RejectFilter F;
+  F.thr = h->thr;
+  F.cval = h->cand_val;
+  F.crow = h->cand_row;
+  F.count = h->count;
+  F.cap = h->cap;
+  F.row_base = row_base;
+  bool filtered = false;
+  ELFIHIP_TRY(run(&F, &filtered));
+  if (!filtered && n > 0) {
+    int g = (int)((n + 255) / 256);
+    if (g > ctx->cu_count * 8) g = ctx->cu_count * 8;
+    hipLaunchKernelGGL(reject_filter_kernel, dim3(g), dim3(256), 0, st, dsel, n, stride, F);
+  }
+  // Merge interval: the p-th push after the state became full offers about k / p candidates (batches of one
+  // distribution), so merging every p / 2 pushes -- at most every REJ_MERGE_EVERY-th -- keeps a merge at about k / 2
+  // candidates: early on, while the threshold still falls quickly, after every push.
+  ++h->armed_pushes;
+  int64_t interval = h->armed_pushes / 2;
+  interval = interval < 1 ? 1 : (interval > REJ_MERGE_EVERY ? REJ_MERGE_EVERY : interval);
+  if (++h->unmerged >= interval) return reject_flush(h);
+  return launch_status(ctx, "distance pass with selection");
+}
+
+elfihip_ctx* reject_ctx(elfihip_reject* h) { return h->ctx; }
+
+int reject_push_rows_impl(elfihip_reject* h, int metric, const double* dX, int64_t n, int m, int64_t ldx,
+                          const double* dy, const double* daux, double p, double* dout, int64_t row_base) {
+  elfihip_ctx* ctx = h->ctx;
+  return reject_push(h, n, dout, 1, (long long)row_base, [&](const RejectFilter* F, bool* filtered) {
+    return dist_rows_dev_impl(ctx, metric, dX, n, m, ldx, dy, daux, p, dout, F, filtered);
+  });
+}
+
+}  // namespace elfihip
+
+using namespace elfihip;
+
+extern "C" {
+
+int elfihip_reject_free(elfihip_reject* h) {
+  if (!h) return ELFIHIP_OK;
+  DeviceGuard g(h->ctx->device);
+  (void)hipStreamSynchronize(h->ctx->stream);
+  h->mem.release();
+  delete h;
+  return ELFIHIP_OK;
+}
+
+int elfihip_reject_create(elfihip_ctx* ctx, int64_t k, elfihip_reject** out) {
+  if (!ctx || !out) return fail(ctx, ELFIHIP_ERR_ARG, "NULL argument");
+  *out = nullptr;
+  ELFIHIP_REQUIRE(ctx, k >= 1 && k <= REJ_MAX_K, "k = %lld outside [1, %lld] (larger sample sets: elfihip_topk_smallest "
+                  "per batch and a host merge)", (long long)k, (long long)REJ_MAX_K);
+  DeviceGuard g(ctx->device);
+  elfihip_reject* h = new elfihip_reject();
+  h->ctx = ctx;
+  h->k = k;
+  h->cap = REJ_CAP;
+  const size_t bytes = (size_t)k * 16 + 64 + (size_t)h->cap * 16;
+  hipError_t e = h->mem.reserve(bytes);
+  if (e != hipSuccess) {
+    delete h;
+    return fail(ctx, ELFIHIP_ERR_NOMEM, "sampler state allocation failed: %s", hipGetErrorString(e));
+  }
+  char* p = reinterpret_cast<char*>(h->mem.p);
+  h->best_val = reinterpret_cast<double*>(p);
+  p += (size_t)k * 8;
+  h->best_row = reinterpret_cast<long long*>(p);
+  p += (size_t)k * 8;
+  h->thr = reinterpret_cast<double*>(p);
+  h->count = reinterpret_cast<unsigned int*>(p + 8);
+  h->status = reinterpret_cast<unsigned int*>(p + 12);
+  p += 64;
+  h->cand_val = reinterpret_cast<double*>(p);
+  p += (size_t)h->cap * 8;
+  h->cand_row = reinterpret_cast<long long*>(p);
+  int rc = reject_reset_impl(h);
+  if (rc != ELFIHIP_OK) {
+    elfihip_reject_free(h);
+    return rc;
+  }
+  *out = h;
+  return ELFIHIP_OK;
+}
+
+int elfihip_reject_reset(elfihip_reject* h) {
+  if (!h) return fail(nullptr, ELFIHIP_ERR_ARG, "state is NULL");
+  DeviceGuard g(h->ctx->device);
+  return reject_reset_impl(h);
+}
+
+int elfihip_reject_flush(elfihip_reject* h) {
+  if (!h) return fail(nullptr, ELFIHIP_ERR_ARG, "state is NULL");
+  DeviceGuard g(h->ctx->device);
+  return reject_flush(h);
+}
+
+int elfihip_reject_push_rows_dev(elfihip_reject* h, int metric, const double* dX, int64_t n, int m, int64_t ldx,
+                                 const double* dy, const double* daux, double p, double* dout, int64_t row_base) {
+  if (!h) return fail(nullptr, ELFIHIP_ERR_ARG, "state is NULL");
+  elfihip_ctx* ctx = h->ctx;
+  ELFIHIP_REQUIRE(ctx, n >= 0 && (n == 0 || dout), "the batch's distances need a destination (dout)");
+  DeviceGuard g(ctx->device);
+  return reject_push_rows_impl(h, metric, dX, n, m, ldx, dy, daux, p, dout, row_base);
+}
+
+int elfihip_reject_push_multiw_dev(elfihip_reject* h, const double* dX, int64_t n, int m, int64_t ldx, const double* dy,
+                                   const double* dW, int K, double* dout, int64_t row_base) {
+  if (!h) return fail(nullptr, ELFIHIP_ERR_ARG, "state is NULL");
+  elfihip_ctx* ctx = h->ctx;
+  ELFIHIP_REQUIRE(ctx, n >= 0 && K >= 1 && (n == 0 || dout), "the batch's distances need a destination (dout)");
+  DeviceGuard g(ctx->device);
+  // nested distances are ranked by their LAST column (samplers.py:233)
+  return reject_push(h, n, dout ? dout + (K - 1) : nullptr, K, (long long)row_base,
+                     [&](const RejectFilter* F, bool* filtered) {
+                       return dist_multiw_dev_impl(ctx, dX, n, m, ldx, dy, dW, K, dout, F, filtered);
+                     });
+}
+
+int elfihip_reject_push_dev(elfihip_reject* h, const double* dD, int64_t n, int64_t stride, int64_t row_base) {
+  if (!h) return fail(nullptr, ELFIHIP_ERR_ARG, "state is NULL");
+  elfihip_ctx* ctx = h->ctx;
+  ELFIHIP_REQUIRE(ctx, n >= 0 && stride >= 1 && (n == 0 || dD), "bad arguments");
+  DeviceGuard g(ctx->device);
+  return reject_push(h, n, dD, stride, (long long)row_base, [&](const RejectFilter*, bool* filtered) {
+    *filtered = false;   // the distances exist already: candidates come from the separate pass
+    return ELFIHIP_OK;
+  });
+}
+
+int elfihip_reject_state_dev(elfihip_reject* h, double** dvals, int64_t** drows) {
+  if (!h) return fail(nullptr, ELFIHIP_ERR_ARG, "state is NULL");
+  DeviceGuard g(h->ctx->device);
+  ELFIHIP_TRY(reject_flush(h));   // work queued on the context's stream after this call sees every batch merged
+  if (dvals) *dvals = h->best_val;
+  if (drows) *drows = reinterpret_cast<int64_t*>(h->best_row);
+  return ELFIHIP_OK;
+}
+
+int elfihip_reject_export_dev(elfihip_reject* h, void* ddst) {
+  if (!h) return fail(nullptr, ELFIHIP_ERR_ARG, "state is NULL");
+  h->export_dst = ddst;   // from the next merge on; NULL stops it
+  return ELFIHIP_OK;
+}
+
+int elfihip_reject_result(elfihip_reject* h, double* vals, int64_t* rows, int64_t* count) {
+  if (!h) return fail(nullptr, ELFIHIP_ERR_ARG, "state is NULL");
+  elfihip_ctx* ctx = h->ctx;
+  ELFIHIP_REQUIRE(ctx, vals && rows, "NULL result pointer");
+  DeviceGuard g(ctx->device);
+  ELFIHIP_TRY(reject_flush(h));
+  unsigned int status = 0;
+  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(vals, h->best_val, (size_t)h->k * 8, hipMemcpyDeviceToHost, ctx->stream));
+  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(rows, h->best_row, (size_t)h->k * 8, hipMemcpyDeviceToHost, ctx->stream));
+  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(&status, h->status, sizeof status, hipMemcpyDeviceToHost, ctx->stream));
+  ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (status & 1u)
+    return fail(ctx, ELFIHIP_ERR_STATE, "more than %u candidates below the running threshold were offered between two "
+                "merges (batches that improve this much need elfihip_reject_reset between rounds)", h->cap);
+  if (count) *count = h->filled;
+  return ELFIHIP_OK;
+}
+
+}  // extern "C"

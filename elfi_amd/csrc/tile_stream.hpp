@@ -25,6 +25,37 @@ __device__ __forceinline__ uint32_t fastdiv(uint32_t x, FastDiv f) {
   return q;
 }
 
+// Fused selection (reject.hip): a distance kernel that is handed a filter also appends every row whose distance is
+// below the running threshold -- the current k-th best distance of the sampler state, what Rejection._merge_batch
+// (elfi/methods/inference/samplers.py:209-237) would keep of the batch -- to a candidate list, so that the selection
+// after the distance costs one small merge instead of passes over all n distances.  thr == nullptr: no filter.
+struct RejectFilter {
+  const double* thr;          // device scalar: rows with d < *thr are candidates
+  double* cval;               // candidate distances
+  long long* crow;            // candidate row numbers (row_base + row inside this batch)
+  unsigned int* count;        // candidates offered so far (may exceed cap: the list holds the first cap)
+  unsigned int cap;
+  long long row_base;
+};
+
+// Append (d, row) for the lanes with `hit`: one atomic per wave (ballot + prefix count), all lanes of the wave must call.
+__device__ __forceinline__ void reject_offer(const RejectFilter& F, bool hit, double d, long long row) {
+  const unsigned long long mask = __ballot(hit);
+  if (mask == 0) return;
+  const int lane = threadIdx.x & 63;
+  const int leader = __ffsll((long long)mask) - 1;
+  unsigned int base = 0;
+  if (lane == leader) base = atomicAdd(F.count, (unsigned int)__popcll(mask));
+  base = __shfl(base, leader, 64);
+  if (hit) {
+    const unsigned int idx = base + (unsigned int)__popcll(mask & ((1ull << lane) - 1ull));
+    if (idx < F.cap) {
+      F.cval[idx] = d;
+      F.crow[idx] = row;
+    }
+  }
+}
+
 struct RowArgs {
   const double* X;
   int64_t n;
@@ -39,6 +70,7 @@ struct RowArgs {
   int R;          // pipelined kernels: rows per tile (<= blockDim.x); T * U >= R * m / 2
   int nt;         // pipelined kernels: non-temporal loads
   FastDiv div_h;  // by m/2 (vec2) or m
+  RejectFilter F; // fused selection (thr == nullptr: off)
 };
 
 // Stream one tile of `rows` rows starting at row0 into LDS (pitch mp).

@@ -27,6 +27,7 @@
 #include <numeric>
 
 #include "common.hpp"
+#include "internal.hpp"
 
 namespace elfihip {
 
@@ -523,8 +524,8 @@ __global__ __launch_bounds__(SEL_NT) void sel_persistent_kernel(const double* d,
 }
 
 // force_multi: use the nine-launch form (the host entry point does when the resident form reports a timed-out barrier)
-static int topk_dev_impl(elfihip_ctx* ctx, const double* dD, int64_t n, int64_t stride, int64_t k, double* dvals,
-                         int64_t* didx, bool force_multi = false) {
+int topk_dev_impl(elfihip_ctx* ctx, const double* dD, int64_t n, int64_t stride, int64_t k, double* dvals,
+                  int64_t* didx, bool force_multi) {
   ELFIHIP_REQUIRE(ctx, n >= 0 && k >= 0 && stride >= 1, "bad arguments n=%lld k=%lld stride=%lld", (long long)n,
                   (long long)k, (long long)stride);
   if (k > n) k = n;
@@ -583,7 +584,7 @@ int elfihip_topk_smallest_dev(elfihip_ctx* ctx, const double* dD, int64_t n, int
                               int64_t* didx) {
   if (!ctx) return fail(nullptr, ELFIHIP_ERR_ARG, "ctx is NULL");
   DeviceGuard g(ctx->device);
-  return topk_dev_impl(ctx, dD, n, stride, k, dvals, didx);
+  return topk_dev_impl(ctx, dD, n, stride, k, dvals, didx, false);
 }
 
 int elfihip_topk_smallest(elfihip_ctx* ctx, const double* D, int64_t n, int64_t stride, int64_t k, double* vals,

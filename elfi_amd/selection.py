@@ -10,6 +10,8 @@ smallest so far, sorted), but only k rows of every batch array are touched on th
 Tie-breaking differs from the reference only where NumPy's default quicksort leaves the order
 unspecified (equal distances): here the lower row / the earlier batch wins.
 """
+import ctypes as C
+
 import numpy as np
 
 from . import _lib
@@ -68,3 +70,70 @@ def merge_batch(samples, batch, discrepancy_name, n_samples, threshold=None, ctx
         merged = np.concatenate([v, np.asarray(batch[name])[rows]], axis=0)
         out[name] = merged[order]
     return out
+
+
+class RunningBest:
+    """The sampler's running best-k on the GPU, updated by the distance pass itself (include/elfihip.h:
+    elfihip_reject_*; csrc/reject.hip).
+
+    What Rejection._merge_batch (samplers.py:209-237) maintains batch after batch -- the n_samples smallest distances
+    seen so far -- as device state: `push(X, y)` computes a batch's distances (returned, as the Distance node must
+    return them) and folds the batch in during the same pass; `result()` gives the k best (distance, row) pairs,
+    ascending, ties to the earlier row.  Row numbers are global (row_base + row inside the batch): the host looks the
+    accepted rows' parameters and summaries up in its own batch store.  k <= 2048."""
+
+    def __init__(self, k, metric='euclidean', w=None, p=2.0, ctx=None):
+        self.ctx = ctx or _lib.default_context()
+        self.lib = self.ctx.lib
+        self.k = int(k)
+        if metric not in _lib.METRICS:
+            raise ValueError('unknown metric %r' % (metric,))
+        self.metric = _lib.METRICS[metric]
+        self.aux = None if w is None else np.ascontiguousarray(w, dtype=np.float64)
+        self.p = float(p)
+        h = C.c_void_p()
+        self.ctx.call("elfihip_reject_create", self.k, C.byref(h))
+        self.h = h
+        self.n_pushed = 0
+
+    def close(self):
+        if getattr(self, 'h', None) is not None:
+            self.lib.elfihip_reject_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != _lib.OK:
+            _lib._raise(self.lib, self.ctx.handle, rc)
+
+    def reset(self):
+        self._check(self.lib.elfihip_reject_reset(self.h))
+        self.n_pushed = 0
+
+    def push(self, X, y, row_base=None):
+        """Distances of the rows of X (n, m) to y (1, m) -- returned, shape (n,) -- with the state updated on the way.
+        row_base: global number of the batch's first row (default: the rows pushed so far)."""
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        y = np.ascontiguousarray(y, dtype=np.float64).reshape(-1)
+        if X.ndim != 2 or X.shape[1] != y.shape[0]:
+            raise ValueError('X must be (n, m) and y (1, m)')
+        n, m = X.shape
+        out = np.empty(n, dtype=np.float64)
+        base = self.n_pushed if row_base is None else int(row_base)
+        self._check(self.lib.elfihip_reject_push_rows(self.h, self.metric, _lib.ptr(X), n, m, m, _lib.ptr(y),
+                                                      _lib.ptr(self.aux), self.p, _lib.ptr(out), base))
+        self.n_pushed += n
+        return out
+
+    def result(self):
+        """(distances, rows) of the best min(k, rows pushed) rows so far, ascending."""
+        vals = np.empty(self.k, dtype=np.float64)
+        rows = np.empty(self.k, dtype=np.int64)
+        cnt = C.c_int64()
+        self._check(self.lib.elfihip_reject_result(self.h, _lib.ptr(vals), _lib.ptr(rows), C.byref(cnt)))
+        return vals[:cnt.value], rows[:cnt.value]

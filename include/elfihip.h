@@ -144,6 +144,42 @@ int elfihip_topk_smallest(elfihip_ctx* ctx, const double* D, int64_t n, int64_t 
 int elfihip_topk_smallest_dev(elfihip_ctx* ctx, const double* dD, int64_t n, int64_t stride, int64_t k,
                               double* dvals, int64_t* didx);
 
+/* ------------------------------------------------------------------- sampler state: running best-k, fused with the distance
+ * Replaces Rejection._merge_batch (elfi/methods/inference/samplers.py:209-237: copy the batch behind the n_samples best
+ * rows, argsort n_samples + batch_size distances on the host, every batch).  An elfihip_reject keeps the k smallest
+ * distances seen so far and their GLOBAL row numbers (row_base + row inside the batch; ties go to the earlier row) in
+ * device memory, ascending.  A push computes a batch's distances (written to dout / out, as the Distance node must
+ * return them) and folds the batch in during the same pass: once the state is full its k-th distance is a threshold and
+ * the distance kernel itself lists the rows below it; a one-workgroup merge keeps the k best.  k <= 2048.
+ * _dev forms are asynchronous (distance pass on the context's stream); elfihip_reject_result synchronises and copies the state out
+ * (vals, rows: k entries; *count = how many are real, i.e. min(k, rows pushed)); it fails with ELFIHIP_ERR_STATE if a
+ * batch offered more than 65536 rows below the threshold (reset the state between SMC rounds).  Nested distances
+ * (n, K) are ranked by their last column (samplers.py:233). */
+typedef struct elfihip_reject elfihip_reject;
+int elfihip_reject_create(elfihip_ctx* ctx, int64_t k, elfihip_reject** out);
+int elfihip_reject_free(elfihip_reject* h);
+int elfihip_reject_reset(elfihip_reject* h);
+int elfihip_reject_push_rows(elfihip_reject* h, int metric, const double* X, int64_t n, int m, int64_t ldx,
+                             const double* y, const double* aux, double p, double* out, int64_t row_base);
+int elfihip_reject_push_rows_dev(elfihip_reject* h, int metric, const double* dX, int64_t n, int m, int64_t ldx,
+                                 const double* dy, const double* daux, double p, double* dout, int64_t row_base);
+int elfihip_reject_push_multiw_dev(elfihip_reject* h, const double* dX, int64_t n, int m, int64_t ldx, const double* dy,
+                                   const double* dW, int K, double* dout, int64_t row_base);
+/* distances that exist already (any Distance / Discrepancy node): dD[i * stride], i < n */
+int elfihip_reject_push_dev(elfihip_reject* h, const double* dD, int64_t n, int64_t stride, int64_t row_base);
+/* device pointers to the state (k values ascending, k rows), e.g. as the send buffers of a gather */
+int elfihip_reject_state_dev(elfihip_reject* h, double** dvals, int64_t** drows);
+/* From the next merge on, every merge also leaves the state as one packed device buffer at ddst -- k doubles (values)
+ * followed by k int64 (rows): the send buffer of a gather -- written by the merges themselves (no extra copy); NULL
+ * stops it. */
+int elfihip_reject_export_dev(elfihip_reject* h, void* ddst);
+/* Candidates are merged into the state after every push at first and, once the threshold has settled, after every 8th
+ * (a one-workgroup merge after every distance pass would cost a third of the pass); in between the list keeps growing against the last merged threshold, which still bounds the
+ * current k-th distance from above, so nothing is missed.  elfihip_reject_flush merges what is pending now
+ * (asynchronous); _result, _state_dev do so themselves. */
+int elfihip_reject_flush(elfihip_reject* h);
+int elfihip_reject_result(elfihip_reject* h, double* vals, int64_t* rows, int64_t* count);
+
 /* ------------------------------------------------------------------ SMC proposal density
  * GMDistribution.pdf (elfi/methods/utils.py:142-183): density of a Gaussian mixture with shared
  * covariance at M points, out[r] = sum_i weights[i] * N(x_r; means[i], cov).  The caller passes the

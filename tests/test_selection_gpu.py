@@ -113,3 +113,104 @@ def test_smallest_k_many_equal_keys_large(hip_ctx):
         vals, idx = elfi_amd.smallest_k(d, k)
         rv, ri = _ref(d, k)
         assert np.array_equal(idx, ri) and np.array_equal(vals, rv)
+
+
+def _best_ref(d_all, k):
+    order = np.lexsort((np.arange(len(d_all)), d_all))[:k]
+    return d_all[order], order
+
+
+@pytest.mark.parametrize('metric,m,kw', [('euclidean', 32, {}), ('cityblock', 6, {}), ('euclidean', 7, {}),
+                                         ('euclidean', 64, {'w': True}), ('minkowski', 10, {'p': 3.0})])
+def test_running_best_equals_the_reference_merge_over_batches(hip_ctx, metric, m, kw):
+    """elfihip_reject_*: the state after every batch is what Rejection._merge_batch (samplers.py:209-237) would hold
+    -- the k smallest distances so far, ties to the earlier row -- and the distances returned are the Distance node's
+    (bit-exact for these metrics except general Minkowski, where selection is still exact on the returned values)."""
+    import elfi_amd
+    import distance_oracle as O
+    rs = np.random.RandomState(m)
+    k = 500
+    w = rs.uniform(0.5, 2, m) if kw.get('w') else None
+    rb = elfi_amd.RunningBest(k, metric=metric, w=w, p=kw.get('p', 2.0))
+    y = rs.randn(1, m)
+    seen = []
+    for n in (120, 300, 1000, 50000, 7, 200000, 33333):        # the first three fill the state (120 + 300 < 500)
+        X = rs.randn(n, m) * (1.0 + 0.5 * rs.rand())
+        d = rb.push(X, y)
+        if metric != 'minkowski':
+            assert np.array_equal(d, O.cdist_rows(X, y, metric, w=w))
+        seen.append(d)
+        vals, rows = rb.result()
+        dv, dr = _best_ref(np.concatenate(seen), k)
+        assert np.array_equal(vals, dv) and np.array_equal(rows, dr), (n, len(vals))
+    rb.reset()
+    d = rb.push(X[:10], y)
+    vals, rows = rb.result()
+    assert np.array_equal(vals, np.sort(d)) and len(rows) == 10
+
+
+def test_running_best_ties_and_explicit_row_numbers(hip_ctx):
+    import elfi_amd
+    rs = np.random.RandomState(1)
+    rb = elfi_amd.RunningBest(64, metric='cityblock')
+    y = np.zeros((1, 4))
+    alld, allr = [], []
+    for b in range(6):
+        X = rs.randint(0, 3, (5000, 4)).astype(float)           # distances in {0..8}: massive ties
+        base = 1000000 * b                                      # batch index -> global row numbers
+        alld.append(rb.push(X, y, row_base=base))
+        allr.append(base + np.arange(5000))
+    d, r = np.concatenate(alld), np.concatenate(allr)
+    order = np.lexsort((r, d))[:64]
+    vals, rows = rb.result()
+    assert np.array_equal(vals, d[order]) and np.array_equal(rows, r[order])
+    with pytest.raises(ValueError):
+        elfi_amd.RunningBest(5000)
+
+
+def test_running_best_device_batches_nested_and_overflow(hip_ctx):
+    """Device-resident batches: nested (n, K) distances ranked by the last column; a batch that floods the candidate
+    list is reported, loudly, by result()."""
+    import ctypes as C
+    import torch
+    import elfi_amd
+    import distance_oracle as O
+    from elfi_amd import _lib
+    rs = np.random.RandomState(2)
+    n, m, K, k = 300000, 64, 3, 1000
+    lib = hip_ctx.lib
+    h = C.c_void_p()
+    hip_ctx.call("elfihip_reject_create", k, C.byref(h))
+    W = np.vstack([np.ones(m), rs.uniform(0.5, 2, m), rs.uniform(0.5, 2, m)])
+    y = rs.randn(1, m)
+    dW, dy = torch.from_numpy(W).cuda(), torch.from_numpy(y).cuda()
+    hip_ctx.synchronize()
+    cols = []
+    for b in range(3):
+        X = rs.randn(n, m)
+        dX = torch.from_numpy(X).cuda()
+        out = torch.empty(n, K, dtype=torch.float64, device='cuda')
+        torch.cuda.synchronize()
+        rc = lib.elfihip_reject_push_multiw_dev(h, dX.data_ptr(), n, m, m, dy.data_ptr(), dW.data_ptr(), K,
+                                                out.data_ptr(), b * n)
+        assert rc == 0
+        hip_ctx.synchronize()
+        oh = out.cpu().numpy()
+        assert np.array_equal(oh[:4096, 2], O.cdist_rows(X[:4096], y, 'euclidean', w=W[2]))
+        cols.append(oh[:, K - 1].copy())
+    vals, rows = np.empty(k), np.empty(k, dtype=np.int64)
+    cnt = C.c_int64()
+    assert lib.elfihip_reject_result(h, _lib.ptr(vals), _lib.ptr(rows), C.byref(cnt)) == 0 and cnt.value == k
+    dv, dr = _best_ref(np.concatenate(cols), k)
+    assert np.array_equal(vals, dv) and np.array_equal(rows, dr)
+    # distances that exist already, then a batch in which far more than 65536 rows beat the threshold
+    d2 = torch.from_numpy(np.concatenate(cols)[: 2 * n] * 1e-3).cuda()
+    torch.cuda.synchronize()
+    assert lib.elfihip_reject_push_dev(h, d2.data_ptr(), 2 * n, 1, 10 * n) == 0
+    assert lib.elfihip_reject_result(h, _lib.ptr(vals), _lib.ptr(rows), C.byref(cnt)) == _lib.ERR_STATE
+    assert lib.elfihip_reject_reset(h) == 0
+    assert lib.elfihip_reject_push_dev(h, d2.data_ptr(), 2 * n, 1, 0) == 0
+    assert lib.elfihip_reject_result(h, _lib.ptr(vals), _lib.ptr(rows), C.byref(cnt)) == 0
+    dv, dr = _best_ref(d2.cpu().numpy(), k)
+    assert np.array_equal(vals, dv) and np.array_equal(rows, dr)
+    lib.elfihip_reject_free(h)
