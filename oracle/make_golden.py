@@ -265,7 +265,7 @@ def make_weighted(elfi):
 def main(argv):
     os.makedirs(GOLDEN, exist_ok=True)
     elfi = ref_shim.install()
-    which = set(argv) or {'ma2', 'adaptive', 'metrics', 'gp', 'gm', 'posterior', 'weighted'}
+    which = set(argv) or {'ma2', 'adaptive', 'metrics', 'gp', 'gm', 'posterior', 'weighted', 'docrun'}
     if 'ma2' in which:
         make_ma2(elfi)
     if 'adaptive' in which:
@@ -283,6 +283,9 @@ def main(argv):
             print('gp fixtures: generator not present yet')
         else:
             make_golden_gp.main(elfi, GOLDEN)
+    if 'docrun' in which:          # ~1 min: the documented BOLFI run replayed through the reference's loop
+        import make_golden_gp
+        make_golden_gp.make_doc_run(elfi, GOLDEN)
     if 'posterior' in which:
         import make_golden_posterior
         make_golden_posterior.main(elfi, GOLDEN)

@@ -178,3 +178,52 @@ def make_bolfi_trace(elfi, golden_dir):
     n_opt = sum(1 for r in tm.log if r[2])
     print('gp_bolfi_trace: %d updates (%d with optimisation), %d acquisitions, final hyper %s'
           % (len(tm.log), n_opt, len(mins), {k: round(v, 4) for k, v in tm.hyper.items()}))
+
+
+# docs/usage/BOLFI.rst:36-153 -- the one place where the reference publishes GPy-side numbers of a BOLFI run:
+# MA2 `seed_obs=1`, elfi.BOLFI(log_d, batch_size=1, initial_evidence=20, update_interval=10, bounds, acq_noise_var,
+# seed=1).fit(n_evidence=200) on a 2017 GPy / SciPy / NumPy stack printed
+DOC_PRINTED = dict(objective=151.86636065302943, var=0.321697451372, ls=0.541352150083, bias=0.021827430988,
+                   noise=0.183562040169, threshold=-1.6146, prior_var=0.024, prior_ls=1.3, prior_bias=0.006)
+
+
+def make_doc_run(elfi, golden_dir):
+    """Replay of the documented run with the oracle model inside the reference's real loop.  The evidence cannot be
+    the 2017 run's (other RNG consumers, other L-BFGS-B) but it is a run of the same recipe, so the printed MAP
+    hyper-parameters must be near-optimal for it: the fixture records the evidence, the oracle's last MAP search
+    (start, end, objective) and the objective the printed values reach on this evidence."""
+    import gp_hyper_oracle as HO
+    from elfi.examples import ma2
+    from oracle_gp_model import OracleGPRegression
+    seed = 1
+    np.random.seed(seed)
+    m = ma2.get_model(seed_obs=seed)
+    log_d = elfi.Operation(np.log, m['d'], name='log_d')
+    bounds = {'t1': (-2, 2), 't2': (-1, 1)}
+    tm = OracleGPRegression(['t1', 't2'], bounds=bounds, max_opt_iters=50)
+    bolfi = elfi.BOLFI(log_d, batch_size=1, initial_evidence=20, update_interval=10, bounds=bounds,
+                       target_model=tm, acq_noise_var={'t1': 0.1, 't2': 0.1}, seed=seed)
+    post = bolfi.fit(n_evidence=200, bar=False)
+    opt_steps = [i for i, r in enumerate(tm.log) if r[2]]
+    last = opt_steps[-1]
+    assert last == len(tm.log) - 1 and tm.X.shape == (200, 2)
+    start = tm.log[opt_steps[-2]][3]            # the hyper-parameters the last search started from
+    obj = HO.MapObjective(tm.X, tm.Y, tm.priors)
+    to_phi = lambda h: HO.softplus_inv(np.array([h[k] for k in HO.ORDER]))
+    printed = {k: DOC_PRINTED[k] for k in HO.ORDER}
+    out = dict(X=tm.X, Y=tm.Y,
+               priors=np.array([[tm.priors[k][0], tm.priors[k][1]] for k in ('var', 'ls', 'bias')]),
+               hyper_start=np.array([start[k] for k in HO.ORDER]),
+               hyper_oracle=np.array([tm.hyper[k] for k in HO.ORDER]),
+               objective_oracle=np.float64(obj.value(to_phi(tm.hyper))),
+               objective_start=np.float64(obj.value(to_phi(start))),
+               hyper_printed=np.array([printed[k] for k in HO.ORDER]),
+               objective_at_printed=np.float64(obj.value(to_phi(printed))),
+               objective_printed_in_doc=np.float64(DOC_PRINTED['objective']),
+               threshold_oracle=np.float64(post.threshold), threshold_printed=np.float64(DOC_PRINTED['threshold']),
+               n_optimisations=np.int64(len(opt_steps)))
+    np.savez_compressed(os.path.join(golden_dir, 'bolfi_doc_run.npz'), **out)
+    print('bolfi_doc_run: oracle MAP', {k: round(v, 4) for k, v in tm.hyper.items()}, 'objective %.4f' % out['objective_oracle'],
+          '| printed values on this evidence: objective %.4f' % out['objective_at_printed'],
+          '| priors (a, b):', {k: tuple(np.round(v, 4)) for k, v in tm.priors.items()},
+          '| threshold %.4f (doc %.4f)' % (out['threshold_oracle'], DOC_PRINTED['threshold']))

@@ -107,3 +107,36 @@ def test_update_with_optimize_flag(hip_ctx):
     assert h1 != G.initial_hyper(y[:100])
     m.update(X[100:], y[100:])          # no optimisation: hyper-parameters carried over (:306-310)
     assert m._hyper == h1 and m.n_evidence == 120
+
+
+def test_map_search_reaches_the_reference_s_published_optimum(hip_ctx):
+    """a10 pinned: on the evidence of the documented BOLFI run (tests/golden/bolfi_doc_run.npz; the CPU oracle
+    reproduces the print-out of docs/usage/BOLFI.rst:144-153 digit for digit, tests/test_oracle_pinning_gp.py) the
+    device MAP search, started where the run's last search started, must end at the PRINTED hyper-parameters and
+    objective.  SCG stops on a relative objective change of 1e-6, so the end points of two correct implementations
+    agree to about the square root of that in the well-determined directions."""
+    import os
+    from conftest import GOLDEN
+    from elfi_amd import HipGPRegression
+    from elfi_amd import hyperopt as H
+    g = np.load(os.path.join(GOLDEN, 'bolfi_doc_run.npz'))
+    names = ['t1', 't2']
+    m = HipGPRegression(names, bounds={'t1': (-2, 2), 't2': (-1, 1)})
+    m.update(g['X'], g['Y'])
+    m._priors = {k: (float(g['priors'][i, 0]), float(g['priors'][i, 1])) for i, k in enumerate(('var', 'ls', 'bias'))}
+    m._hyper = dict(zip(H.NAMES, (float(v) for v in g['hyper_start'])))
+    m._refit()
+    obj = H.MarginalObjective(m)
+    printed = g['hyper_printed']
+    f_printed = obj.f(H.logexp_inv(printed))
+    # the device objective at the printed values is the printed objective (151.866...)
+    assert abs(f_printed - float(g['objective_printed_in_doc'])) <= 1e-6 * 151.87, f_printed
+    assert abs(f_printed - float(g['objective_at_printed'])) <= 1e-9 * 151.87
+    m.optimize()
+    got = np.array([m._hyper[k] for k in H.NAMES])
+    f_got = m._opt_info['objective'][-1]
+    assert abs(f_got - float(g['objective_printed_in_doc'])) <= 1e-6 * 151.87, (f_got, m._opt_info['status'])
+    np.testing.assert_allclose(got[[0, 1, 3]], printed[[0, 1, 3]], rtol=2e-3)
+    np.testing.assert_allclose(got[2], printed[2], rtol=5e-2)          # the flat bias direction
+    # and the gradient of the device objective vanishes at the printed optimum to the search's own tolerance
+    assert np.max(np.abs(obj.grad(H.logexp_inv(printed)))) <= 5e-3

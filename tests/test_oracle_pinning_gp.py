@@ -97,3 +97,32 @@ def test_posterior_oracle_equals_the_reference_bolfi_posterior():
     np.testing.assert_allclose(gr, g['grad'], rtol=1e-8, atol=1e-8)   # the reference's prior gradient is numerical
     # the threshold the reference finds on its own is the minimum of the GP mean in the box
     assert float(g['threshold_auto']) <= float(g['min_of_mean_over_evidence']) + 1e-9
+
+
+def test_documented_bolfi_run_is_reproduced_digit_for_digit():
+    """docs/usage/BOLFI.rst:36-153 is the one place where the reference publishes GPy-side numbers: MA2 seed_obs=1,
+    elfi.BOLFI(log_d, batch_size=1, initial_evidence=20, update_interval=10, bounds, acq_noise_var, seed=1)
+    .fit(n_evidence=200) printed the MAP objective 151.866..., the four hyper-parameters, the Gamma priors and the
+    posterior threshold.  tests/golden/bolfi_doc_run.npz is that recipe run HERE through the reference's real loop
+    with oracle/oracle_gp_model.py as the surrogate (oracle/make_golden_gp.py:make_doc_run): 180 acquisitions and 18
+    hyper-parameter searches later the restatement of GPy / paramz lands on the printed numbers.  This pins the whole
+    a10 chain -- kernel, inference, priors and their Jacobian, SCG, LCB, multi-start L-BFGS-B -- to the reference's
+    published output."""
+    import gp_hyper_oracle as HO
+    g = np.load(os.path.join(GOLDEN, 'bolfi_doc_run.npz'))
+    printed, ours = g['hyper_printed'], g['hyper_oracle']
+    # rbf.variance, rbf.lengthscale, bias.variance, Gaussian_noise.variance as printed (12 digits)
+    np.testing.assert_allclose(ours[[0, 1, 3]], printed[[0, 1, 3]], rtol=1e-5)
+    np.testing.assert_allclose(ours[2], printed[2], rtol=2e-4)          # the flat direction (Ga(0.006, 1) prior)
+    assert abs(float(g['objective_oracle']) - float(g['objective_printed_in_doc'])) <= 1e-6 * 151.87
+    assert abs(float(g['threshold_oracle']) - float(g['threshold_printed'])) <= 5e-5       # printed with 4 decimals
+    # the printed priors: Ga(0.024, 1), Ga(1.3, 1), Ga(0.006, 1) for rbf.variance, lengthscale, bias.variance
+    np.testing.assert_allclose(g['priors'][:, 0], [0.024, 1.3, 0.006], rtol=5e-2)        # printed with 2 digits
+    assert np.all(g['priors'][:, 1] == 1.0)
+    # the fixture is what the oracle computes on its evidence, and its search from the recorded start ends there
+    pri = {k: tuple(g['priors'][i]) for i, k in enumerate(('var', 'ls', 'bias'))}
+    obj = HO.MapObjective(g['X'], g['Y'], pri)
+    assert abs(obj.value(HO.softplus_inv(ours)) - float(g['objective_oracle'])) <= 1e-9 * 151.87
+    assert abs(obj.value(HO.softplus_inv(printed)) - float(g['objective_at_printed'])) <= 1e-9 * 151.87
+    h, info = HO.optimize(g['X'], g['Y'], dict(zip(HO.ORDER, g['hyper_start'])), pri, max_iters=50)
+    np.testing.assert_allclose([h[k] for k in HO.ORDER], ours, rtol=1e-9)
