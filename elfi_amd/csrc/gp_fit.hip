@@ -175,6 +175,13 @@ typedef __attribute__((address_space(1))) double gdouble;    // global memory, s
 typedef double v2d_t __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(1))) v2d_t gdouble2;   // instance below generic pointers would become FLAT accesses
 
+#ifdef ELFIHIP_POTF2_STAMP   // developer probe (scripts/native/potf2_probe.hip): cycle stamps per wave, panel and phase
+__device__ long long g_potf2_stamp[16 * 8 * 8];
+#define STAMP(p, slot) do { if ((threadIdx.x & 63) == 0) g_potf2_stamp[((threadIdx.x >> 6) * 8 + (p)) * 8 + (slot)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define STAMP(p, slot) do { } while (0)
+#endif
+
 template <int NT>
 __device__ __forceinline__ void potf2_tiles_body(double* Akk_, int64_t lda, double* Wkk_, int64_t ldw, double* W11_, int* info,
                                                  int kblock, double* sm) {
@@ -314,6 +321,7 @@ __device__ __forceinline__ void potf2_tiles_body(double* Akk_, int64_t lda, doub
     lds_barrier();
     for (int p = 0; p < NB / 16; ++p) {
       double* P2w = P2 + (p & 1) * NB * PP;
+      STAMP(p, 0);
       // U2 of the previous panel on the waves of the SIMD without a phase-A wave: every tile right of column p (column p
       // itself was brought up to date in U1)
       if (p > 0) {
@@ -324,9 +332,12 @@ __device__ __forceinline__ void potf2_tiles_body(double* Akk_, int64_t lda, doub
           const int C = t >> 3, R = t & 7;
           if (t < 64 && C > p && (R >= C || R <= p - 1)) apply(x[s_], R, C, p - 1, P2r);
         }
+        STAMP(p, 1);
         write_out(p - 1);
       }
+      STAMP(p, 2);
       lds_barrier();
+      STAMP(p, 3);
       // U1: tile column p+1 receives panel p and goes to PB for the next phase A
       if (p + 1 < NB / 16) {
 #pragma unroll
@@ -339,15 +350,19 @@ __device__ __forceinline__ void potf2_tiles_body(double* Akk_, int64_t lda, doub
           }
         }
       }
+      STAMP(p, 4);
       lds_barrier();
+      STAMP(p, 5);
     }
     write_out(NB / 16 - 1);
+    STAMP(7, 6);
   } else {
     lds_barrier();
     for (int p = 0; p < NB / 16; ++p) {
       const int c0 = 16 * p;
       const int ntop = NB - 16 - c0;  // rows below the tile
       double* P2w = P2 + (p & 1) * NB * PP;
+      STAMP(p, 0);
       // ---- phase A (see above): one lane per row of the tile column, elimination in registers
       const bool is_tile = l < 16;
       const int o = 48 * w + (l - 16);
@@ -371,6 +386,7 @@ __device__ __forceinline__ void potf2_tiles_body(double* Akk_, int64_t lda, doub
                         "+v"(a[15]));
 #pragma unroll
       for (int c = 0; c < 16; ++c) a[c] = ((keep_r >> c) & 1u) ? a[c] : (((diag_m >> c) & 1u) ? 1.0 : 0.0);
+      STAMP(p, 1);
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
         double acc0 = a[c], acc1 = 0.0;
@@ -395,6 +411,7 @@ __device__ __forceinline__ void potf2_tiles_body(double* Akk_, int64_t lda, doub
         if (!(pc > 0.0) && bad == 0) bad = kblock * NB + c0 + c + 1;
         a[c] = fma(ay0 * ec, sc_, ay0);  // on tile row c this is p / sqrt(p): the diagonal of the factor
       }
+      STAMP(p, 2);
       // the solved panel: densely into P2 for the updates ...
       if (is_other) {
         double* pp = P2w + o * PP;
@@ -406,8 +423,11 @@ __device__ __forceinline__ void potf2_tiles_body(double* Akk_, int64_t lda, doub
 #pragma unroll
         for (int c = 0; c < 16; ++c) tb[c] = a[c];
       }
+      STAMP(p, 3);
       lds_barrier();
+      STAMP(p, 4);
       lds_barrier();
+      STAMP(p, 5);
     }
   }
   if (bad != 0 && tid == 0) atomicCAS(info, 0, bad);

@@ -67,17 +67,29 @@ struct RejArgs {
   double* export_val;   // packed copy of the new state for the caller (may be NULL)
 };
 
+constexpr size_t REJ_MERGE_LDS = REJ_MAX_K * 16 + REJ_CHUNK * 16 + 2 * (REJ_MAX_K + 4) * 4 + REJ_CHUNK * 4 + 64 * 4;
+
 __global__ __launch_bounds__(1024) void reject_merge_kernel(RejArgs S) {
   // Merge by ranks, REJ_CHUNK candidates at a time: an element's place in the merged order is the number of elements
-  // before it -- for a state entry its index plus the candidates below it, for a candidate the state entries below it
-  // (binary search: the state is sorted) plus the candidates below it (a scan: a chunk is small).  Row numbers are
-  // unique, so (distance, row) is a strict order and every place is taken once.  Three barriers per chunk instead of
-  // the seventy-eight of a 4096-pair bitonic sort (measured: 50 us per merge that way).
-  __shared__ double bv[REJ_MAX_K];
-  __shared__ long long br[REJ_MAX_K];
-  __shared__ double cv[REJ_CHUNK];
-  __shared__ long long cr[REJ_CHUNK];
-  const int t = threadIdx.x, k = S.k;
+  // before it.  A candidate x finds its SLOT by binary search (the state is sorted): slot(x) = number of state entries
+  // below x.  With cnt[s] = candidates in slot s and pre[s] = candidates in slots before s (one scan over the slots):
+  //   state entry e   moves to  e + pre[e + 1]                      (the candidates of slots <= e are exactly those below it)
+  //   candidate x     moves to  slot + pre[slot] + (candidates of the SAME slot below x)
+  // and the candidates of a slot are on a linked list (one atomic exchange each), so the last term costs the length
+  // of that list -- about one -- instead of a scan over the chunk.  (distance, row) is a strict order, rows being
+  // unique, so every place is taken once.  Candidates that are not below the current k-th entry take no part.
+  // History: a 4096-pair bitonic sort measured 50 us per merge; ranks by scanning the whole chunk for every element
+  // 30 us per chunk (92 us per merge on the bench's rotating batches, a fifth of the step rate).
+  extern __shared__ __align__(16) unsigned char rej_sm[];
+  double* bv = reinterpret_cast<double*>(rej_sm);
+  long long* br = reinterpret_cast<long long*>(bv + REJ_MAX_K);
+  double* cv = reinterpret_cast<double*>(br + REJ_MAX_K);
+  long long* cr = reinterpret_cast<long long*>(cv + REJ_CHUNK);
+  int* pre = reinterpret_cast<int*>(cr + REJ_CHUNK);   // (k + 2): counts per slot, then their exclusive prefix sums
+  int* head = pre + REJ_MAX_K + 4;                      // (k + 1): first candidate of the slot's list, -1 = none
+  int* nxt = head + REJ_MAX_K + 4;                      // (chunk)
+  int* wsum = nxt + REJ_CHUNK;                          // (16) per-wave totals of the scan
+  const int t = threadIdx.x, k = S.k, lane = t & 63, w = t >> 6;
   unsigned int c = S.ncand >= 0 ? (unsigned int)S.ncand : *S.count;
   if (c > S.cap) {
     if (t == 0) atomicOr(S.status, 1u);   // the list is incomplete: the state can no longer be trusted (reported by result)
@@ -87,52 +99,97 @@ __global__ __launch_bounds__(1024) void reject_merge_kernel(RejArgs S) {
     bv[e] = S.best_val[e];
     br[e] = S.best_row[e];
   }
+  constexpr int SPT = (REJ_MAX_K + 2 + 1023) / 1024;   // slots per thread in the scan (consecutive)
   for (unsigned int c0 = 0; c0 < c; c0 += REJ_CHUNK) {
     const int nc = (int)min((unsigned int)REJ_CHUNK, c - c0);
+    for (int e = t; e < k + 2; e += 1024) {
+      pre[e] = 0;
+      head[e < k + 1 ? e : 0] = -1;
+    }
+    __syncthreads();   // also: the state of the previous round is in place
+    double xv = 0.0;
+    long long xr = 0;
+    int slot = -1;
     if (t < nc) {
-      cv[t] = S.cand_val[c0 + t];
-      cr[t] = S.cand_row[c0 + t] + S.row_offset;
-    }
-    __syncthreads();
-    double xv[3];
-    long long xr[3];
-    int pos[3];
-#pragma unroll
-    for (int u = 0; u < 3; ++u) {
-      const int e = t + 1024 * u;
-      pos[u] = k;  // "no place"
-      xv[u] = 0.0;
-      xr[u] = 0;
-      if (e < k + nc) {
-        const bool is_state = e < k;
-        xv[u] = is_state ? bv[e] : cv[e - k];
-        xr[u] = is_state ? br[e] : cr[e - k];
-        int below = 0;
-        for (int j2 = 0; j2 < nc; ++j2) below += rej_less(cv[j2], cr[j2], xv[u], xr[u]) ? 1 : 0;
-        if (is_state) {
-          pos[u] = e + below;
-        } else {
-          int lo = 0, hi = k;   // first state entry that is not below x
-          while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (rej_less(bv[mid], br[mid], xv[u], xr[u]))
-              lo = mid + 1;
-            else
-              hi = mid;
-          }
-          pos[u] = lo + below;
+      xv = S.cand_val[c0 + t];
+      xr = S.cand_row[c0 + t] + S.row_offset;
+      cv[t] = xv;
+      cr[t] = xr;
+      if (rej_less(xv, xr, bv[k - 1], br[k - 1])) {
+        int lo = 0, hi = k - 1;   // first state entry that is not below x (entry k-1 is not)
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (rej_less(bv[mid], br[mid], xv, xr))
+            lo = mid + 1;
+          else
+            hi = mid;
         }
+        slot = lo;
+        atomicAdd(&pre[slot], 1);
+        nxt[t] = atomicExch(&head[slot], t);
       }
     }
     __syncthreads();
+    // exclusive scan of pre[0 .. k+1] (SPT consecutive slots per thread, wave scan, wave totals)
+    int loc[SPT], sum = 0;
 #pragma unroll
-    for (int u = 0; u < 3; ++u)
-      if (pos[u] < k) {
-        bv[pos[u]] = xv[u];
-        br[pos[u]] = xr[u];
-      }
+    for (int i = 0; i < SPT; ++i) {
+      const int e = SPT * t + i;
+      loc[i] = e < k + 2 ? pre[e] : 0;
+      sum += loc[i];
+    }
+    int inc = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += o;
+    }
+    if (lane == 63) wsum[w] = inc;
     __syncthreads();
+    int base = inc - sum;
+    for (int j = 0; j < w; ++j) base += wsum[j];
+#pragma unroll
+    for (int i = 0; i < SPT; ++i) {
+      const int e = SPT * t + i;
+      if (e < k + 2) pre[e] = base;
+      base += loc[i];
+    }
+    __syncthreads();
+    // places: values travel in registers across the barrier, the scatter is in place
+    double sv[2];
+    long long sr[2];
+    int sp[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int e = t + 1024 * u;
+      sp[u] = k;
+      sv[u] = 0.0;
+      sr[u] = 0;
+      if (e < k) {
+        sv[u] = bv[e];
+        sr[u] = br[e];
+        sp[u] = e + pre[e + 1];
+      }
+    }
+    int cp = k;
+    if (slot >= 0) {
+      int below = 0;
+      for (int j = head[slot]; j >= 0; j = nxt[j]) below += (j != t && rej_less(cv[j], cr[j], xv, xr)) ? 1 : 0;
+      cp = slot + pre[slot] + below;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      if (sp[u] < k) {
+        bv[sp[u]] = sv[u];
+        br[sp[u]] = sr[u];
+      }
+    if (cp < k) {
+      bv[cp] = xv;
+      br[cp] = xr;
+    }
   }
+  __syncthreads();
   long long* export_row = reinterpret_cast<long long*>(S.export_val + k);
   for (int e = t; e < k; e += 1024) {
     S.best_val[e] = bv[e];
@@ -194,7 +251,7 @@ static RejArgs merge_args(elfihip_reject* h, int ncand, long long row_offset) {
 // merge whatever the list holds (asynchronous, context's stream)
 static int reject_flush(elfihip_reject* h) {
   if (h->unmerged == 0) return ELFIHIP_OK;
-  hipLaunchKernelGGL(reject_merge_kernel, dim3(1), dim3(1024), 0, h->ctx->stream, merge_args(h, -1, 0));
+  hipLaunchKernelGGL(reject_merge_kernel, dim3(1), dim3(1024), REJ_MERGE_LDS, h->ctx->stream, merge_args(h, -1, 0));
   h->unmerged = 0;
   return launch_status(h->ctx, "reject_merge_kernel");
 }
@@ -222,7 +279,7 @@ static int reject_push(elfihip_reject* h, int64_t n, const double* dsel, int64_t
     const int64_t kb = n < h->k ? n : h->k;
     if (kb > 0) {
       ELFIHIP_TRY(topk_dev_impl(ctx, dsel, n, stride, kb, h->cand_val, reinterpret_cast<int64_t*>(h->cand_row), true));
-      hipLaunchKernelGGL(reject_merge_kernel, dim3(1), dim3(1024), 0, st, merge_args(h, (int)kb, row_base));
+      hipLaunchKernelGGL(reject_merge_kernel, dim3(1), dim3(1024), REJ_MERGE_LDS, st, merge_args(h, (int)kb, row_base));
     }
     h->filled = h->filled + n < h->k ? h->filled + n : h->k;
     return launch_status(ctx, "reject_merge_kernel");
@@ -282,6 +339,8 @@ int elfihip_reject_create(elfihip_ctx* ctx, int64_t k, elfihip_reject** out) {
   ELFIHIP_REQUIRE(ctx, k >= 1 && k <= REJ_MAX_K, "k = %lld outside [1, %lld] (larger sample sets: elfihip_topk_smallest "
                   "per batch and a host merge)", (long long)k, (long long)REJ_MAX_K);
   DeviceGuard g(ctx->device);
+  ELFIHIP_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(reject_merge_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)REJ_MERGE_LDS));
   elfihip_reject* h = new elfihip_reject();
   h->ctx = ctx;
   h->k = k;
