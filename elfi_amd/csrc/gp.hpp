@@ -3,6 +3,8 @@
 
 #include "common.hpp"
 
+#include <vector>
+
 namespace elfihip {
 constexpr int NB = 128;          // block size of the factorisation (one MFMA GEMM tile)
 constexpr int FUSED_BELOW_NB = 65;  // block columns below which the fused-step schedule is the default (gp_fit.hip):
@@ -43,6 +45,12 @@ struct elfihip_gp {
   // schedule of the factorisation sweep (elfihip_gp_set_schedule): 0 = by size, 1 = streams, 2 = fused steps;
   // panel_group 0 = by size, else 1 / 2 / 4 panels per pass over the trailing matrix (stream schedule)
   int schedule = 0, panel_group = 0;
+  // fused schedule: the update plan of sweep_sched.hpp for sched_nb block columns on sched_nwg workgroups, uploaded
+  elfihip::DevBuf sched_mem;
+  const void* sched_units = nullptr;
+  const void* sched_wgoff = nullptr;
+  std::vector<int> sched_step_off, sched_step_nwg;   // per step: first offset entry, workgroups with work
+  int sched_nb = 0, sched_nwg = 0;
   // per-phase device timing (elfihip_gp_profile): HIP events around the phases of a fit / prediction / gradient call
   // while enabled; sums in milliseconds and call counts per phase (indices: ELFIHIP_PHASE_* in include/elfihip.h)
   bool profile = false;

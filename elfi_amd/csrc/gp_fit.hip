@@ -20,6 +20,11 @@
 // Flops: n^3/3 (Cholesky) + n^3/3 (L^-T) on v_mfma_f64_16x16x4_f64.
 #include "gp.hpp"
 #include "mfma_f64.hpp"
+#include "sweep_sched.hpp"
+
+#include <map>
+#include <memory>
+#include <mutex>
 
 namespace elfihip {
 
@@ -357,6 +362,9 @@ __device__ __forceinline__ void potf2_tiles_body(double* Akk_, int64_t lda, doub
     write_out(NB / 16 - 1);
     STAMP(7, 6);
   } else {
+#ifdef POTF2_PRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
     lds_barrier();
     for (int p = 0; p < NB / 16; ++p) {
       const int c0 = 16 * p;
@@ -697,76 +705,49 @@ __device__ __noinline__ void potf2_tiles_call(double* Akk, int64_t lda, double* 
 // Before it, per step: trsm_gemm_kernel (all row blocks of panel k) and the update of tile (k+1, k+1) alone
 // (lookahead_tile_kernel<1>, 16 workgroups) -- the only tile the next diagonal block needs.
 //
-// Which tiles receive which panels.  A K = 128 update of a 128 x 128 tile moves 512 KB (its old and new values and both
-// operand blocks) for 4.2 MFLOP: 8 flop per byte.  With every tile right of panel k updated in every step the launch
-// ran at the fabric's 5 TB/s, 25 us per tile against 13.6 us of matrix-pipe time (measured, n = 4096).  So a block
-// column is updated every OTHER step with the last TWO panels (K = 256: the tile's values move once per two panels):
-//   near   block column k+1 (needed by the next panel solve) receives panel k:                  K = 128
-//   far    block columns c = k+2, k+4, ... (the parity of k) receive panels k-1 and k:         K = 256 (K = 128 at k = 0)
-// Column c was last updated at step c-2-2j ... and becomes the near column at step c-1, having received every panel
-// up to c-2 by then.  Row kinds of a column's tiles: Cholesky rows i >= c (C -= P_i P_c^T), the y block, L^-T rows
-// r <= k (created -- overwritten, not accumulated -- by the first panels that reach them: r >= k-1 far, r == k near;
-// the strictly lower blocks WT(r, j < r) an operand row may span are zero from allocation).
+// Which tiles receive which columns of the factor in which step is decided on the host (sweep_sched.hpp): every step's
+// update work is a list of UNITS -- the upper or lower 64 rows of a 128 x 128 tile receiving a contiguous range of
+// 32-column k-tiles of the factor, K = 64 ... 416 -- dealt to the workgroups so that all of them, in every step, are busy
+// for about as long as the diagonal block takes.  (A K = 128 update of a tile moves 512 KB for 4.2 MFLOP; updating every
+// tile right of panel k in every step ran at the fabric's 5 TB/s, 25 us per tile against 13.6 us of matrix-pipe time,
+// and made the first third of the steps three units long while the last third left most compute units idle.)
+// Row kinds of a column's tiles: Cholesky rows i >= c (C -= P_i P_c^T), the y block, L^-T rows r (created --
+// overwritten, not accumulated -- by the unit that brings block (r, r), the first non-zero block of that row; the
+// strictly lower blocks WT(r, j < r) a unit's k range may start in are zero from allocation).
 // 1024 threads per workgroup (what the diagonal block needs), so one workgroup per CU: the update workgroups are
-// PERSISTENT -- 8 x 31 of them, one per CU beside workgroup 0 -- and walk their share of the unit list with the next
-// unit's first operand loads and old C values in flight while the current unit is multiplied.  A unit is a whole tile
-// (RT = 2) or its upper / lower 64 rows (RT = 1), whichever leaves the shorter tail for this step (host's choice).
-// XCD-aware: workgroups go round-robin over the 8 XCDs, so XCD x works through the contiguous stretch
-// [x per, (x+1) per) of the unit list; the list runs column by column (consecutive units share their B operand,
-// the column's own panel rows, in that XCD's L2), far columns first, the cheaper near units last.
+// PERSISTENT -- one per CU beside workgroup 0 -- and walk their list with the next unit's first operand loads and old
+// C values in flight while the current unit is multiplied.
 struct StepArgs {
   PanelArgs P;
   double* W11;
   int* info;
-  int kbeg;    // first panel of the far updates: max(k - 1, 0)
-  int nfar;    // far tiles
-  int nnear;   // near tiles (block column k+1 without its diagonal tile)
+  const SweepUnit* units;   // the schedule's unit table (all steps)
+  const int32_t* wg_off;    // this step: offsets into `units`, one per update workgroup + 1
 };
 
 struct StepUnit {
-  const double* Ap;   // unit's rows of the panel(s) (64 RT x K)
-  const double* Bp;   // the block column's rows of the panel(s) (128 x K)
+  const double* Ap;   // unit's rows of the factor's columns (64 x K)
+  const double* Bp;   // the block column's rows of the same columns (128 x K)
   double* C;          // unit's rows of the tile
-  double keep;        // 1: C -= P P^T, 0: C = -P P^T (the panels that create an L^-T row)
+  double keep;        // 1: C -= P P^T, 0: C = -P P^T (the unit that creates an L^-T tile)
   int nkt;            // 32-deep k-tiles: K / 32
 };
 
-template <int RT>
-__device__ __forceinline__ StepUnit step_decode(const StepArgs& S, int unit) {
-  constexpr int UPT = 2 / RT;
+__device__ __forceinline__ StepUnit step_unit(const StepArgs& S, int i) {
   const PanelArgs& P = S.P;
-  const int k = P.k, nb = P.nb;
-  int idx = unit / UPT;
-  const int half = unit - idx * UPT;
+  const int4 r = *reinterpret_cast<const int4*>(S.units + i);   // {row, c | kt0 << 16, nkt | half << 16 | keep << 24, pad}
+  const int row = r.x, c = r.y & 0xffff, kt0 = (r.y >> 16) & 0xffff;
+  const int nkt = r.z & 0xffff, half = (r.z >> 16) & 0xff, keep = (r.z >> 24) & 0xff;
+  const double* base = row <= P.nb ? P.A + ((int64_t)row * NB) * P.lda : P.WT + ((int64_t)(row - P.nb - 1) * NB) * P.lda;
   StepUnit U;
-  U.keep = 1.0;
-  int c, kb, row;        // block column, first panel, row block (0..nb-1: A rows, nb: y block, nb+1+r: L^-T row r)
-  if (idx < S.nfar) {
-    c = k + 2;
-    kb = S.kbeg;
-    for (int t = (nb - c) + k + 2; idx >= t; t -= 2) {  // the column's tiles: nb-c Cholesky rows, y, k+1 L^-T rows
-      idx -= t;
-      c += 2;
-    }
-    row = idx <= nb - c ? c + idx : idx + c;  // idx < nb-c: row c+idx; == nb-c: y (row nb); beyond: nb+1+r, r = idx-(nb-c)-1
-    if (row > nb && row - nb - 1 >= k - 1) U.keep = 0.0;
-  } else {
-    idx -= S.nfar;
-    c = k + 1;
-    kb = k;
-    const int mm = nb - 1 - c;   // Cholesky rows below the column's diagonal tile
-    row = idx < mm ? c + 1 + idx : nb + (idx - mm);
-    if (row == nb + 1 + k) U.keep = 0.0;
-  }
-  const double* base = row <= nb ? P.A + ((int64_t)row * NB) * P.lda : P.WT + ((int64_t)(row - nb - 1) * NB) * P.lda;
-  U.Ap = base + (int64_t)kb * NB + (int64_t)half * (64 * RT) * P.lda;
-  U.C = const_cast<double*>(base) + (int64_t)c * NB + (int64_t)half * (64 * RT) * P.lda;
-  U.Bp = P.A + ((int64_t)c * NB) * P.lda + (int64_t)kb * NB;
-  U.nkt = (k - kb + 1) * (NB / GK2);
+  U.Ap = base + (int64_t)kt0 * GK2 + (int64_t)half * 64 * P.lda;
+  U.C = const_cast<double*>(base) + (int64_t)c * NB + (int64_t)half * 64 * P.lda;
+  U.Bp = P.A + ((int64_t)c * NB) * P.lda + (int64_t)kt0 * GK2;
+  U.keep = keep ? 1.0 : 0.0;
+  U.nkt = nkt;
   return U;
 }
 
-template <int RT>
 __global__ __launch_bounds__(1024) void step_kernel(StepArgs S) {
   extern __shared__ __align__(16) double sm[];
   const PanelArgs& P = S.P;
@@ -777,16 +758,11 @@ __global__ __launch_bounds__(1024) void step_kernel(StepArgs S) {
     potf2_tiles_call(Akk, P.lda, Wkk, P.lda, S.W11, S.info, kk, sm);
     return;
   }
+  constexpr int RT = 1;                 // 16-row MFMA tiles per wave along the rows
   constexpr int ROWS = 64 * RT;         // rows of a unit
-  constexpr int UPT = 2 / RT;           // units per tile
   constexpr int BUF = (ROWS + 128) * GLP2;  // doubles of one LDS stage: A rows, then B rows
-  const int nunit = (S.nfar + S.nnear) * UPT;
-  const int b = (int)blockIdx.x - 1;
-  const int gx = ((int)gridDim.x - 1) >> 3;            // update workgroups per XCD
-  const int per = (nunit + 7) >> 3;                    // units per XCD
-  const int x = b & 7;
-  int u = x * per + (b >> 3);
-  const int uend = min((x + 1) * per, nunit);
+  int u = S.wg_off[blockIdx.x - 1];
+  const int uend = S.wg_off[blockIdx.x];
   if (u >= uend) return;
   const int t = threadIdx.x, l = t & 63, w = t >> 6;
   const int wr = w >> 2, wc = w & 3;
@@ -802,7 +778,7 @@ __global__ __launch_bounds__(1024) void step_kernel(StepArgs S) {
   // The k-tiles of a workgroup's units form ONE stream e = (unit, kt) through two LDS stages: while stage p is
   // multiplied, the next element (in registers since the previous step) is written to stage p^1 and the loads of the
   // element after it are issued -- one barrier per k-tile, and the LDS stores overlap other waves' MFMAs.
-  StepUnit cur = step_decode<RT>(S, u);
+  StepUnit cur = step_unit(S, u);
   double2 pa0, pa1, pb0, pb1;
   auto issue = [&](const double* A_, const double* B_) {
     pa0 = *reinterpret_cast<const double2*>(A_ + goff);
@@ -831,9 +807,9 @@ __global__ __launch_bounds__(1024) void step_kernel(StepArgs S) {
   issue(cur.Ap + GK2, cur.Bp + GK2);
   __syncthreads();
   for (;;) {
-    const int un = u + gx;
+    const int un = u + 1;
     const bool more = un < uend;
-    const StepUnit nxt = more ? step_decode<RT>(S, un) : cur;
+    const StepUnit nxt = more ? step_unit(S, un) : cur;
     v4d acc[RT][2];
 #pragma unroll
     for (int i = 0; i < RT; ++i)
@@ -892,24 +868,7 @@ __global__ __launch_bounds__(1024) void step_kernel(StepArgs S) {
   }
 }
 
-// Longest workgroup of a step under the static deal (far units cost 2, near units 1; x 0.53 for half-tile units, which
-// carry the whole B operand for half the flops): the host picks whole or half tiles per step by this.
-static double step_tail_cost(int nfar, int nnear, int upt, int gx) {
-  const int nfu = nfar * upt, nunit = (nfar + nnear) * upt;
-  const int per = (nunit + 7) / 8;
-  const double w_far = (upt == 2 ? 0.53 : 1.0) * 2.0, w_near = (upt == 2 ? 0.53 : 1.0);
-  double worst = 0.0;
-  for (int x = 0; x < 8; ++x) {
-    const int lo = x * per, hi = std::min((x + 1) * per, nunit);
-    for (int s_ = 0; s_ < gx && lo + s_ < hi; ++s_) {
-      double c = 0.0;
-      for (int u = lo + s_; u < hi; u += gx) c += u < nfu ? w_far : w_near;
-      worst = std::max(worst, c);
-    }
-  }
-  return worst;
-}
-constexpr size_t STEP_LDS_BYTES = 2 * (128 + 128) * GLP2 * sizeof(double);  // two stages of a whole-tile unit (> potf2's)
+constexpr size_t STEP_LDS_BYTES = 2 * (64 + 128) * GLP2 * sizeof(double);  // two stages of a unit (> the diagonal block's)
 static_assert(STEP_LDS_BYTES >= POTF2T_LDS_DOUBLES * sizeof(double) && STEP_LDS_BYTES <= 160 * 1024, "LDS budget");
 
 // --------------------------------------------------------------- alpha, logdet, y^T K^-1 y
@@ -964,13 +923,55 @@ static int enable_lds(elfihip_ctx* ctx, K k, size_t bytes) {
 //   potf2(0);  for k = 0 .. nb-1:  trsm(k) | tile (k+1, k+1) -= P P^T | step_kernel(k) = potf2(k+1) beside the trailing update
 // Chain per step: 8 + 5 + max(30, update) us + three same-stream kernel boundaries (1.5-2 us each), against
 // potf2 -> trsm -> look-ahead column -> two event hops (measured 82 us per step at n = 4096) of the stream schedule.
+// The update work of every step comes from the schedule of sweep_sched.hpp, built once per (nb, update workgroups) in
+// this process and uploaded once per GP object and nb.
+static std::mutex g_sched_mutex;
+static std::map<std::pair<int, int>, std::shared_ptr<const SweepSchedule>> g_sched_cache;
+
+static std::shared_ptr<const SweepSchedule> sweep_schedule_for(int nb, int nwg) {
+  std::lock_guard<std::mutex> lock(g_sched_mutex);
+  auto key = std::make_pair(nb, nwg);
+  auto it = g_sched_cache.find(key);
+  if (it != g_sched_cache.end()) return it->second;
+  auto S = std::make_shared<SweepSchedule>();
+  sweep_build(nb, nwg, S.get());
+  g_sched_cache[key] = S;
+  return S;
+}
+
+static int sweep_plan(elfihip_gp* gp, int nb, int nwg, hipStream_t st) {
+  if (gp->sched_nb == nb && gp->sched_nwg == nwg) return ELFIHIP_OK;
+  elfihip_ctx* ctx = gp->ctx;
+  std::shared_ptr<const SweepSchedule> S = sweep_schedule_for(nb, nwg);
+  const size_t ub = S->units.size() * sizeof(SweepUnit), ob = S->wg_off.size() * sizeof(int32_t);
+  // the previous table may still be read by a sweep in flight on this stream
+  ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(st));
+  ELFIHIP_CHECK_HIP(ctx, gp->sched_mem.reserve(ub + ob + 64));
+  char* base = reinterpret_cast<char*>(gp->sched_mem.p);
+  if (ub) ELFIHIP_CHECK_HIP(ctx, hipMemcpy(base, S->units.data(), ub, hipMemcpyHostToDevice));
+  const size_t o_off = (ub + 63) / 64 * 64;
+  if (ob) ELFIHIP_CHECK_HIP(ctx, hipMemcpy(base + o_off, S->wg_off.data(), ob, hipMemcpyHostToDevice));
+  gp->sched_units = base;
+  gp->sched_wgoff = base + o_off;
+  gp->sched_step_off.clear();
+  gp->sched_step_nwg.clear();
+  for (const SweepStep& x : S->steps) {
+    gp->sched_step_off.push_back(x.off0);
+    gp->sched_step_nwg.push_back(x.nwg);
+  }
+  gp->sched_nb = nb;
+  gp->sched_nwg = nwg;
+  return ELFIHIP_OK;
+}
+
 static int sweep_fused(elfihip_gp* gp, int nb, hipStream_t st) {
   elfihip_ctx* ctx = gp->ctx;
   if (!ctx->step_lds_enabled) {
-    ELFIHIP_TRY(enable_lds(ctx, step_kernel<1>, STEP_LDS_BYTES));
-    ELFIHIP_TRY(enable_lds(ctx, step_kernel<2>, STEP_LDS_BYTES));
+    ELFIHIP_TRY(enable_lds(ctx, step_kernel, STEP_LDS_BYTES));
     ctx->step_lds_enabled = true;
   }
+  const int nwg = std::max(8, ctx->cu_count - 8);   // update workgroups: one per CU, the diagonal block's CU and a few spare left out
+  ELFIHIP_TRY(sweep_plan(gp, nb, nwg, st));
   PanelArgs P;
   P.A = gp->A;
   P.WT = gp->WT;
@@ -989,23 +990,13 @@ static int sweep_fused(elfihip_gp* gp, int nb, hipStream_t st) {
     const int m = nb - 1 - k;
     if (m == 0) break;
     hipLaunchKernelGGL(lookahead_tile_kernel<1>, dim3(16), dim3(256), LOOKAHEAD_TILE_LDS, st, P, k + 1);
-    // far block columns c = k+2, k+4, ...: panels k-1 and k; near column k+1: panel k (see step_kernel)
     StepArgs S;
     S.P = P;
     S.W11 = gp->W11;
     S.info = gp->info;
-    S.kbeg = std::max(k - 1, 0);
-    S.nfar = 0;
-    for (int c = k + 2; c < nb; c += 2) S.nfar += (nb - c) + k + 2;
-    S.nnear = (m - 1) + 1 + (k + 1);
-    const int gx = std::max(1, (ctx->cu_count - 1) / 8);   // update workgroups per XCD: one per CU beside workgroup 0
-    const bool halves = step_tail_cost(S.nfar, S.nnear, 2, gx) < step_tail_cost(S.nfar, S.nnear, 1, gx);
-    const int per = ((S.nfar + S.nnear) * (halves ? 2 : 1) + 7) / 8;
-    const int grid = 1 + 8 * std::min(gx, per);
-    if (halves)
-      hipLaunchKernelGGL(step_kernel<1>, dim3(grid), dim3(1024), STEP_LDS_BYTES, st, S);
-    else
-      hipLaunchKernelGGL(step_kernel<2>, dim3(grid), dim3(1024), STEP_LDS_BYTES, st, S);
+    S.units = reinterpret_cast<const SweepUnit*>(gp->sched_units);
+    S.wg_off = reinterpret_cast<const int32_t*>(gp->sched_wgoff) + gp->sched_step_off[k];
+    hipLaunchKernelGGL(step_kernel, dim3(1 + gp->sched_step_nwg[k]), dim3(1024), STEP_LDS_BYTES, st, S);
   }
   return launch_status(ctx, "cholesky sweep (fused steps)");
 }
@@ -1244,6 +1235,7 @@ int elfihip_gp_free(elfihip_gp* gp) {
   if (gp->Pint) (void)hipFree(gp->Pint);
   gp->ws.release();
   gp->ws2.release();
+  gp->sched_mem.release();
   delete gp;
   return ELFIHIP_OK;
 }

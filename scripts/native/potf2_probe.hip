@@ -1,6 +1,7 @@
 // Developer probe: where the 128 x 128 diagonal-block kernel spends its cycles (per wave, panel and phase).
 //   cd scripts/native && hipcc -O3 -std=c++17 --offload-arch=gfx950 -mllvm -amdgpu-mfma-vgpr-form -DELFIHIP_POTF2_STAMP \
-//       -I../../elfi_amd/csrc -I../../include -o potf2_probe potf2_probe.hip -L../../elfi_amd -lelfihip -Wl,-rpath,'$ORIGIN/../../elfi_amd'
+//       -I../../elfi_amd/csrc -I../../include -c -o /tmp/potf2_probe.o potf2_probe.hip && \
+//   hipcc --offload-arch=gfx950 -o potf2_probe /tmp/potf2_probe.o $(ls ../../elfi_amd/csrc/build/*.o | grep -v gp_fit.o)
 //   ./potf2_probe
 // The kernel under test is compiled from gp_fit.hip itself (included below) with the stamps switched on.
 #include "../../elfi_amd/csrc/gp_fit.hip"

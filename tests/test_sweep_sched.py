@@ -1,0 +1,39 @@
+"""The fused sweep's update schedule (elfi_amd/csrc/sweep_sched.hpp) replayed on the host for every block-column count it
+serves: each tile half receives exactly the k range of the factor it must, contiguously and in order, never from a
+panel that is not solved yet, created once (L^-T tiles), complete at its deadline, and never from two workgroups in one
+step.  The header is host-only C++; the checker (tests/native/sweep_sched_check.cpp) is compiled with g++ here."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def checker(tmp_path_factory):
+    gxx = shutil.which('g++')
+    if gxx is None:
+        pytest.skip('no g++')
+    exe = str(tmp_path_factory.mktemp('sched') / 'sweep_sched_check')
+    subprocess.run([gxx, '-O2', '-std=c++17', '-I', os.path.join(ROOT, 'elfi_amd', 'csrc'), '-o', exe,
+                    os.path.join(ROOT, 'tests', 'native', 'sweep_sched_check.cpp')], check=True)
+    return exe
+
+
+@pytest.mark.parametrize('nwg', [248, 96, 8])
+def test_every_schedule_is_complete_and_in_order(checker, nwg):
+    hi = 64 if nwg == 248 else 40
+    r = subprocess.run([checker, '2', str(hi), str(nwg)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('nb')]
+    assert len(lines) == hi - 1 and all(l.rstrip().endswith('ok') for l in lines)
+
+
+def test_the_schedule_levels_the_steps(checker):
+    """n = 4096 (32 block columns) on 248 workgroups: all steps but the first two are as long as the diagonal block."""
+    r = subprocess.run([checker, '32', '32', '248', 'v'], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0
+    steps = [float(x.split('/')[0]) for x in r.stdout.splitlines()[1].split()]
+    assert len(steps) == 31 and max(steps[2:]) <= 36.0 and max(steps) <= 60.0
