@@ -755,7 +755,7 @@ __global__ __launch_bounds__(1024) void step_kernel(StepArgs S) {
     const int kk = P.k + 1;
     double* Akk = P.A + ((int64_t)kk * NB) * P.lda + (int64_t)kk * NB;
     double* Wkk = P.WT + ((int64_t)kk * NB) * P.lda + (int64_t)kk * NB;
-    potf2_tiles_call(Akk, P.lda, Wkk, P.lda, S.W11, S.info, kk, sm);
+    if (S.W11) potf2_tiles_call(Akk, P.lda, Wkk, P.lda, S.W11, S.info, kk, sm);   // (NULL: the update alone, scripts/native/step_probe.hip)
     return;
   }
   constexpr int RT = 1;                 // 16-row MFMA tiles per wave along the rows

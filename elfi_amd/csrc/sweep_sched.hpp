@@ -66,11 +66,13 @@ struct SweepSchedule {
   std::vector<SweepStep> steps;    // nb - 1 of them
 };
 
-// cost model (microseconds), calibrated on MI355X at n = 4096: a half-tile unit costs a fixed part (old and new C,
-// pipeline fill) plus 2.6 us per k-tile; the chain of a step (diagonal block beside the update, panel solve, diagonal
-// tile) is 35 + 16.
-constexpr double SWEEP_UNIT_FIXED_US = 1.0;
-constexpr double SWEEP_UNIT_KT_US = 2.6;
+// cost model (microseconds), measured on MI355X with scripts/native/step_probe.hip (248 workgroups, 1 / 2 / 4 units each,
+// 2 ... 52 k-tiles deep): a workgroup needs 7 us before its first unit multiplies (launch, offset and unit records,
+// the first operands), a unit 2.1 us (old and new C values, refilling the pipeline) plus 2.05 us per k-tile.  The
+// chain of a step: the diagonal block beside the update 35 us, panel solve and diagonal tile 16.
+constexpr double SWEEP_WG_START_US = 7.0;
+constexpr double SWEEP_UNIT_FIXED_US = 2.1;
+constexpr double SWEEP_UNIT_KT_US = 2.05;
 constexpr double SWEEP_POTF2_US = 35.0;
 constexpr double SWEEP_CHAIN_US = 16.0;
 
@@ -192,7 +194,7 @@ inline double sweep_simulate(int nb, int nwg, double T, int ktmax, SweepSchedule
         sweep_touch_units(nb, c, rem[c] - x, rem[c], false, tu2);
         tally(tu, -1);
         tally(tu2, 1);
-        if (sweep_bins_needed(count, std::max(max_nkt, x), T) <= nwg) {
+        if (sweep_bins_needed(count, std::max(max_nkt, x), T - SWEEP_WG_START_US) <= nwg) {
           take[c] = x;
           max_nkt = std::max(max_nkt, x);
           break;
@@ -220,7 +222,7 @@ inline double sweep_simulate(int nb, int nwg, double T, int ktmax, SweepSchedule
       std::vector<char> placed(units.size(), 0);
       size_t first = 0;
       for (int w = 0; w < nwg && first < ord.size(); ++w) {
-        double room = T + 1e-9;
+        double room = T - SWEEP_WG_START_US + 1e-9;
         bool any = false;
         for (size_t p = first; p < ord.size(); ++p) {
           const int i = ord[p];
@@ -247,6 +249,7 @@ inline double sweep_simulate(int nb, int nwg, double T, int ktmax, SweepSchedule
         loads[w] += sweep_unit_cost(units[i].nkt);
       }
       for (int w = 0; w < nwg; ++w) worst = std::max(worst, loads[w]);
+      worst += SWEEP_WG_START_US;
     }
     makespan[k] = worst;
     total += std::max(SWEEP_POTF2_US, worst) + SWEEP_CHAIN_US;
@@ -304,14 +307,14 @@ inline void sweep_build(int nb, int nwg, SweepSchedule* S) {
     work += 2.0 * ((double)(nb - c + 1) * 4 * c - 4);
     for (int r = 0; r < c; ++r) work += 2.0 * (4 * c - 4 * r);
   }
-  const double avg = 1.04 * work * SWEEP_UNIT_KT_US / ((double)std::max(1, nb - 1) * nwg);
+  const double avg = SWEEP_WG_START_US + 1.12 * work * SWEEP_UNIT_KT_US / ((double)std::max(1, nb - 1) * nwg);
   const double T0 = std::max(SWEEP_POTF2_US, avg);
   static const double F[] = {1.0, 1.03, 1.06, 1.12};
   double best = -1.0, bT = T0;
   int bk = 8;
   for (double f : F) {
     const double T = T0 * f;
-    const int big = std::min(SWEEP_MAX_NKT, std::max(4, (int)((T - SWEEP_UNIT_FIXED_US) / SWEEP_UNIT_KT_US)));
+    const int big = std::min(SWEEP_MAX_NKT, std::max(4, (int)((T - SWEEP_WG_START_US - SWEEP_UNIT_FIXED_US) / SWEEP_UNIT_KT_US)));
     const double t = sweep_simulate(nb, nwg, T, big, nullptr);
     if (best < 0.0 || t < best) {
       best = t;
