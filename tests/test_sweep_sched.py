@@ -32,8 +32,9 @@ def test_every_schedule_is_complete_and_in_order(checker, nwg):
 
 
 def test_the_schedule_levels_the_steps(checker):
-    """n = 4096 (32 block columns) on 248 workgroups: all steps but the first two are as long as the diagonal block."""
+    """n = 4096 (32 block columns) on 248 workgroups: every step's update is about as long as the diagonal block (35 us)
+    -- the plain right-looking order has three units per workgroup (63 us) in the first third and idles in the last."""
     r = subprocess.run([checker, '32', '32', '248', 'v'], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0
     steps = [float(x.split('/')[0]) for x in r.stdout.splitlines()[1].split()]
-    assert len(steps) == 31 and max(steps[2:]) <= 36.0 and max(steps) <= 60.0
+    assert len(steps) == 31 and max(steps) <= 42.0 and max(steps) <= 1.1 * sorted(steps)[15]
