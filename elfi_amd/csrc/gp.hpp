@@ -49,6 +49,7 @@ struct elfihip_gp {
   elfihip::DevBuf sched_mem;
   const void* sched_units = nullptr;
   const void* sched_wgoff = nullptr;
+  const void* sched_heads = nullptr;
   std::vector<int> sched_step_off, sched_step_nwg;   // per step: first offset entry, workgroups with work
   int sched_nb = 0, sched_nwg = 0;
   // per-phase device timing (elfihip_gp_profile): HIP events around the phases of a fit / prediction / gradient call

@@ -478,6 +478,59 @@ __global__ __launch_bounds__(256) void trsm_gemm_kernel(PanelArgs P) {
   acc32_foreach(acc, [&](int row, int col, double v) { Pb[(int64_t)row * P.lda + col] = v; });
 }
 
+// The panel solve for the fused sweep, where it sits on the critical chain of every step: ONE memory round trip per
+// workgroup and only the lower triangle of W11.  A workgroup owns 16 rows of a row block (8 workgroups per block: one
+// per CU at n = 4096); each lane loads the MFMA operands of its wave straight from global memory -- the 16 x 128 strip of
+// the panel (the same for the four waves) and the rows of W11 = L11^-1 of its two 16-column tiles -- all loads issued
+// before the first wait, no LDS.  W11 is lower triangular: column tile t needs k < 16 (t + 1) only, and wave w takes
+// tiles w and 7 - w (nine 16-deep k blocks each).  k is permuted as in lookahead_tile_kernel (lane group q of MFMA
+// 2o / 2o+1 holds k = 8o + 2q / + 1), so a 16-byte load feeds two MFMAs.  In place: the barrier separates the strip's
+// last read from its first overwrite.  (The LDS-staged 32-row form above: 8.3 us per launch at n = 4096.)
+template <int W>
+__device__ __forceinline__ void trsm16_wave(double* Pb, int64_t lda, const double* W11, int l) {
+  constexpr int T0 = W, T1 = 7 - W;              // the wave's column tiles
+  constexpr int O0 = 2 * (T0 + 1), O1 = 2 * (T1 + 1);   // k octets they need
+  const int q2 = 2 * (l >> 4);
+  const double* pa = Pb + (int64_t)(l & 15) * lda + q2;
+  const double* pb0 = W11 + (int64_t)(16 * T0 + (l & 15)) * NB + q2;
+  const double* pb1 = W11 + (int64_t)(16 * T1 + (l & 15)) * NB + q2;
+  double2 a[O1], b0[O0], b1[O1];
+#pragma unroll
+  for (int o = 0; o < O1; ++o) a[o] = *reinterpret_cast<const double2*>(pa + 8 * o);
+#pragma unroll
+  for (int o = 0; o < O0; ++o) b0[o] = *reinterpret_cast<const double2*>(pb0 + 8 * o);
+#pragma unroll
+  for (int o = 0; o < O1; ++o) b1[o] = *reinterpret_cast<const double2*>(pb1 + 8 * o);
+  v4d c0 = (v4d){0.0, 0.0, 0.0, 0.0}, c1 = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int o = 0; o < O1; ++o) {
+    if (o < O0) {
+      c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[o].x, b0[o].x, c0, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[o].y, b0[o].y, c0, 0, 0, 0);
+    }
+    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[o].x, b1[o].x, c1, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[o].y, b1[o].y, c1, 0, 0, 0);
+  }
+  __syncthreads();   // every wave holds its copy of the strip: it may be overwritten
+  double* po = Pb + (int64_t)(l >> 4) * lda + (l & 15);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    po[(int64_t)(4 * r) * lda + 16 * T0] = c0[r];
+    po[(int64_t)(4 * r) * lda + 16 * T1] = c1[r];
+  }
+}
+
+__global__ __launch_bounds__(256) void trsm16_kernel(PanelArgs P) {
+  double* Pb = panel_block(P, blockIdx.x >> 3) + (int64_t)(blockIdx.x & 7) * 16 * P.lda;
+  const int l = threadIdx.x & 63;
+  switch (threadIdx.x >> 6) {
+    case 0: trsm16_wave<0>(Pb, P.lda, P.W11, l); break;
+    case 1: trsm16_wave<1>(Pb, P.lda, P.W11, l); break;
+    case 2: trsm16_wave<2>(Pb, P.lda, P.W11, l); break;
+    default: trsm16_wave<3>(Pb, P.lda, P.W11, l); break;
+  }
+}
+
 // --------------------------------------------------------------- trailing update on the matrix cores
 // Tiles for block column k (m = nb-1-k remaining block columns):
 //   [0, tA)            Cholesky rows: (i, c), k < c <= i < nb      C -= P_i P_c^T   (SYRK)
@@ -722,7 +775,9 @@ struct StepArgs {
   double* W11;
   int* info;
   const SweepUnit* units;   // the schedule's unit table (all steps)
-  const int32_t* wg_off;    // this step: offsets into `units`, one per update workgroup + 1
+  const int32_t* wg_off;    // this step: offset of every update workgroup's first unit in `units`
+  const SweepUnit* heads;   // this step: every update workgroup's first unit again (pad = its unit count), so that the
+                            // first operand addresses are one load away from the workgroup number
 };
 
 struct StepUnit {
@@ -733,9 +788,8 @@ struct StepUnit {
   int nkt;            // 32-deep k-tiles: K / 32
 };
 
-__device__ __forceinline__ StepUnit step_unit(const StepArgs& S, int i) {
-  const PanelArgs& P = S.P;
-  const int4 r = *reinterpret_cast<const int4*>(S.units + i);   // {row, c | kt0 << 16, nkt | half << 16 | keep << 24, pad}
+__device__ __forceinline__ StepUnit step_decode(const StepArgs& S, const int4 r) {
+  const PanelArgs& P = S.P;   // r = {row, c | kt0 << 16, nkt | half << 16 | keep << 24, pad}
   const int row = r.x, c = r.y & 0xffff, kt0 = (r.y >> 16) & 0xffff;
   const int nkt = r.z & 0xffff, half = (r.z >> 16) & 0xff, keep = (r.z >> 24) & 0xff;
   const double* base = row <= P.nb ? P.A + ((int64_t)row * NB) * P.lda : P.WT + ((int64_t)(row - P.nb - 1) * NB) * P.lda;
@@ -746,6 +800,10 @@ __device__ __forceinline__ StepUnit step_unit(const StepArgs& S, int i) {
   U.keep = keep ? 1.0 : 0.0;
   U.nkt = nkt;
   return U;
+}
+
+__device__ __forceinline__ StepUnit step_unit(const StepArgs& S, int i) {
+  return step_decode(S, *reinterpret_cast<const int4*>(S.units + i));
 }
 
 __global__ __launch_bounds__(1024) void step_kernel(StepArgs S) {
@@ -761,9 +819,10 @@ __global__ __launch_bounds__(1024) void step_kernel(StepArgs S) {
   constexpr int RT = 1;                 // 16-row MFMA tiles per wave along the rows
   constexpr int ROWS = 64 * RT;         // rows of a unit
   constexpr int BUF = (ROWS + 128) * GLP2;  // doubles of one LDS stage: A rows, then B rows
+  const int4 head = *reinterpret_cast<const int4*>(S.heads + (blockIdx.x - 1));
   int u = S.wg_off[blockIdx.x - 1];
-  const int uend = S.wg_off[blockIdx.x];
-  if (u >= uend) return;
+  if (head.w <= 0) return;
+  const int uend = u + head.w;
   const int t = threadIdx.x, l = t & 63, w = t >> 6;
   const int wr = w >> 2, wc = w & 3;
   const int64_t lda = P.lda;
@@ -778,7 +837,7 @@ __global__ __launch_bounds__(1024) void step_kernel(StepArgs S) {
   // The k-tiles of a workgroup's units form ONE stream e = (unit, kt) through two LDS stages: while stage p is
   // multiplied, the next element (in registers since the previous step) is written to stage p^1 and the loads of the
   // element after it are issued -- one barrier per k-tile, and the LDS stores overlap other waves' MFMAs.
-  StepUnit cur = step_unit(S, u);
+  StepUnit cur = step_decode(S, head);
   double2 pa0, pa1, pb0, pb1;
   auto issue = [&](const double* A_, const double* B_) {
     pa0 = *reinterpret_cast<const double2*>(A_ + goff);
@@ -943,16 +1002,28 @@ static int sweep_plan(elfihip_gp* gp, int nb, int nwg, hipStream_t st) {
   if (gp->sched_nb == nb && gp->sched_nwg == nwg) return ELFIHIP_OK;
   elfihip_ctx* ctx = gp->ctx;
   std::shared_ptr<const SweepSchedule> S = sweep_schedule_for(nb, nwg);
+  // every workgroup's first unit of every step once more, contiguous per step (an empty workgroup: count 0)
+  std::vector<SweepUnit> heads;
+  for (const SweepStep& x : S->steps)
+    for (int w = 0; w < nwg; ++w) {
+      const int lo = S->wg_off[x.off0 + w], hi = S->wg_off[x.off0 + w + 1];
+      SweepUnit h = {};
+      if (hi > lo) h = S->units[lo];
+      heads.push_back(h);
+    }
   const size_t ub = S->units.size() * sizeof(SweepUnit), ob = S->wg_off.size() * sizeof(int32_t);
+  const size_t hb = heads.size() * sizeof(SweepUnit);
   // the previous table may still be read by a sweep in flight on this stream
   ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(st));
-  ELFIHIP_CHECK_HIP(ctx, gp->sched_mem.reserve(ub + ob + 64));
+  ELFIHIP_CHECK_HIP(ctx, gp->sched_mem.reserve(ub + ob + hb + 192));
   char* base = reinterpret_cast<char*>(gp->sched_mem.p);
   if (ub) ELFIHIP_CHECK_HIP(ctx, hipMemcpy(base, S->units.data(), ub, hipMemcpyHostToDevice));
-  const size_t o_off = (ub + 63) / 64 * 64;
+  const size_t o_off = (ub + 63) / 64 * 64, h_off = (o_off + ob + 63) / 64 * 64;
   if (ob) ELFIHIP_CHECK_HIP(ctx, hipMemcpy(base + o_off, S->wg_off.data(), ob, hipMemcpyHostToDevice));
+  if (hb) ELFIHIP_CHECK_HIP(ctx, hipMemcpy(base + h_off, heads.data(), hb, hipMemcpyHostToDevice));
   gp->sched_units = base;
   gp->sched_wgoff = base + o_off;
+  gp->sched_heads = base + h_off;
   gp->sched_step_off.clear();
   gp->sched_step_nwg.clear();
   for (const SweepStep& x : S->steps) {
@@ -981,12 +1052,11 @@ static int sweep_fused(elfihip_gp* gp, int nb, hipStream_t st) {
   P.kun = 1;
   hipLaunchKernelGGL(potf2_tiles_kernel<1024>, dim3(1), dim3(1024), POTF2T_LDS_DOUBLES * sizeof(double), st, gp->A,
                      gp->lda, gp->WT, gp->lda, gp->W11, gp->info, 0);
-  const size_t lds32 = GEMM32_LDS_DOUBLES * sizeof(double);
   for (int k = 0; k < nb; ++k) {
     P.k = k;
     P.ku0 = k;
     const int nrows = (nb - 1 - k) + 1 + k;  // below + y block + L^-T rows above
-    hipLaunchKernelGGL(trsm_gemm_kernel, dim3(4 * nrows), dim3(256), lds32, st, P);
+    hipLaunchKernelGGL(trsm16_kernel, dim3(8 * nrows), dim3(256), 0, st, P);
     const int m = nb - 1 - k;
     if (m == 0) break;
     hipLaunchKernelGGL(lookahead_tile_kernel<1>, dim3(16), dim3(256), LOOKAHEAD_TILE_LDS, st, P, k + 1);
@@ -996,6 +1066,7 @@ static int sweep_fused(elfihip_gp* gp, int nb, hipStream_t st) {
     S.info = gp->info;
     S.units = reinterpret_cast<const SweepUnit*>(gp->sched_units);
     S.wg_off = reinterpret_cast<const int32_t*>(gp->sched_wgoff) + gp->sched_step_off[k];
+    S.heads = reinterpret_cast<const SweepUnit*>(gp->sched_heads) + (size_t)k * nwg;
     hipLaunchKernelGGL(step_kernel, dim3(1 + gp->sched_step_nwg[k]), dim3(1024), STEP_LDS_BYTES, st, S);
   }
   return launch_status(ctx, "cholesky sweep (fused steps)");

@@ -47,7 +47,7 @@ struct SweepUnit {   // 16 bytes, read by step_kernel
   int16_t nkt;       // k-tiles (>= 2: the kernel keeps two in flight)
   uint8_t half;      // upper / lower 64 rows
   uint8_t keep;      // 1: C -= P P^T;  0: C = -P P^T
-  int32_t pad;
+  int32_t pad;       // first unit of a workgroup: the number of its units in this step (else 0)
 };
 static_assert(sizeof(SweepUnit) == 16, "unit record layout");
 
@@ -270,7 +270,10 @@ inline double sweep_simulate(int nb, int nwg, double T, int ktmax, SweepSchedule
           return x.half < y.half;
         });
         for (int i : m) out.push_back(units[i]);
-        if (!m.empty()) ++step_active[k];
+        if (!m.empty()) {
+          ++step_active[k];
+          out[out.size() - m.size()].pad = (int32_t)m.size();   // a workgroup's first unit carries its unit count
+        }
       }
       off.push_back((int32_t)out.size());
     }

@@ -21,12 +21,12 @@ int main() {
   CK(hipFuncSetAttribute((const void*)step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)STEP_LDS_BYTES));
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  SweepUnit* dU; int32_t* dO;
-  CK(hipMalloc(&dU, 16 * 8192)); CK(hipMalloc(&dO, 4 * (nwg + 1)));
+  SweepUnit *dU, *dH; int32_t* dO;
+  CK(hipMalloc(&dU, 16 * 8192)); CK(hipMalloc(&dH, 16 * nwg)); CK(hipMalloc(&dO, 4 * (nwg + 1)));
   printf("%5s %4s | %8s  per unit\n", "nkt", "per", "us");
   for (int nkt : {2, 3, 4, 6, 8, 13, 16, 26, 52})
     for (int per : {1, 2, 4}) {
-      std::vector<SweepUnit> U;
+      std::vector<SweepUnit> U, H;
       std::vector<int32_t> O;
       int tile = 0;
       for (int w = 0; w < nwg; ++w) {
@@ -36,15 +36,17 @@ int main() {
           const int c = 16 + (tile / 2) % 16, row = c + ((tile / 2) / 16) % (nb - c);
           SweepUnit u;
           u.row = row; u.c = (int16_t)c; u.kt0 = 0; u.nkt = (int16_t)nkt; u.half = (uint8_t)(tile & 1); u.keep = 1; u.pad = 0;
+          if (i == 0) { u.pad = per; H.push_back(u); }
           U.push_back(u);
         }
       }
       O.push_back((int32_t)U.size());
       CK(hipMemcpy(dU, U.data(), U.size() * 16, hipMemcpyHostToDevice));
       CK(hipMemcpy(dO, O.data(), O.size() * 4, hipMemcpyHostToDevice));
+      CK(hipMemcpy(dH, H.data(), H.size() * 16, hipMemcpyHostToDevice));
       StepArgs S;
       S.P.A = A; S.P.WT = WT; S.P.W11 = nullptr; S.P.lda = lda; S.P.k = 0; S.P.nb = nb; S.P.ku0 = 0; S.P.kun = 1;
-      S.W11 = nullptr; S.info = nullptr; S.units = dU; S.wg_off = dO;
+      S.W11 = nullptr; S.info = nullptr; S.units = dU; S.wg_off = dO; S.heads = dH;
       float best = 1e9f;
       for (int rep = 0; rep < 12; ++rep) {
         CK(hipEventRecord(e0));
