@@ -94,6 +94,14 @@ PROTOTYPES = {
                                        C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
     "elfihip_ma2_distance_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_void_p,
                                            C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "elfihip_gauss_distance": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int64, C.c_int, C.c_void_p,
+                                         C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p]),
+    "elfihip_gauss_distance_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64, C.c_int64, C.c_int,
+                                             C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_void_p]),
+    "elfihip_randn_dev": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int64, C.c_double, C.c_double, C.c_void_p]),
+    "elfihip_random_bits_dev": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int64, C.c_void_p]),
     "elfihip_gp_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, c_void_pp]),
     "elfihip_gp_free": (C.c_int, [C.c_void_p]),
     "elfihip_gp_set_hyper": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double]),

@@ -79,3 +79,33 @@ def ma2_distance(w, t1, t2, observed, ctx=None):
     ctx.call("elfihip_ma2_distance", _lib.ptr(w), n, L - 2, _lib.ptr(t1), _lib.ptr(t2), C.c_double(o[0]),
              C.c_double(o[1]), _lib.ptr(S1), _lib.ptr(S2), _lib.ptr(D))
     return S1, S2, D
+
+
+def gauss_distance(mu, sigma, observed, n_obs=50, z=None, seed=0, stream=0, return_y=False, ctx=None):
+    """Fused Gaussian example (elfi/examples/gauss.py: gauss -> ss_mean, ss_var -> euclidean distance).
+
+    mu, sigma: (batch,) or scalars; observed: the two observed summaries (ss_mean(y_obs), ss_var(y_obs)).
+    z: (batch, n_obs) standard normals as `random_state.standard_normal((batch, n_obs))` draws them -- what
+    ss.norm.rvs(loc=mu, scale=sigma, size=(batch, n_obs), random_state=...) consumes (gauss.py:31-33) -- for results
+    bit-identical to the reference; z=None draws on the device (Philox4x32-10 keyed by `seed`, stream `stream`), in
+    which case the batch size comes from mu / sigma.  Returns (ss_mean, ss_var, d) [, y]."""
+    mu = np.asarray(mu, dtype=np.float64).reshape(-1)
+    sigma = np.asarray(sigma, dtype=np.float64).reshape(-1)
+    if z is not None:
+        z = np.ascontiguousarray(_rows(z))
+        n, n_obs = z.shape
+    else:
+        n = max(mu.shape[0], sigma.shape[0])
+        n_obs = int(n_obs)
+    mu = np.ascontiguousarray(np.broadcast_to(mu, (n,)))
+    sigma = np.ascontiguousarray(np.broadcast_to(sigma, (n,)))
+    o = np.asarray(observed, dtype=np.float64).reshape(-1)
+    if o.shape[0] != 2:
+        raise ValueError('observed must hold the two observed summaries')
+    S1, S2, D = np.empty(n), np.empty(n), np.empty(n)
+    Y = np.empty((n, n_obs)) if return_y else None
+    ctx = ctx or _lib.default_context()
+    ctx.call("elfihip_gauss_distance", _lib.ptr(z), C.c_uint64(int(seed)), C.c_uint64(int(stream)), n, n_obs,
+             _lib.ptr(mu), _lib.ptr(sigma), C.c_double(o[0]), C.c_double(o[1]), _lib.ptr(Y), _lib.ptr(S1), _lib.ptr(S2),
+             _lib.ptr(D))
+    return (S1, S2, D, Y) if return_y else (S1, S2, D)

@@ -220,6 +220,26 @@ int elfihip_ma2_distance(elfihip_ctx* ctx, const double* W, int64_t n, int n_obs
 int elfihip_ma2_distance_dev(elfihip_ctx* ctx, const double* dW, int64_t n, int n_obs, int64_t ldw, const double* dt1,
                              const double* dt2, double obs1, double obs2, double* dS1, double* dS2, double* dD);
 
+/* The Gaussian example model, fused (elfi/examples/gauss.py:11-35 gauss, :142-173 ss_mean / ss_var, :133
+ * elfi.Distance('euclidean', ss_mean, ss_var)): y = z * sigma + mu for n simulations of n_obs observations (what
+ * ss.norm.rvs(loc, scale) computes from standard normals z), S1 = np.mean(y, axis=1), S2 = np.var(y, axis=1),
+ * D = sqrt((S1 - obs_mean)^2 + (S2 - obs_var)^2) -- bit-identical to NumPy / SciPy on the same z -- in one pass.
+ * Z (n, n_obs) holds the standard normals (drawn by the caller from the reference's MT19937 stream when results must
+ * match the reference); Z == NULL draws them on the device: Philox4x32-10, counter = (pair index, stream), key = seed,
+ * Box-Muller, element e of the row-major (n, n_obs) matrix from pair e / 2 -- a pure function of (seed, stream, e).
+ * Y (optional, (n, n_obs)) receives the simulator output.  mu, sigma: n values each. */
+int elfihip_gauss_distance(elfihip_ctx* ctx, const double* Z, uint64_t seed, uint64_t stream, int64_t n, int n_obs,
+                           const double* mu, const double* sigma, double obs_mean, double obs_var, double* Y, double* S1,
+                           double* S2, double* D);
+int elfihip_gauss_distance_dev(elfihip_ctx* ctx, const double* dZ, int64_t ldz, uint64_t seed, uint64_t stream, int64_t n,
+                               int n_obs, const double* dmu, const double* dsigma, double obs_mean, double obs_var,
+                               double* dY, double* dS1, double* dS2, double* dD);
+/* Device-resident synthetic inputs from the same generator: dout[e] = z_e * scale + loc, e < n (the simulator
+ * outputs of BASELINE configs[1] / configs[3]); the raw Philox4x32-10 blocks (4 x uint32 per block, counter =
+ * (block, stream), key = seed) for known-answer tests. */
+int elfihip_randn_dev(elfihip_ctx* ctx, uint64_t seed, uint64_t stream, int64_t n, double loc, double scale, double* dout);
+int elfihip_random_bits_dev(elfihip_ctx* ctx, uint64_t seed, uint64_t stream, int64_t nblocks, uint32_t* dout);
+
 /* ------------------------------------------------------------------- GP surrogate
  * Replaces the GPy model behind elfi.methods.bo.gpy_regression.GPyRegression
  * (elfi/methods/bo/gpy_regression.py:15-364): kernel RBF(variance, lengthscale) + Bias

@@ -87,6 +87,38 @@ def make_ma2(elfi):
     print('ma2_tutorial: batches', S1b.shape, 'threshold', repr(float(res.threshold)))
 
 
+def make_gauss(elfi):
+    """The Gaussian example (elfi/examples/gauss.py) through the reference's own functions: simulator output for known
+    parameters and a known RandomState, both summaries, and the Distance node's operation on them."""
+    from functools import partial
+    import scipy.spatial.distance
+    from elfi.examples import gauss as G
+    from elfi.model.utils import distance_as_discrepancy
+    out = {}
+    for tag, B, n_obs, seed in (('a', 300, 50, 11), ('b', 257, 7, 12), ('c', 48, 200, 13), ('d', 33, 129, 14)):
+        rs = np.random.RandomState(seed)
+        mu = rs.uniform(-1, 9, B)
+        sigma = rs.uniform(0.01, 5.0, B)
+        draw_seed = 1000 + seed
+        y = G.gauss(mu, sigma, n_obs=n_obs, batch_size=B, random_state=np.random.RandomState(draw_seed))
+        y_obs = G.gauss(4, 0.4, n_obs=n_obs, random_state=np.random.RandomState(seed + 50))
+        sm, sv = G.ss_mean(y), G.ss_var(y)
+        om, ov = G.ss_mean(y_obs), G.ss_var(y_obs)
+        d = distance_as_discrepancy(partial(scipy.spatial.distance.cdist, metric='euclidean'), sm, sv, observed=(om, ov))
+        out.update({'mu_' + tag: mu, 'sigma_' + tag: sigma, 'y_' + tag: y, 'ss_mean_' + tag: sm, 'ss_var_' + tag: sv,
+                    'observed_' + tag: np.array([om[0], ov[0]]), 'd_' + tag: d,
+                    'draw_seed_' + tag: np.int64(draw_seed), 'n_obs_' + tag: np.int64(n_obs)})
+    out['cases'] = np.array(['a', 'b', 'c', 'd'])
+    # the whole example model once: what the nodes hand to one another in a batch
+    m = G.get_model(n_obs=50, seed_obs=3)
+    batch = m.generate(200, outputs=['mu', 'sigma', 'gauss', 'ss_mean', 'ss_var', 'd'], seed=5)
+    for k, v in batch.items():
+        out['model_' + k] = v
+    out['model_observed'] = np.array([G.ss_mean(m.observed['gauss'])[0], G.ss_var(m.observed['gauss'])[0]])
+    np.savez_compressed(os.path.join(GOLDEN, 'gauss_example.npz'), **out)
+    print('gauss_example:', [out['y_' + t].shape for t in out['cases']], 'model batch', batch['gauss'].shape)
+
+
 def _trace_adaptive(elfi, simulator, prior, observed, batch_size, seed, calls, tag):
     """Run AdaptiveDistanceSMC on the real reference with a recording AdaptiveDistance."""
     events = []
@@ -265,7 +297,7 @@ def make_weighted(elfi):
 def main(argv):
     os.makedirs(GOLDEN, exist_ok=True)
     elfi = ref_shim.install()
-    which = set(argv) or {'ma2', 'adaptive', 'metrics', 'gp', 'gm', 'posterior', 'weighted', 'docrun'}
+    which = set(argv) or {'ma2', 'gauss', 'adaptive', 'metrics', 'gp', 'gm', 'posterior', 'weighted', 'docrun'}
     if 'ma2' in which:
         make_ma2(elfi)
     if 'adaptive' in which:
@@ -274,6 +306,8 @@ def main(argv):
         make_metrics(elfi)
     if 'gm' in which:
         make_gm(elfi)
+    if 'gauss' in which:
+        make_gauss(elfi)
     if 'weighted' in which:
         make_weighted(elfi)
     if 'gp' in which:
