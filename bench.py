@@ -61,6 +61,8 @@ def parse():
     ap.add_argument("--n", type=int, default=None, help="samples per GPU per step (weak scaling)")
     ap.add_argument("--total", type=int, default=10 ** 7, help="samples per step over all GPUs (strong scaling)")
     ap.add_argument("--m", type=int, default=None, help="summaries per sample (32 distance / 64 adaptive)")
+    ap.add_argument("--data", choices=["device", "torch"], default="device",
+                    help="synthetic inputs from the library's own generator (elfihip_randn_dev, Philox4x32-10) or torch.randn")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bolfi", action="store_true")
     ap.add_argument("--bolfi-iters", type=int, default=50)
@@ -191,6 +193,20 @@ class Job:
         for e in self.ev_free:
             e.record(self.side)
 
+    def randn(self, shape, seed, stream=0, device_gen=True):
+        """Standard normals of the given shape on this rank's GPU: the library's counter-based generator (no torch kernel in
+        the trace), or torch.randn."""
+        import ctypes as C
+        torch = self.torch
+        if not device_gen:
+            gen = torch.Generator(device=self.dev)
+            gen.manual_seed(int(seed) * 1000 + int(stream))
+            return torch.randn(*shape, dtype=torch.float64, device=self.dev, generator=gen)
+        out = torch.empty(*shape, dtype=torch.float64, device=self.dev)
+        self.ctx.call("elfihip_randn_dev", C.c_uint64(int(seed)), C.c_uint64(int(stream)), out.numel(), C.c_double(0.0),
+                      C.c_double(1.0), out.data_ptr())
+        return out
+
     def new_state(self, k):
         """The sampler state of this rank: the k best (distance, global row) pairs so far, on the device."""
         import ctypes as C
@@ -250,14 +266,15 @@ def run_distance(args, job):
     torch, dev, world, rank, ctx = job.torch, job.dev, job.world, job.rank, job.ctx
     m = args.m or 32
     scaling = args.scaling or "weak"
-    n = (args.n or 10 ** 6) if scaling == "weak" else -(-args.total // world)
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(1234 + rank)
+    # weak: every rank its own n rows per step; strong: the job's --total rows split over the ranks (sharding.py)
+    from elfi_amd.sharding import strong_partition
+    n = (args.n or 10 ** 6) if scaling == "weak" else strong_partition(args.total, world)[rank][1]
+    units = world * n if scaling == "weak" else args.total       # distances per step over all ranks
     # NBUF independent batches, visited round-robin: the working set (NBUF x 8nm bytes) exceeds the
     # 256 MiB Infinity Cache, so every step streams its batch from HBM instead of re-hitting the MALL
     NBUF = max(3, int(-(-(400 << 20) // (8 * n * m))))
     NBUF = min(NBUF, 8)
-    Xs = [torch.randn(n, m, dtype=torch.float64, device=dev, generator=gen) for _ in range(NBUF)]
+    Xs = [job.randn((n, m), 1234 + rank, b, args.data == "device") for b in range(NBUF)]
     y = torch.from_numpy(np.random.RandomState(1).randn(1, m)).to(dev)
     outs = [torch.empty(n, dtype=torch.float64, device=dev) for _ in range(2)]
     out_t = torch.empty(n, dtype=torch.float64, device=dev)   # target of the kernel-only timing loop
@@ -322,10 +339,11 @@ def run_distance(args, job):
     except (OSError, ValueError, KeyError):
         pass
     return {
-        "metric": "ABC distances/sec", "value": world * n * args.steps / elapsed, "unit": "distances/s",
+        "metric": "ABC distances/sec", "value": units * args.steps / elapsed, "unit": "distances/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-        "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "scaling": scaling, "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic (device)" if args.data == "device" else "synthetic",
         "config": {"workload": "configs[1]: synthetic Gaussian summaries, %d samples x %d summaries per GPU per step, "
                                "elfi.Distance('euclidean'), inputs resident in HBM" % (n, m),
                    "samples_per_gpu": n, "summaries": m, "layout": "row-major (n,m) f64", "batches_in_rotation": NBUF,
@@ -351,11 +369,10 @@ def run_adaptive(args, job):
     torch, dev, world, rank, ctx = job.torch, job.dev, job.world, job.rank, job.ctx
     m, K = args.m or 64, 3
     scaling = args.scaling or "strong"
-    n = (args.n or 1250000) if scaling == "weak" else -(-args.total // world)
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(100 + rank)
-    X = torch.randn(n, m, dtype=torch.float64, device=dev, generator=gen) * torch.linspace(0.5, 20, m, device=dev,
-                                                                                            dtype=torch.float64)
+    from elfi_amd.sharding import strong_partition
+    n = (args.n or 1250000) if scaling == "weak" else strong_partition(args.total, world)[rank][1]
+    units = world * n if scaling == "weak" else args.total
+    X = job.randn((n, m), 100 + rank, 0, args.data == "device") * torch.linspace(0.5, 20, m, device=dev, dtype=torch.float64)
     y = torch.from_numpy(np.random.RandomState(1).randn(1, m)).to(dev)
     outs = [torch.empty(n, K, dtype=torch.float64, device=dev) for _ in range(2)]
     out_t = torch.empty(n, K, dtype=torch.float64, device=dev)
@@ -414,10 +431,11 @@ def run_adaptive(args, job):
     assert N_ == world * n and np.array_equal(Wh[1], 1.0 / (M2_ / N_)), "device merge differs from the host merge"
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
     return {
-        "metric": "ABC distances/sec", "value": world * n * args.steps / elapsed,
+        "metric": "ABC distances/sec", "value": units * args.steps / elapsed,
         "unit": "distances/s (rows; K=3 nested each)",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-        "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic (device)" if args.data == "device" else "synthetic",
         "config": {"workload": "configs[3]: AdaptiveDistance round, %d samples x %d summaries %s, K=%d nested weights"
                                % (n * world if scaling == "strong" else n, m,
                                   "in total" if scaling == "strong" else "per GPU", K),

@@ -94,6 +94,7 @@ PROTOTYPES = {
                                        C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
     "elfihip_ma2_distance_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_void_p,
                                            C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "elfihip_topk_set_form": (C.c_int, [C.c_void_p, C.c_int]),
     "elfihip_gauss_distance": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int64, C.c_int, C.c_void_p,
                                          C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_void_p]),

@@ -113,6 +113,13 @@ int elfihip_ctx_set_stream(elfihip_ctx* ctx, void* hip_stream) {
   return ELFIHIP_OK;
 }
 
+int elfihip_topk_set_form(elfihip_ctx* ctx, int form) {
+  if (!ctx) return fail(nullptr, ELFIHIP_ERR_ARG, "ctx is NULL");
+  ELFIHIP_REQUIRE(ctx, form == 0 || form == 1, "form %d is neither 0 (resident) nor 1 (nine launches)", form);
+  ctx->topk_form = form;
+  return ELFIHIP_OK;
+}
+
 int elfihip_ctx_synchronize(elfihip_ctx* ctx) {
   if (!ctx) return fail(nullptr, ELFIHIP_ERR_ARG, "ctx is NULL");
   DeviceGuard g(ctx->device);

@@ -38,9 +38,7 @@ static int lcb_minimize_impl(elfihip_gp* gp, const double* starts, int64_t S, co
   std::vector<int64_t> who;
   who.reserve((size_t)S);
   for (int64_t i = 0; i < S; ++i) opt[(size_t)i].init(dim, lo, hi, starts + i * dim, maxiter);
-  int64_t n_eval = 0, n_steps = 0;
-  static const bool trace = std::getenv("ELFIHIP_ACQ_TRACE") != nullptr;  // developer aid: steps and time per call
-  const auto t_begin = std::chrono::steady_clock::now();
+  int64_t n_eval = 0;
   for (;;) {
     who.clear();
     for (int64_t i = 0; i < S; ++i)
@@ -53,7 +51,6 @@ static int lcb_minimize_impl(elfihip_gp* gp, const double* starts, int64_t S, co
     }
     ELFIHIP_TRY(predict_impl(gp, px.data(), A, 1, 1, beta, nullptr, nullptr, nullptr, nullptr, pv.data(), pg.data()));
     n_eval += A;
-    ++n_steps;
     for (int64_t k = 0; k < A; ++k) opt[(size_t)who[k]].feed(pv[(size_t)k], &pg[(size_t)k * dim]);
   }
   for (int64_t i = 0; i < S; ++i) {
@@ -63,11 +60,6 @@ static int lcb_minimize_impl(elfihip_gp* gp, const double* starts, int64_t S, co
     if (iters_out) iters_out[i] = o.iterations();
   }
   if (n_eval_out) *n_eval_out = n_eval;
-  if (trace) {
-    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count();
-    std::fprintf(stderr, "[elfihip] lcb_minimize n=%lld S=%lld: %lld lock-steps, %lld evaluations, %.1f us (%.1f us/step)\n",
-                 (long long)gp->n, (long long)S, (long long)n_steps, (long long)n_eval, us, us / (double)n_steps);
-  }
   return ELFIHIP_OK;
 }
 

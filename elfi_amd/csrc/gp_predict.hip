@@ -572,11 +572,6 @@ static int ensure_ws(elfihip_gp* gp, PredictWs* W, int64_t npass) {
 // ---- a prediction call in four steps: host preparation, input fill, device enqueue, result read.
 // (Replaying the enqueue part from a hipGraph was measured and is slower here: +90 us per launch on
 // this stack for a 9-node graph with two copy nodes, against ~25 us of plain launch cost.)
-static bool zero_copy_disabled() {
-  static const bool off = std::getenv("ELFIHIP_NO_ZERO_COPY") != nullptr;  // developer switch: always stage through copies
-  return off;
-}
-
 int predict_prepare(elfihip_gp* gp, int64_t S, PredictPlan* P) {
   elfihip_ctx* ctx = gp->ctx;
   if (!gp->factored)
@@ -606,7 +601,7 @@ int predict_prepare(elfihip_gp* gp, int64_t S, PredictPlan* P) {
   }
   // copy-free when the call is one group of passes: points from the kernel arguments (one pass, <= 24 dimensions) or
   // read by the first kernel straight from this buffer, results and flags written by the last kernel
-  P->direct = P->npass <= W.group && !zero_copy_disabled();
+  P->direct = P->npass <= W.group;
   P->by_args = P->direct && P->npass == 1 && gp->dp <= QUERY_ARGS_MAX_DP;
   P->flag = reinterpret_cast<unsigned long long*>(gp->h_stage);
   P->n_flags = (int)S;

@@ -532,8 +532,7 @@ int topk_dev_impl(elfihip_ctx* ctx, const double* dD, int64_t n, int64_t stride,
   if (k == 0) return ELFIHIP_OK;
   ELFIHIP_REQUIRE(ctx, dD && dvals && didx, "NULL data pointer");
   hipStream_t st = ctx->stream;
-  const char* multi_env = getenv("ELFIHIP_TOPK_MULTI");  // read per call: the tests exercise both forms in one process
-  const bool multi = multi_env && atoi(multi_env) != 0;
+  const bool multi = ctx->topk_form == 1;   // elfihip_topk_set_form: the tests and the timing script exercise both forms
   if (!multi && !force_multi) {
     // 16 keys per thread and pass at least; at most one workgroup per two CUs, so that two selections running at the
     // same time (two contexts on one GPU) are still resident together

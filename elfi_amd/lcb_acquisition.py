@@ -44,7 +44,8 @@ def _allgather_starts(locs, vals, iters, n_starts, world, device):
     buf[:len(vals), :d] = locs
     buf[:len(vals), d] = vals
     buf[:len(vals), d + 1] = iters
-    t = torch.from_numpy(buf).to(device)
+    from .sharding import collective_device
+    t = torch.from_numpy(buf).to(collective_device(device))
     out = [torch.empty_like(t) for _ in range(world)]
     dist.all_gather(out, t)
     full_l, full_v, full_i = np.empty((n_starts, d)), np.empty(n_starts), np.empty(n_starts, dtype=np.int32)
@@ -104,7 +105,7 @@ class HipLCBSC:
         # same evidence and therefore the same deterministic factorisation), the start points are dealt
         # round-robin over the ranks and the optima are all-gathered (SURVEY.md section 8e, configs[4]).
         self.shard_starts = True
-        self.dist_device = 'cpu'   # 'cuda' under the nccl (RCCL) backend
+        self.dist_device = None    # None: by the process group's backend (sharding.collective_device)
 
     # -- argument handling, same accepted forms and error texts as acquisition.py:75-109
     def _noise_spec(self, noise_var):

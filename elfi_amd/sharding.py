@@ -29,6 +29,27 @@ def owned_batches(n_batches, rank, world_size):
     return list(range(int(rank), int(n_batches), int(world_size)))
 
 
+def strong_partition(total, world_size):
+    """Rows [row0, row0 + rows) of a job of `total` rows for every rank: equal blocks of ceil(total / world), the last
+    ranks take what is left (possibly nothing).  Global row numbers are what the ranks' sampler states carry, so the
+    merged result names rows of the whole job."""
+    total, world_size = int(total), int(world_size)
+    per = -(-total // world_size)
+    return [(min(r * per, total), max(0, min(per, total - r * per))) for r in range(world_size)]
+
+
+def merge_best(states, k):
+    """The k smallest (distance, global row) pairs of the union of the ranks' sampler states, ascending, ties to the
+    lower row -- what Rejection._merge_batch (samplers.py:209-237) would hold had it seen every rank's rows.
+    states: iterable of (values, rows) per rank; unfilled entries are +inf."""
+    vals = np.concatenate([np.asarray(v, dtype=np.float64) for v, _ in states])
+    rows = np.concatenate([np.asarray(r, dtype=np.int64) for _, r in states])
+    keep = np.isfinite(vals)
+    vals, rows = vals[keep], rows[keep]
+    order = np.lexsort((rows, vals))[:int(k)]
+    return vals[order], rows[order]
+
+
 def merge_welford(states):
     """Chan et al. pairwise merge of (count, mean, M2) triples, left to right (fixed order)."""
     N, mean, M2 = 0, 0.0, 0.0
@@ -74,12 +95,24 @@ def _dist():
     return dist
 
 
+def collective_device(device=None):
+    """Where the buffers of a collective live: what the caller says, else what the process group's backend needs --
+    the rank's GPU under nccl (RCCL moves device memory over xGMI), host memory under gloo."""
+    if device is not None:
+        return device
+    dist = _dist()
+    if dist.is_available() and dist.is_initialized() and dist.get_backend() == 'nccl':
+        import torch
+        return torch.device('cuda', torch.cuda.current_device())
+    return 'cpu'
+
+
 def _tensor(a, device):
     import torch
-    return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    return torch.from_numpy(np.ascontiguousarray(a)).to(collective_device(device))
 
 
-def all_gather_small(vec, device='cpu'):
+def all_gather_small(vec, device=None):
     """All-gather a small float64 vector; returns the list in rank order (identical everywhere)."""
     import torch
     dist = _dist()
@@ -91,7 +124,7 @@ def all_gather_small(vec, device='cpu'):
     return [o.cpu().numpy() for o in out]
 
 
-def gather_rows(local, dst=0, device='cpu'):
+def gather_rows(local, dst=0, device=None):
     """Gather per-rank row blocks (possibly of different lengths) to `dst`.
 
     Returns the list of arrays in rank order on `dst`, None elsewhere.  Lengths travel first (one
@@ -132,7 +165,7 @@ class ShardedAdaptiveDistance:
     ranks' states (all-gather + fixed-order Chan merge) so that update_distance() appends the
     same weights on every rank; nested_distance() is purely local."""
 
-    def __init__(self, m, backend=None, device='cpu'):
+    def __init__(self, m, backend=None, device=None):
         self.m = int(m)
         self.backend = backend or HipBackend()
         self.device = device

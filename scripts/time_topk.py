@@ -1,9 +1,10 @@
-"""Developer tool: time elfihip_topk_smallest_dev (ELFIHIP_TOPK_MULTI=1 selects the nine-launch form)."""
+"""Developer tool: time elfihip_topk_smallest_dev.  usage: python scripts/time_topk.py [form]  (1 = nine-launch form)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import elfi_amd
 ctx = elfi_amd.Context(0)
+ctx.call('elfihip_topk_set_form', int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 dev = torch.device('cuda', 0)
 for n, k in [(10**6, 1000), (10**6, 100000), (10**7, 1000), (65536, 100), (4096, 10)]:
     d = torch.rand(n, dtype=torch.float64, device=dev)

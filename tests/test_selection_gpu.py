@@ -5,6 +5,15 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture
+def topk_form(hip_ctx):
+    """Select the implementation for one test (elfihip_topk_set_form), restore the default afterwards."""
+    def choose(form):
+        hip_ctx.call("elfihip_topk_set_form", 1 if form == 'nine-launch' else 0)
+    yield choose
+    hip_ctx.call("elfihip_topk_set_form", 0)
+
+
 def _ref(d, k):
     d = np.asarray(d, dtype=np.float64)
     order = np.lexsort((np.arange(len(d)), np.where(np.isnan(d), np.inf, d), np.isnan(d)))[:k]
@@ -14,9 +23,9 @@ def _ref(d, k):
 @pytest.mark.parametrize('form', ['resident', 'nine-launch'])
 @pytest.mark.parametrize('n,k', [(1, 1), (10, 3), (1000, 1000), (1000, 5000), (4097, 100), (10**6, 1000),
                                  (10**6, 1), (300000, 10000), (2 * 10**6 + 17, 64)])
-def test_smallest_k_matches_numpy(hip_ctx, monkeypatch, form, n, k):
+def test_smallest_k_matches_numpy(hip_ctx, topk_form, form, n, k):
     import elfi_amd
-    monkeypatch.setenv('ELFIHIP_TOPK_MULTI', '1' if form == 'nine-launch' else '0')
+    topk_form(form)
     rs = np.random.RandomState(n + k)
     d = np.abs(rs.randn(n)) * rs.uniform(0.1, 10)
     vals, idx = elfi_amd.smallest_k(d, k)
@@ -25,9 +34,9 @@ def test_smallest_k_matches_numpy(hip_ctx, monkeypatch, form, n, k):
 
 
 @pytest.mark.parametrize('form', ['resident', 'nine-launch'])
-def test_smallest_k_ties_negatives_nan_inf(hip_ctx, monkeypatch, form):
+def test_smallest_k_ties_negatives_nan_inf(hip_ctx, topk_form, form):
     import elfi_amd
-    monkeypatch.setenv('ELFIHIP_TOPK_MULTI', '1' if form == 'nine-launch' else '0')
+    topk_form(form)
     rs = np.random.RandomState(0)
     d = rs.randint(-5, 5, 20000).astype(float)            # massive ties, negative values
     d[::97] = np.nan

@@ -105,6 +105,56 @@ def test_sharded_adaptive_distance_matches_single_process(tmp_path, n_batches):
     np.testing.assert_allclose(got, np.vstack([ref.nested_distance(X, y) for X in data]), rtol=1e-11)
 
 
+def _strong_worker(rank, world, port, total, m, k, out_dir):
+    for p in (ROOT, os.path.join(ROOT, 'oracle'), os.path.join(ROOT, 'tests')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    from elfi_amd import sharding as S
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        X = np.random.RandomState(5).randn(total, m)          # the whole job; a rank touches only its rows
+        y = np.random.RandomState(6).randn(1, m)
+        row0, rows = S.strong_partition(total, world)[rank]
+        best_v, best_r = np.full(k, np.inf), np.full(k, np.iinfo(np.int64).max)
+        steps = 3
+        for st in range(steps):                                # the rank's rows in `steps` pushes, a gather after each
+            lo = row0 + rows * st // steps
+            hi = row0 + rows * (st + 1) // steps
+            d = O.cdist_rows(X[lo:hi], y, 'euclidean')
+            best_v, best_r = S.merge_best([(best_v, best_r), (d, np.arange(lo, hi))], k)
+            pad_v, pad_r = np.full(k, np.inf), np.zeros(k)
+            pad_v[:len(best_v)], pad_r[:len(best_r)] = best_v, best_r
+            got = S.gather_rows(np.column_stack([pad_v, pad_r]), dst=0)      # ONE exchange per step, as bench.py
+            if rank == 0:
+                gv, gr = S.merge_best([(g[:, 0], g[:, 1].astype(np.int64)) for g in got], k)
+        if rank == 0:
+            np.savez(os.path.join(out_dir, 'best.npz'), v=gv, r=gr)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('total', [1001, 64, 3])
+def test_strong_scaling_partition_and_best_k_exchange(tmp_path, total):
+    """--scaling strong: the job's rows are split over the ranks, every rank keeps the best k of ITS rows under global
+    row numbers, rank 0 merges the gathered states: equal to the best k of the whole job."""
+    import torch.multiprocessing as mp
+    from elfi_amd.sharding import strong_partition
+    world, m, k = 2, 5, 40
+    parts = strong_partition(total, world)
+    assert sum(r for _, r in parts) == total and parts[0][0] == 0 and parts[1][0] == parts[0][1]
+    assert strong_partition(10, 4) == [(0, 3), (3, 3), (6, 3), (9, 1)] and strong_partition(2, 4)[2:] == [(2, 0), (2, 0)]
+    mp.spawn(_strong_worker, args=(world, _free_port(), total, m, k, str(tmp_path)), nprocs=world, join=True)
+    got = np.load(tmp_path / 'best.npz')
+    X = np.random.RandomState(5).randn(total, m)
+    y = np.random.RandomState(6).randn(1, m)
+    d = O.cdist_rows(X, y, 'euclidean')
+    order = np.lexsort((np.arange(total), d))[:k]
+    assert np.array_equal(got['r'], order) and np.array_equal(got['v'], d[order])
+
+
 def test_merge_welford_equals_pooled_statistics():
     from elfi_amd.sharding import merge_welford, batch_owner, owned_batches, interleave_batches
     rs = np.random.RandomState(0)
