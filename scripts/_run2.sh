@@ -1,2 +1,3 @@
 set -u
-timeout 600 python -m pytest tests/test_gauss_gpu.py -m gpu -x -q 2>&1 | tail -15
+timeout 900 python -m pytest tests/test_distance_gpu.py -m gpu -x -q 2>&1 | tail -8
+timeout 600 python scripts/bench_kernels.py 2>/dev/null | grep -i "mahal"

@@ -43,6 +43,12 @@ for (n, m) in ((10**6, 32), (1250000, 64), (4 * 10**6, 2)):
         ms = timed(lambda: ctx.call('elfihip_dist_rows_dev', metric, nxt().data_ptr(), n, m, m, y.data_ptr(),
                                     aux.data_ptr() if aux is not None else None, p, out.data_ptr()))
         rows.append(('dist_rows %s' % name, n, m, ms, (8 * m + 8) * n))
+    if m <= 64:
+        A_ = torch.randn(m, m, dtype=torch.float64, device=dev)
+        VI = (A_ @ A_.t() / m + torch.eye(m, dtype=torch.float64, device=dev)).contiguous()
+        ms = timed(lambda: ctx.call('elfihip_dist_rows_dev', 6, nxt().data_ptr(), n, m, m, y.data_ptr(), VI.data_ptr(), 2.0,
+                                    out.data_ptr()))
+        rows.append(('dist_rows mahalanobis (2 m^2 flop/row)', n, m, ms, (8 * m + 8) * n))
     K = 3
     W = torch.rand(K, m, dtype=torch.float64, device=dev) + 0.5
     outk = torch.empty(n, K, dtype=torch.float64, device=dev)

@@ -48,7 +48,10 @@ def _is_exact(metric, kw):
 
 def _check(got, ref, exact, what):
     assert got.shape == ref.shape, what
-    if exact:
+    if 'mahalanobis' in what:
+        # d' VI d on the matrix cores: the additions come in the MFMA's order; SciPy's own come in its BLAS's
+        np.testing.assert_allclose(got, ref, rtol=1e-13, atol=0, err_msg=what)
+    elif exact:
         assert np.array_equal(got, ref), '%s: max rel %g' % (
             what, np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1e-300)))
     else:
@@ -155,6 +158,25 @@ def test_shapes_vs_oracle(hip_ctx, n, m):
             cols = [np.ascontiguousarray(X[:, j]) for j in range(m)]
             got = elfi_amd.cdist_cols(cols, y, metric, **kw)
             assert np.array_equal(got, O.cdist_rows(X, y, metric, **kw)), ('cols', metric, n, m)
+
+
+@pytest.mark.parametrize('n', [1, 15, 64, 65, 1000, 4099])
+@pytest.mark.parametrize('m', [1, 2, 3, 5, 16, 17, 32, 33, 64, 65, 100])
+def test_mahalanobis_shapes_vs_oracle(hip_ctx, n, m):
+    """sqrt(d' VI d): the matrix-core kernel (m <= 64, every padding case of its 4-deep / 16-wide tiles) and the
+    lane-per-row kernel beyond, against SciPy's cdist through the oracle.  VI is a proper inverse covariance with
+    negative off-diagonal entries, so the quadratic form's terms cancel."""
+    import elfi_amd
+    rs = np.random.RandomState(77 * m + n)
+    Z = rs.randn(4 * m + 5, m) @ rs.randn(m, m)
+    VI = np.linalg.inv(np.cov(Z.T).reshape(m, m) + 0.1 * np.eye(m))
+    VI = 0.5 * (VI + VI.T)
+    X, y = rs.randn(n, m) * 2, rs.randn(1, m)
+    big = np.zeros((n, m + 3))
+    big[:, 1:m + 1] = X                                     # a row pitch that is not the width
+    ref = O.cdist_rows(X, y, 'mahalanobis', VI=VI)
+    np.testing.assert_allclose(elfi_amd.cdist_rows(X, y, 'mahalanobis', VI=VI), ref, rtol=1e-13, atol=0)
+    np.testing.assert_allclose(elfi_amd.cdist_rows(big[:, 1:m + 1], y, 'mahalanobis', VI=VI), ref, rtol=1e-13, atol=0)
 
 
 def test_strided_rows_and_dtypes(hip_ctx):
