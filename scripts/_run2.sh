@@ -1,3 +1,4 @@
 set -u
-timeout 900 python -m pytest tests/test_distance_gpu.py -m gpu -x -q 2>&1 | tail -8
-timeout 600 python scripts/bench_kernels.py 2>/dev/null | grep -i "mahal"
+timeout 900 python -m pytest tests/test_gp_gpu.py tests/test_acquisition_gpu.py -m gpu -x -q -k "not large_n and not cfg5" 2>&1 | tail -3
+echo fused; timeout 300 python scripts/time_step.py 4096 10 10 2>&1 | tail -3
+echo separate; ELFIHIP_NO_FUSE=1 timeout 300 python scripts/time_step.py 4096 10 10 2>&1 | tail -3
