@@ -36,6 +36,7 @@ struct elfihip_gp {
   double* alpha = nullptr;  // (cap) K^-1 y
   double* red = nullptr;    // small reduction scratch
   int* info = nullptr;      // device: 1-based index of the first non-positive pivot, 0 if none
+  double* h_fit = nullptr;  // pinned, device-visible: sum log L_ii, z'z and the pivot report of the latest rebuild
   // integration points of ExpIntVar (elfihip_gp_set_integration_points): V_P = L^-1 K(X, P) stored k-major
   double* VP = nullptr;     // (np, m_pad)
   double* Pint = nullptr;   // (m_pad, dp) the points, zero padded

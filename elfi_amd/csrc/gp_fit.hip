@@ -41,6 +41,7 @@ struct GramArgs {
   int64_t lda, n, np;
   int dp;
   double var, neg_half_inv_ls2, bias, diag_add;
+  int* info;   // the factorisation's pivot report: cleared here, by the first kernel of a rebuild
 };
 
 __global__ __launch_bounds__(256) void gram_kernel(GramArgs G) {
@@ -51,6 +52,7 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs G) {
   // decode lower-triangular tile pair (ti >= tj) from the linear block index
   const int64_t nt = G.np / 64;
   int64_t b = blockIdx.x;
+  if (b == 0 && threadIdx.x == 0) *G.info = 0;
   int64_t ti = (int64_t)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
   while (ti * (ti + 1) / 2 > b) --ti;
   while ((ti + 1) * (ti + 2) / 2 <= b) ++ti;
@@ -931,44 +933,62 @@ constexpr size_t STEP_LDS_BYTES = 2 * (64 + 128) * GLP2 * sizeof(double);  // tw
 static_assert(STEP_LDS_BYTES >= POTF2T_LDS_DOUBLES * sizeof(double) && STEP_LDS_BYTES <= 160 * 1024, "LDS budget");
 
 // --------------------------------------------------------------- alpha, logdet, y^T K^-1 y
-// alpha_i = sum_{k >= i} WT[i][k] z_k : one wavefront per row, coalesced along k.
-__global__ void alpha_kernel(const double* WT, const double* z, double* alpha, int64_t n, int64_t np, int64_t lda) {
+// ONE launch.  Workgroups [1, np / 4]: alpha_i = sum_{k >= i} WT[i][k] z_k, one wavefront per row, coalesced along k,
+// eight loads of the row in flight per lane (the long rows at the top of the triangle are what the launch waits for:
+// 24 us with one load per iteration); the sums of the eight strands are added in order.  Workgroup 0:
+// red[0] = sum log L_ii (i < n), red[1] = sum z_i^2 (fixed order), red[2] = the pivot report -- written straight to
+// pinned host memory (two device-to-host copies, 25 us on this stack, replaced by the stream wait alone).
+__global__ __launch_bounds__(256) void alpha_logdet_kernel(const double* WT, const double* A, const double* z, double* alpha,
+                                                           double* red, const int* info, int64_t n, int64_t np, int64_t lda) {
+  if (blockIdx.x == 0) {   // first, so that it is under way while the long rows of the triangle stream
+    __shared__ double s0[256], s1[256];
+    double a = 0.0, b = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 256) {
+      a += log(A[i * lda + i]);
+      b += z[i] * z[i];
+    }
+    s0[threadIdx.x] = a;
+    s1[threadIdx.x] = b;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+      if (threadIdx.x < off) {
+        s0[threadIdx.x] += s0[threadIdx.x + off];
+        s1[threadIdx.x] += s1[threadIdx.x + off];
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {   // `red` is pinned host memory: the rebuild's three scalars need no copy
+      red[0] = s0[0];
+      red[1] = s1[0];
+      red[2] = (double)*info;
+    }
+    return;
+  }
   const int lane = threadIdx.x & 63;
-  const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (row >= np) return;
+  const int64_t row = (int64_t)(blockIdx.x - 1) * 4 + (threadIdx.x >> 6);
   double s = 0.0;
   if (row < n) {
     const double* w = WT + row * lda;
-    for (int64_t k = (row & ~(int64_t)63) + lane; k < n; k += 64)
-      if (k >= row) s += w[k] * z[k];
+    double p[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    int64_t k = (row & ~(int64_t)63) + lane;
+    for (; k + 7 * 64 < n; k += 512) {
+      double wv[8], zv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        wv[u] = w[k + 64 * u];
+        zv[u] = z[k + 64 * u];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) p[u] += (k + 64 * u >= row) ? wv[u] * zv[u] : 0.0;
+    }
+    double tail = 0.0;
+    for (; k < n; k += 64)
+      if (k >= row) tail += w[k] * z[k];
+    s = (((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]))) + tail;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
   }
-  if (lane == 0) alpha[row] = s;
-}
-
-// red[0] = sum log L_ii (i < n), red[1] = sum z_i^2.  Single workgroup, fixed order.
-__global__ void logdet_kernel(const double* A, const double* z, double* red, int64_t n, int64_t lda) {
-  __shared__ double s0[256], s1[256];
-  double a = 0.0, b = 0.0;
-  for (int64_t i = threadIdx.x; i < n; i += 256) {
-    a += log(A[i * lda + i]);
-    b += z[i] * z[i];
-  }
-  s0[threadIdx.x] = a;
-  s1[threadIdx.x] = b;
-  __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) {
-    if (threadIdx.x < off) {
-      s0[threadIdx.x] += s0[threadIdx.x + off];
-      s1[threadIdx.x] += s1[threadIdx.x + off];
-    }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    red[0] = s0[0];
-    red[1] = s1[0];
-  }
+  if (lane == 0 && row < np) alpha[row] = s;
 }
 
 template <class K>
@@ -1041,7 +1061,7 @@ static int sweep_fused(elfihip_gp* gp, int nb, hipStream_t st) {
     ELFIHIP_TRY(enable_lds(ctx, step_kernel, STEP_LDS_BYTES));
     ctx->step_lds_enabled = true;
   }
-  const int nwg = std::max(8, ctx->cu_count - 8);   // update workgroups: one per CU, the diagonal block's CU and a few spare left out
+  const int nwg = std::max(8, ctx->cu_count - 1);   // update workgroups: one per CU beside the diagonal block
   ELFIHIP_TRY(sweep_plan(gp, nb, nwg, st));
   PanelArgs P;
   P.A = gp->A;
@@ -1187,7 +1207,6 @@ int gp_factorize_impl(elfihip_gp* gp) {
   hipStream_t st = ctx->stream;
   const int64_t np = gp->np;
   const int nb = (int)(np / NB);
-  ELFIHIP_CHECK_HIP(ctx, hipMemsetAsync(gp->info, 0, sizeof(int), st));
   prof_mark(gp, 0);
   {
     const int T = 256;
@@ -1206,6 +1225,7 @@ int gp_factorize_impl(elfihip_gp* gp) {
     G.neg_half_inv_ls2 = -0.5 / (gp->ls * gp->ls);
     G.bias = gp->bias;
     G.diag_add = gp->noise + GP_JITTER;
+    G.info = gp->info;
     const int64_t nt = np / 64;
     const size_t lds = 2 * 64 * (size_t)(gp->dp + 1) * sizeof(double);
     hipLaunchKernelGGL(gram_kernel, dim3((unsigned)(nt * (nt + 1) / 2)), dim3(256), lds, st, G);
@@ -1220,16 +1240,13 @@ int gp_factorize_impl(elfihip_gp* gp) {
     ELFIHIP_TRY(sweep_streams(gp, nb, st));
   prof_mark(gp, 2);
   const double* z = gp->A + np * gp->lda;  // row np of A: z = L^-1 y
-  hipLaunchKernelGGL(alpha_kernel, dim3((unsigned)((np * 64 + 255) / 256)), dim3(256), 0, st, gp->WT, z, gp->alpha,
-                     gp->n, np, gp->lda);
-  hipLaunchKernelGGL(logdet_kernel, dim3(1), dim3(256), 0, st, gp->A, z, gp->red, gp->n, gp->lda);
+  hipLaunchKernelGGL(alpha_logdet_kernel, dim3((unsigned)(np / 4 + 1)), dim3(256), 0, st, gp->WT, gp->A, z, gp->alpha,
+                     gp->h_fit, gp->info, gp->n, np, gp->lda);
   ELFIHIP_TRY(launch_status(ctx, "alpha/logdet"));
   prof_mark(gp, 3);
-  double red[2];
-  int info = 0;
-  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(red, gp->red, sizeof red, hipMemcpyDeviceToHost, st));
-  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(&info, gp->info, sizeof info, hipMemcpyDeviceToHost, st));
   ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(st));
+  const double red[2] = {gp->h_fit[0], gp->h_fit[1]};
+  const int info = (int)gp->h_fit[2];
   prof_add(gp, ELFIHIP_PHASE_GRAM, 0, 1);
   prof_add(gp, ELFIHIP_PHASE_SWEEP, 1, 2);
   prof_add(gp, ELFIHIP_PHASE_ALPHA, 2, 3);
@@ -1281,6 +1298,9 @@ int elfihip_gp_create(elfihip_ctx* ctx, int d, int64_t capacity, elfihip_gp** ou
   alloc(&gp->alpha, (size_t)gp->cap * sizeof(double));
   alloc(&gp->red, 64 * sizeof(double));
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&gp->info), sizeof(int));
+  if (e == hipSuccess) e = hipMemsetAsync(gp->info, 0, sizeof(int), ctx->stream);
+  if (e == hipSuccess)
+    e = hipHostMalloc(reinterpret_cast<void**>(&gp->h_fit), 8 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   if (e != hipSuccess) {
     int rc = fail(ctx, e == hipErrorOutOfMemory ? ELFIHIP_ERR_NOMEM : ELFIHIP_ERR_HIP, "GP allocation failed: %s",
@@ -1300,6 +1320,7 @@ int elfihip_gp_free(elfihip_gp* gp) {
     if (p) (void)hipFree(p);
   if (gp->info) (void)hipFree(gp->info);
   if (gp->h_stage) (void)hipHostFree(gp->h_stage);
+  if (gp->h_fit) (void)hipHostFree(gp->h_fit);
   for (auto e : gp->pev)
     if (e) (void)hipEventDestroy(e);
   if (gp->VP) (void)hipFree(gp->VP);
