@@ -499,6 +499,28 @@ __global__ __launch_bounds__(256) void mirror_kernel(const double* WT, double* W
   }
 }
 
+// Prior covariance between two point sets, k(a, b) = s_f exp(-|a - b|^2 / 2 l^2) + s_b -- what GPy's kern.K(X, X2)
+// returns for ELFI's rbf + bias kernel ([GPy-upstream] Stationary._unscaled_dist: (|a|^2 + |b|^2) - 2 a.b clipped at 0,
+// exactly 0 on the diagonal when X2 is None).  One thread per entry.
+__global__ __launch_bounds__(256) void kernel_matrix_kernel(const double* A, const double* B, int64_t na, int64_t nb, int d,
+                                                            double var, double neg_half_inv_ls2, double bias, int same,
+                                                            double* out) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= na * nb) return;
+  const int64_t i = e / nb, j = e - i * nb;
+  double a2 = 0.0, b2 = 0.0, dot = 0.0;
+  for (int c = 0; c < d; ++c) {
+    const double a = A[i * d + c], b = B[j * d + c];
+    a2 += a * a;
+    b2 += b * b;
+    dot += a * b;
+  }
+  double r2 = (a2 + b2) + (-2.0 * dot);
+  r2 = r2 > 0.0 ? r2 : 0.0;
+  if (same && i == j) r2 = 0.0;
+  out[e] = var * exp(r2 * neg_half_inv_ls2) + bias;
+}
+
 // L^-1 (row-wise) for the second triangular product: mirrored from L^-T once per factorisation, on first use
 // (hyper-parameter searches factorise many times without predicting).
 static int ensure_wl(elfihip_gp* gp) {
@@ -1151,6 +1173,31 @@ int elfihip_gp_cross_cov(elfihip_gp* gp, const double* Q, int64_t S, double* cov
     return fail(gp->ctx, ELFIHIP_ERR_STATE, "GP is not factorised (call elfihip_gp_factorize first)");
   DeviceGuard g(gp->ctx->device);
   return cross_cov_impl(gp, Q, S, cov, var_q);
+}
+
+int elfihip_gp_kernel_matrix(elfihip_gp* gp, const double* A, int64_t na, const double* B, int64_t nb, double* out) {
+  if (!gp) return fail(nullptr, ELFIHIP_ERR_ARG, "gp is NULL");
+  elfihip_ctx* ctx = gp->ctx;
+  ELFIHIP_REQUIRE(ctx, na >= 0 && nb >= 0 && (na == 0 || A) && (na * (B ? nb : na) == 0 || out), "bad arguments");
+  const bool same = B == nullptr;
+  if (same) nb = na;
+  if (na == 0 || nb == 0) return ELFIHIP_OK;
+  DeviceGuard g(ctx->device);
+  const int d = gp->d;
+  const size_t n_in = (size_t)(na + (same ? 0 : nb)) * d, n_out = (size_t)na * nb;
+  ELFIHIP_CHECK_HIP(ctx, ctx->in.reserve(n_in * sizeof(double)));
+  ELFIHIP_CHECK_HIP(ctx, ctx->out.reserve(n_out * sizeof(double)));
+  double* dA = ctx->in.as<double>();
+  double* dB = same ? dA : dA + (size_t)na * d;
+  hipStream_t st = ctx->stream;
+  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(dA, A, (size_t)na * d * sizeof(double), hipMemcpyHostToDevice, st));
+  if (!same) ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(dB, B, (size_t)nb * d * sizeof(double), hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(kernel_matrix_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, st, dA, dB, na, nb, d, gp->var,
+                     -0.5 / (gp->ls * gp->ls), gp->bias, same ? 1 : 0, ctx->out.as<double>());
+  ELFIHIP_TRY(launch_status(ctx, "kernel_matrix_kernel"));
+  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(out, ctx->out.p, n_out * sizeof(double), hipMemcpyDeviceToHost, st));
+  ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(st));
+  return ELFIHIP_OK;
 }
 
 }  // extern "C"

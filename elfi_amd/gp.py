@@ -18,6 +18,7 @@ Use:  elfi.BOLFI(model, target_model=HipGPRegression(parameter_names, bounds=bou
 """
 import copy
 import ctypes as C
+import sys
 import logging
 
 import numpy as np
@@ -186,6 +187,15 @@ class GPHandle:
     def form_kinv(self):
         self._check(self.lib.elfihip_gp_form_kinv(self.h))
 
+    def kernel_matrix(self, A, B=None):
+        """Prior covariance k(A, B) (k(A, A) when B is None) under the current hyper-parameters: GPy's kern.K."""
+        A = self._xs(A)
+        Bc = None if B is None else self._xs(B)
+        out = np.empty((A.shape[0], A.shape[0] if Bc is None else Bc.shape[0]))
+        self._check(self.lib.elfihip_gp_kernel_matrix(self.h, _lib.ptr(A), A.shape[0], _lib.ptr(Bc),
+                                                      0 if Bc is None else Bc.shape[0], _lib.ptr(out)))
+        return out
+
     def lcb_minimize(self, starts, bounds, beta, maxiter=1000):
         """Lock-step multi-start minimisation of the LCB; returns (x (S,d), f (S,), iters (S,), n_eval)."""
         starts = self._xs(starts)
@@ -251,10 +261,8 @@ class _GPShim:
         m = self._m
 
         def K(X, X2=None):
-            # acquisition.py:754 (ExpIntVar) evaluates the kernel matrix through GPy; that rule is outside
-            # this package's scope and the product has no host-side arithmetic
-            raise NotImplementedError('kern.K: the kernel matrix is not exposed; ExpIntVar needs the reference '
-                                      'GPyRegression')
+            # acquisition.py:754,770 (the reference's ExpIntVar) evaluates the prior kernel matrix through GPy
+            return m._handle.kernel_matrix(X, X2)
 
         return _Part(K=K, rbf=_Part(variance=_Param(m._hyper['var']), lengthscale=_Param(m._hyper['ls'])),
                      bias=_Part(variance=_Param(m._hyper['bias']),
@@ -289,9 +297,46 @@ class _GPShim:
                 (self.num_data, self._m._log_marginal, h['var'], h['ls'], h['bias'], h['noise']))
 
 
+_REFERENCE_SUBCLASSES = {}
+
+
+def _reference_base():
+    """The reference's GPyRegression class if (and only if) the running program has imported it already."""
+    mod = sys.modules.get('elfi.methods.bo.gpy_regression')
+    return getattr(mod, 'GPyRegression', None) if mod is not None else None
+
+
+def _rebuild_gp(origin, state):
+    obj = origin.__new__(origin)
+    obj.__setstate__(state)
+    return obj
+
+
 class HipGPRegression:
     """Gaussian-process regression on the GPU with the interface of GPyRegression
-    (elfi/methods/bo/gpy_regression.py:15-364)."""
+    (elfi/methods/bo/gpy_regression.py:15-364).
+
+    Code that asks `isinstance(model, GPyRegression)` (elfi/methods/inference/bolfire.py:329-331) is satisfied as well:
+    when the reference's class has been imported by the time an object is made, the object's class is a subclass of
+    BOTH (this class first in the method resolution order, the reference's __init__ never runs); nothing of ELFI or
+    GPy is imported from here."""
+
+    def __new__(cls, *args, **kwargs):
+        base = _reference_base()
+        if base is not None and not issubclass(cls, base):
+            sub = _REFERENCE_SUBCLASSES.get((cls, base))
+            if sub is None:
+                sub = type(cls.__name__, (cls, base), {'__module__': cls.__module__, '__doc__': cls.__doc__,
+                                                       '_hip_origin': cls})
+                _REFERENCE_SUBCLASSES[(cls, base)] = sub
+            cls = sub
+        return object.__new__(cls)
+
+    _hip_origin = None
+
+    def __reduce__(self):
+        # pickle / copy by the importable class: the two-base class is re-derived where the object is rebuilt
+        return _rebuild_gp, (type(self)._hip_origin or type(self), self.__getstate__())
 
     def __init__(self, parameter_names=None, bounds=None, optimizer="scg", max_opt_iters=50, gp=None,
                  device=-1, **gp_params):

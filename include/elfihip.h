@@ -342,6 +342,11 @@ int elfihip_gp_lcb_minimize(elfihip_gp* gp, const double* starts, int64_t S, con
  * predictive variance var_q (S) of the S candidates Q (S, d): one streaming pass over V_P per 128 candidates. */
 int elfihip_gp_set_integration_points(elfihip_gp* gp, const double* P, int64_t M);
 int elfihip_gp_cross_cov(elfihip_gp* gp, const double* Q, int64_t S, double* cov, double* var_q);
+/* The PRIOR covariance between two point sets under the GP's current hyper-parameters, out (na, nb) row-major:
+ * k(a, b) = rbf.variance exp(-|a - b|^2 / 2 lengthscale^2) + bias.variance -- GPy's `kern.K(X, X2)`, which the reference's
+ * ExpIntVar reaches for through `model._gp.kern.K` (elfi/methods/bo/acquisition.py:754,770).  B == NULL: k(A, A) with an
+ * exact diagonal.  Host pointers; no factorisation needed. */
+int elfihip_gp_kernel_matrix(elfihip_gp* gp, const double* A, int64_t na, const double* B, int64_t nb, double* out);
 /* MaxVar / RandMaxVar surface (elfi/methods/bo/acquisition.py:392-463): the variance of the unnormalised approximate
  * posterior prior(x)^2 [Phi_skew(eps) - Phi(eps)^2] at S points and its gradient, from ONE batched prediction with the
  * skew-normal / Owen's-T epilogue on the device (the reference: three single-point GP predictions and SciPy's skewnorm
@@ -375,6 +380,26 @@ int elfihip_lbfgsb_feed(elfihip_lbfgsb* h, int64_t n, const double* f, const dou
  * any of f / iters / status may be NULL. */
 int elfihip_lbfgsb_result(const elfihip_lbfgsb* h, double* x, double* f, int* iters, int* status);
 int elfihip_lbfgsb_free(elfihip_lbfgsb* h);
+
+/* ------------------------------------------------------------------- multi-GPU exchange (one process per GPU)
+ * Replaces the pickled returns of ELFI's batch farm (elfi/client.py:268-274; the per-batch farm-out of
+ * elfi/methods/parameter_inference.py:283-292): the ranks' small per-round results travel device to device over RCCL
+ * (xGMI), and a factorised GP can be handed from one rank to the others.  RCCL (librccl.so) is loaded at run time by the
+ * first of these calls; everything runs on the context's stream and does not synchronise.  Bootstrap as with NCCL: rank 0
+ * calls elfihip_comm_unique_id (128 bytes), hands them to the other ranks by any out-of-band means (the launcher's
+ * rendezvous, a file, MPI), every rank calls elfihip_comm_init_rank with its context (= its GPU). */
+typedef struct elfihip_comm elfihip_comm;
+int elfihip_comm_unique_id(elfihip_ctx* ctx, void* id128);
+int elfihip_comm_init_rank(elfihip_ctx* ctx, const void* id128, int rank, int world_size, elfihip_comm** out);
+int elfihip_comm_free(elfihip_comm* comm);
+/* drecv (world_size * count) in rank order, on every rank / on `root` only (NULL elsewhere). */
+int elfihip_comm_allgather_f64(elfihip_comm* comm, const double* dsend, int64_t count, double* drecv);
+int elfihip_comm_gather_f64(elfihip_comm* comm, const double* dsend, int64_t count, double* drecv, int root);
+int elfihip_comm_bcast_f64(elfihip_comm* comm, double* dbuf, int64_t count, int root);
+/* The root's factorised GP (evidence, hyper-parameters, L, L^-T, K^-1 y, log-marginal terms) to every rank's GP object of
+ * the same input dimension and capacity -- instead of the same rebuild on every GPU (the kernels are deterministic, so
+ * replicas are bit-identical either way); synchronises the stream (a header travels first). */
+int elfihip_comm_bcast_factor(elfihip_comm* comm, elfihip_gp* gp, int root);
 
 #ifdef __cplusplus
 }

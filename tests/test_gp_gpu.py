@@ -2,8 +2,8 @@
 
 Tolerances: L and L^-T relative 1e-10 (of the largest entry), alpha, mu,
 var, gradients, log-marginal relative 1e-8 -- the conditioning of K with the default noise
-max(y)^2/100 is benign.  Hyper-parameter optimisation is "parity unpinned" (see
-oracle/gp_oracle.py) and is tested for self-consistency only.
+max(y)^2/100 is benign.  The hyper-parameter search has its own file (tests/test_gp_hyper_gpu.py: pinned to the
+reference's documented BOLFI run).
 """
 import numpy as np
 import pytest
@@ -310,3 +310,32 @@ def test_large_n_full_matrix_parity(hip_ctx, n, d, schedule):
         _close(grad, G.lcb_evaluate_gradient(post, xs, t), 1e-7, 'lcb grad')
     _, g = gp.nlml_grad()
     assert np.max(np.abs(g - post.log_marginal_grad())) <= 1e-7 * np.max(np.abs(g))
+
+
+def test_prior_kernel_matrix_is_gpys_kern_K(hip_ctx):
+    """`model._gp.kern.K(X, X2)` (what the reference's ExpIntVar evaluates through GPy, acquisition.py:754,770) on the
+    device: rbf + bias with [GPy-upstream] Stationary's squared distances, exact diagonal for X2 = None."""
+    from elfi_amd import HipGPRegression
+    rs = np.random.RandomState(4)
+    names = ['a', 'b', 'c']
+    m = HipGPRegression(names, bounds={k: (-2, 2) for k in names})
+    X, y = rs.uniform(-2, 2, (40, 3)), rs.randn(40, 1)
+    m.update(X, y)
+    m._hyper = dict(var=1.7, ls=0.6, bias=0.3, noise=0.05)
+    m._refit()
+    A, B = rs.uniform(-2, 2, (17, 3)), rs.uniform(-2, 2, (5, 3))
+
+    def ref(P, Q=None):
+        same = Q is None
+        Q = P if same else Q
+        r2 = (np.sum(P * P, 1)[:, None] + np.sum(Q * Q, 1)[None, :]) - 2.0 * P @ Q.T
+        r2 = np.clip(r2, 0, np.inf)
+        if same:
+            np.fill_diagonal(r2, 0.0)
+        return 1.7 * np.exp(-0.5 * r2 / 0.6 ** 2) + 0.3
+
+    np.testing.assert_allclose(m._gp.kern.K(A, B), ref(A, B), rtol=1e-13, atol=1e-15)
+    K = m._gp.kern.K(A)
+    np.testing.assert_allclose(K, ref(A), rtol=1e-13, atol=1e-15)
+    assert np.all(np.diag(K) == 1.7 + 0.3) and K.shape == (17, 17)
+    np.testing.assert_allclose(m._gp.kern.K(X)[:5, :5], ref(X)[:5, :5], rtol=1e-13)

@@ -73,6 +73,27 @@ def test_bolfi_accepts_the_hip_surrogate_and_acquisition(elfi):
     assert gp.n_evidence == 0 and gp.bounds == [(-2, 2), (-1, 1)]
 
 
+def test_surrogate_is_an_instance_of_the_reference_class(elfi):
+    """bolfire.py:329-331 insists on `isinstance(target_model, GPyRegression)`: with the reference imported, objects of
+    HipGPRegression (and of user subclasses) are instances of both classes; our methods come first, pickling and
+    copying go through the importable class."""
+    import copy
+    import elfi_amd
+    from elfi.methods.bo.gpy_regression import GPyRegression
+    gp = elfi_amd.HipGPRegression(['t1', 't2'], bounds={'t1': (-2, 2), 't2': (-1, 1)})
+    assert isinstance(gp, GPyRegression) and isinstance(gp, elfi_amd.HipGPRegression)
+    assert type(gp).__name__ == 'HipGPRegression' and type(gp).__mro__[1] is elfi_amd.HipGPRegression
+    assert type(gp).predict is elfi_amd.HipGPRegression.predict and type(gp).update is elfi_amd.HipGPRegression.update
+    gp2 = pickle.loads(pickle.dumps(gp))
+    assert isinstance(gp2, GPyRegression) and gp2.bounds == gp.bounds and gp2.parameter_names == ['t1', 't2']
+    assert isinstance(copy.copy(gp), GPyRegression) and isinstance(gp.copy(), GPyRegression)
+
+    class Mine(elfi_amd.HipGPRegression):
+        pass
+    assert isinstance(Mine(['a'], bounds={'a': (0, 1)}), GPyRegression)
+    assert type(elfi_amd.HipGPRegression(['a'], bounds={'a': (0, 1)})) is type(gp)      # one derived class, cached
+
+
 @pytest.mark.timeout(180)
 def test_gpu_client_reproduces_the_native_client(elfi):
     import elfi.clients.native as native
