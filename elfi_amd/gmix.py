@@ -66,8 +66,8 @@ class GMDistribution:
         d = mu.shape[1]
         if xa.shape[1] != d:
             raise ValueError('x has %d columns but the means have %d' % (xa.shape[1], d))
-        if d > 16:
-            raise NotImplementedError('GMDistribution on the GPU supports up to 16 dimensions')
+        if d > 64:
+            raise NotImplementedError('GMDistribution on the GPU supports up to 64 dimensions')
         U, log_pdet, rank = _psd_factor(cov, d)
         xa = np.ascontiguousarray(xa)
         mu = np.ascontiguousarray(mu, dtype=np.float64)

@@ -187,7 +187,8 @@ int elfihip_reject_result(elfihip_reject* h, double* vals, int64_t* rows, int64_
  * GMDistribution.pdf (elfi/methods/utils.py:142-183): density of a Gaussian mixture with shared
  * covariance at M points, out[r] = sum_i weights[i] * N(x_r; means[i], cov).  The caller passes the
  * covariance in the factored form SciPy's multivariate_normal uses: U (d x d, row-major) with
- * cov^+ = U U^T, and log_norm = rank*log(2 pi) + log pdet(cov); weights already normalised.  d <= 16. */
+ * cov^+ = U U^T, and log_norm = rank*log(2 pi) + log pdet(cov); weights already normalised.  d <= 64 (above 16 both point sets are
+ * transformed by U once and a pair costs d subtractions). */
 int elfihip_gm_pdf(elfihip_ctx* ctx, const double* x, int64_t M, int d, const double* means, int64_t N,
                    const double* weights, const double* U, double log_norm, double* out);
 

@@ -51,4 +51,20 @@ def test_errors(hip_ctx):
     with pytest.raises(np.linalg.LinAlgError):
         elfi_amd.GMDistribution.pdf(np.zeros((3, 2)), np.zeros((4, 2)), cov=np.ones((2, 2)))
     with pytest.raises(NotImplementedError):
-        elfi_amd.GMDistribution.pdf(np.zeros((3, 17)), np.zeros((4, 17)))
+        elfi_amd.GMDistribution.pdf(np.zeros((3, 65)), np.zeros((4, 65)))
+
+
+@pytest.mark.parametrize('d', [17, 20, 32, 33, 64])
+def test_many_parameters(hip_ctx, d):
+    """16 < d <= 64: both point sets are transformed by the covariance factor once, a pair then costs d subtractions."""
+    import elfi_amd
+    import gm_oracle as GM
+    rs = np.random.RandomState(d)
+    M, N = 777, 300
+    x, means = rs.randn(M, d), rs.randn(N, d) * 0.8
+    A = rs.randn(d, d)
+    cov = A @ A.T / d + 0.5 * np.eye(d)
+    w = rs.uniform(0.5, 1.5, N)
+    ref = GM.pdf(x, means, cov=cov, weights=w)
+    np.testing.assert_allclose(elfi_amd.GMDistribution.pdf(x, means, cov=cov, weights=w), ref, rtol=1e-11, atol=1e-300)
+    np.testing.assert_allclose(elfi_amd.GMDistribution.logpdf(x, means, cov=cov, weights=w), np.log(ref), rtol=1e-11, atol=1e-11)
