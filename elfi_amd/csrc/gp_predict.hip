@@ -100,13 +100,12 @@ __global__ __launch_bounds__(256) void kstar_kernel(const double* X, const doubl
     kr[(int64_t)s * np + i] = k;
     kb[i * PC + s] = i < n ? k + bias : 0.0;  // right-hand side of the first triangular product, [k][s]
   }
-  red[threadIdx.x] = contrib;
+  // fixed order: butterfly inside the wave, then the four waves in order (one barrier instead of nine)
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) contrib += __shfl_xor(contrib, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = contrib;
   __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) {
-    if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) mu_part[s * gridDim.x + blockIdx.x] = red[0];
+  if (threadIdx.x == 0) mu_part[s * gridDim.x + blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
 }
 
 // ---- triangular skinny products on the matrix cores ------------------------------------
@@ -257,7 +256,7 @@ __global__ __launch_bounds__(256) void grad_kernel(const double* __restrict__ X,
                                                    const double* __restrict__ xs, const double* __restrict__ kr,
                                                    const double* __restrict__ part, int nkc,
                                                    double* __restrict__ g_part, int64_t n, int64_t np, int dp) {
-  __shared__ double red[4][PC][8];
+  __shared__ double red[4][PC][32];
   const int t = threadIdx.x, s = t & 15, ig = t >> 4, w = t >> 6;
   xs += (int64_t)blockIdx.y * PC * dp;                 // per-pass slices (blockIdx.y = pass)
   kr += (int64_t)blockIdx.y * PC * np;
@@ -277,35 +276,49 @@ __global__ __launch_bounds__(256) void grad_kernel(const double* __restrict__ X,
     }
   }
   typedef double v4 __attribute__((ext_vector_type(4)));
-  for (int a0 = 0; a0 < dp; a0 += 4) {
-    const v4 x4 = *reinterpret_cast<const v4*>(xs + s * dp + a0);
-    v4 g1 = (v4){0, 0, 0, 0}, g2 = (v4){0, 0, 0, 0};
+  // sixteen dimensions per round (dp <= 16: one round, two barriers): register sums over the thread's rows, two
+  // butterfly steps over the wave's row groups, the four waves in order
+  for (int a0 = 0; a0 < dp; a0 += 16) {
+    v4 g1[4], g2[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const v4 diff = x4 - *reinterpret_cast<const v4*>(X + (i0 + ig + 16 * r) * dp + a0);  // rows < np exist (zeros)
-      g1 += c1[r] * diff;
-      g2 += c2[r] * diff;
-    }
+    for (int q = 0; q < 4; ++q) {
+      g1[q] = (v4){0, 0, 0, 0};
+      g2[q] = (v4){0, 0, 0, 0};
+      if (a0 + 4 * q < dp) {
+        const v4 x4 = *reinterpret_cast<const v4*>(xs + s * dp + a0 + 4 * q);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      g1[j] += __shfl_xor(g1[j], 16, 64);
-      g2[j] += __shfl_xor(g2[j], 16, 64);
-      g1[j] += __shfl_xor(g1[j], 32, 64);
-      g2[j] += __shfl_xor(g2[j], 32, 64);
+        for (int r = 0; r < 4; ++r) {
+          const v4 diff = x4 - *reinterpret_cast<const v4*>(X + (i0 + ig + 16 * r) * dp + a0 + 4 * q);  // rows < np exist (zeros)
+          g1[q] += c1[r] * diff;
+          g2[q] += c2[r] * diff;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          g1[q][j] += __shfl_xor(g1[q][j], 16, 64);
+          g2[q][j] += __shfl_xor(g2[q][j], 16, 64);
+          g1[q][j] += __shfl_xor(g1[q][j], 32, 64);
+          g2[q][j] += __shfl_xor(g2[q][j], 32, 64);
+        }
+      }
     }
     __syncthreads();  // red free
     if ((t & 63) < 16) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        red[w][s][j] = g1[j];
-        red[w][s][4 + j] = g2[j];
-      }
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          red[w][s][4 * q + j] = g1[q][j];
+          red[w][s][16 + 4 * q + j] = g2[q][j];
+        }
     }
     __syncthreads();
-    if (t < PC * 8) {
-      const int ss = t >> 3, j = t & 7;
-      const double v = ((red[0][ss][j] + red[1][ss][j]) + red[2][ss][j]) + red[3][ss][j];
-      g_part[((int64_t)ss * gridDim.x + blockIdx.x) * 2 * dp + (j < 4 ? a0 + j : dp + a0 + j - 4)] = v;
+    for (int e = t; e < PC * 32; e += 256) {
+      const int ss = e >> 5, j = e & 31;
+      const int a = a0 + (j & 15);
+      if (a < dp) {
+        const double v = ((red[0][ss][j] + red[1][ss][j]) + red[2][ss][j]) + red[3][ss][j];
+        g_part[((int64_t)ss * gridDim.x + blockIdx.x) * 2 * dp + (j < 16 ? a : dp + a)] = v;
+      }
     }
   }
 }
@@ -314,18 +327,6 @@ __global__ __launch_bounds__(256) void grad_kernel(const double* __restrict__ X,
 // out layout per pass: mu[16] var[16] val[16] dmu[16*dp] dvar[16*dp] grad[16*dp]
 // One workgroup per query point (blockIdx.x = column s, blockIdx.y = pass): every sum below is a fixed-order
 // reduction of that column's partials.  S_left = real points from the first pass of this launch on.
-__device__ inline double block_sum_256(double* red, double v) {  // fixed tree; every thread gets the total
-  const int t = threadIdx.x;
-  __syncthreads();
-  red[t] = v;
-  __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) {
-    if (t < off) red[t] += red[t + off];
-    __syncthreads();
-  }
-  return red[0];
-}
-
 __global__ __launch_bounds__(256) void finish_kernel(const double* mu_part, int nblk_k, const double* var_part,
                                                      int nblk_v, const double* g_part, int ngc, double* out, int dp,
                                                      int S_left, double prior_var, double noise_add, double inv_ls2,
@@ -357,8 +358,19 @@ __global__ __launch_bounds__(256) void finish_kernel(const double* mu_part, int 
   double m = 0.0, q = 0.0;
   for (int b = t; b < nblk_k; b += 256) m += mu_part[s * nblk_k + b];
   for (int b = t; b < nblk_v; b += 256) q += var_part[(int64_t)b * PC + s];
-  m = block_sum_256(red, m);
-  q = block_sum_256(red, q);
+  // both sums at once: butterfly inside the wave, the four waves in order (two barriers instead of twenty)
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    m += __shfl_xor(m, off, 64);
+    q += __shfl_xor(q, off, 64);
+  }
+  if ((t & 63) == 0) {
+    red[t >> 6] = m;
+    red[4 + (t >> 6)] = q;
+  }
+  __syncthreads();
+  m = ((red[0] + red[1]) + red[2]) + red[3];
+  q = ((red[4] + red[5]) + red[6]) + red[7];
   double v = prior_var - q;
   v = v > 1e-15 ? v : 1e-15;  // [GPy-upstream] predict clips the variance at 1e-15
   if (t == 0) {
