@@ -219,78 +219,10 @@ __device__ __forceinline__ void acc32_foreach(const GemmAcc32& acc, F f) {
       for (int r = 0; r < 4; ++r) f(i * 16 + (l >> 4) + 4 * r, w * 32 + j * 16 + (l & 15), acc.c[i][j][r]);
 }
 
-// ---- the 128 x 128 tile on SIXTEEN waves (1024 threads, 4 x 4 waves of 32 x 32): the form of the fused step kernel
-// (gp_fit.hip), where the workgroups of ONE launch are either the next diagonal block's factorisation (1024 threads)
-// or update tiles.  k-tiles are 32 deep (two 16-byte loads of A and of B per thread and k-tile; 32 MFMAs per wave
-// between barriers, so a k-tile's loads have 8192 matrix-pipe cycles per SIMD to land in).  LDS rows have a 36-double
-// pitch: 16-byte slot = 18 row + q + 4 h, i.e. (2 row + q) mod 16 -- distinct for the 4 x 16 lane groups of
-// ds_read_b128 -- and the ds_write_b128 stores of 8 consecutive lanes fill one 128-byte stretch of a row.
+// ---- staging constants of the fused step kernel (gp_fit.hip: step_kernel): k-tiles are 32 deep (two 16-byte loads of A
+// and of B per thread and k-tile).  LDS rows have a 36-double pitch: 16-byte slot = 18 row + q + 4 h, i.e. (2 row + q)
+// mod 16 -- distinct for the 4 x 16 lane groups of ds_read_b128 -- and the ds_write_b128 stores of 8 consecutive lanes
+// fill one 128-byte stretch of a row.
 constexpr int GK2 = 32;
 constexpr int GLP2 = 36;
-constexpr int GEMM16_LDS_DOUBLES = 2 * GT * GLP2;
-
-// acc += A(128 x K) * B(128 x K)^T for k in [kbeg, kend), both multiples of 32, kbeg < kend.
-__device__ __forceinline__ void gemm_tile_nt16(GemmAcc32& acc, const double* __restrict__ A, int64_t lda,
-                                               const double* __restrict__ B, int64_t ldb, int kbeg, int kend,
-                                               double* lds) {
-  double* As = lds;
-  double* Bs = lds + GT * GLP2;
-  const int t = threadIdx.x, l = t & 63, w = t >> 6;
-  const int wr = w >> 2, wc = w & 3;
-  const double* pa = A + (int64_t)(t >> 4) * lda + 2 * (t & 15) + kbeg;
-  const double* pb = B + (int64_t)(t >> 4) * ldb + 2 * (t & 15) + kbeg;
-  double* da = As + (t >> 4) * GLP2 + 2 * (t & 15);
-  double* db = Bs + (t >> 4) * GLP2 + 2 * (t & 15);
-  double2 a0 = *reinterpret_cast<const double2*>(pa);
-  double2 a1 = *reinterpret_cast<const double2*>(pa + 64 * lda);
-  double2 b0 = *reinterpret_cast<const double2*>(pb);
-  double2 b1 = *reinterpret_cast<const double2*>(pb + 64 * ldb);
-  const double* fa = As + (wr * 32 + (l & 15)) * GLP2 + 2 * (l >> 4);
-  const double* fb = Bs + (wc * 32 + (l & 15)) * GLP2 + 2 * (l >> 4);
-  for (int k0 = kbeg; k0 < kend; k0 += GK2) {
-    __syncthreads();  // previous k-tile fully consumed
-    *reinterpret_cast<double2*>(da) = a0;
-    *reinterpret_cast<double2*>(da + 64 * GLP2) = a1;
-    *reinterpret_cast<double2*>(db) = b0;
-    *reinterpret_cast<double2*>(db + 64 * GLP2) = b1;
-    __syncthreads();
-    if (k0 + GK2 < kend) {  // the next k-tile lands while this one is multiplied
-      pa += GK2;
-      pb += GK2;
-      a0 = *reinterpret_cast<const double2*>(pa);
-      a1 = *reinterpret_cast<const double2*>(pa + 64 * lda);
-      b0 = *reinterpret_cast<const double2*>(pb);
-      b1 = *reinterpret_cast<const double2*>(pb + 64 * ldb);
-    }
-#pragma unroll
-    for (int h = 0; h < 4; ++h) {
-      double2 a[2], b[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        a[i] = *reinterpret_cast<const double2*>(fa + i * 16 * GLP2 + 8 * h);
-        b[i] = *reinterpret_cast<const double2*>(fb + i * 16 * GLP2 + 8 * h);
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          acc.c[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].x, b[j].x, acc.c[i][j], 0, 0, 0);
-          acc.c[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].y, b[j].y, acc.c[i][j], 0, 0, 0);
-        }
-    }
-  }
-}
-
-template <class F>
-__device__ __forceinline__ void acc16_foreach(const GemmAcc32& acc, F f) {
-  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int wr = w >> 2, wc = w & 3;
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) f(wr * 32 + i * 16 + (l >> 4) + 4 * r, wc * 32 + j * 16 + (l & 15), acc.c[i][j][r]);
-}
-
 }  // namespace elfihip
