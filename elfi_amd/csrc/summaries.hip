@@ -209,11 +209,14 @@ static int launch_summary(elfihip_ctx* ctx, SumArgs S) {
   // 8 KiB in flight per workgroup (128 threads x 4 x 16 bytes), eight workgroups per CU: measured best for these
   // streaming kernels (L = 100: mean 5.6 TB/s against 4.9 with 32 KiB tiles and 4.5 with 4 KiB)
   int T;
-  constexpr int U = 4;
+  // the fused MA2 path does several LDS passes per row: whole rounds of 16 rows (eight lanes per row, all 128 lanes busy)
+  // matter more to it than a small tile, so it streams 16 KiB per workgroup (2 10^6 x 102: 0.92 -> 0.79 ms; 32 KiB: 1.00)
+  constexpr int U = KIND == SUM_MA2 ? 8 : 4;
   if (pipe) {
     T = 128;
     int R = 2 * T * U / L;
     if (R > T) R = T;
+    if (KIND == SUM_MA2 && R >= 16) R = R / 16 * 16;
     A.R = R;
   } else {
     // generic path: as many rows per tile as fit a 48 KiB tile, at most 64
