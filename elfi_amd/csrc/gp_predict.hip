@@ -132,10 +132,11 @@ __global__ __launch_bounds__(256) void tri_apply_kernel(TriArgs T) {
   // against B[k][s] from LDS.  All (up to 16) loads of a lane are issued before the first MFMA, so a workgroup
   // has its whole <= 64 KiB in flight at once; the four waves' partial tiles are added in fixed order at the end.
   __shared__ __align__(16) double Bs[KC * PC];  // right-hand sides of this chunk [k][s]; later the wave partials
-  // blockIdx.x = (rb / 8 * npass + pass) * 8 + rb % 8: workgroups are dealt to the 8 XCDs round-robin, so the
-  // passes of one rb land on the same XCD, 8 dispatch slots apart, and share the rows of W in that XCD's L2
-  const int x_lo = blockIdx.x & 7, bq = blockIdx.x >> 3;
-  const int rb = (bq / T.npass) * 8 + x_lo, pass = bq % T.npass, kc = blockIdx.y;
+  // One workgroup serves ALL passes of the launch for its (row block, chunk): the matrix operands stay in registers
+  // and only the right-hand sides change -- with a workgroup per pass every pass pulled its 64 KiB of the matrix
+  // through L2 again (16 passes at n = 8192: 8.6 GB per evaluation round, L2-bound at 1.6 ms against 0.45 ms of
+  // matrix-pipe time).
+  const int rb = blockIdx.x, kc = blockIdx.y;
   if (rb >= T.nrb) return;
   const int64_t i0 = (int64_t)rb * RB;
   int64_t k0 = (int64_t)kc * KC, k1 = k0 + KC;
@@ -151,17 +152,20 @@ __global__ __launch_bounds__(256) void tri_apply_kernel(TriArgs T) {
   const int len = (int)(k1 - k0);
   const int t = threadIdx.x, l = t & 63, w = t >> 6;
   typedef double v2d __attribute__((ext_vector_type(2)));
-  const double* bin = T.bin + ((int64_t)pass * T.np + k0) * PC;
   const int nbr = len / 32, nq = len / 16;  // 16-byte pieces of B per thread, MFMA pairs per wave
   // Straight-line code for every chunk length: pieces past the end of a clipped chunk re-read its last piece
   // (cache hit) and are multiplied by zero right-hand sides.
   v2d breg[8], wr[16];
+  auto load_b = [&](int pass) {
+    const double* bin = T.bin + ((int64_t)pass * T.np + k0) * PC;
 #pragma unroll
-  for (int p = 0; p < 8; ++p) {
-    const int pp = p < nbr ? p : nbr - 1;
-    const v2d x = *reinterpret_cast<const v2d*>(bin + pp * 512 + 2u * (unsigned)t);
-    breg[p] = p < nbr ? x : (v2d){0.0, 0.0};
-  }
+    for (int p = 0; p < 8; ++p) {
+      const int pp = p < nbr ? p : nbr - 1;
+      const v2d x = *reinterpret_cast<const v2d*>(bin + pp * 512 + 2u * (unsigned)t);
+      breg[p] = p < nbr ? x : (v2d){0.0, 0.0};
+    }
+  };
+  load_b(0);
   // uniform row base + 32-bit lane offset
   const double* wbase = T.W + k0 * T.lda + i0;
   const unsigned lane_off = (unsigned)(4 * w + (l >> 4)) * (unsigned)T.lda + 2u * (l & 15);
@@ -170,30 +174,34 @@ __global__ __launch_bounds__(256) void tri_apply_kernel(TriArgs T) {
     const int qq = q < nq ? q : nq - 1;
     wr[q] = *reinterpret_cast<const v2d*>(wbase + (int64_t)16 * qq * T.lda + lane_off);
   }
+  for (int pass = 0; pass < T.npass; ++pass) {
+    if (pass > 0) __syncthreads();   // the previous pass's partial sums have been read
 #pragma unroll
-  for (int p = 0; p < 8; ++p) *reinterpret_cast<v2d*>(Bs + p * 512 + 2 * t) = breg[p];
-  __syncthreads();
-  v4d acc0 = (v4d){0, 0, 0, 0}, acc1 = (v4d){0, 0, 0, 0};
+    for (int p = 0; p < 8; ++p) *reinterpret_cast<v2d*>(Bs + p * 512 + 2 * t) = breg[p];
+    __syncthreads();
+    if (pass + 1 < T.npass) load_b(pass + 1);   // in flight during this pass's products
+    v4d acc0 = (v4d){0, 0, 0, 0}, acc1 = (v4d){0, 0, 0, 0};
 #pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    const double b = Bs[(16 * q + 4 * w + (l >> 4)) * PC + (l & 15)];
-    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(wr[q].x, b, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(wr[q].y, b, acc1, 0, 0, 0);
-  }
-  __syncthreads();
-  // wave partials -> LDS as [w][i local][s] (i local = 2 * (MFMA row) + even/odd), then fixed-order sums
+    for (int q = 0; q < 16; ++q) {
+      const double b = Bs[(16 * q + 4 * w + (l >> 4)) * PC + (l & 15)];
+      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(wr[q].x, b, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(wr[q].y, b, acc1, 0, 0, 0);
+    }
+    __syncthreads();
+    // wave partials -> LDS as [w][i local][s] (i local = 2 * (MFMA row) + even/odd), then fixed-order sums
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int ip = (l >> 4) + 4 * r;
-    Bs[(w * RB + 2 * ip) * PC + (l & 15)] = acc0[r];
-    Bs[(w * RB + 2 * ip + 1) * PC + (l & 15)] = acc1[r];
-  }
-  __syncthreads();
-  double* out = T.part + (((int64_t)pass * T.nkc + kc) * T.nout + i0) * PC;
+    for (int r = 0; r < 4; ++r) {
+      const int ip = (l >> 4) + 4 * r;
+      Bs[(w * RB + 2 * ip) * PC + (l & 15)] = acc0[r];
+      Bs[(w * RB + 2 * ip + 1) * PC + (l & 15)] = acc1[r];
+    }
+    __syncthreads();
+    double* out = T.part + (((int64_t)pass * T.nkc + kc) * T.nout + i0) * PC;
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int e = t + 256 * h;  // (i local, s) = (e >> 4, e & 15)
-    out[e] = ((Bs[e] + Bs[RB * PC + e]) + Bs[2 * RB * PC + e]) + Bs[3 * RB * PC + e];
+    for (int h = 0; h < 2; ++h) {
+      const int e = t + 256 * h;  // (i local, s) = (e >> 4, e & 15)
+      out[e] = ((Bs[e] + Bs[RB * PC + e]) + Bs[2 * RB * PC + e]) + Bs[3 * RB * PC + e];
+    }
   }
 }
 
@@ -556,7 +564,7 @@ static void launch_tri(const elfihip_gp* gp, const PredictWs& W, bool lower, con
   T.nrb = (int)(gp->np / RB);
   T.nkc = W.nkc;
   T.npass = (int)g;
-  const dim3 grid((unsigned)((T.nrb + 7) / 8 * 8) * g, (unsigned)W.nkc);
+  const dim3 grid((unsigned)T.nrb, (unsigned)W.nkc);
   if (lower)
     hipLaunchKernelGGL((tri_apply_kernel<1>), grid, dim3(256), 0, gp->ctx->stream, T);
   else
@@ -1046,8 +1054,7 @@ static int cross_cov_impl(elfihip_gp* gp, const double* Q, int64_t S, double* co
     T.nrb = (int)(m_pad / RB);
     T.nkc = W.nkc;
     T.npass = (int)g;
-    hipLaunchKernelGGL((tri_apply_kernel<2>), dim3((unsigned)((T.nrb + 7) / 8 * 8) * g, (unsigned)W.nkc), dim3(256), 0,
-                       st, T);
+    hipLaunchKernelGGL((tri_apply_kernel<2>), dim3((unsigned)T.nrb, (unsigned)W.nkc), dim3(256), 0, st, T);
     hipLaunchKernelGGL(tri_reduce_kernel, dim3((unsigned)(m_pad * PC / 256), g), dim3(256), 0, st, part2, dot,
                        (double*)nullptr, m_pad, W.nkc, 2, 0);
     hipLaunchKernelGGL(cross_finish_kernel, dim3((unsigned)((M * PC + 255) / 256), g), dim3(256), 0, st, gp->Pint,

@@ -1,9 +1,9 @@
 set -u
-OUT=gpurun_out/r2q; mkdir -p $OUT
-( time timeout 900 python bench.py --no-cpu-baseline ) > $OUT/bench.json 2> $OUT/bench.err; tail -4 $OUT/bench.err
+timeout 1200 python -m pytest tests/test_gp_gpu.py tests/test_acquisition_gpu.py tests/test_maxvar_gpu.py tests/test_posterior_gpu.py tests/test_bolfi_trace_gpu.py -m gpu -x -q -k "not large_n" 2>&1 | tail -3
+timeout 300 python scripts/time_step.py 4096 10 10 2>&1 | tail -3
+timeout 300 python scripts/time_predict.py 2>&1 | tail -12
 python - <<'P'
-import json
-r=json.load(open('gpurun_out/r2q/bench.json'))
-print(r['value'], r['bolfi']['value'], r['bolfi']['ms_fit'], r['bolfi']['ms_acquire'])
-print(r['bolfi']['cfg5'])
+import sys; sys.path.insert(0,'.')
+from elfi_amd import bolfi_bench
+print(bolfi_bench.cfg5_leg())
 P
