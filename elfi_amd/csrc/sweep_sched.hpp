@@ -6,7 +6,7 @@
 // last: updating "everything that can be updated" makes the first third of the steps update-bound (3 units per
 // workgroup, 63 us, measured) and leaves the last third with idle compute units.  But a block column c is only READ
 // when it becomes the panel (step c), so the columns of the factor it still has to receive can wait.  The schedule
-// below gives every step the same update time T -- about what the diagonal block takes anyway, on the 248 compute
+// below gives every step the same update time T -- about what the diagonal block takes anyway, on the 255 compute
 // units it leaves free -- and moves the excess of the early steps to the late ones, where it arrives as deeper updates
 // (K up to 416 instead of 128-256: the tile's values move once).
 //

@@ -22,9 +22,9 @@ def checker(tmp_path_factory):
     return exe
 
 
-@pytest.mark.parametrize('nwg', [248, 96, 8])
+@pytest.mark.parametrize('nwg', [255, 248, 96, 8])
 def test_every_schedule_is_complete_and_in_order(checker, nwg):
-    hi = 64 if nwg == 248 else 40
+    hi = 64 if nwg >= 248 else 40
     r = subprocess.run([checker, '2', str(hi), str(nwg)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('nb')]
@@ -32,9 +32,9 @@ def test_every_schedule_is_complete_and_in_order(checker, nwg):
 
 
 def test_the_schedule_levels_the_steps(checker):
-    """n = 4096 (32 block columns) on 248 workgroups: every step's update is about as long as the diagonal block (35 us)
+    """n = 4096 (32 block columns) on 255 workgroups: every step's update is about as long as the diagonal block (35 us)
     -- the plain right-looking order has three units per workgroup (63 us) in the first third and idles in the last."""
-    r = subprocess.run([checker, '32', '32', '248', 'v'], capture_output=True, text=True, timeout=120)
+    r = subprocess.run([checker, '32', '32', '255', 'v'], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0
     steps = [float(x.split('/')[0]) for x in r.stdout.splitlines()[1].split()]
     assert len(steps) == 31 and max(steps) <= 42.0 and max(steps) <= 1.1 * sorted(steps)[15]
