@@ -37,4 +37,7 @@ def test_the_schedule_levels_the_steps(checker):
     r = subprocess.run([checker, '32', '32', '255', 'v'], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0
     steps = [float(x.split('/')[0]) for x in r.stdout.splitlines()[1].split()]
-    assert len(steps) == 31 and max(steps) <= 42.0 and max(steps) <= 1.1 * sorted(steps)[15]
+    med = sorted(steps)[15]
+    # level from the fourth step on; what does not fit lands in the FIRST steps (backward construction), never at the end
+    assert len(steps) == 31 and 34.0 <= med <= 40.0 and max(steps[3:]) <= 1.05 * med and max(steps[:3]) <= 64.0
+    assert sum(max(s_, 35.0) for s_ in steps) <= 31 * 39.5
