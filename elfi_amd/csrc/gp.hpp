@@ -7,8 +7,9 @@
 
 namespace elfihip {
 constexpr int NB = 128;          // block size of the factorisation (one MFMA GEMM tile)
-constexpr int FUSED_BELOW_NB = 65;  // block columns below which the fused-step schedule is the default (gp_fit.hip):
-                                    // measured ahead of the stream schedule at every size up to n = 8192
+constexpr int FUSED_BELOW_NB = 97;  // block columns below which the fused-step schedule is the default (gp_fit.hip):
+                                    // measured ahead of the stream schedule at every size up to n = 12288 (15.5 against
+                                    // 16.6 ms at n = 10240, 26.0 against 26.3 ms at 12288)
 constexpr double GP_JITTER = 1e-8;  // [GPy-upstream] ExactGaussianInference: Ky = K + (noise + 1e-8) I
 inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 }  // namespace elfihip

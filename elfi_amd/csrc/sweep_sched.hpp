@@ -312,10 +312,13 @@ inline void sweep_build(int nb, int nwg, SweepSchedule* S) {
   }
   const double avg = SWEEP_WG_START_US + 1.12 * work * SWEEP_UNIT_KT_US / ((double)std::max(1, nb - 1) * nwg);
   const double T0 = std::max(SWEEP_POTF2_US, avg);
+  // where the update sets the step length by a wide margin (many block columns) the packing is loose enough for one try
   static const double F[] = {1.0, 1.03, 1.06, 1.12};
+  const int ntry = avg > 2.0 * SWEEP_POTF2_US ? 1 : 4;
   double best = -1.0, bT = T0;
-  int bk = 8;
-  for (double f : F) {
+  int bk = std::min(SWEEP_MAX_NKT, std::max(4, (int)((T0 - SWEEP_WG_START_US - SWEEP_UNIT_FIXED_US) / SWEEP_UNIT_KT_US)));
+  for (int fi = 0; fi < ntry && ntry > 1; ++fi) {
+    const double f = F[fi];
     const double T = T0 * f;
     const int big = std::min(SWEEP_MAX_NKT, std::max(4, (int)((T - SWEEP_WG_START_US - SWEEP_UNIT_FIXED_US) / SWEEP_UNIT_KT_US)));
     const double t = sweep_simulate(nb, nwg, T, big, nullptr);

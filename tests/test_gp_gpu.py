@@ -285,7 +285,8 @@ def test_both_sweep_schedules_vs_oracle(hip_ctx, n, d, schedule, group):
     (4096, 10, 0), (4096, 10, 1), (4096, 10, 2),      # cfg3 metric shape: nb = 32
     (5120, 10, 0), (5120, 10, 1), (5120, 10, 2),      # nb = 40: stream schedule switches to groups of 2 + fine pass
     (6144, 10, 1), (6144, 10, 2),                     # nb = 48: groups of 4 + fine pass
-    (8192, 20, 0), (8192, 20, 1), (8192, 20, 2)])     # cfg5 shape: nb = 64
+    (8192, 20, 0), (8192, 20, 1), (8192, 20, 2),      # cfg5 shape: nb = 64
+    (10240, 10, 0)])                                  # nb = 80: the fused schedule's largest sizes (default up to 96)
 def test_large_n_full_matrix_parity(hip_ctx, n, d, schedule):
     """Every entry of L, L^-T, alpha and the log marginal at the sizes of BASELINE.json configs[2] / configs[4], plus
     mean / variance / gradients / LCB at 64 points, against the CPU posterior (LAPACK)."""

@@ -24,7 +24,7 @@ def checker(tmp_path_factory):
 
 @pytest.mark.parametrize('nwg', [255, 248, 96, 8])
 def test_every_schedule_is_complete_and_in_order(checker, nwg):
-    hi = 64 if nwg >= 248 else 40
+    hi = 96 if nwg == 255 else (64 if nwg == 248 else 40)     # the library runs 255 workgroups up to 96 block columns
     r = subprocess.run([checker, '2', str(hi), str(nwg)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('nb')]
