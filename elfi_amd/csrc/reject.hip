@@ -446,7 +446,13 @@ int elfihip_reject_result(elfihip_reject* h, double* vals, int64_t* rows, int64_
   if (status & 1u)
     return fail(ctx, ELFIHIP_ERR_STATE, "more than %u candidates below the running threshold were offered between two "
                 "merges (batches that improve this much need elfihip_reject_reset between rounds)", h->cap);
-  if (count) *count = h->filled;
+  if (count) {
+    // entries in use: rows offered so far, capped at k, minus the slots NaN distances left empty (a NaN never enters the
+    // state; the reference would list such rows last, after every finite distance)
+    int64_t c = 0;
+    while (c < h->filled && rows[c] != std::numeric_limits<int64_t>::max()) ++c;
+    *count = c;
+  }
   return ELFIHIP_OK;
 }
 

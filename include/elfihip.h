@@ -181,6 +181,9 @@ int elfihip_reject_export_dev(elfihip_reject* h, void* ddst);
  * current k-th distance from above, so nothing is missed.  elfihip_reject_flush merges what is pending now
  * (asynchronous); _result, _state_dev do so themselves. */
 int elfihip_reject_flush(elfihip_reject* h);
+/* vals / rows: k entries each; *count = entries in use.  A NaN distance never enters the state (the reference's argsort
+ * would list such rows last, after every finite distance): while fewer than k finite distances have been seen, count is
+ * their number. */
 int elfihip_reject_result(elfihip_reject* h, double* vals, int64_t* rows, int64_t* count);
 
 /* ------------------------------------------------------------------ SMC proposal density

@@ -223,3 +223,28 @@ def test_running_best_device_batches_nested_and_overflow(hip_ctx):
     dv, dr = _best_ref(d2.cpu().numpy(), k)
     assert np.array_equal(vals, dv) and np.array_equal(rows, dr)
     lib.elfihip_reject_free(h)
+
+
+def test_running_best_ignores_nan_distances(hip_ctx):
+    """NaN distances (a simulator that failed) never enter the state: the count says how many entries are in use while
+    fewer than k finite distances exist; afterwards the state equals the reference merge, which sorts NaN last."""
+    import elfi_amd
+    rs = np.random.RandomState(0)
+    rb = elfi_amd.RunningBest(50, metric='euclidean')
+    y = np.zeros((1, 3))
+    X = rs.randn(40, 3)
+    X[5] = np.nan
+    X[17, 1] = np.nan
+    d = rb.push(X, y)
+    assert np.isnan(d).sum() == 2
+    v, r = rb.result()
+    assert len(v) == 38 and np.all(np.isfinite(v)) and np.array_equal(v, np.sort(d[np.isfinite(d)]))
+    seen = [d]
+    for n, scale in ((1000, 1.0), (5000, 0.1)):
+        X = rs.randn(n, 3) * scale
+        X[::97] = np.nan
+        seen.append(rb.push(X, y))
+        alld = np.concatenate(seen)
+        order = np.lexsort((np.arange(len(alld)), np.where(np.isnan(alld), np.inf, alld), np.isnan(alld)))[:50]
+        v, r = rb.result()
+        assert np.array_equal(r, order) and np.array_equal(v, alld[order])
