@@ -482,8 +482,7 @@ class HipGPRegression:
 
     def _append_and_fit(self, x, y):
         n_old = self._X.shape[0]
-        self._X = np.r_[self._X, x]
-        self._Y = np.r_[self._Y, y]
+        self._host_append(x, y)
         if self._ensure_capacity(self._X.shape[0]) or n_old != self._handle.n:
             self._handle.set_data(self._X, self._Y)
         elif (0 < x.shape[0] <= self.incremental_limit and n_old > 0
@@ -493,6 +492,22 @@ class HipGPRegression:
         else:
             self._handle.append(x, y)
         self._refit()
+
+    def _host_append(self, x, y):
+        """The host copy of the evidence (what `X` / `Y` and `_gp.X` show) in a buffer that grows geometrically: an update
+        copies the new rows only (np.r_ of 4096 x 10 doubles was 50 us of every 1.7 ms rebuild)."""
+        n, k = self._X.shape[0], x.shape[0]
+        buf = getattr(self, '_Xbuf', None)
+        if buf is None or buf.shape[0] < n + k or self._X.base is not buf:
+            cap = max(256, int(1.5 * (n + k)))
+            self._Xbuf = np.empty((cap, self.input_dim))
+            self._Ybuf = np.empty((cap, 1))
+            self._Xbuf[:n] = self._X
+            self._Ybuf[:n] = self._Y
+        self._Xbuf[n:n + k] = x
+        self._Ybuf[n:n + k] = y
+        self._X = self._Xbuf[:n + k]
+        self._Y = self._Ybuf[:n + k]
 
     def _refit(self):
         h = self._hyper
@@ -560,6 +575,10 @@ class HipGPRegression:
     def __getstate__(self):
         st = dict(self.__dict__)
         st['_handle'] = None  # device state is rebuilt on first use after unpickling
+        st.pop('_Xbuf', None)   # growth buffers: rebuilt on the next update
+        st.pop('_Ybuf', None)
+        if st.get('_X') is not None:
+            st['_X'], st['_Y'] = np.array(st['_X']), np.array(st['_Y'])
         st['_gp'] = None if self._gp is None else True
         return st
 
