@@ -44,6 +44,8 @@ struct elfihip_gp {
   int64_t n_int = 0, m_pad = 0;
   unsigned long long fact_gen = 0, vp_gen = 0;  // factorisation counter / the one VP belongs to
   elfihip::DevBuf ws2;      // partials and result tile of the dense product V_P^T v
+  elfihip::DevBuf hyper_items;   // work list of the gradient kernel, cached per padded size (gp_hyper.hip)
+  int64_t hyper_items_key = 0, hyper_items_n = 0;
   // schedule of the factorisation sweep (elfihip_gp_set_schedule): 0 = by size, 1 = streams, 2 = fused steps;
   // panel_group 0 = by size, else 1 / 2 / 4 panels per pass over the trailing matrix (stream schedule)
   int schedule = 0, panel_group = 0;

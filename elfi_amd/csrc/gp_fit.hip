@@ -1327,6 +1327,7 @@ int elfihip_gp_free(elfihip_gp* gp) {
   if (gp->Pint) (void)hipFree(gp->Pint);
   gp->ws.release();
   gp->ws2.release();
+  gp->hyper_items.release();
   gp->sched_mem.release();
   delete gp;
   return ELFIHIP_OK;

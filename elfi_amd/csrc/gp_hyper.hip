@@ -176,6 +176,7 @@ static int hyper_grad_impl(elfihip_gp* gp, bool store_kinv, double* grad) {
   // work list: (tile, k chunk) with chunks of about total depth / (2 workgroups per CU), longest first
   static thread_local std::vector<HyperItem> items;
   items.clear();
+  const bool cached = gp->hyper_items_key == (store_kinv ? -np : np);
   int64_t depth = 0;
   for (int64_t ti = 0; ti < nt; ++ti) depth += (ti + 1) * (np - ti * NB);
   // measured (nlml_grad, ms): n=2048: 0.40 uncut, 0.26 with chunks of 512; n=4096: 0.83 uncut, 0.66 with 1024;
@@ -183,7 +184,7 @@ static int hyper_grad_impl(elfihip_gp* gp, bool store_kinv, double* grad) {
   int64_t kchunk = round_up(depth / ((int64_t)ctx->cu_count * 3) + 1, 2 * NB);
   if (kchunk < 4 * NB) kchunk = 4 * NB;
   if (store_kinv || kchunk > np) kchunk = np;
-  for (int64_t ti = 0; ti < nt; ++ti)
+  for (int64_t ti = 0; ti < nt && !cached; ++ti)
     for (int64_t tj = 0; tj <= ti; ++tj) {
       const int64_t len = np - ti * NB, nch = (len + kchunk - 1) / kchunk;
       const int64_t per = round_up((len + nch - 1) / nch, NB);  // equal chunks of a tile
@@ -192,12 +193,19 @@ static int hyper_grad_impl(elfihip_gp* gp, bool store_kinv, double* grad) {
     }
   std::stable_sort(items.begin(), items.end(),
                    [](const HyperItem& a, const HyperItem& c) { return a.k1 - a.k0 > c.k1 - c.k0; });
-  const int64_t nitems = (int64_t)items.size();
+  const int64_t nitems = cached ? gp->hyper_items_n : (int64_t)items.size();
   const size_t part_bytes = (size_t)nitems * 4 * sizeof(double);
-  ELFIHIP_CHECK_HIP(ctx, gp->ws.reserve(part_bytes + (size_t)nitems * sizeof(HyperItem)));
-  HyperItem* d_items = reinterpret_cast<HyperItem*>(gp->ws.as<char>() + part_bytes);
-  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(d_items, items.data(), (size_t)nitems * sizeof(HyperItem),
-                                        hipMemcpyHostToDevice, st));
+  ELFIHIP_CHECK_HIP(ctx, gp->ws.reserve(part_bytes));
+  // the work list depends on the padded size only: uploaded once per size (a search evaluates ~100 gradients at one size)
+  const int64_t list_key = store_kinv ? -np : np;
+  if (gp->hyper_items_key != list_key) {
+    ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(st));   // a launch in flight may still read the old list
+    ELFIHIP_CHECK_HIP(ctx, gp->hyper_items.reserve((size_t)nitems * sizeof(HyperItem)));
+    ELFIHIP_CHECK_HIP(ctx, hipMemcpy(gp->hyper_items.p, items.data(), (size_t)nitems * sizeof(HyperItem), hipMemcpyHostToDevice));
+    gp->hyper_items_key = list_key;
+    gp->hyper_items_n = nitems;
+  }
+  HyperItem* d_items = gp->hyper_items.as<HyperItem>();
   HyperArgs H;
   H.items = d_items;
   H.WT = gp->WT;
@@ -220,12 +228,11 @@ static int hyper_grad_impl(elfihip_gp* gp, bool store_kinv, double* grad) {
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   prof_mark(gp, 0);
   hipLaunchKernelGGL(kinv_grad_kernel, dim3((unsigned)nitems), dim3(256), lds, st, H);
-  hipLaunchKernelGGL(hyper_reduce_kernel, dim3(1), dim3(256), 0, st, H.part, nitems, gp->red);
+  hipLaunchKernelGGL(hyper_reduce_kernel, dim3(1), dim3(256), 0, st, H.part, nitems, gp->h_fit + 2);   // pinned: no copy
   prof_mark(gp, 1);
   ELFIHIP_TRY(launch_status(ctx, "kinv_grad_kernel"));
-  double s[4];
-  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(s, gp->red + 2, sizeof s, hipMemcpyDeviceToHost, st));
   ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(st));
+  const double s[4] = {gp->h_fit[4], gp->h_fit[5], gp->h_fit[6], gp->h_fit[7]};
   prof_add(gp, ELFIHIP_PHASE_KINV_GRAD, 0, 1);
   if (store_kinv) gp->has_kinv = true;
   if (grad) {
