@@ -160,13 +160,24 @@ int elfihip_comm_gather_f64(elfihip_comm* c, const double* dsend, int64_t count,
                   "bad arguments");
   if (count == 0) return ELFIHIP_OK;
   DeviceGuard g(ctx->device);
-  // point-to-point under one group: every rank sends its block to the root, the root posts world receives
+  // point-to-point under one group: every rank sends its block to the root, the root posts world receives.  A call
+  // that fails inside the group must not leave it open (every later RCCL call of this thread would be queued into a
+  // group nobody closes): remember the first failure, close the group, then report.
   ELFIHIP_CHECK_RCCL(ctx, g_rccl.GroupStart());
+  int rc = ncclSuccess;
+  const char* what = "";
   if (c->rank == root)
-    for (int r = 0; r < c->world; ++r)
-      ELFIHIP_CHECK_RCCL(ctx, g_rccl.Recv(drecv + (size_t)r * count, (size_t)count, ncclFloat64, r, c->comm, ctx->stream));
-  ELFIHIP_CHECK_RCCL(ctx, g_rccl.Send(dsend, (size_t)count, ncclFloat64, root, c->comm, ctx->stream));
-  ELFIHIP_CHECK_RCCL(ctx, g_rccl.GroupEnd());
+    for (int r = 0; r < c->world && rc == ncclSuccess; ++r) {
+      rc = g_rccl.Recv(drecv + (size_t)r * count, (size_t)count, ncclFloat64, r, c->comm, ctx->stream);
+      what = "ncclRecv";
+    }
+  if (rc == ncclSuccess) {
+    rc = g_rccl.Send(dsend, (size_t)count, ncclFloat64, root, c->comm, ctx->stream);
+    what = "ncclSend";
+  }
+  const int rc_end = g_rccl.GroupEnd();
+  if (rc != ncclSuccess) return fail(ctx, ELFIHIP_ERR_HIP, "%s failed: %s", what, g_rccl.GetErrorString(rc));
+  if (rc_end != ncclSuccess) return fail(ctx, ELFIHIP_ERR_HIP, "ncclGroupEnd failed: %s", g_rccl.GetErrorString(rc_end));
   return ELFIHIP_OK;
 }
 
@@ -187,19 +198,45 @@ int elfihip_comm_bcast_factor(elfihip_comm* c, elfihip_gp* gp, int root) {
   ELFIHIP_REQUIRE(ctx, root >= 0 && root < c->world, "root %d outside [0, %d)", root, c->world);
   DeviceGuard g(ctx->device);
   hipStream_t st = ctx->stream;
-  // header first (host values travel through a device scalar block): evidence count, hyper-parameters, log det, y'K^-1 y
-  double* hdr = gp->red + 16;
-  double h[8] = {(double)gp->n, gp->var, gp->ls, gp->bias, gp->noise, gp->logdet, gp->yKy, gp->factored ? 1.0 : 0.0};
-  if (c->rank == root) {
-    ELFIHIP_REQUIRE(ctx, gp->factored, "the root's GP is not factorised");
-    ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(hdr, h, sizeof h, hipMemcpyHostToDevice, st));
-  }
-  ELFIHIP_CHECK_RCCL(ctx, g_rccl.Broadcast(hdr, hdr, 8, ncclFloat64, root, c->comm, st));
+  // Header first (host values travel through a device scalar block): evidence count, hyper-parameters, log det,
+  // y'K^-1 y, whether the root is factorised at all, and the root's LAYOUT (input dimension, its padding, capacity, row
+  // pitch).  ncclBroadcast does not compare counts across ranks, and the bulk broadcasts below move whole rows at the
+  // local pitch: a receiver laid out differently would be corrupted silently (or hang).  So every rank checks the
+  // header against its own object, the verdicts are all-gathered, and ALL ranks return the same status before any
+  // bulk transfer -- no rank is left waiting in a collective its peers never enter.
+  ELFIHIP_REQUIRE(ctx, c->world <= 64, "bcast_factor supports up to 64 ranks");
+  ELFIHIP_CHECK_HIP(ctx, ctx->par.reserve((12 + 2 * 64) * sizeof(double)));
+  double* hdr = ctx->par.as<double>();          // 12 header doubles, then one verdict per rank, then this rank's own
+  double* verdicts = hdr + 12;
+  double h[12] = {(double)gp->n, gp->var, gp->ls, gp->bias, gp->noise, gp->logdet, gp->yKy, gp->factored ? 1.0 : 0.0,
+                  (double)gp->d, (double)gp->dp, (double)gp->cap, (double)gp->lda};
+  if (c->rank == root) ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(hdr, h, sizeof h, hipMemcpyHostToDevice, st));
+  ELFIHIP_CHECK_RCCL(ctx, g_rccl.Broadcast(hdr, hdr, 12, ncclFloat64, root, c->comm, st));
   ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(h, hdr, sizeof h, hipMemcpyDeviceToHost, st));
   ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(st));
   const int64_t n = (int64_t)h[0];
-  ELFIHIP_REQUIRE(ctx, n >= 1 && n <= gp->cap, "the root's GP holds %lld points, this one has room for %lld", (long long)n,
-                  (long long)gp->cap);
+  // verdict of this rank: 0 fine, 1 root not factorised, 2 no room, 3 different layout
+  double mine = 0.0;
+  if (h[7] != 1.0 || n < 1)
+    mine = 1.0;
+  else if (n > gp->cap)
+    mine = 2.0;
+  else if ((int)h[8] != gp->d || (int)h[9] != gp->dp || (int64_t)h[10] != gp->cap || (int64_t)h[11] != gp->lda)
+    mine = 3.0;
+  double all[64];
+  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(verdicts + 64, &mine, sizeof mine, hipMemcpyHostToDevice, st));
+  ELFIHIP_CHECK_RCCL(ctx, g_rccl.AllGather(verdicts + 64, verdicts, 1, ncclFloat64, c->comm, st));
+  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(all, verdicts, (size_t)c->world * sizeof(double), hipMemcpyDeviceToHost, st));
+  ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(st));
+  for (int r = 0; r < c->world; ++r) {
+    if (all[r] == 0.0) continue;
+    if (all[r] == 1.0) return fail(ctx, ELFIHIP_ERR_STATE, "the root's GP (rank %d) is not factorised", root);
+    if (all[r] == 2.0)
+      return fail(ctx, ELFIHIP_ERR_ARG, "the root's GP holds %lld points, the GP of rank %d has no room for them", (long long)n, r);
+    return fail(ctx, ELFIHIP_ERR_ARG,
+                "the GP of rank %d is laid out differently from the root's (d %d, padded d %d, capacity %lld, pitch %lld): "
+                "create every rank's GP with the same d and capacity", r, (int)h[8], (int)h[9], (long long)h[10], (long long)h[11]);
+  }
   if (c->rank != root) {
     gp->n = n;
     gp->np = round_up(n, NB);
@@ -211,8 +248,7 @@ int elfihip_comm_bcast_factor(elfihip_comm* c, elfihip_gp* gp, int root) {
     gp->yKy = h[6];
   }
   const int64_t np = gp->np;
-  // evidence, factor L (+ the z row block), L^-T, alpha: the rows in use, whole rows (the pitch is the same on all ranks
-  // for equal capacities -- checked through the byte counts RCCL compares)
+  // evidence, factor L (+ the z row block), L^-T, alpha: the rows in use, whole rows (equal pitch on all ranks: checked above)
   ELFIHIP_CHECK_RCCL(ctx, g_rccl.Broadcast(gp->X, gp->X, (size_t)np * gp->dp, ncclFloat64, root, c->comm, st));
   ELFIHIP_CHECK_RCCL(ctx, g_rccl.Broadcast(gp->x2, gp->x2, (size_t)np, ncclFloat64, root, c->comm, st));
   ELFIHIP_CHECK_RCCL(ctx, g_rccl.Broadcast(gp->y, gp->y, (size_t)np, ncclFloat64, root, c->comm, st));
