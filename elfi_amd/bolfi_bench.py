@@ -200,8 +200,12 @@ def cfg5_leg(n=8192, d=20, S=256, refit_every=64, reps=3):
     E = float(np.mean(evals))
     # the two triangular products stream the factor once per 128 points (8 passes share a launch): bytes per round
     rounds = float(np.max(steps))
+    # S = 256 right-hand sides are 64 flop per byte of the factor -- the acquisition of this config is bound
+    # by the FP64 matrix pipes, 2 n^2 + 6 n d + 4 n flops per point evaluation
+    fl = E * (2.0 * n * n + 6.0 * n * d + 4.0 * n)
     return {"n": n, "d": d, "starts": S, "refit_every": refit_every, "ms_fit": 1e3 * t_fit, "ms_acquire": 1e3 * ta,
             "point_evaluations_per_acquire": E, "max_lbfgs_iterations": int(np.max(steps)),
+            "acquire_flops": fl, "acquire_tflops": fl / ta / 1e12, "acquire_frac_mfma": fl / ta / 1e12 / FP64_MFMA_PEAK_TFLOPS,
             "iters_per_s_amortised": 1.0 / (ta + t_fit / refit_every),
             "note": "one GPU holds all %d starts; sharded over 8 GPUs every rank searches %d of them" % (S, S // 8)}
 

@@ -69,6 +69,12 @@ struct elfihip_gp {
   double* h_stage = nullptr;
   size_t h_cap = 0;  // doubles
   unsigned long long done_seq = 0;  // value of the completion flag after the latest single-pass prediction
+  // dense predictor (gp_dense.hip): workspace and pinned staging of calls with many points
+  unsigned* tri_cnt = nullptr;   // 2 x (cap / 32) arrival counters of the fused triangular products (gp_predict.hip)
+  int64_t dense_min = 0;   // points from which a call takes the dense form; 0 = default (elfihip_gp_set_dense_threshold)
+  elfihip::DevBuf ws_dense;
+  double* h_dense = nullptr;
+  size_t hd_cap = 0;  // doubles
 };
 
 namespace elfihip {
@@ -128,4 +134,15 @@ void predict_read(const elfihip_gp* gp, const PredictPlan& P, int64_t S, double*
 // mode 0 = values only, 1 = + gradients.  Any output pointer may be NULL.
 int predict_impl(elfihip_gp* gp, const double* Xs, int64_t S, int mode, int noiseless, double beta, double* mu,
                  double* var, double* dmu, double* dvar, double* val, double* grad);
+// gp_dense.hip: the same for many points (S >= dense_min_points()): both triangular products as dense 64 x 64 MFMA tiles
+int predict_dense_impl(elfihip_gp* gp, const double* Xs, int64_t S, int mode, int noiseless, double beta, double* mu,
+                       double* var, double* dmu, double* dvar, double* val, double* grad);
+int64_t dense_min_points(const elfihip_gp* gp);
+// pieces of gp_predict.hip the dense path shares
+int ensure_wl_public(elfihip_gp* gp);
+void launch_kstar_passes(elfihip_gp* gp, const double* xs, const double* xs2, double* kr, double* kbt, double* mu_part,
+                         int nblk_k, unsigned npass);
+void launch_finish_passes(elfihip_gp* gp, const double* mu_part, int nblk_k, const double* var_part, int nblk_v,
+                          const double* g_part, int ngc, double* out, int s_left, int noiseless, double beta, int mode,
+                          unsigned npass);
 }  // namespace elfihip

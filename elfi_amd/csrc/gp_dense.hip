@@ -1,0 +1,380 @@
+// GP prediction for MANY points at once (S >= ~100): the two triangular products as dense matrix-core GEMMs.
+//
+// Same quantities as gp_predict.hip (GPyRegression.predict / predictive_gradients,
+// elfi/methods/bo/gpy_regression.py:127-140,206-218; the lock-step of the multi-start search of
+// elfi/methods/bo/utils.py:97-103 when BASELINE configs[4] asks for 256 starts; many-chain posterior sampling):
+//
+//   V = L^-1 KB^T     V[i][s] = sum_{k <= i} WL[i][k] KB[s][k]       WL = L^-1 (row-major, gp->WL)
+//   U = L^-T V        U[i][s] = sum_{k >= i} WT[i][k] VT[s][k]       WT = L^-T (row-major, gp->WT)
+//
+// With S right-hand sides the products have S/4 flops per byte of the factor: from S ~ 50 on they are
+// bound by the FP64 matrix pipes, not by HBM.  The streaming kernel of gp_predict.hip pushes 16 columns per pass through
+// (row block, k chunk) workgroups and leaves split-k partials [pass][chunk][i][s] behind -- 33 MB written and re-read
+// per pass and product at n = 8192 -- which is the right shape for S <= 16..64 (one read of the factor, nothing else
+// matters) and the wrong one for S = 256 (0.17 of the matrix peak, round 2).  Here:
+//   * both operands are read row-wise along k ("NT"), so one 64 x 64 x 32 MFMA tile loop serves both products; V is
+//     written TRANSPOSED (VT[s][k]) so that it is the k-contiguous operand of the second product;
+//   * FULL-k accumulation: a workgroup owns output tiles (64 rows x 64 points) from first to last k, no partials;
+//   * the triangle is balanced by PAIRING: row block rb needs rb + 1 k blocks in the first product (nrb - rb in the
+//     second), so the workgroup of pair p takes row blocks p and nrb - 1 - p -- every workgroup multiplies nrb + 1
+//     blocks, 256 workgroups at n = 8192, S = 256 (one per CU);
+//   * XCD-aware order: the column blocks of one pair (same rows of the factor) sit on the same XCD and share its L2;
+//   * epilogues fused: the first product leaves sum_i v^2 per (row block, point) for the variance, the second turns its
+//     tile of U straight into the gradient sums  sum_i alpha_i k_si (x_s - X_i),  sum_i u_is k_si (x_s - X_i)  per
+//     (row block, point) -- U itself is never written.  kstar_kernel (kernel rows, mean partials) and finish_kernel
+//     (assembly) are those of gp_predict.hip, unchanged.
+// Four launches per evaluation round whatever S is.
+#include "gp.hpp"
+#include "mfma_f64.hpp"
+
+#include <cstdlib>
+
+namespace elfihip {
+
+constexpr int DT = 64;            // tile edge (rows of the factor, points)
+constexpr int DK = 32;            // k-tile depth
+constexpr int DLP = 36;           // LDS row pitch in doubles (as the step kernel's stages: conflict-free b128 reads)
+constexpr int DSTAGE = 2 * DT * DLP;   // doubles of one stage: A rows, then B rows
+constexpr int DEP = 65;           // pitch of the epilogue tiles
+// LDS: two stages of the tile loop (73,728 bytes); the gradient epilogue lays its tiles over them and needs more:
+// U tile + kernel rows (64 x 65 each) + evidence rows and query points (64 x 24 each) + alpha
+constexpr size_t DENSE_LDS_BYTES = (size_t)(2 * DT * DEP + 2 * DT * 24 + DT) * sizeof(double);   // 91,648
+static_assert(DENSE_LDS_BYTES >= (size_t)2 * DSTAGE * sizeof(double), "staging must fit");
+
+struct DenseAcc {
+  v4d c[2][2];
+};
+
+// acc += A(64 x K) B(64 x K)^T for k in [kbeg, kend), multiples of 32.  256 threads = 4 waves as 2 x 2, each 32 x 32.
+// Two LDS stages, one barrier per k-tile: while stage p is multiplied the next k-tile (in registers since the previous
+// step) is written to stage p ^ 1 and the loads of the one after it are issued.
+__device__ __forceinline__ void gemm64_nt(DenseAcc& acc, const double* __restrict__ A, int64_t lda,
+                                          const double* __restrict__ B, int64_t ldb, int kbeg, int kend, double* sm) {
+  const int t = threadIdx.x, l = t & 63, w = t >> 6;
+  const int wr = w >> 1, wc = w & 1;
+  // global -> LDS: thread t carries k pair 2 (t & 15) of rows (t >> 4) + 16 j
+  const double* pa = A + (int64_t)(t >> 4) * lda + 2 * (t & 15) + kbeg;
+  const double* pb = B + (int64_t)(t >> 4) * ldb + 2 * (t & 15) + kbeg;
+  const int doff = (t >> 4) * DLP + 2 * (t & 15);
+  const int faoff = (wr * 32 + (l & 15)) * DLP + 2 * (l >> 4);
+  const int fboff = (DT + wc * 32 + (l & 15)) * DLP + 2 * (l >> 4);
+  // (plain scalars and macros: a lambda capturing a register array sends the array to scratch memory)
+  double2 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+#define DENSE_ISSUE(a_, b_)                                                    \
+  do {                                                                         \
+    const double* ia_ = (a_);                                                  \
+    const double* ib_ = (b_);                                                  \
+    ra0 = *reinterpret_cast<const double2*>(ia_);                              \
+    ra1 = *reinterpret_cast<const double2*>(ia_ + (int64_t)16 * lda);          \
+    ra2 = *reinterpret_cast<const double2*>(ia_ + (int64_t)32 * lda);          \
+    ra3 = *reinterpret_cast<const double2*>(ia_ + (int64_t)48 * lda);          \
+    rb0 = *reinterpret_cast<const double2*>(ib_);                              \
+    rb1 = *reinterpret_cast<const double2*>(ib_ + (int64_t)16 * ldb);          \
+    rb2 = *reinterpret_cast<const double2*>(ib_ + (int64_t)32 * ldb);          \
+    rb3 = *reinterpret_cast<const double2*>(ib_ + (int64_t)48 * ldb);          \
+  } while (0)
+#define DENSE_STAGE(buf_)                                                      \
+  do {                                                                         \
+    double* sb_ = (buf_) + doff;                                               \
+    *reinterpret_cast<double2*>(sb_) = ra0;                                    \
+    *reinterpret_cast<double2*>(sb_ + 16 * DLP) = ra1;                         \
+    *reinterpret_cast<double2*>(sb_ + 32 * DLP) = ra2;                         \
+    *reinterpret_cast<double2*>(sb_ + 48 * DLP) = ra3;                         \
+    *reinterpret_cast<double2*>(sb_ + DT * DLP) = rb0;                         \
+    *reinterpret_cast<double2*>(sb_ + (DT + 16) * DLP) = rb1;                  \
+    *reinterpret_cast<double2*>(sb_ + (DT + 32) * DLP) = rb2;                  \
+    *reinterpret_cast<double2*>(sb_ + (DT + 48) * DLP) = rb3;                  \
+  } while (0)
+  const int nkt = (kend - kbeg) / DK;
+  DENSE_ISSUE(pa, pb);
+  __syncthreads();   // whoever used the staging area before (previous tile's epilogue) is done
+  DENSE_STAGE(sm);
+  if (nkt > 1) DENSE_ISSUE(pa + DK, pb + DK);
+  __syncthreads();
+  int p = 0;
+#pragma unroll 1
+  for (int kt = 0; kt < nkt; ++kt) {
+    const double* buf = sm + p * DSTAGE;
+    if (kt + 1 < nkt) {
+      DENSE_STAGE(sm + (p ^ 1) * DSTAGE);
+      if (kt + 2 < nkt) DENSE_ISSUE(pa + (int64_t)(kt + 2) * DK, pb + (int64_t)(kt + 2) * DK);
+    }
+    const double* fa = buf + faoff;
+    const double* fb = buf + fboff;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      double2 a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        a[i] = *reinterpret_cast<const double2*>(fa + i * 16 * DLP + 8 * h);
+        b[i] = *reinterpret_cast<const double2*>(fb + i * 16 * DLP + 8 * h);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc.c[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].x, b[j].x, acc.c[i][j], 0, 0, 0);
+          acc.c[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].y, b[j].y, acc.c[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    p ^= 1;
+  }
+#undef DENSE_ISSUE
+#undef DENSE_STAGE
+}
+
+struct DenseArgs {
+  const double* W;      // WL (first product) or WT (second)
+  const double* Bm;     // KBT (first) or VT (second): [S_pad][np], k contiguous
+  int64_t lda, np, n;
+  int nrb, ncb;         // 64-row blocks of the factor, 64-point column blocks
+  // first product
+  double* VT;           // [S_pad][np]
+  double* var_part;     // [pass][nrb][16]
+  // second product
+  const double* kr;     // [S_pad][np] kernel rows without the bias
+  const double* X;      // (np, dp)
+  const double* alpha;
+  const double* xs;     // [S_pad][dp]
+  double* g_part;       // [pass][16][nrb][2 dp]
+  int dp;
+};
+
+// blockIdx -> (pair, column block): the ncb column blocks of a pair are consecutive in the LOGICAL order and the logical
+// order runs down each XCD in turn (hardware: block b on XCD b % 8), so they share an L2.  gridDim.x is a multiple of 8.
+__device__ __forceinline__ bool dense_decode(const DenseArgs& D, int* pair, int* cb) {
+  const int lb = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  *pair = lb / D.ncb;
+  *cb = lb - *pair * D.ncb;
+  return *pair < D.nrb / 2;
+}
+
+// MODE 0: V = L^-1 KB^T, written transposed + sum_i v^2.   MODE 1: U = L^-T V folded into the gradient sums.
+template <int MODE>
+__global__ __launch_bounds__(256) void dense_tri_kernel(DenseArgs D) {
+  extern __shared__ __align__(16) double sm[];
+  int pair, cb;
+  if (!dense_decode(D, &pair, &cb)) return;
+  const int t = threadIdx.x, l = t & 63, w = t >> 6;
+  const int wr = w >> 1, wc = w & 1;
+  const int64_t s0 = (int64_t)cb * DT;
+#pragma unroll 1
+  for (int half = 0; half < 2; ++half) {
+    // longer tile first in both products
+    const int rb = MODE == 0 ? (half == 0 ? D.nrb - 1 - pair : pair) : (half == 0 ? pair : D.nrb - 1 - pair);
+    const int64_t i0 = (int64_t)rb * DT;
+    const int kbeg = MODE == 0 ? 0 : (int)i0;
+    const int kend = MODE == 0 ? (int)(i0 + DT) : (int)D.np;
+    DenseAcc acc;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc.c[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+    gemm64_nt(acc, D.W + i0 * D.lda, D.lda, D.Bm + s0 * D.np, D.np, kbeg, kend, sm);
+    // the tile as [i][s] in LDS (the GEMM's last barrier has passed: the staging area is free)
+    double* T = sm;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          T[(wr * 32 + i * 16 + (l >> 4) + 4 * r) * DEP + wc * 32 + j * 16 + (l & 15)] = acc.c[i][j][r];
+    __syncthreads();
+    if (MODE == 0) {
+      // VT[s0 + s][i0 + i]: thread (i = t & 63, s = (t >> 6) + 4 q) -> 512-byte runs along i
+#pragma unroll 4
+      for (int q = 0; q < 16; ++q) {
+        const int s = (t >> 6) + 4 * q;
+        D.VT[(s0 + s) * D.np + i0 + (t & 63)] = T[(t & 63) * DEP + s];
+      }
+      if (t < DT) {   // sum_i v[i][s]^2 over the tile's rows, fixed order
+        double q2 = 0.0;
+        for (int i = 0; i < DT; ++i) {
+          const double v = T[i * DEP + t];
+          q2 += v * v;
+        }
+        const int64_t sg = s0 + t;
+        D.var_part[((sg >> 4) * D.nrb + rb) * 16 + (sg & 15)] = q2;
+      }
+    } else {
+      // gradient sums of this (row block, 64 points): needs k_si, X_i, alpha_i, x_s
+      const int dp = D.dp;
+      double* KR = sm + DT * DEP;           // [s][i]
+      double* XI = KR + DT * DEP;           // [i][dp]
+      double* XS = XI + DT * 24;            // [s][dp]   (dp <= 24 by the caller's check)
+      double* AL = XS + DT * 24;            // [i]
+#pragma unroll 4
+      for (int q = 0; q < 16; ++q) {
+        const int s = (t >> 6) + 4 * q;
+        KR[s * DEP + (t & 63)] = D.kr[(s0 + s) * D.np + i0 + (t & 63)];
+      }
+      for (int e = t; e < DT * dp; e += 256) {
+        const int r = e / dp, c = e - r * dp;
+        XI[r * 24 + c] = D.X[(i0 + r) * dp + c];
+        XS[r * 24 + c] = D.xs[(s0 + r) * dp + c];
+      }
+      if (t < DT) AL[t] = (i0 + t) < D.n ? D.alpha[i0 + t] : 0.0;
+      __syncthreads();
+      // thread (s = t & 63, q = t >> 6): dimensions a = q, q + 4, ... ; sums over the 64 rows in order
+      const int s = t & 63, q = t >> 6;
+      double g1[6], g2[6], xa[6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        g1[j] = 0.0;
+        g2[j] = 0.0;
+        xa[j] = (q + 4 * j) < dp ? XS[s * 24 + q + 4 * j] : 0.0;
+      }
+      for (int i = 0; i < DT; ++i) {
+        const double k = KR[s * DEP + i];
+        const double c1 = AL[i] * k, c2 = T[i * DEP + s] * k;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          const double diff = xa[j] - XI[i * 24 + ((q + 4 * j) < dp ? q + 4 * j : 0)];
+          g1[j] += c1 * diff;
+          g2[j] += c2 * diff;
+        }
+      }
+      const int64_t sg = s0 + s;
+      double* gp_ = D.g_part + (((sg >> 4) * 16 + (sg & 15)) * D.nrb + rb) * 2 * dp;
+#pragma unroll
+      for (int j = 0; j < 6; ++j)
+        if (q + 4 * j < dp) {
+          gp_[q + 4 * j] = g1[j];
+          gp_[dp + q + 4 * j] = g2[j];
+        }
+    }
+    // (gemm64_nt opens with a barrier: the epilogue's LDS reads are over before the next tile stages)
+  }
+}
+
+int64_t dense_min_points(const elfihip_gp* gp) {
+  if (gp->dense_min > 0) return gp->dense_min;
+  static const int64_t v = [] {
+    const char* e = std::getenv("ELFIHIP_DENSE_MIN");   // process-wide default, for experiments
+    const long long x = e ? std::atoll(e) : 0;
+    return (int64_t)(x > 0 ? x : 96);
+  }();
+  return v;
+}
+
+// mode: 0 = mean / variance, 1 = + gradients (and LCB); same outputs as predict_impl.
+int predict_dense_impl(elfihip_gp* gp, const double* Xs, int64_t S, int mode, int noiseless, double beta, double* mu,
+                       double* var, double* dmu, double* dvar, double* val, double* grad) {
+  elfihip_ctx* ctx = gp->ctx;
+  hipStream_t st = ctx->stream;
+  if (!gp->factored)
+    return fail(ctx, ELFIHIP_ERR_STATE, "GP is not factorised (call elfihip_gp_factorize after changing data)");
+  const int dp = gp->dp, d = gp->d;
+  ELFIHIP_REQUIRE(ctx, dp <= 24, "the dense predictor handles up to 24 input dimensions");
+  const int64_t np = gp->np;
+  const int64_t S_pad = round_up(S, DT);
+  const int npass = (int)(S_pad / 16);
+  const int nrb = (int)(np / DT), ncb = (int)(S_pad / DT);
+  const int nblk_k = (int)((np + 255) / 256);
+  const size_t outsz = (size_t)3 * 16 + 3 * 16 * dp;
+  // workspace (doubles): xs | xs2 | kr | kbt | VT | mu_part | var_part | g_part | out
+  size_t off = 0;
+  auto take = [&](size_t doubles) {
+    size_t o = off;
+    off += (doubles + 15) & ~(size_t)15;
+    return o;
+  };
+  const size_t o_xs = take((size_t)S_pad * dp), o_xs2 = take((size_t)S_pad), o_kr = take((size_t)S_pad * np),
+               o_kbt = take((size_t)S_pad * np), o_vt = take((size_t)S_pad * np),
+               o_mu = take((size_t)npass * 16 * nblk_k), o_var = take((size_t)npass * nrb * 16),
+               o_g = take((size_t)npass * 16 * nrb * 2 * dp), o_out = take((size_t)npass * outsz);
+  ELFIHIP_CHECK_HIP(ctx, gp->ws_dense.reserve(off * sizeof(double)));
+  double* base = gp->ws_dense.as<double>();
+  // pinned staging: points + norms up, results down (one copy each way)
+  const size_t n_in = (size_t)S_pad * dp + (size_t)S_pad, n_out = (size_t)npass * outsz;
+  if (gp->hd_cap < n_in + n_out) {
+    if (gp->h_dense) ELFIHIP_CHECK_HIP(ctx, hipHostFree(gp->h_dense));
+    gp->h_dense = nullptr;
+    gp->hd_cap = 0;
+    const size_t want = 2 * (n_in + n_out) + 1024;
+    ELFIHIP_CHECK_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&gp->h_dense), want * sizeof(double), hipHostMallocDefault));
+    gp->hd_cap = want;
+  }
+  double* hx = gp->h_dense;
+  double* hout = hx + n_in;
+  std::fill(hx, hx + n_in, 0.0);
+  for (int64_t s = 0; s < S; ++s) {
+    double q = 0.0;
+    for (int c = 0; c < d; ++c) {
+      const double x = Xs[s * d + c];
+      hx[(size_t)s * dp + c] = x;
+      q += x * x;
+    }
+    hx[(size_t)S_pad * dp + s] = q;
+  }
+  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(base + o_xs, hx, n_in * sizeof(double), hipMemcpyHostToDevice, st));
+  // (xs2 directly follows xs: S_pad * dp is a multiple of the workspace's 16-double granule)
+  ELFIHIP_TRY(ensure_wl_public(gp));   // L^-1 row-wise is the FIRST product's matrix here
+  launch_kstar_passes(gp, base + o_xs, base + o_xs2, base + o_kr, base + o_kbt, base + o_mu, nblk_k, (unsigned)npass);
+  if (!ctx->dense_lds_enabled) {
+    ELFIHIP_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(dense_tri_kernel<0>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)DENSE_LDS_BYTES));
+    ELFIHIP_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(dense_tri_kernel<1>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)DENSE_LDS_BYTES));
+    ctx->dense_lds_enabled = true;
+  }
+  DenseArgs D;
+  D.lda = gp->lda;
+  D.np = np;
+  D.n = gp->n;
+  D.nrb = nrb;
+  D.ncb = ncb;
+  D.VT = base + o_vt;
+  D.var_part = base + o_var;
+  D.kr = base + o_kr;
+  D.X = gp->X;
+  D.alpha = gp->alpha;
+  D.xs = base + o_xs;
+  D.g_part = base + o_g;
+  D.dp = dp;
+  const unsigned grid = (unsigned)round_up((int64_t)ncb * (nrb / 2), 8);
+  const bool prof = gp->profile;
+  if (prof) prof_mark(gp, 0);
+  D.W = gp->WL;
+  D.Bm = base + o_kbt;
+  hipLaunchKernelGGL((dense_tri_kernel<0>), dim3(grid), dim3(256), DENSE_LDS_BYTES, st, D);
+  if (prof) prof_mark(gp, 1);
+  if (mode == 1) {
+    D.W = gp->WT;
+    D.Bm = base + o_vt;
+    hipLaunchKernelGGL((dense_tri_kernel<1>), dim3(grid), dim3(256), DENSE_LDS_BYTES, st, D);
+  }
+  if (prof) prof_mark(gp, 2);
+  launch_finish_passes(gp, base + o_mu, nblk_k, base + o_var, nrb, base + o_g, nrb, base + o_out, (int)S, noiseless, beta, mode,
+                       (unsigned)npass);
+  ELFIHIP_TRY(launch_status(ctx, "dense prediction"));
+  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(hout, base + o_out, n_out * sizeof(double), hipMemcpyDeviceToHost, st));
+  ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(st));
+  if (prof) {
+    prof_add(gp, ELFIHIP_PHASE_TRI_FIRST, 0, 1);
+    if (mode == 1) prof_add(gp, ELFIHIP_PHASE_TRI_SECOND, 1, 2);
+  }
+  for (int64_t s = 0; s < S; ++s) {
+    const double* o = hout + (size_t)(s / 16) * outsz;
+    const int q = (int)(s % 16);
+    if (mu) mu[s] = o[q];
+    if (var) var[s] = o[16 + q];
+    if (val) val[s] = o[2 * 16 + q];
+    for (int c = 0; c < d; ++c) {
+      if (dmu) dmu[s * d + c] = o[3 * 16 + q * dp + c];
+      if (dvar) dvar[s * d + c] = o[3 * 16 + 16 * dp + q * dp + c];
+      if (grad) grad[s * d + c] = o[3 * 16 + 2 * 16 * dp + q * dp + c];
+    }
+  }
+  return ELFIHIP_OK;
+}
+
+}  // namespace elfihip
+
+extern "C" int elfihip_gp_set_dense_threshold(elfihip_gp* gp, int64_t min_points) {
+  if (!gp) return elfihip::fail(nullptr, ELFIHIP_ERR_ARG, "gp is NULL");
+  gp->dense_min = min_points > 0 ? min_points : 0;
+  return ELFIHIP_OK;
+}

@@ -1325,8 +1325,11 @@ int elfihip_gp_free(elfihip_gp* gp) {
     if (e) (void)hipEventDestroy(e);
   if (gp->VP) (void)hipFree(gp->VP);
   if (gp->Pint) (void)hipFree(gp->Pint);
+  if (gp->h_dense) (void)hipHostFree(gp->h_dense);
+  if (gp->tri_cnt) (void)hipFree(gp->tri_cnt);
   gp->ws.release();
   gp->ws2.release();
+  gp->ws_dense.release();
   gp->hyper_items.release();
   gp->sched_mem.release();
   delete gp;

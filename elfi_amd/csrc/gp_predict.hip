@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void kstar_kernel(const double* X, const doubl
                                                     const double* xs, const double* xs2, double* kr, double* kb,
                                                     double* mu_part, int64_t n, int64_t np, int dp, double var,
                                                     double neg_half_inv_ls2, double bias, double* xs_copy,
-                                                    int from_args, QueryArgs q) {
+                                                    int from_args, QueryArgs q, double* kbt) {
   __shared__ double red[256];
   __shared__ double sx[256 + 1];  // this workgroup's query point and its squared norm
   const int s = blockIdx.y;
@@ -59,7 +59,8 @@ __global__ __launch_bounds__(256) void kstar_kernel(const double* X, const doubl
   xs += (int64_t)blockIdx.z * PC * dp;
   xs2 += (int64_t)blockIdx.z * PC;
   kr += (int64_t)blockIdx.z * PC * np;
-  kb += (int64_t)blockIdx.z * PC * np;
+  if (kb) kb += (int64_t)blockIdx.z * PC * np;
+  if (kbt) kbt += (int64_t)blockIdx.z * PC * np;   // [point][k]: the k-contiguous form the dense products read (gp_dense.hip)
   mu_part += (int64_t)blockIdx.z * PC * gridDim.x;
   if (from_args) {
     // single-pass call: the point comes with the arguments (uniform index: two wide scalar loads); workgroup
@@ -98,7 +99,9 @@ __global__ __launch_bounds__(256) void kstar_kernel(const double* X, const doubl
       contrib = (k + bias) * alpha[i];
     }
     kr[(int64_t)s * np + i] = k;
-    kb[i * PC + s] = i < n ? k + bias : 0.0;  // right-hand side of the first triangular product, [k][s]
+    const double kbv = i < n ? k + bias : 0.0;  // right-hand side of the first triangular product
+    if (kb) kb[i * PC + s] = kbv;               // [k][s] for the streaming kernel
+    if (kbt) kbt[(int64_t)s * np + i] = kbv;
   }
   // fixed order: butterfly inside the wave, then the four waves in order (one barrier instead of nine)
 #pragma unroll
@@ -122,10 +125,40 @@ struct TriArgs {
   int64_t nout;  // rows of the output (np for the triangular products, the padded point count for the dense one)
   int nrb, nkc;
   int npass;   // 16-point passes in this launch (see the blockIdx mapping in the kernel)
+  // FUSED form (one launch instead of product + reduction / product + gradient sums): the LAST workgroup to arrive at
+  // a row block sums that block's chunk partials and runs the epilogue the separate launch ran
+  unsigned* cnt;          // (nrb) arrival counters, zero between launches (the last arriver resets its counter)
+  double* vout;           // MODE 0: v[pass][i][s]
+  double* sq_part;        // MODE 0: sum_i v^2 per 16-row block [pass][np / 16][16]
+  const double* X;        // MODE 1: gradient sums of the row block
+  const double* alpha;
+  const double* xs;       // [pass][16][dp]
+  const double* kr;       // [pass][16][np]
+  double* g_part;         // [pass][16][nrb][2 dp]
+  int64_t n;
+  int dp;
 };
 
-template <int MODE>
-__global__ __launch_bounds__(256) void tri_apply_kernel(TriArgs T) {
+typedef __attribute__((address_space(1))) unsigned long long gu64_t;
+typedef __attribute__((address_space(1))) unsigned int gu32_t;
+
+// One 8-byte WRITE-THROUGH store (global_store_dwordx2 ... sc1): the value leaves this XCD's L2 with the store itself, so
+// publishing a workgroup's partials needs no release fence (buffer_wbl2 of a whole L2: 1.7-6.5 us per workgroup, times
+// the workgroups per CU -- what made round 2's last-arriver reduction slower than the launch it saved).
+__device__ __forceinline__ void store_wt(double* p, double v) {
+  __hip_atomic_store((gu64_t*)(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ inline double sum_partials(const double* __restrict__ part, int64_t np, int64_t e, int lo, int hi);
+template <int ROWS_PER_THREAD, int QN>
+__device__ __forceinline__ void grad_rows(const double* __restrict__ X, const double* __restrict__ alpha,
+                                          const double* __restrict__ xs, const double* __restrict__ kr,
+                                          const double* __restrict__ part, int nkc, double* __restrict__ g_part, int chunk,
+                                          int nchunks, int64_t i0, int64_t n, int64_t np, int dp, double (*red)[PC][32]);
+
+template <int MODE, bool FUSE>
+__global__ __launch_bounds__(256, 3) void tri_apply_kernel(TriArgs T) {   // three workgroups per CU: <= 168 registers
   // No LDS staging of the matrix: a lane's 16-byte load IS its MFMA operand.  Lane (kq = l >> 4, ip = l & 15)
   // of wave w loads W[k][i0 + 2 ip .. + 1] for k = k0 + 16 q + 4 w + kq, q = 0 .. len/16: one instruction covers
   // 4 rows x 256 contiguous bytes, and its two doubles feed two v_mfma_f64_16x16x4 (even rows i / odd rows i)
@@ -200,8 +233,61 @@ __global__ __launch_bounds__(256) void tri_apply_kernel(TriArgs T) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int e = t + 256 * h;  // (i local, s) = (e >> 4, e & 15)
-      out[e] = ((Bs[e] + Bs[RB * PC + e]) + Bs[2 * RB * PC + e]) + Bs[3 * RB * PC + e];
+      const double v = ((Bs[e] + Bs[RB * PC + e]) + Bs[2 * RB * PC + e]) + Bs[3 * RB * PC + e];
+      if (FUSE)
+        store_wt(out + e, v);
+      else
+        out[e] = v;
     }
+  }
+  if (!FUSE || MODE == 2) return;
+  // ---- arrival at the row block (MI355X_MICROARCH.md, hand-off price list: write-through payload, every storing wave
+  // drains, ONE lane arrives on the block's counter with a relaxed device-scope atomic; the last arriver takes ONE
+  // agent-scope acquire -- its CU's L1 may hold the other workgroups' lines from an earlier launch -- then plain loads)
+  __shared__ int s_last;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (t == 0) {
+    // chunks inside the triangle for this row block = workgroups that arrive
+    const unsigned expected = MODE == 0 ? (unsigned)((i0 + RB - 1) / KC + 1) : (unsigned)(T.nkc - (int)(i0 / KC));
+    gu32_t* c = (gu32_t*)(T.cnt + rb);   // global address space said explicitly: no flat atomics
+    const unsigned old = __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = old + 1u == expected;
+    if (last) {
+      __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    s_last = last;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  if (MODE == 0) {
+    // what tri_reduce_kernel does for these 32 rows (same order of summation, same per-16-row blocks of v^2)
+    const int ib = (int)(i0 / NB);
+    for (int pass = 0; pass < T.npass; ++pass) {
+      const double* part = T.part + (int64_t)pass * T.nkc * T.np * PC;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int64_t e = i0 * PC + t + 256 * h;
+        const double v = sum_partials(part, T.np, e, 0, ib / KCH + 1);
+        T.vout[(int64_t)pass * T.np * PC + e] = v;
+        __syncthreads();
+        Bs[t] = v * v;
+        __syncthreads();
+        if (t < PC) {
+          double q = 0.0;
+          for (int r = 0; r < 16; ++r) q += Bs[r * PC + t];
+          T.sq_part[((int64_t)pass * (T.np / 16) + (i0 / 16 + h)) * PC + t] = q;
+        }
+      }
+    }
+  } else {
+    // what grad_kernel does, for this block's 32 rows (chunk = row block)
+    double(*red)[PC][32] = reinterpret_cast<double(*)[PC][32]>(Bs);
+    for (int pass = 0; pass < T.npass; ++pass)
+      grad_rows<2, 2>(T.X, T.alpha, T.xs + (int64_t)pass * PC * T.dp, T.kr + (int64_t)pass * PC * T.np,
+                   T.part + (int64_t)pass * T.nkc * T.np * PC, T.nkc,
+                   T.g_part + (int64_t)pass * PC * T.nrb * 2 * T.dp, rb, T.nrb, i0, T.n, T.np, T.dp, red);
   }
 }
 
@@ -260,20 +346,17 @@ __global__ __launch_bounds__(256) void tri_reduce_kernel(const double* part, dou
 // (same order as tri_reduce_kernel), which saves that kernel on the prediction path.  Four dimensions at a time:
 // register sums over the thread's rows, two butterfly steps over the wave's row groups, the four waves in order.
 constexpr int GR = 64;
-__global__ __launch_bounds__(256) void grad_kernel(const double* __restrict__ X, const double* __restrict__ alpha,
-                                                   const double* __restrict__ xs, const double* __restrict__ kr,
-                                                   const double* __restrict__ part, int nkc,
-                                                   double* __restrict__ g_part, int64_t n, int64_t np, int dp) {
-  __shared__ double red[4][PC][32];
+// The sums of RPT x 16 evidence rows from i0 on (thread (s, ig) owns rows ig + 16 r), written as chunk `chunk` of
+// `nchunks`: the body of grad_kernel (RPT = 4) and of the fused second product's last arriver (RPT = 2, gp_predict.hip above).
+template <int RPT, int QN>   // QN: groups of four dimensions per round (4: grad_kernel; 2 keeps the fused product at 3 workgroups per CU)
+__device__ __forceinline__ void grad_rows(const double* __restrict__ X, const double* __restrict__ alpha,
+                                          const double* __restrict__ xs, const double* __restrict__ kr,
+                                          const double* __restrict__ part, int nkc, double* __restrict__ g_part, int chunk,
+                                          int nchunks, int64_t i0, int64_t n, int64_t np, int dp, double (*red)[PC][32]) {
   const int t = threadIdx.x, s = t & 15, ig = t >> 4, w = t >> 6;
-  xs += (int64_t)blockIdx.y * PC * dp;                 // per-pass slices (blockIdx.y = pass)
-  kr += (int64_t)blockIdx.y * PC * np;
-  part += (int64_t)blockIdx.y * nkc * np * PC;
-  g_part += (int64_t)blockIdx.y * PC * gridDim.x * 2 * dp;
-  const int64_t i0 = (int64_t)blockIdx.x * GR;
-  double c1[4], c2[4];
+  double c1[RPT], c2[RPT];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
+  for (int r = 0; r < RPT; ++r) {
     const int64_t i = i0 + ig + 16 * r;
     c1[r] = 0.0;
     c2[r] = 0.0;
@@ -286,16 +369,16 @@ __global__ __launch_bounds__(256) void grad_kernel(const double* __restrict__ X,
   typedef double v4 __attribute__((ext_vector_type(4)));
   // sixteen dimensions per round (dp <= 16: one round, two barriers): register sums over the thread's rows, two
   // butterfly steps over the wave's row groups, the four waves in order
-  for (int a0 = 0; a0 < dp; a0 += 16) {
-    v4 g1[4], g2[4];
+  for (int a0 = 0; a0 < dp; a0 += 4 * QN) {
+    v4 g1[QN], g2[QN];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < QN; ++q) {
       g1[q] = (v4){0, 0, 0, 0};
       g2[q] = (v4){0, 0, 0, 0};
       if (a0 + 4 * q < dp) {
         const v4 x4 = *reinterpret_cast<const v4*>(xs + s * dp + a0 + 4 * q);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < RPT; ++r) {
           const v4 diff = x4 - *reinterpret_cast<const v4*>(X + (i0 + ig + 16 * r) * dp + a0 + 4 * q);  // rows < np exist (zeros)
           g1[q] += c1[r] * diff;
           g2[q] += c2[r] * diff;
@@ -312,7 +395,7 @@ __global__ __launch_bounds__(256) void grad_kernel(const double* __restrict__ X,
     __syncthreads();  // red free
     if ((t & 63) < 16) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
+      for (int q = 0; q < QN; ++q)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           red[w][s][4 * q + j] = g1[q][j];
@@ -323,12 +406,24 @@ __global__ __launch_bounds__(256) void grad_kernel(const double* __restrict__ X,
     for (int e = t; e < PC * 32; e += 256) {
       const int ss = e >> 5, j = e & 31;
       const int a = a0 + (j & 15);
-      if (a < dp) {
+      if ((j & 15) < 4 * QN && a < dp) {
         const double v = ((red[0][ss][j] + red[1][ss][j]) + red[2][ss][j]) + red[3][ss][j];
-        g_part[((int64_t)ss * gridDim.x + blockIdx.x) * 2 * dp + (j < 16 ? a : dp + a)] = v;
+        g_part[((int64_t)ss * nchunks + chunk) * 2 * dp + (j < 16 ? a : dp + a)] = v;
       }
     }
   }
+}
+
+__global__ __launch_bounds__(256) void grad_kernel(const double* __restrict__ X, const double* __restrict__ alpha,
+                                                   const double* __restrict__ xs, const double* __restrict__ kr,
+                                                   const double* __restrict__ part, int nkc,
+                                                   double* __restrict__ g_part, int64_t n, int64_t np, int dp) {
+  __shared__ double red[4][PC][32];
+  xs += (int64_t)blockIdx.y * PC * dp;                 // per-pass slices (blockIdx.y = pass)
+  kr += (int64_t)blockIdx.y * PC * np;
+  part += (int64_t)blockIdx.y * nkc * np * PC;
+  g_part += (int64_t)blockIdx.y * PC * gridDim.x * 2 * dp;
+  grad_rows<4, 4>(X, alpha, xs, kr, part, nkc, g_part, (int)blockIdx.x, (int)gridDim.x, (int64_t)blockIdx.x * GR, n, np, dp, red);
 }
 
 // ---- final assembly: mu, var, dmu, dvar, LCB value and gradient ---------------------------
@@ -393,8 +488,17 @@ __global__ __launch_bounds__(256) void finish_kernel(const double* mu_part, int 
     for (int a0 = 0; a0 < 2 * dp; a0 += 32) {
       const int idx = a0 + (t & 31), cs = t >> 5;
       double acc = 0.0;
-      if (idx < 2 * dp)
-        for (int c = cs; c < ngc; c += 8) acc += gp1[(int64_t)c * 2 * dp + idx];
+      if (idx < 2 * dp) {
+        // eight chunk values in flight per round (the loop with one load per iteration waits a memory round trip per
+        // chunk: 16 of them at n = 4096), added in chunk order
+        for (int c = cs; c < ngc; c += 64) {
+          double gv[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) gv[u] = (c + 8 * u < ngc) ? gp1[(int64_t)(c + 8 * u) * 2 * dp + idx] : 0.0;
+#pragma unroll
+          for (int u = 0; u < 8; ++u) acc += gv[u];
+        }
+      }
       __syncthreads();
       gs[cs][t & 31] = acc;
       __syncthreads();
@@ -552,8 +656,30 @@ static int ensure_wl(elfihip_gp* gp) {
   return ELFIHIP_OK;
 }
 
+int ensure_wl_public(elfihip_gp* gp) { return ensure_wl(gp); }
+
+// kstar / finish for `npass` 16-point passes in one launch each, for the dense path (gp_dense.hip)
+void launch_kstar_passes(elfihip_gp* gp, const double* xs, const double* xs2, double* kr, double* kbt, double* mu_part,
+                         int nblk_k, unsigned npass) {
+  const double inv_ls2 = 1.0 / (gp->ls * gp->ls);
+  hipLaunchKernelGGL(kstar_kernel, dim3(nblk_k, PC, npass), dim3(256), 0, gp->ctx->stream, gp->X, gp->x2, gp->alpha, xs, xs2,
+                     kr, (double*)nullptr, mu_part, gp->n, gp->np, gp->dp, gp->var, -0.5 * inv_ls2, gp->bias,
+                     (double*)nullptr, 0, QueryArgs(), kbt);
+}
+
+void launch_finish_passes(elfihip_gp* gp, const double* mu_part, int nblk_k, const double* var_part, int nblk_v,
+                          const double* g_part, int ngc, double* out, int s_left, int noiseless, double beta, int mode,
+                          unsigned npass) {
+  const double inv_ls2 = 1.0 / (gp->ls * gp->ls);
+  hipLaunchKernelGGL(finish_kernel, dim3(PC, npass), dim3(256), 0, gp->ctx->stream, mu_part, nblk_k, var_part, nblk_v, g_part,
+                     ngc, out, gp->dp, s_left, gp->var + gp->bias, noiseless ? 0.0 : gp->noise, inv_ls2, beta, mode,
+                     (double*)nullptr, (unsigned long long*)nullptr, 0ull);
+}
+
 // One triangular product for `g` passes: part[pass][kc][i][s] from bin[pass][k][s].
-static void launch_tri(const elfihip_gp* gp, const PredictWs& W, bool lower, const double* bin, unsigned g) {
+// fused = the reduction (first product) / the gradient sums (second product) by the last workgroup of every row block
+static void launch_tri(const elfihip_gp* gp, const PredictWs& W, bool lower, const double* bin, unsigned g, bool fused = false,
+                       const double* xs = nullptr) {
   TriArgs T;
   T.W = lower ? gp->WL : gp->WT;
   T.bin = bin;
@@ -564,11 +690,43 @@ static void launch_tri(const elfihip_gp* gp, const PredictWs& W, bool lower, con
   T.nrb = (int)(gp->np / RB);
   T.nkc = W.nkc;
   T.npass = (int)g;
+  T.cnt = gp->tri_cnt ? gp->tri_cnt + (lower ? gp->cap / RB : 0) : nullptr;
+  T.vout = W.v;
+  T.sq_part = W.var_part;
+  T.X = gp->X;
+  T.alpha = gp->alpha;
+  T.xs = xs;
+  T.kr = W.kr;
+  T.g_part = W.g_part;
+  T.n = gp->n;
+  T.dp = gp->dp;
   const dim3 grid((unsigned)T.nrb, (unsigned)W.nkc);
-  if (lower)
-    hipLaunchKernelGGL((tri_apply_kernel<1>), grid, dim3(256), 0, gp->ctx->stream, T);
+  if (fused && lower)
+    hipLaunchKernelGGL((tri_apply_kernel<1, true>), grid, dim3(256), 0, gp->ctx->stream, T);
+  else if (fused)
+    hipLaunchKernelGGL((tri_apply_kernel<0, true>), grid, dim3(256), 0, gp->ctx->stream, T);
+  else if (lower)
+    hipLaunchKernelGGL((tri_apply_kernel<1, false>), grid, dim3(256), 0, gp->ctx->stream, T);
   else
-    hipLaunchKernelGGL((tri_apply_kernel<0>), grid, dim3(256), 0, gp->ctx->stream, T);
+    hipLaunchKernelGGL((tri_apply_kernel<0, false>), grid, dim3(256), 0, gp->ctx->stream, T);
+}
+
+// The fused lock-step (four launches instead of six) is the default; ELFIHIP_LOCKSTEP_FUSE=0 keeps the six-launch form
+// (same numbers for mean / variance, gradient sums in 64-row instead of 32-row chunks).
+static bool lockstep_fused() {
+  static const bool v = [] {
+    const char* e = std::getenv("ELFIHIP_LOCKSTEP_FUSE");
+    return !(e && e[0] == '0');
+  }();
+  return v;
+}
+
+static int ensure_tri_counters(elfihip_gp* gp) {
+  if (gp->tri_cnt) return ELFIHIP_OK;
+  const size_t bytes = (size_t)2 * (gp->cap / RB) * sizeof(unsigned);
+  ELFIHIP_CHECK_HIP(gp->ctx, hipMalloc(reinterpret_cast<void**>(&gp->tri_cnt), bytes));
+  ELFIHIP_CHECK_HIP(gp->ctx, hipMemsetAsync(gp->tri_cnt, 0, bytes, gp->ctx->stream));
+  return ELFIHIP_OK;
 }
 
 static int ensure_ws(elfihip_gp* gp, PredictWs* W, int64_t npass) {
@@ -577,7 +735,8 @@ static int ensure_ws(elfihip_gp* gp, PredictWs* W, int64_t npass) {
   const int nb = (int)(np / NB);
   W->nblk_k = (int)((np + 255) / 256);
   W->nkc = (nb + KCH - 1) / KCH;
-  W->ngc = (int)((gp->n + GR - 1) / GR);
+  // gradient chunks: 64-row workgroups of grad_kernel, or the 32-row blocks of the fused second product
+  W->ngc = lockstep_fused() ? (int)(np / RB) : (int)((gp->n + GR - 1) / GR);
   size_t off = 0;
   auto take = [&](size_t doubles) {
     size_t o = off;
@@ -681,6 +840,8 @@ int predict_enqueue(elfihip_gp* gp, const PredictPlan& P, int64_t S_active, int 
   // W.xs and W.xs2 are adjacent in the workspace (PC * dp is a multiple of the 16-double granule)
   if (!P.direct) ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(W.xs, P.hx, P.n_in * sizeof(double), hipMemcpyHostToDevice, st));
   if (mode == 1) ELFIHIP_TRY(ensure_wl(gp));
+  const bool fused = lockstep_fused();
+  if (fused) ELFIHIP_TRY(ensure_tri_counters(gp));
   const int rblocks = (int)(np * PC / 256);
   static thread_local QueryArgs qa;  // only filled (and read by the kernel) for single-pass calls
   for (int64_t pass0 = 0; pass0 < P.npass; pass0 += W.group) {
@@ -702,17 +863,26 @@ int predict_enqueue(elfihip_gp* gp, const PredictPlan& P, int64_t S_active, int 
     hipLaunchKernelGGL(kstar_kernel, dim3(W.nblk_k, PC, g), dim3(256), 0, st, gp->X, gp->x2, gp->alpha,
                        from_host ? P.hx : xs, from_host ? P.hx + (size_t)P.npass * PC * dp : xs2, W.kr, W.kb,
                        W.mu_part, gp->n, np, dp, gp->var, -0.5 * inv_ls2, gp->bias,
-                       P.direct ? W.xs : (double*)nullptr, P.by_args ? 1 : 0, qa);
+                       P.direct ? W.xs : (double*)nullptr, P.by_args ? 1 : 0, qa, (double*)nullptr);
     if (prof) prof_mark(gp, 1);
-    launch_tri(gp, W, false, W.kb, g);
-    hipLaunchKernelGGL(tri_reduce_kernel, dim3(rblocks, g), dim3(256), 0, st, W.part, W.v, W.var_part, np, W.nkc, 0,
-                       1);
-    if (prof) prof_mark(gp, 2);
-    if (mode == 1) {
-      launch_tri(gp, W, true, W.v, g);
-      if (prof) prof_mark(gp, 3);
-      hipLaunchKernelGGL(grad_kernel, dim3(W.ngc, g), dim3(256), 0, st, gp->X, gp->alpha, xs, W.kr, W.part, W.nkc,
-                         W.g_part, gp->n, np, dp);
+    if (fused) {
+      launch_tri(gp, W, false, W.kb, g, true);
+      if (prof) prof_mark(gp, 2);
+      if (mode == 1) {
+        launch_tri(gp, W, true, W.v, g, true, xs);
+        if (prof) prof_mark(gp, 3);
+      }
+    } else {
+      launch_tri(gp, W, false, W.kb, g);
+      hipLaunchKernelGGL(tri_reduce_kernel, dim3(rblocks, g), dim3(256), 0, st, W.part, W.v, W.var_part, np, W.nkc, 0,
+                         1);
+      if (prof) prof_mark(gp, 2);
+      if (mode == 1) {
+        launch_tri(gp, W, true, W.v, g);
+        if (prof) prof_mark(gp, 3);
+        hipLaunchKernelGGL(grad_kernel, dim3(W.ngc, g), dim3(256), 0, st, gp->X, gp->alpha, xs, W.kr, W.part, W.nkc,
+                           W.g_part, gp->n, np, dp);
+      }
     }
     hipLaunchKernelGGL(finish_kernel, dim3(PC, g), dim3(256), 0, st, W.mu_part, W.nblk_k, W.var_part, rblocks, W.g_part,
                        W.ngc, out, dp, s_left, gp->var + gp->bias, noiseless ? 0.0 : gp->noise, inv_ls2, beta, mode,
@@ -774,6 +944,9 @@ int predict_impl(elfihip_gp* gp, const double* Xs, int64_t S, int mode, int nois
   ELFIHIP_REQUIRE(ctx, S >= 0, "negative S");
   if (S == 0) return ELFIHIP_OK;
   ELFIHIP_REQUIRE(ctx, Xs, "Xs is NULL");
+  // many points: the products are bound by the matrix pipes, not by the read of the factor -> dense tiles (gp_dense.hip)
+  if (S >= dense_min_points(gp) && gp->dp <= 24)
+    return predict_dense_impl(gp, Xs, S, mode, noiseless, beta, mu, var, dmu, dvar, val, grad);
   PredictPlan P;
   ELFIHIP_TRY(predict_prepare(gp, S, &P));
   predict_fill(gp, P, Xs, S);
@@ -894,7 +1067,7 @@ static int extend_one(elfihip_gp* gp, const double* x, double ynew) {
   ELFIHIP_TRY(ensure_wl(gp));
   hipLaunchKernelGGL(kstar_kernel, dim3(W.nblk_k, PC), dim3(256), 0, st, gp->X, gp->x2, gp->alpha, W.xs, W.xs2, W.kr,
                      W.kb, W.mu_part, n, np, dp, gp->var, -0.5 * inv_ls2, gp->bias, by_args ? W.xs : (double*)nullptr,
-                     by_args ? 1 : 0, qa);
+                     by_args ? 1 : 0, qa, (double*)nullptr);
   const int rblocks = (int)(np * PC / 256);
   launch_tri(gp, W, false, W.kb, 1);
   hipLaunchKernelGGL(tri_reduce_kernel, dim3(rblocks), dim3(256), 0, st, W.part, W.v, W.var_part, np, W.nkc, 0, 1);
@@ -966,7 +1139,7 @@ static void enqueue_v(elfihip_gp* gp, const PredictWs& W, int64_t pass0, unsigne
   const double inv_ls2 = 1.0 / (gp->ls * gp->ls);
   hipLaunchKernelGGL(kstar_kernel, dim3(W.nblk_k, PC, g), dim3(256), 0, st, gp->X, gp->x2, gp->alpha,
                      W.xs + (size_t)pass0 * PC * dp, W.xs2 + (size_t)pass0 * PC, W.kr, W.kb, W.mu_part, gp->n, np, dp,
-                     gp->var, -0.5 * inv_ls2, gp->bias, (double*)nullptr, 0, QueryArgs());
+                     gp->var, -0.5 * inv_ls2, gp->bias, (double*)nullptr, 0, QueryArgs(), (double*)nullptr);
   launch_tri(gp, W, false, W.kb, g);
   hipLaunchKernelGGL(tri_reduce_kernel, dim3((unsigned)(np * PC / 256), g), dim3(256), 0, st, W.part, W.v, W.var_part,
                      np, W.nkc, 0, 1);
@@ -1054,7 +1227,7 @@ static int cross_cov_impl(elfihip_gp* gp, const double* Q, int64_t S, double* co
     T.nrb = (int)(m_pad / RB);
     T.nkc = W.nkc;
     T.npass = (int)g;
-    hipLaunchKernelGGL((tri_apply_kernel<2>), dim3((unsigned)T.nrb, (unsigned)W.nkc), dim3(256), 0, st, T);
+    hipLaunchKernelGGL((tri_apply_kernel<2, false>), dim3((unsigned)T.nrb, (unsigned)W.nkc), dim3(256), 0, st, T);
     hipLaunchKernelGGL(tri_reduce_kernel, dim3((unsigned)(m_pad * PC / 256), g), dim3(256), 0, st, part2, dot,
                        (double*)nullptr, m_pad, W.nkc, 2, 0);
     hipLaunchKernelGGL(cross_finish_kernel, dim3((unsigned)((M * PC + 255) / 256), g), dim3(256), 0, st, gp->Pint,

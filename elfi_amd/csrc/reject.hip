@@ -16,10 +16,22 @@
 //   * only while the state is still filling up (the first batch) the batch goes through the radix selection of topk.hip.
 // Only the k best rows ever leave the GPU; row numbers are global (row_base + row in the batch), so the host fetches the
 // parameters / summaries of the accepted rows from its own batch store (as ELFI's OutputPool keeps them).
+//
+// The state never fails for valid input (round 2's fixed 65 536-entry list could overflow -- a small first batch, a
+// round change without reset -- and reported it only at result(), when the batches were gone):
+//   * the list holds 8 x (largest batch pushed) entries and merges happen at least every 8th push, so it cannot overflow;
+//   * a push expected to offer many candidates (n k / rows seen > 8192: the threshold is still weak) takes the radix
+//     selection of its k best instead of the list -- exact either way, this only keeps one-workgroup merges short.
+// k > 2048 ("host-merge" states, up to 2^20): the candidates of every push -- a few hundred rows once the threshold has
+// settled -- are merged into a sorted host copy of the state, the k-th distance goes back as the device threshold.
+// An acceptance threshold (the objective of Rejection.sample(threshold=...), samplers.py:219-225: EVERY nested column of
+// a row must be <= threshold) is applied by the candidate pass; accepted rows are counted on the device.
 #include "internal.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <limits>
+#include <vector>
 
 struct elfihip_reject {
   elfihip_ctx* ctx = nullptr;
@@ -37,6 +49,18 @@ struct elfihip_reject {
   int unmerged = 0;                // pushes since the last merge
   int64_t armed_pushes = 0;        // pushes since the state became full (sets the merge interval)
   void* export_dst = nullptr;      // optional: every merge also leaves the packed state (k values, k rows) here
+  elfihip::DevBuf cand_mem;        // the candidate list (cap pairs), grown to 8 x the largest batch
+  int64_t rows_seen = 0;           // rows offered so far
+  int64_t pending_rows = 0;        // rows of the filtered pushes since the last merge: bounds the list's length
+  // acceptance threshold (samplers.py:219-225)
+  bool has_accept = false;
+  double accept = 0.0;
+  unsigned long long* acc_count = nullptr;   // device: rows accepted so far
+  unsigned long long acc_seen = 0;           // ... as of the previous meta() read
+  // k > REJ_MAX_K: sorted host copy of the state, merged on the host after every push
+  bool host_mode = false, host_dirty = false;
+  std::vector<double> hval;
+  std::vector<long long> hrow;
 };
 
 namespace elfihip {
@@ -44,7 +68,9 @@ namespace elfihip {
 constexpr int64_t REJ_MAX_K = 2048;       // state entries (LDS-resident during a merge)
 constexpr int REJ_CHUNK = 1024;           // candidates merged per round
 constexpr int REJ_MERGE_EVERY = 8;        // pushes per merge
-constexpr unsigned int REJ_CAP = 1u << 16;
+constexpr unsigned int REJ_CAP = 1u << 16;   // smallest candidate list
+constexpr int64_t REJ_MAX_K_HOST = 1 << 20;  // host-merge states
+constexpr double REJ_HEAVY = 8192.0;         // expected candidates from which a push takes the radix selection
 
 __device__ __forceinline__ bool rej_less(double av, long long ar, double bv, long long br) {
   return av < bv || (av == bv && ar < br);
@@ -190,13 +216,12 @@ __global__ __launch_bounds__(1024) void reject_merge_kernel(RejArgs S) {
     }
   }
   __syncthreads();
-  long long* export_row = reinterpret_cast<long long*>(S.export_val + k);
   for (int e = t; e < k; e += 1024) {
     S.best_val[e] = bv[e];
     S.best_row[e] = br[e];
     if (S.export_val) {
       S.export_val[e] = bv[e];
-      export_row[e] = br[e];
+      reinterpret_cast<long long*>(S.export_val + k)[e] = br[e];
     }
   }
   if (t == 0) {
@@ -205,19 +230,29 @@ __global__ __launch_bounds__(1024) void reject_merge_kernel(RejArgs S) {
   }
 }
 
-// The candidate pass for distance kernels without the fused filter: d (n, stride apart) against the threshold.
-__global__ __launch_bounds__(256) void reject_filter_kernel(const double* d, int64_t n, int64_t stride, RejectFilter F) {
+// The candidate pass for distance kernels without the fused filter: d (n rows, `stride` apart, pointing at the ranking
+// column = the last of `ncols` nested columns) against the threshold.  accept != NULL: a row takes part only if EVERY
+// one of its columns is <= *accept (samplers.py:219-225), and the rows that do are counted.
+__global__ __launch_bounds__(256) void reject_filter_kernel(const double* d, int64_t n, int64_t stride, int ncols,
+                                                            RejectFilter F, int use_accept, double accept,
+                                                            unsigned long long* acc_count) {
   const double thr = *F.thr;
   const int64_t nround = (n + (int64_t)gridDim.x * 256 - 1) / ((int64_t)gridDim.x * 256);
+  unsigned long long mine = 0;
   for (int64_t r = 0; r < nround; ++r) {
     const int64_t i = (r * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
     const double v = i < n ? d[i * stride] : 0.0;
-    reject_offer(F, i < n && v < thr, v, F.row_base + i);
+    bool ok = i < n;
+    if (use_accept && ok)
+      for (int c = 0; c < ncols; ++c) ok = ok && d[i * stride - c] <= accept;
+    if (use_accept) mine += __popcll(__ballot(ok));   // uniform branch: every lane of the wave holds the wave's count
+    reject_offer(F, ok && v < thr, v, F.row_base + i);
   }
+  if (use_accept && (threadIdx.x & 63) == 0 && mine) atomicAdd(acc_count, mine);
 }
 
 __global__ void reject_init_kernel(double* best_val, long long* best_row, double* thr, unsigned int* count,
-                                   unsigned int* status, int k) {
+                                   unsigned int* status, unsigned long long* acc_count, int k) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   const double inf = __longlong_as_double(0x7ff0000000000000ll);
   if (e < k) {
@@ -228,6 +263,7 @@ __global__ void reject_init_kernel(double* best_val, long long* best_row, double
     *thr = inf;
     *count = 0u;
     *status = 0u;
+    *acc_count = 0ull;
   }
 }
 
@@ -248,42 +284,166 @@ static RejArgs merge_args(elfihip_reject* h, int ncand, long long row_offset) {
   return S;
 }
 
-// merge whatever the list holds (asynchronous, context's stream)
+static int host_merge(elfihip_reject* h, unsigned int ncand, long long row_offset);
+
+// merge whatever the list holds (asynchronous on the context's stream; host-merge states synchronise)
 static int reject_flush(elfihip_reject* h) {
   if (h->unmerged == 0) return ELFIHIP_OK;
-  hipLaunchKernelGGL(reject_merge_kernel, dim3(1), dim3(1024), REJ_MERGE_LDS, h->ctx->stream, merge_args(h, -1, 0));
   h->unmerged = 0;
+  h->pending_rows = 0;
+  if (h->host_mode) return host_merge(h, ~0u, 0);
+  hipLaunchKernelGGL(reject_merge_kernel, dim3(1), dim3(1024), REJ_MERGE_LDS, h->ctx->stream, merge_args(h, -1, 0));
   return launch_status(h->ctx, "reject_merge_kernel");
 }
 
 static int reject_reset_impl(elfihip_reject* h) {
-  hipLaunchKernelGGL(reject_init_kernel, dim3((unsigned)((h->k + 255) / 256)), dim3(256), 0, h->ctx->stream, h->best_val,
-                     h->best_row, h->thr, h->count, h->status, (int)h->k);
+  hipLaunchKernelGGL(reject_init_kernel, dim3((unsigned)((std::min<int64_t>(h->k, REJ_MAX_K) + 255) / 256)), dim3(256), 0,
+                     h->ctx->stream, h->best_val, h->best_row, h->thr, h->count, h->status, h->acc_count,
+                     (int)std::min<int64_t>(h->k, REJ_MAX_K));
   h->filled = 0;
   h->unmerged = 0;
   h->armed_pushes = 0;
+  h->rows_seen = 0;
+  h->pending_rows = 0;
+  h->acc_seen = 0;
+  h->hval.clear();
+  h->hrow.clear();
+  h->host_dirty = h->host_mode;
   return launch_status(h->ctx, "reject_init_kernel");
 }
 
-// Fold a batch into the state.  run(F, &filtered) launches the distance pass with the filter F (or without: F == nullptr)
-// on the context's stream; dsel / stride address the batch's ranking distances for the passes that need them.
-template <class Run>
-static int reject_push(elfihip_reject* h, int64_t n, const double* dsel, int64_t stride, long long row_base, Run run) {
+// The list holds 8 x the largest batch (>= 65 536 entries): with a merge every 8th push at the latest it cannot
+// overflow.  Growing it merges what is pending, waits, and reallocates.
+static int ensure_cap(elfihip_reject* h, int64_t n) {
+  const int64_t want = std::max<int64_t>(REJ_CAP, REJ_MERGE_EVERY * n);
+  if (want <= (int64_t)h->cap) return ELFIHIP_OK;
+  elfihip_ctx* ctx = h->ctx;
+  ELFIHIP_REQUIRE(ctx, want < (int64_t)1 << 31, "batch of %lld rows is too large for the sampler state", (long long)n);
+  ELFIHIP_TRY(reject_flush(h));
+  ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  hipError_t e = h->cand_mem.reserve((size_t)want * 16);
+  if (e != hipSuccess) return fail(ctx, ELFIHIP_ERR_NOMEM, "candidate list allocation failed: %s", hipGetErrorString(e));
+  const size_t have = h->cand_mem.cap / 16;
+  h->cap = (unsigned int)std::min<size_t>(have, 0x7fffffffu);
+  h->cand_val = h->cand_mem.as<double>();
+  h->cand_row = reinterpret_cast<long long*>(h->cand_val + h->cap);
+  return ELFIHIP_OK;
+}
+
+// ---- host-merge states (k > REJ_MAX_K): the candidates of a push come down, are sorted and merged into the sorted
+// host copy; the new k-th distance goes back as the device threshold.  ncand == ~0u: read the list's counter.
+static int host_merge(elfihip_reject* h, unsigned int ncand, long long row_offset) {
   elfihip_ctx* ctx = h->ctx;
   hipStream_t st = ctx->stream;
-  if (h->filled < h->k) {
-    // state still filling up: every row could enter.  Plain distance pass, radix selection of the batch's k best
-    // (batch-local rows), merge.
+  unsigned int c = ncand;
+  if (ncand == ~0u) {
+    ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(&c, h->count, sizeof c, hipMemcpyDeviceToHost, st));
+    ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(st));
+    ELFIHIP_CHECK_HIP(ctx, hipMemsetAsync(h->count, 0, sizeof c, st));
+    if (c > h->cap) return fail(ctx, ELFIHIP_ERR_STATE, "internal: candidate list overflow (%u > %u)", c, h->cap);
+  }
+  std::vector<double> cv(c);
+  std::vector<long long> cr(c);
+  if (c) {
+    ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(cv.data(), h->cand_val, (size_t)c * 8, hipMemcpyDeviceToHost, st));
+    ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(cr.data(), h->cand_row, (size_t)c * 8, hipMemcpyDeviceToHost, st));
+  }
+  ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(st));
+  std::vector<size_t> perm;
+  perm.reserve(c);
+  for (size_t i = 0; i < c; ++i)
+    if (cv[i] == cv[i]) perm.push_back(i);   // a NaN never enters the state
+  for (size_t i : perm) cr[i] += row_offset;
+  std::sort(perm.begin(), perm.end(), [&](size_t a, size_t b) { return cv[a] < cv[b] || (cv[a] == cv[b] && cr[a] < cr[b]); });
+  const size_t k = (size_t)h->k, ns = h->hval.size();
+  std::vector<double> mv;
+  std::vector<long long> mr;
+  mv.reserve(std::min(k, ns + perm.size()));
+  mr.reserve(std::min(k, ns + perm.size()));
+  size_t a = 0, b = 0;
+  while (mv.size() < k && (a < ns || b < perm.size())) {
+    bool take_state;
+    if (a >= ns)
+      take_state = false;
+    else if (b >= perm.size())
+      take_state = true;
+    else {
+      const size_t q = perm[b];
+      take_state = h->hval[a] < cv[q] || (h->hval[a] == cv[q] && h->hrow[a] <= cr[q]);
+    }
+    if (take_state) {
+      mv.push_back(h->hval[a]);
+      mr.push_back(h->hrow[a]);
+      ++a;
+    } else {
+      mv.push_back(cv[perm[b]]);
+      mr.push_back(cr[perm[b]]);
+      ++b;
+    }
+  }
+  h->hval.swap(mv);
+  h->hrow.swap(mr);
+  const double thr = h->hval.size() == k ? h->hval[k - 1] : std::numeric_limits<double>::infinity();
+  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(h->thr, &thr, sizeof thr, hipMemcpyHostToDevice, st));
+  ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(st));   // `thr` is a stack variable
+  h->host_dirty = true;
+  return ELFIHIP_OK;
+}
+
+// device copy of a host-merge state (state_dev / export): uploaded when asked for
+static int host_upload(elfihip_reject* h) {
+  if (!h->host_mode || !h->host_dirty) return ELFIHIP_OK;
+  elfihip_ctx* ctx = h->ctx;
+  const size_t k = (size_t)h->k;
+  std::vector<double> v(h->hval);
+  std::vector<long long> r(h->hrow);
+  v.resize(k, std::numeric_limits<double>::infinity());
+  r.resize(k, std::numeric_limits<long long>::max());
+  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(h->best_val, v.data(), k * 8, hipMemcpyHostToDevice, ctx->stream));
+  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(h->best_row, r.data(), k * 8, hipMemcpyHostToDevice, ctx->stream));
+  if (h->export_dst) {
+    ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(h->export_dst, v.data(), k * 8, hipMemcpyHostToDevice, ctx->stream));
+    ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(reinterpret_cast<char*>(h->export_dst) + k * 8, r.data(), k * 8,
+                                          hipMemcpyHostToDevice, ctx->stream));
+  }
+  ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  h->host_dirty = false;
+  return ELFIHIP_OK;
+}
+
+// Fold a batch into the state.  run(F, &filtered) launches the distance pass with the filter F (or without: F == nullptr)
+// on the context's stream; dsel / stride address the batch's ranking distances (the last of `ncols` nested columns) for
+// the passes that need them.
+template <class Run>
+static int reject_push(elfihip_reject* h, int64_t n, const double* dsel, int64_t stride, int ncols, long long row_base,
+                       Run run) {
+  elfihip_ctx* ctx = h->ctx;
+  hipStream_t st = ctx->stream;
+  ELFIHIP_TRY(ensure_cap(h, n));
+  const bool full = h->host_mode ? (int64_t)h->hval.size() >= h->k : h->filled >= h->k;
+  // rows this push is expected to offer against the current threshold (batches of one distribution): n k / rows seen
+  const double expect = full ? (double)n * (double)h->k / (double)std::max<int64_t>(h->rows_seen, 1) : 1e300;
+  const bool select = !h->has_accept && (!full || expect > REJ_HEAVY);
+  h->rows_seen += n;
+  if (select) {
+    // every row could enter (state still filling up) or very many would: plain distance pass, radix selection of the
+    // batch's k best (batch-local rows), merge.  What the list holds from earlier pushes is merged first -- the
+    // selection writes its result there.
+    ELFIHIP_TRY(reject_flush(h));
     bool dummy = false;
     ELFIHIP_TRY(run(nullptr, &dummy));
     const int64_t kb = n < h->k ? n : h->k;
     if (kb > 0) {
       ELFIHIP_TRY(topk_dev_impl(ctx, dsel, n, stride, kb, h->cand_val, reinterpret_cast<int64_t*>(h->cand_row), true));
-      hipLaunchKernelGGL(reject_merge_kernel, dim3(1), dim3(1024), REJ_MERGE_LDS, st, merge_args(h, (int)kb, row_base));
+      if (h->host_mode)
+        ELFIHIP_TRY(host_merge(h, (unsigned int)kb, row_base));
+      else
+        hipLaunchKernelGGL(reject_merge_kernel, dim3(1), dim3(1024), REJ_MERGE_LDS, st, merge_args(h, (int)kb, row_base));
     }
     h->filled = h->filled + n < h->k ? h->filled + n : h->k;
     return launch_status(ctx, "reject_merge_kernel");
   }
+  if (h->pending_rows + n > (int64_t)h->cap) ELFIHIP_TRY(reject_flush(h));   // (cannot happen with a merge every 8th push)
   RejectFilter F;
   F.thr = h->thr;
   F.cval = h->cand_val;
@@ -292,18 +452,24 @@ static int reject_push(elfihip_reject* h, int64_t n, const double* dsel, int64_t
   F.cap = h->cap;
   F.row_base = row_base;
   bool filtered = false;
-  ELFIHIP_TRY(run(&F, &filtered));
-  if (!filtered && n > 0) {
+  // an acceptance threshold needs every column of a row: the separate candidate pass applies it
+  ELFIHIP_TRY(run(h->has_accept ? nullptr : &F, &filtered));
+  if ((!filtered || h->has_accept) && n > 0) {
     int g = (int)((n + 255) / 256);
     if (g > ctx->cu_count * 8) g = ctx->cu_count * 8;
-    hipLaunchKernelGGL(reject_filter_kernel, dim3(g), dim3(256), 0, st, dsel, n, stride, F);
+    hipLaunchKernelGGL(reject_filter_kernel, dim3(g), dim3(256), 0, st, dsel, n, stride, ncols, F, h->has_accept ? 1 : 0,
+                       h->accept, h->acc_count);
   }
+  h->pending_rows += n;
+  if (!full) h->filled = h->filled + n < h->k ? h->filled + n : h->k;   // (acceptance mode fills through the list)
   // Merge interval: the p-th push after the state became full offers about k / p candidates (batches of one
   // distribution), so merging every p / 2 pushes -- at most every REJ_MERGE_EVERY-th -- keeps a merge at about k / 2
-  // candidates: early on, while the threshold still falls quickly, after every push.
+  // candidates: early on, while the threshold still falls quickly, after every push.  Host-merge states and states
+  // that are still filling merge after every push.
   ++h->armed_pushes;
   int64_t interval = h->armed_pushes / 2;
   interval = interval < 1 ? 1 : (interval > REJ_MERGE_EVERY ? REJ_MERGE_EVERY : interval);
+  if (h->host_mode || !full) interval = 1;
   if (++h->unmerged >= interval) return reject_flush(h);
   return launch_status(ctx, "distance pass with selection");
 }

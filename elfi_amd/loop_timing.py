@@ -19,6 +19,7 @@ class LoopTimes:
         self.updates = 0
         self.acquires = 0
         self.searches = []      # (n_evidence, seconds, device fits, SCG status)
+        self.t_first_acquire = None   # seconds from instrument() to the first acquire(): the initial-evidence phase
 
     def summary(self, wall_s, n_points):
         n_fits = sum(s[2] for s in self.searches)
@@ -41,6 +42,7 @@ def instrument(gp, acq):
     T = LoopTimes()
     update, optimize, acquire = gp.update, gp.optimize, acq.acquire
     inside = {"search": 0.0}
+    t_begin = time.perf_counter()
 
     def timed_optimize():
         t0 = time.perf_counter()
@@ -64,6 +66,8 @@ def instrument(gp, acq):
 
     def timed_acquire(n, t=None):
         t0 = time.perf_counter()
+        if T.t_first_acquire is None:
+            T.t_first_acquire = t0 - t_begin
         try:
             return acquire(n, t)
         finally:

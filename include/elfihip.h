@@ -274,6 +274,14 @@ int elfihip_gp_factorize(elfihip_gp* gp, double* log_marginal);
  * panel_group 0 = by size, else 1 / 2 / 4 panels per pass over the trailing matrix (schedule 1).  Results agree to
  * rounding between schedules; each is deterministic. */
 int elfihip_gp_set_schedule(elfihip_gp* gp, int schedule, int panel_group);
+/* Which form the two triangular products of a prediction call take (no reference counterpart: the reference predicts
+ * one point per call, gpy_regression.py:98-147,179-223; bo/utils.py:97-103 runs its starts one after the other).  Calls
+ * with fewer than min_points query points stream the factor once per <= 128 points through (row block, k chunk)
+ * workgroups -- HBM-bound, right for the 10 starts of the default LCBSC; calls with at least min_points points (default
+ * 96: the 256 parallel starts of BASELINE configs[4], many-chain sampling) run both products as dense 64 x 64 MFMA
+ * tiles with full-k accumulation -- matrix-pipe-bound (csrc/gp_dense.hip).  min_points <= 0 restores the default;
+ * a huge value keeps every call on the streaming form.  Results agree to rounding; each form is deterministic. */
+int elfihip_gp_set_dense_threshold(elfihip_gp* gp, int64_t min_points);
 /* Device time per phase, for roofline accounting (bench.py; no reference counterpart).  While enabled, HIP events on the
  * GP's stream bracket the phases of elfihip_gp_factorize (Gram matrix | sweep | alpha + log-determinant), of single-group
  * prediction calls -- elfihip_gp_predict / _predict_grad / _lcb and every step of elfihip_gp_lcb_minimize -- (kernel row |

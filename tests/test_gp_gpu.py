@@ -311,6 +311,16 @@ def test_large_n_full_matrix_parity(hip_ctx, n, d, schedule):
         _close(grad, G.lcb_evaluate_gradient(post, xs, t), 1e-7, 'lcb grad')
     _, g = gp.nlml_grad()
     assert np.max(np.abs(g - post.log_marginal_grad())) <= 1e-7 * np.max(np.abs(g))
+    if schedule == 0 and n in (4096, 8192):
+        # a 256-point block (configs[4]'s parallel starts): the dense form of the two products
+        xs = np.random.RandomState(n + 1).uniform(-2, 2, (256, d))
+        mu, var, dmu, dvar = gp.predict_grad(xs)
+        rmu, rvar = post.predict(xs, noiseless=True)
+        gmu, gvar = post.predictive_gradients(xs)
+        _close(mu, rmu, 1e-8, 'mu (256 points)')
+        assert np.max(np.abs(var - rvar)) <= 1e-8 * (post.var + post.bias), 'var (256 points)'
+        _close(dmu, gmu, 1e-8, 'grad mu (256 points)')
+        _close(dvar, gvar, 1e-7, 'grad var (256 points)')
 
 
 def test_prior_kernel_matrix_is_gpys_kern_K(hip_ctx):
@@ -340,3 +350,39 @@ def test_prior_kernel_matrix_is_gpys_kern_K(hip_ctx):
     np.testing.assert_allclose(K, ref(A), rtol=1e-13, atol=1e-15)
     assert np.all(np.diag(K) == 1.7 + 0.3) and K.shape == (17, 17)
     np.testing.assert_allclose(m._gp.kern.K(X)[:5, :5], ref(X)[:5, :5], rtol=1e-13)
+
+
+@pytest.mark.parametrize('n,d,S', [(300, 2, 100), (1000, 10, 256), (2048, 10, 200), (4096, 10, 256), (4100, 3, 97),
+                                   (8192, 20, 256)])
+def test_dense_form_of_the_products_vs_streaming_form_and_oracle(hip_ctx, n, d, S):
+    """Calls with many points run both triangular products as dense 64 x 64 MFMA tiles (csrc/gp_dense.hip).  Same
+    quantities as the streaming form: compared with it on the same GP (1e-11: two summation orders of one formula) and
+    with the CPU posterior at the usual tolerances (gpy_regression.py:127-140,206-218)."""
+    X, y, bounds = _problem(n, d, seed=n + S)
+    gp, _, ref = _fit(X, y, bounds)
+    xs = np.random.RandomState(5).uniform(-2, 2, (S, d))
+    xs[0] = X[n // 3]
+    beta = G.lcb_beta(7, d)
+    gp.set_dense_threshold(1 << 40)                   # streaming form for every call
+    m0, v0, dm0, dv0 = gp.predict_grad(xs)
+    val0, g0 = gp.lcb(xs, beta)
+    mm0, vv0 = gp.predict(xs, noiseless=False)
+    gp.set_dense_threshold(64)                        # dense form
+    m1, v1, dm1, dv1 = gp.predict_grad(xs)
+    val1, g1 = gp.lcb(xs, beta)
+    mm1, vv1 = gp.predict(xs, noiseless=False)
+    _close(m1, m0, 1e-12, 'mu dense/stream')
+    assert np.max(np.abs(v1 - v0)) <= 1e-11 * (ref.var + ref.bias)
+    assert np.max(np.abs(vv1 - vv0)) <= 1e-11 * (ref.var + ref.bias) and np.array_equal(mm1, m1)
+    _close(dm1, dm0, 1e-11, 'grad mu dense/stream')
+    _close(dv1, dv0, 1e-10, 'grad var dense/stream')
+    _close(val1, val0, 1e-11, 'lcb dense/stream')
+    _close(g1, g0, 1e-10, 'lcb grad dense/stream')
+    if n <= 4100:
+        rmu, rvar = ref.predict(xs, noiseless=True)
+        gmu, gvar = ref.predictive_gradients(xs)
+        _close(m1, rmu, 1e-8, 'mu')
+        assert np.max(np.abs(v1 - rvar)) <= 1e-8 * (ref.var + ref.bias), 'var'
+        _close(dm1, gmu, 1e-8, 'grad mu')
+        _close(dv1, gvar, 1e-7, 'grad var')
+    gp.set_dense_threshold(0)

@@ -162,3 +162,46 @@ def test_real_bolfi_fit_1024_on_the_gpu(hip_ctx, elfi):
     post_ref = b.extract_posterior()
     lp = post_ref.logpdf(np.array([[0.6, 0.2], [0.0, 0.0]]))
     assert np.all(np.isfinite(lp)) and lp[0] > lp[1]
+
+
+@pytest.mark.timeout(2400)
+def test_config2_bolfi_fit_4096_through_the_reference_loop(hip_ctx, elfi):
+    """BASELINE.json configs[2] itself: elfi.BOLFI(log_d, batch_size=1, initial_evidence=512, update_interval=10,
+    bounds, acq_noise_var=0.1, seed=1, target_model=HipGPRegression, acquisition_method=HipLCBSC).fit(4096) through the
+    reference's loop (bolfi.py:201-254,289-292): 3584 acquisitions, a MAP search of the hyper-parameters every 10 of them."""
+    from elfi_amd.loop_timing import instrument
+    n0, n1, interval = 512, 4096, 10
+    hip = _bolfi(elfi, True, n0, interval)
+    T = instrument(hip.target_model, hip.acquisition_method)
+    hip.fit(n_evidence=n1, bar=False)
+    T.restore()
+    res = hip.extract_result()
+    gp = hip.target_model
+    assert gp.n_evidence == n1 and gp.X.shape == (n1, 2) and np.all(np.isfinite(gp.Y))
+    assert T.updates == n1 and T.acquires == n1 - n0
+    assert len(T.searches) == (n1 - n0) // interval              # at n = 522, 532, ..., 4092 (bolfi.py:289-292)
+    lo, hi = np.array([(-2, 2), (-1, 1)]).T
+    assert np.all(gp.X >= lo) and np.all(gp.X <= hi)
+    # (a) the acquisitions before the first hyper-parameter search (n = 522), next to the oracle model in the same loop
+    # (reference LCBSC + scipy L-BFGS-B on the NumPy GP)
+    cpu = _bolfi(elfi, False, n0, interval)
+    cpu.fit(n_evidence=n0 + interval - 1, bar=False)
+    Xc = cpu.target_model.X
+    assert np.array_equal(gp.X[:n0], Xc[:n0])
+    first = slice(n0, n0 + interval - 1)
+    dev = np.max(np.abs(gp.X[first] - Xc[first]), axis=1)
+    assert np.count_nonzero(dev <= 2e-5) >= interval - 2, dev
+    assert dev[0] <= 1e-6
+    # (b) the reference's statistical assertion (tests/functional/test_inference.py:136-190)
+    assert abs(res.x_min['t1'] - 0.6) < 0.2 and abs(res.x_min['t2'] - 0.2) < 0.2
+    # (c) the GP the run leaves behind = ONE CPU posterior of its 4096 evidence points at its final hyper-parameters
+    import gp_oracle as G
+    post = G.Posterior(gp.X, gp.Y, **gp._hyper)
+    xs = np.random.RandomState(0).uniform(lo, hi, (16, 2))
+    mu, var = gp.predict(xs, noiseless=True)
+    rmu, rvar = post.predict(xs, noiseless=True)
+    assert np.max(np.abs(mu - rmu)) <= 1e-7 * np.max(np.abs(rmu))
+    assert np.max(np.abs(var - rvar)) <= 1e-7 * np.max(rvar + 1)
+    dmu, dvar = gp.predictive_gradients(xs)
+    rdmu, rdvar = post.predictive_gradients(xs)
+    assert np.max(np.abs(dmu - rdmu)) <= 1e-6 * np.max(np.abs(rdmu)) and np.max(np.abs(dvar - rdvar)) <= 1e-6 * (np.max(np.abs(rdvar)) + 1)
