@@ -20,6 +20,7 @@ from .gmix import GMDistribution  # noqa: F401
 from .weighted import weighted_sample_quantile, weighted_var  # noqa: F401
 from .gp import GPHandle, HipGPRegression  # noqa: F401
 from .selection import RunningBest, merge_batch, smallest_k  # noqa: F401
+from .sampler import HipRejection, hip_rejection_class  # noqa: F401
 from .summaries import autocov, ma2_distance, ss_mean, ss_var  # noqa: F401
 from .lcb_acquisition import HipLCBSC  # noqa: F401
 from .posterior import HipBolfiPosterior, sample_posterior  # noqa: F401

@@ -77,6 +77,9 @@ PROTOTYPES = {
     "elfihip_reject_push_multiw_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_void_p,
                                                 C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
     "elfihip_reject_push_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64]),
+    "elfihip_reject_push": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int64]),
+    "elfihip_reject_set_accept": (C.c_int, [C.c_void_p, C.c_int, C.c_double]),
+    "elfihip_reject_meta": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "elfihip_reject_state_dev": (C.c_int, [C.c_void_p, c_void_pp, c_void_pp]),
     "elfihip_reject_export_dev": (C.c_int, [C.c_void_p, C.c_void_p]),
     "elfihip_reject_flush": (C.c_int, [C.c_void_p]),
@@ -119,7 +122,7 @@ PROTOTYPES = {
     "elfihip_gp_factorize": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "elfihip_gp_profile": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "elfihip_gp_set_schedule": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
-    "elfihip_gp_set_dense_threshold": (C.c_int, [C.c_void_p, C.c_int64]),
+    "elfihip_gp_set_dense_threshold": (C.c_int, [C.c_void_p, C.c_int64, C.c_int]),
     "elfihip_gp_nlml_grad": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_void_p]),
     "elfihip_gp_form_kinv": (C.c_int, [C.c_void_p]),
     "elfihip_gp_extend": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_double)]),

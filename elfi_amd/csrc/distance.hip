@@ -802,14 +802,14 @@ int elfihip_reject_push_rows(elfihip_reject* h, int metric, const double* X, int
   elfihip_ctx* ctx = reject_ctx(h);
   ELFIHIP_REQUIRE(ctx, n >= 0 && m >= 1 && ldx >= m, "bad shape n=%lld m=%d ldx=%lld", (long long)n, m,
                   (long long)ldx);
-  ELFIHIP_REQUIRE(ctx, y && (n == 0 || (X && out)), "NULL data pointer");
+  ELFIHIP_REQUIRE(ctx, y && (n == 0 || X), "NULL data pointer");   // out == NULL: the distances stay on the device
   DeviceGuard g(ctx->device);
   double *dX, *dy, *daux;
   ELFIHIP_TRY(stage_params(ctx, y, aux, m, aux ? aux_len(metric, m) : 0, &dy, &daux));
   ELFIHIP_TRY(stage_rows(ctx, X, n, m, ldx, &dX));
   ELFIHIP_CHECK_HIP(ctx, ctx->out.reserve((size_t)(n ? n : 1) * sizeof(double)));
   ELFIHIP_TRY(reject_push_rows_impl(h, metric, dX, n, m, m, dy, daux, p, ctx->out.as<double>(), row_base));
-  if (n)
+  if (n && out)
     ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(out, ctx->out.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return ELFIHIP_OK;

@@ -15,6 +15,7 @@
 // number of lock-steps of a call is the largest evaluation count any single start needs
 // (typically 10-25 at the BASELINE shapes).
 #include <chrono>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -22,8 +23,24 @@
 
 #include "gp.hpp"
 #include "lbfgsb.hpp"
+#include "round_pool.hpp"
 
 namespace elfihip {
+
+// Host threads for the quasi-Newton algebra of many starts (256 starts x a few microseconds per state-machine step is
+// as long as the device evaluation of the round): ELFIHIP_HOST_THREADS, default min(8, hardware threads).
+static int host_threads() {
+  static const int v = [] {
+    const char* e = std::getenv("ELFIHIP_HOST_THREADS");
+    int t = e ? std::atoi(e) : 0;
+    if (t <= 0) {
+      const unsigned hc = std::thread::hardware_concurrency();
+      t = (int)std::min<unsigned>(8u, hc ? hc : 1u);
+    }
+    return t < 1 ? 1 : (t > 64 ? 64 : t);
+  }();
+  return v;
+}
 
 static int lcb_minimize_impl(elfihip_gp* gp, const double* starts, int64_t S, const double* lo, const double* hi,
                              double beta, int maxiter, double* x_out, double* f_out, int* iters_out,
@@ -38,8 +55,13 @@ static int lcb_minimize_impl(elfihip_gp* gp, const double* starts, int64_t S, co
   std::vector<int64_t> who;
   who.reserve((size_t)S);
   for (int64_t i = 0; i < S; ++i) opt[(size_t)i].init(dim, lo, hi, starts + i * dim, maxiter);
+  RoundPool pool(S >= 64 ? host_threads() : 1);
+  static const bool trace = std::getenv("ELFIHIP_ACQ_TRACE") != nullptr;
+  double t_dev = 0.0, t_host = 0.0;
+  int rounds = 0;
   int64_t n_eval = 0;
   for (;;) {
+    const auto t0 = std::chrono::steady_clock::now();
     who.clear();
     for (int64_t i = 0; i < S; ++i)
       if (!opt[(size_t)i].done()) who.push_back(i);
@@ -49,10 +71,21 @@ static int lcb_minimize_impl(elfihip_gp* gp, const double* starts, int64_t S, co
       const double* x = opt[(size_t)who[k]].x();
       std::copy(x, x + dim, px.begin() + k * dim);
     }
+    const auto t1 = std::chrono::steady_clock::now();
     ELFIHIP_TRY(predict_impl(gp, px.data(), A, 1, 1, beta, nullptr, nullptr, nullptr, nullptr, pv.data(), pg.data()));
+    const auto t2 = std::chrono::steady_clock::now();
     n_eval += A;
-    for (int64_t k = 0; k < A; ++k) opt[(size_t)who[k]].feed(pv[(size_t)k], &pg[(size_t)k * dim]);
+    // every start advances its own state machine: independent, so the starts are dealt to the host threads
+    pool.run(A, [&](int64_t k) { opt[(size_t)who[(size_t)k]].feed(pv[(size_t)k], &pg[(size_t)k * dim]); });
+    const auto t3 = std::chrono::steady_clock::now();
+    t_dev += std::chrono::duration<double>(t2 - t1).count();
+    t_host += std::chrono::duration<double>(t1 - t0).count() + std::chrono::duration<double>(t3 - t2).count();
+    ++rounds;
   }
+  if (trace)
+    std::fprintf(stderr, "[elfihip acq] S=%lld n=%lld rounds=%d evals=%lld device %.3f ms host %.3f ms (threads %d)\n",
+                 (long long)S, (long long)gp->n, rounds, (long long)n_eval, 1e3 * t_dev, 1e3 * t_host,
+                 S >= 64 ? host_threads() : 1);
   for (int64_t i = 0; i < S; ++i) {
     const Lbfgsb& o = opt[(size_t)i];
     for (int c = 0; c < dim; ++c) x_out[i * dim + c] = o.best_x()[c];

@@ -31,43 +31,62 @@
 
 namespace elfihip {
 
-constexpr int DT = 64;            // tile edge (rows of the factor, points)
+constexpr int DT = 64;            // points per column block (and the largest row-tile height)
 constexpr int DK = 32;            // k-tile depth
 constexpr int DLP = 36;           // LDS row pitch in doubles (as the step kernel's stages: conflict-free b128 reads)
-constexpr int DSTAGE = 2 * DT * DLP;   // doubles of one stage: A rows, then B rows
-constexpr int DEP = 65;           // pitch of the epilogue tiles
-// LDS: two stages of the tile loop (73,728 bytes); the gradient epilogue lays its tiles over them and needs more:
-// U tile + kernel rows (64 x 65 each) + evidence rows and query points (64 x 24 each) + alpha
-constexpr size_t DENSE_LDS_BYTES = (size_t)(2 * DT * DEP + 2 * DT * 24 + DT) * sizeof(double);   // 91,648
-static_assert(DENSE_LDS_BYTES >= (size_t)2 * DSTAGE * sizeof(double), "staging must fit");
+constexpr int DEP = 65;           // pitch of the [row][point] epilogue tile
+// LDS: two stages of the tile loop, (TM + 64) rows each; the gradient epilogue lays its tiles over them:
+// U tile [TM][65] + kernel rows [64][TM + 1] + evidence rows [TM][24] + query points [64][24] + alpha [TM]
+constexpr size_t dense_lds_bytes(int tm) {
+  const size_t stages = (size_t)2 * (tm + DT) * DLP;
+  const size_t epi = (size_t)tm * DEP + (size_t)DT * (tm + 1) + (size_t)tm * 24 + (size_t)DT * 24 + tm;
+  return (stages > epi ? stages : epi) * sizeof(double);
+}
 
-struct DenseAcc {
-  v4d c[2][2];
+// Wave layout of a TM x 64 output tile on 4 waves:  TM = 64: 2 x 2 waves of 32 x 32;  TM = 32: 2 x 2 waves of 16 x 32;
+// TM = 16: 1 x 4 waves of 16 x 16.  Shorter tiles = more workgroups for the same product (fewer points, smaller n): the
+// matrix pipes of a workgroup are less busy, but the whole chip takes part.
+template <int TM>
+struct DenseShape {
+  static constexpr int WROWS = TM >= 32 ? TM / 2 : 16;
+  static constexpr int WAVES_R = TM / WROWS;         // 2, 2, 1
+  static constexpr int WAVES_C = 4 / WAVES_R;        // 2, 2, 4
+  static constexpr int WCOLS = DT / WAVES_C;         // 32, 32, 16
+  static constexpr int MI = WROWS / 16;              // 2, 1, 1
+  static constexpr int NJ = WCOLS / 16;              // 2, 2, 1
+  static constexpr int STAGE = (TM + DT) * DLP;      // doubles of one stage: A rows, then B rows
 };
 
-// acc += A(64 x K) B(64 x K)^T for k in [kbeg, kend), multiples of 32.  256 threads = 4 waves as 2 x 2, each 32 x 32.
-// Two LDS stages, one barrier per k-tile: while stage p is multiplied the next k-tile (in registers since the previous
-// step) is written to stage p ^ 1 and the loads of the one after it are issued.
-__device__ __forceinline__ void gemm64_nt(DenseAcc& acc, const double* __restrict__ A, int64_t lda,
-                                          const double* __restrict__ B, int64_t ldb, int kbeg, int kend, double* sm) {
+template <int TM>
+struct DenseAcc {
+  v4d c[DenseShape<TM>::MI][DenseShape<TM>::NJ];
+};
+
+// acc += A(TM x K) B(64 x K)^T for k in [kbeg, kend), multiples of 32.  256 threads.  Two LDS stages, one barrier per
+// k-tile: while stage p is multiplied the next k-tile (in registers since the previous step) is written to stage p ^ 1
+// and the loads of the one after it are issued.
+template <int TM>
+__device__ __forceinline__ void gemm_tm_nt(DenseAcc<TM>& acc, const double* __restrict__ A, int64_t lda,
+                                           const double* __restrict__ B, int64_t ldb, int kbeg, int kend, double* sm) {
+  typedef DenseShape<TM> SH;
   const int t = threadIdx.x, l = t & 63, w = t >> 6;
-  const int wr = w >> 1, wc = w & 1;
-  // global -> LDS: thread t carries k pair 2 (t & 15) of rows (t >> 4) + 16 j
+  const int wr = w / SH::WAVES_C, wc = w % SH::WAVES_C;
+  // global -> LDS: thread t carries k pair 2 (t & 15) of rows (t >> 4) + 16 j  (j < TM / 16 for A, j < 4 for B)
   const double* pa = A + (int64_t)(t >> 4) * lda + 2 * (t & 15) + kbeg;
   const double* pb = B + (int64_t)(t >> 4) * ldb + 2 * (t & 15) + kbeg;
   const int doff = (t >> 4) * DLP + 2 * (t & 15);
-  const int faoff = (wr * 32 + (l & 15)) * DLP + 2 * (l >> 4);
-  const int fboff = (DT + wc * 32 + (l & 15)) * DLP + 2 * (l >> 4);
+  const int faoff = (wr * SH::WROWS + (l & 15)) * DLP + 2 * (l >> 4);
+  const int fboff = (TM + wc * SH::WCOLS + (l & 15)) * DLP + 2 * (l >> 4);
   // (plain scalars and macros: a lambda capturing a register array sends the array to scratch memory)
-  double2 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+  double2 ra0, ra1 = {0.0, 0.0}, ra2 = {0.0, 0.0}, ra3 = {0.0, 0.0}, rb0, rb1, rb2, rb3;
 #define DENSE_ISSUE(a_, b_)                                                    \
   do {                                                                         \
     const double* ia_ = (a_);                                                  \
     const double* ib_ = (b_);                                                  \
     ra0 = *reinterpret_cast<const double2*>(ia_);                              \
-    ra1 = *reinterpret_cast<const double2*>(ia_ + (int64_t)16 * lda);          \
-    ra2 = *reinterpret_cast<const double2*>(ia_ + (int64_t)32 * lda);          \
-    ra3 = *reinterpret_cast<const double2*>(ia_ + (int64_t)48 * lda);          \
+    if (TM >= 32) ra1 = *reinterpret_cast<const double2*>(ia_ + (int64_t)16 * lda); \
+    if (TM >= 64) ra2 = *reinterpret_cast<const double2*>(ia_ + (int64_t)32 * lda); \
+    if (TM >= 64) ra3 = *reinterpret_cast<const double2*>(ia_ + (int64_t)48 * lda); \
     rb0 = *reinterpret_cast<const double2*>(ib_);                              \
     rb1 = *reinterpret_cast<const double2*>(ib_ + (int64_t)16 * ldb);          \
     rb2 = *reinterpret_cast<const double2*>(ib_ + (int64_t)32 * ldb);          \
@@ -77,13 +96,13 @@ __device__ __forceinline__ void gemm64_nt(DenseAcc& acc, const double* __restric
   do {                                                                         \
     double* sb_ = (buf_) + doff;                                               \
     *reinterpret_cast<double2*>(sb_) = ra0;                                    \
-    *reinterpret_cast<double2*>(sb_ + 16 * DLP) = ra1;                         \
-    *reinterpret_cast<double2*>(sb_ + 32 * DLP) = ra2;                         \
-    *reinterpret_cast<double2*>(sb_ + 48 * DLP) = ra3;                         \
-    *reinterpret_cast<double2*>(sb_ + DT * DLP) = rb0;                         \
-    *reinterpret_cast<double2*>(sb_ + (DT + 16) * DLP) = rb1;                  \
-    *reinterpret_cast<double2*>(sb_ + (DT + 32) * DLP) = rb2;                  \
-    *reinterpret_cast<double2*>(sb_ + (DT + 48) * DLP) = rb3;                  \
+    if (TM >= 32) *reinterpret_cast<double2*>(sb_ + 16 * DLP) = ra1;           \
+    if (TM >= 64) *reinterpret_cast<double2*>(sb_ + 32 * DLP) = ra2;           \
+    if (TM >= 64) *reinterpret_cast<double2*>(sb_ + 48 * DLP) = ra3;           \
+    *reinterpret_cast<double2*>(sb_ + TM * DLP) = rb0;                         \
+    *reinterpret_cast<double2*>(sb_ + (TM + 16) * DLP) = rb1;                  \
+    *reinterpret_cast<double2*>(sb_ + (TM + 32) * DLP) = rb2;                  \
+    *reinterpret_cast<double2*>(sb_ + (TM + 48) * DLP) = rb3;                  \
   } while (0)
   const int nkt = (kend - kbeg) / DK;
   DENSE_ISSUE(pa, pb);
@@ -94,25 +113,24 @@ __device__ __forceinline__ void gemm64_nt(DenseAcc& acc, const double* __restric
   int p = 0;
 #pragma unroll 1
   for (int kt = 0; kt < nkt; ++kt) {
-    const double* buf = sm + p * DSTAGE;
+    const double* buf = sm + p * SH::STAGE;
     if (kt + 1 < nkt) {
-      DENSE_STAGE(sm + (p ^ 1) * DSTAGE);
+      DENSE_STAGE(sm + (p ^ 1) * SH::STAGE);
       if (kt + 2 < nkt) DENSE_ISSUE(pa + (int64_t)(kt + 2) * DK, pb + (int64_t)(kt + 2) * DK);
     }
     const double* fa = buf + faoff;
     const double* fb = buf + fboff;
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
-      double2 a[2], b[2];
+      double2 a[SH::MI], b[SH::NJ];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        a[i] = *reinterpret_cast<const double2*>(fa + i * 16 * DLP + 8 * h);
-        b[i] = *reinterpret_cast<const double2*>(fb + i * 16 * DLP + 8 * h);
-      }
+      for (int i = 0; i < SH::MI; ++i) a[i] = *reinterpret_cast<const double2*>(fa + i * 16 * DLP + 8 * h);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int j = 0; j < SH::NJ; ++j) b[j] = *reinterpret_cast<const double2*>(fb + j * 16 * DLP + 8 * h);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+      for (int i = 0; i < SH::MI; ++i)
+#pragma unroll
+        for (int j = 0; j < SH::NJ; ++j) {
           acc.c[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].x, b[j].x, acc.c[i][j], 0, 0, 0);
           acc.c[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].y, b[j].y, acc.c[i][j], 0, 0, 0);
         }
@@ -128,7 +146,7 @@ struct DenseArgs {
   const double* W;      // WL (first product) or WT (second)
   const double* Bm;     // KBT (first) or VT (second): [S_pad][np], k contiguous
   int64_t lda, np, n;
-  int nrb, ncb;         // 64-row blocks of the factor, 64-point column blocks
+  int nrb, ncb;         // TM-row blocks of the factor, 64-point column blocks
   // first product
   double* VT;           // [S_pad][np]
   double* var_part;     // [pass][nrb][16]
@@ -151,47 +169,48 @@ __device__ __forceinline__ bool dense_decode(const DenseArgs& D, int* pair, int*
 }
 
 // MODE 0: V = L^-1 KB^T, written transposed + sum_i v^2.   MODE 1: U = L^-T V folded into the gradient sums.
-template <int MODE>
+template <int MODE, int TM>
 __global__ __launch_bounds__(256) void dense_tri_kernel(DenseArgs D) {
+  typedef DenseShape<TM> SH;
   extern __shared__ __align__(16) double sm[];
   int pair, cb;
   if (!dense_decode(D, &pair, &cb)) return;
   const int t = threadIdx.x, l = t & 63, w = t >> 6;
-  const int wr = w >> 1, wc = w & 1;
+  const int wr = w / SH::WAVES_C, wc = w % SH::WAVES_C;
   const int64_t s0 = (int64_t)cb * DT;
 #pragma unroll 1
   for (int half = 0; half < 2; ++half) {
     // longer tile first in both products
     const int rb = MODE == 0 ? (half == 0 ? D.nrb - 1 - pair : pair) : (half == 0 ? pair : D.nrb - 1 - pair);
-    const int64_t i0 = (int64_t)rb * DT;
-    const int kbeg = MODE == 0 ? 0 : (int)i0;
-    const int kend = MODE == 0 ? (int)(i0 + DT) : (int)D.np;
-    DenseAcc acc;
+    const int64_t i0 = (int64_t)rb * TM;
+    // k ranges in multiples of the 32-deep k-tile: [0, end of the diagonal 32-block) / [start of it, np)
+    const int kbeg = MODE == 0 ? 0 : (int)(i0 / DK * DK);
+    const int kend = MODE == 0 ? (int)((i0 + TM + DK - 1) / DK * DK) : (int)D.np;
+    DenseAcc<TM> acc;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < SH::MI; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc.c[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
-    gemm64_nt(acc, D.W + i0 * D.lda, D.lda, D.Bm + s0 * D.np, D.np, kbeg, kend, sm);
+      for (int j = 0; j < SH::NJ; ++j) acc.c[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+    gemm_tm_nt<TM>(acc, D.W + i0 * D.lda, D.lda, D.Bm + s0 * D.np, D.np, kbeg, kend, sm);
     // the tile as [i][s] in LDS (the GEMM's last barrier has passed: the staging area is free)
     double* T = sm;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < SH::MI; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < SH::NJ; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          T[(wr * 32 + i * 16 + (l >> 4) + 4 * r) * DEP + wc * 32 + j * 16 + (l & 15)] = acc.c[i][j][r];
+          T[(wr * SH::WROWS + i * 16 + (l >> 4) + 4 * r) * DEP + wc * SH::WCOLS + j * 16 + (l & 15)] = acc.c[i][j][r];
     __syncthreads();
     if (MODE == 0) {
-      // VT[s0 + s][i0 + i]: thread (i = t & 63, s = (t >> 6) + 4 q) -> 512-byte runs along i
-#pragma unroll 4
-      for (int q = 0; q < 16; ++q) {
-        const int s = (t >> 6) + 4 * q;
-        D.VT[(s0 + s) * D.np + i0 + (t & 63)] = T[(t & 63) * DEP + s];
+      // VT[s0 + s][i0 + i]: consecutive threads walk i (runs of TM doubles)
+      for (int e = t; e < TM * DT; e += 256) {
+        const int i = e % TM, s = e / TM;
+        D.VT[(s0 + s) * D.np + i0 + i] = T[i * DEP + s];
       }
       if (t < DT) {   // sum_i v[i][s]^2 over the tile's rows, fixed order
         double q2 = 0.0;
-        for (int i = 0; i < DT; ++i) {
+        for (int i = 0; i < TM; ++i) {
           const double v = T[i * DEP + t];
           q2 += v * v;
         }
@@ -201,23 +220,26 @@ __global__ __launch_bounds__(256) void dense_tri_kernel(DenseArgs D) {
     } else {
       // gradient sums of this (row block, 64 points): needs k_si, X_i, alpha_i, x_s
       const int dp = D.dp;
-      double* KR = sm + DT * DEP;           // [s][i]
-      double* XI = KR + DT * DEP;           // [i][dp]
-      double* XS = XI + DT * 24;            // [s][dp]   (dp <= 24 by the caller's check)
+      constexpr int KP = TM + 1;
+      double* KR = sm + TM * DEP;           // [s][i], pitch TM + 1
+      double* XI = KR + DT * KP;            // [i][24]
+      double* XS = XI + TM * 24;            // [s][24]   (dp <= 24 by the caller's check)
       double* AL = XS + DT * 24;            // [i]
-#pragma unroll 4
-      for (int q = 0; q < 16; ++q) {
-        const int s = (t >> 6) + 4 * q;
-        KR[s * DEP + (t & 63)] = D.kr[(s0 + s) * D.np + i0 + (t & 63)];
+      for (int e = t; e < TM * DT; e += 256) {
+        const int i = e % TM, s = e / TM;
+        KR[s * KP + i] = D.kr[(s0 + s) * D.np + i0 + i];
+      }
+      for (int e = t; e < TM * dp; e += 256) {
+        const int r = e / dp, c = e - r * dp;
+        XI[r * 24 + c] = D.X[(i0 + r) * dp + c];
       }
       for (int e = t; e < DT * dp; e += 256) {
         const int r = e / dp, c = e - r * dp;
-        XI[r * 24 + c] = D.X[(i0 + r) * dp + c];
         XS[r * 24 + c] = D.xs[(s0 + r) * dp + c];
       }
-      if (t < DT) AL[t] = (i0 + t) < D.n ? D.alpha[i0 + t] : 0.0;
+      if (t < TM) AL[t] = (i0 + t) < D.n ? D.alpha[i0 + t] : 0.0;
       __syncthreads();
-      // thread (s = t & 63, q = t >> 6): dimensions a = q, q + 4, ... ; sums over the 64 rows in order
+      // thread (s = t & 63, q = t >> 6): dimensions a = q, q + 4, ... ; sums over the tile's rows in order
       const int s = t & 63, q = t >> 6;
       double g1[6], g2[6], xa[6];
 #pragma unroll
@@ -226,8 +248,9 @@ __global__ __launch_bounds__(256) void dense_tri_kernel(DenseArgs D) {
         g2[j] = 0.0;
         xa[j] = (q + 4 * j) < dp ? XS[s * 24 + q + 4 * j] : 0.0;
       }
-      for (int i = 0; i < DT; ++i) {
-        const double k = KR[s * DEP + i];
+#pragma unroll 2
+      for (int i = 0; i < TM; ++i) {
+        const double k = KR[s * KP + i];
         const double c1 = AL[i] * k, c2 = T[i * DEP + s] * k;
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
@@ -245,8 +268,46 @@ __global__ __launch_bounds__(256) void dense_tri_kernel(DenseArgs D) {
           gp_[dp + q + 4 * j] = g2[j];
         }
     }
-    // (gemm64_nt opens with a barrier: the epilogue's LDS reads are over before the next tile stages)
+    // (gemm_tm_nt opens with a barrier: the epilogue's LDS reads are over before the next tile stages)
   }
+}
+
+template <int TM>
+static int dense_launch(elfihip_gp* gp, DenseArgs D, int mode, const double* kbt, const double* vt) {
+  elfihip_ctx* ctx = gp->ctx;
+  hipStream_t st = ctx->stream;
+  constexpr size_t lds = dense_lds_bytes(TM);
+  static bool enabled = false;   // per process; the attribute belongs to the function, not to a device object
+  if (!enabled) {
+    ELFIHIP_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(dense_tri_kernel<0, TM>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ELFIHIP_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(dense_tri_kernel<1, TM>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    enabled = true;
+  }
+  D.nrb = (int)(D.np / TM);
+  const unsigned grid = (unsigned)round_up((int64_t)D.ncb * (D.nrb / 2), 8);
+  const bool prof = gp->profile;
+  if (prof) prof_mark(gp, 0);
+  D.W = gp->WL;
+  D.Bm = kbt;
+  hipLaunchKernelGGL((dense_tri_kernel<0, TM>), dim3(grid), dim3(256), lds, st, D);
+  if (prof) prof_mark(gp, 1);
+  if (mode == 1) {
+    D.W = gp->WT;
+    D.Bm = vt;
+    hipLaunchKernelGGL((dense_tri_kernel<1, TM>), dim3(grid), dim3(256), lds, st, D);
+  }
+  if (prof) prof_mark(gp, 2);
+  return ELFIHIP_OK;
+}
+
+// Row-tile height: the tallest of 64 / 32 / 16 that still gives about one workgroup per CU (pairs x column blocks).
+static int dense_tile_rows(const elfihip_gp* gp, int ncb) {
+  const int64_t want = (int64_t)gp->ctx->cu_count * 3 / 4;
+  for (int tm : {64, 32})
+    if ((int64_t)ncb * (gp->np / tm / 2) >= want) return tm;
+  return 16;
 }
 
 int64_t dense_min_points(const elfihip_gp* gp) {
@@ -254,7 +315,7 @@ int64_t dense_min_points(const elfihip_gp* gp) {
   static const int64_t v = [] {
     const char* e = std::getenv("ELFIHIP_DENSE_MIN");   // process-wide default, for experiments
     const long long x = e ? std::atoll(e) : 0;
-    return (int64_t)(x > 0 ? x : 96);
+    return (int64_t)(x > 0 ? x : 112);
   }();
   return v;
 }
@@ -271,7 +332,8 @@ int predict_dense_impl(elfihip_gp* gp, const double* Xs, int64_t S, int mode, in
   const int64_t np = gp->np;
   const int64_t S_pad = round_up(S, DT);
   const int npass = (int)(S_pad / 16);
-  const int nrb = (int)(np / DT), ncb = (int)(S_pad / DT);
+  const int ncb = (int)(S_pad / DT);
+  const int nrb_max = (int)(np / 16);   // chunks of the epilogue sums at the shortest row tile
   const int nblk_k = (int)((np + 255) / 256);
   const size_t outsz = (size_t)3 * 16 + 3 * 16 * dp;
   // workspace (doubles): xs | xs2 | kr | kbt | VT | mu_part | var_part | g_part | out
@@ -283,8 +345,8 @@ int predict_dense_impl(elfihip_gp* gp, const double* Xs, int64_t S, int mode, in
   };
   const size_t o_xs = take((size_t)S_pad * dp), o_xs2 = take((size_t)S_pad), o_kr = take((size_t)S_pad * np),
                o_kbt = take((size_t)S_pad * np), o_vt = take((size_t)S_pad * np),
-               o_mu = take((size_t)npass * 16 * nblk_k), o_var = take((size_t)npass * nrb * 16),
-               o_g = take((size_t)npass * 16 * nrb * 2 * dp), o_out = take((size_t)npass * outsz);
+               o_mu = take((size_t)npass * 16 * nblk_k), o_var = take((size_t)npass * nrb_max * 16),
+               o_g = take((size_t)npass * 16 * nrb_max * 2 * dp), o_out = take((size_t)npass * outsz);
   ELFIHIP_CHECK_HIP(ctx, gp->ws_dense.reserve(off * sizeof(double)));
   double* base = gp->ws_dense.as<double>();
   // pinned staging: points + norms up, results down (one copy each way)
@@ -313,13 +375,8 @@ int predict_dense_impl(elfihip_gp* gp, const double* Xs, int64_t S, int mode, in
   // (xs2 directly follows xs: S_pad * dp is a multiple of the workspace's 16-double granule)
   ELFIHIP_TRY(ensure_wl_public(gp));   // L^-1 row-wise is the FIRST product's matrix here
   launch_kstar_passes(gp, base + o_xs, base + o_xs2, base + o_kr, base + o_kbt, base + o_mu, nblk_k, (unsigned)npass);
-  if (!ctx->dense_lds_enabled) {
-    ELFIHIP_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(dense_tri_kernel<0>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)DENSE_LDS_BYTES));
-    ELFIHIP_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(dense_tri_kernel<1>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)DENSE_LDS_BYTES));
-    ctx->dense_lds_enabled = true;
-  }
+  const int tm = gp->dense_tm > 0 ? gp->dense_tm : dense_tile_rows(gp, ncb);
+  const int nrb = (int)(np / tm);
   DenseArgs D;
   D.lda = gp->lda;
   D.np = np;
@@ -334,19 +391,12 @@ int predict_dense_impl(elfihip_gp* gp, const double* Xs, int64_t S, int mode, in
   D.xs = base + o_xs;
   D.g_part = base + o_g;
   D.dp = dp;
-  const unsigned grid = (unsigned)round_up((int64_t)ncb * (nrb / 2), 8);
   const bool prof = gp->profile;
-  if (prof) prof_mark(gp, 0);
-  D.W = gp->WL;
-  D.Bm = base + o_kbt;
-  hipLaunchKernelGGL((dense_tri_kernel<0>), dim3(grid), dim3(256), DENSE_LDS_BYTES, st, D);
-  if (prof) prof_mark(gp, 1);
-  if (mode == 1) {
-    D.W = gp->WT;
-    D.Bm = base + o_vt;
-    hipLaunchKernelGGL((dense_tri_kernel<1>), dim3(grid), dim3(256), DENSE_LDS_BYTES, st, D);
+  switch (tm) {
+    case 64: ELFIHIP_TRY(dense_launch<64>(gp, D, mode, base + o_kbt, base + o_vt)); break;
+    case 32: ELFIHIP_TRY(dense_launch<32>(gp, D, mode, base + o_kbt, base + o_vt)); break;
+    default: ELFIHIP_TRY(dense_launch<16>(gp, D, mode, base + o_kbt, base + o_vt)); break;
   }
-  if (prof) prof_mark(gp, 2);
   launch_finish_passes(gp, base + o_mu, nblk_k, base + o_var, nrb, base + o_g, nrb, base + o_out, (int)S, noiseless, beta, mode,
                        (unsigned)npass);
   ELFIHIP_TRY(launch_status(ctx, "dense prediction"));
@@ -373,8 +423,11 @@ int predict_dense_impl(elfihip_gp* gp, const double* Xs, int64_t S, int mode, in
 
 }  // namespace elfihip
 
-extern "C" int elfihip_gp_set_dense_threshold(elfihip_gp* gp, int64_t min_points) {
+extern "C" int elfihip_gp_set_dense_threshold(elfihip_gp* gp, int64_t min_points, int tile_rows) {
   if (!gp) return elfihip::fail(nullptr, ELFIHIP_ERR_ARG, "gp is NULL");
+  if (!(tile_rows == 0 || tile_rows == 16 || tile_rows == 32 || tile_rows == 64))
+    return elfihip::fail(gp->ctx, ELFIHIP_ERR_ARG, "tile_rows must be 0, 16, 32 or 64");
   gp->dense_min = min_points > 0 ? min_points : 0;
+  gp->dense_tm = tile_rows;
   return ELFIHIP_OK;
 }

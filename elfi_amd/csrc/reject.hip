@@ -479,7 +479,7 @@ elfihip_ctx* reject_ctx(elfihip_reject* h) { return h->ctx; }
 int reject_push_rows_impl(elfihip_reject* h, int metric, const double* dX, int64_t n, int m, int64_t ldx,
                           const double* dy, const double* daux, double p, double* dout, int64_t row_base) {
   elfihip_ctx* ctx = h->ctx;
-  return reject_push(h, n, dout, 1, (long long)row_base, [&](const RejectFilter* F, bool* filtered) {
+  return reject_push(h, n, dout, 1, 1, (long long)row_base, [&](const RejectFilter* F, bool* filtered) {
     return dist_rows_dev_impl(ctx, metric, dX, n, m, ldx, dy, daux, p, dout, F, filtered);
   });
 }
@@ -495,6 +495,7 @@ int elfihip_reject_free(elfihip_reject* h) {
   DeviceGuard g(h->ctx->device);
   (void)hipStreamSynchronize(h->ctx->stream);
   h->mem.release();
+  h->cand_mem.release();
   delete h;
   return ELFIHIP_OK;
 }
@@ -502,18 +503,24 @@ int elfihip_reject_free(elfihip_reject* h) {
 int elfihip_reject_create(elfihip_ctx* ctx, int64_t k, elfihip_reject** out) {
   if (!ctx || !out) return fail(ctx, ELFIHIP_ERR_ARG, "NULL argument");
   *out = nullptr;
-  ELFIHIP_REQUIRE(ctx, k >= 1 && k <= REJ_MAX_K, "k = %lld outside [1, %lld] (larger sample sets: elfihip_topk_smallest "
-                  "per batch and a host merge)", (long long)k, (long long)REJ_MAX_K);
+  ELFIHIP_REQUIRE(ctx, k >= 1 && k <= REJ_MAX_K_HOST, "k = %lld outside [1, %lld]", (long long)k, (long long)REJ_MAX_K_HOST);
   DeviceGuard g(ctx->device);
-  ELFIHIP_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(reject_merge_kernel),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)REJ_MERGE_LDS));
+  // the merge kernel keeps the state, a chunk of candidates and its rank tables in 69,920 bytes of LDS: more than the
+  // 64 KiB of earlier CDNA parts -- this library is built for gfx950 (160 KiB per CU) only
+  hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(reject_merge_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)REJ_MERGE_LDS);
+  if (ea != hipSuccess)
+    return fail(ctx, ELFIHIP_ERR_HIP, "the sampler state's merge kernel needs %zu bytes of LDS per workgroup (gfx950): %s",
+                REJ_MERGE_LDS, hipGetErrorString(ea));
   elfihip_reject* h = new elfihip_reject();
   h->ctx = ctx;
   h->k = k;
-  h->cap = REJ_CAP;
-  const size_t bytes = (size_t)k * 16 + 64 + (size_t)h->cap * 16;
+  h->host_mode = k > REJ_MAX_K;
+  const size_t bytes = (size_t)k * 16 + 64;
   hipError_t e = h->mem.reserve(bytes);
+  if (e == hipSuccess) e = h->cand_mem.reserve((size_t)REJ_CAP * 16);
   if (e != hipSuccess) {
+    h->mem.release();
     delete h;
     return fail(ctx, ELFIHIP_ERR_NOMEM, "sampler state allocation failed: %s", hipGetErrorString(e));
   }
@@ -525,10 +532,10 @@ int elfihip_reject_create(elfihip_ctx* ctx, int64_t k, elfihip_reject** out) {
   h->thr = reinterpret_cast<double*>(p);
   h->count = reinterpret_cast<unsigned int*>(p + 8);
   h->status = reinterpret_cast<unsigned int*>(p + 12);
-  p += 64;
-  h->cand_val = reinterpret_cast<double*>(p);
-  p += (size_t)h->cap * 8;
-  h->cand_row = reinterpret_cast<long long*>(p);
+  h->acc_count = reinterpret_cast<unsigned long long*>(p + 16);
+  h->cap = (unsigned int)std::min<size_t>(h->cand_mem.cap / 16, 0x7fffffffu);
+  h->cand_val = h->cand_mem.as<double>();
+  h->cand_row = reinterpret_cast<long long*>(h->cand_val + h->cap);
   int rc = reject_reset_impl(h);
   if (rc != ELFIHIP_OK) {
     elfihip_reject_free(h);
@@ -566,7 +573,7 @@ int elfihip_reject_push_multiw_dev(elfihip_reject* h, const double* dX, int64_t 
   ELFIHIP_REQUIRE(ctx, n >= 0 && K >= 1 && (n == 0 || dout), "the batch's distances need a destination (dout)");
   DeviceGuard g(ctx->device);
   // nested distances are ranked by their LAST column (samplers.py:233)
-  return reject_push(h, n, dout ? dout + (K - 1) : nullptr, K, (long long)row_base,
+  return reject_push(h, n, dout ? dout + (K - 1) : nullptr, K, K, (long long)row_base,
                      [&](const RejectFilter* F, bool* filtered) {
                        return dist_multiw_dev_impl(ctx, dX, n, m, ldx, dy, dW, K, dout, F, filtered);
                      });
@@ -577,7 +584,7 @@ int elfihip_reject_push_dev(elfihip_reject* h, const double* dD, int64_t n, int6
   elfihip_ctx* ctx = h->ctx;
   ELFIHIP_REQUIRE(ctx, n >= 0 && stride >= 1 && (n == 0 || dD), "bad arguments");
   DeviceGuard g(ctx->device);
-  return reject_push(h, n, dD, stride, (long long)row_base, [&](const RejectFilter*, bool* filtered) {
+  return reject_push(h, n, dD, stride, 1, (long long)row_base, [&](const RejectFilter*, bool* filtered) {
     *filtered = false;   // the distances exist already: candidates come from the separate pass
     return ELFIHIP_OK;
   });
@@ -587,6 +594,7 @@ int elfihip_reject_state_dev(elfihip_reject* h, double** dvals, int64_t** drows)
   if (!h) return fail(nullptr, ELFIHIP_ERR_ARG, "state is NULL");
   DeviceGuard g(h->ctx->device);
   ELFIHIP_TRY(reject_flush(h));   // work queued on the context's stream after this call sees every batch merged
+  ELFIHIP_TRY(host_upload(h));    // (host-merge states: the device copy is brought up to date)
   if (dvals) *dvals = h->best_val;
   if (drows) *drows = reinterpret_cast<int64_t*>(h->best_row);
   return ELFIHIP_OK;
@@ -604,21 +612,75 @@ int elfihip_reject_result(elfihip_reject* h, double* vals, int64_t* rows, int64_
   ELFIHIP_REQUIRE(ctx, vals && rows, "NULL result pointer");
   DeviceGuard g(ctx->device);
   ELFIHIP_TRY(reject_flush(h));
+  if (h->host_mode) {
+    const size_t c = h->hval.size();
+    for (size_t i = 0; i < (size_t)h->k; ++i) {
+      vals[i] = i < c ? h->hval[i] : std::numeric_limits<double>::infinity();
+      rows[i] = i < c ? (int64_t)h->hrow[i] : std::numeric_limits<int64_t>::max();
+    }
+    if (count) *count = (int64_t)c;
+    return ELFIHIP_OK;
+  }
   unsigned int status = 0;
   ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(vals, h->best_val, (size_t)h->k * 8, hipMemcpyDeviceToHost, ctx->stream));
   ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(rows, h->best_row, (size_t)h->k * 8, hipMemcpyDeviceToHost, ctx->stream));
   ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(&status, h->status, sizeof status, hipMemcpyDeviceToHost, ctx->stream));
   ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  if (status & 1u)
-    return fail(ctx, ELFIHIP_ERR_STATE, "more than %u candidates below the running threshold were offered between two "
-                "merges (batches that improve this much need elfihip_reject_reset between rounds)", h->cap);
+  if (status & 1u)   // cannot happen: the list holds 8 x the largest batch and is merged every 8th push at the latest
+    return fail(ctx, ELFIHIP_ERR_STATE, "internal: the candidate list (%u entries) overflowed", h->cap);
   if (count) {
-    // entries in use: rows offered so far, capped at k, minus the slots NaN distances left empty (a NaN never enters the
-    // state; the reference would list such rows last, after every finite distance)
+    // entries in use: slots that hold a row (a NaN distance never enters the state; the reference would list such rows
+    // last, after every finite distance; rows above an acceptance threshold never enter either)
     int64_t c = 0;
-    while (c < h->filled && rows[c] != std::numeric_limits<int64_t>::max()) ++c;
+    while (c < h->k && rows[c] != std::numeric_limits<int64_t>::max()) ++c;
     *count = c;
   }
+  return ELFIHIP_OK;
+}
+
+int elfihip_reject_set_accept(elfihip_reject* h, int enable, double threshold) {
+  if (!h) return fail(nullptr, ELFIHIP_ERR_ARG, "state is NULL");
+  ELFIHIP_REQUIRE(h->ctx, !enable || threshold == threshold, "the acceptance threshold is NaN");
+  ELFIHIP_REQUIRE(h->ctx, h->rows_seen == 0, "set the acceptance threshold before the first push (or after a reset)");
+  h->has_accept = enable != 0;
+  h->accept = threshold;
+  return ELFIHIP_OK;
+}
+
+int elfihip_reject_push(elfihip_reject* h, const double* D, int64_t n, int ncols, int64_t row_base) {
+  if (!h) return fail(nullptr, ELFIHIP_ERR_ARG, "state is NULL");
+  elfihip_ctx* ctx = h->ctx;
+  ELFIHIP_REQUIRE(ctx, n >= 0 && ncols >= 1 && (n == 0 || D), "bad arguments");
+  if (n == 0) return ELFIHIP_OK;
+  DeviceGuard g(ctx->device);
+  const size_t bytes = (size_t)n * ncols * sizeof(double);
+  ELFIHIP_CHECK_HIP(ctx, ctx->in.reserve(bytes));
+  double* dD = ctx->in.as<double>();
+  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(dD, D, bytes, hipMemcpyHostToDevice, ctx->stream));
+  ELFIHIP_TRY(reject_push(h, n, dD + (ncols - 1), ncols, ncols, (long long)row_base, [&](const RejectFilter*, bool* filtered) {
+    *filtered = false;
+    return ELFIHIP_OK;
+  }));
+  // the staging buffer is the context's: merged before the next call may overwrite it (selection route: already done)
+  ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ELFIHIP_OK;
+}
+
+int elfihip_reject_meta(elfihip_reject* h, double* kth, int64_t* in_use, int64_t* accepted_last, int64_t* accepted_total) {
+  if (!h) return fail(nullptr, ELFIHIP_ERR_ARG, "state is NULL");
+  elfihip_ctx* ctx = h->ctx;
+  DeviceGuard g(ctx->device);
+  ELFIHIP_TRY(reject_flush(h));
+  double thr = 0.0;
+  unsigned long long acc = 0;
+  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(&thr, h->thr, sizeof thr, hipMemcpyDeviceToHost, ctx->stream));
+  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(&acc, h->acc_count, sizeof acc, hipMemcpyDeviceToHost, ctx->stream));
+  ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (kth) *kth = thr;                      // +inf while fewer than k rows have entered
+  if (in_use) *in_use = h->host_mode ? (int64_t)h->hval.size() : -1;   // device states: ask elfihip_reject_result
+  if (accepted_last) *accepted_last = (int64_t)(acc - h->acc_seen);
+  if (accepted_total) *accepted_total = (int64_t)acc;
+  h->acc_seen = acc;
   return ELFIHIP_OK;
 }
 

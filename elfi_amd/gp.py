@@ -87,10 +87,10 @@ class GPHandle:
         """Sweep schedule of factorize(): 0 by size, 1 two-stream look-ahead, 2 fused steps (include/elfihip.h)."""
         self._check(self.lib.elfihip_gp_set_schedule(self.h, int(schedule), int(panel_group)))
 
-    def set_dense_threshold(self, min_points=0):
+    def set_dense_threshold(self, min_points=0, tile_rows=0):
         """Calls with at least min_points query points use the dense (matrix-pipe-bound) form of the triangular products
-        (include/elfihip.h: elfihip_gp_set_dense_threshold); 0 = default (96)."""
-        self._check(self.lib.elfihip_gp_set_dense_threshold(self.h, int(min_points)))
+        (include/elfihip.h: elfihip_gp_set_dense_threshold); 0 = default.  tile_rows: 0 = by size, else 64 / 32 / 16."""
+        self._check(self.lib.elfihip_gp_set_dense_threshold(self.h, int(min_points), int(tile_rows)))
 
     PHASES = ('gram', 'sweep', 'alpha', 'kstar', 'tri_first', 'tri_second', 'grad_finish', 'kinv_grad')
 

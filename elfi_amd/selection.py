@@ -80,9 +80,12 @@ class RunningBest:
     seen so far -- as device state: `push(X, y)` computes a batch's distances (returned, as the Distance node must
     return them) and folds the batch in during the same pass; `result()` gives the k best (distance, row) pairs,
     ascending, ties to the earlier row.  Row numbers are global (row_base + row inside the batch): the host looks the
-    accepted rows' parameters and summaries up in its own batch store.  k <= 2048."""
+    accepted rows' parameters and summaries up in its own batch store.  k <= 2048: device state, asynchronous merges;
+    larger k (up to 2^20): the candidates of every push are merged into a sorted host copy (csrc/reject.hip).
+    `accept`: the acceptance threshold of a threshold objective (samplers.py:219-225) -- a row takes part only if every
+    nested column of its distance is <= accept."""
 
-    def __init__(self, k, metric='euclidean', w=None, p=2.0, ctx=None):
+    def __init__(self, k, metric='euclidean', w=None, p=2.0, ctx=None, accept=None):
         self.ctx = ctx or _lib.default_context()
         self.lib = self.ctx.lib
         self.k = int(k)
@@ -95,6 +98,9 @@ class RunningBest:
         self.ctx.call("elfihip_reject_create", self.k, C.byref(h))
         self.h = h
         self.n_pushed = 0
+        self.accept = None
+        if accept is not None:
+            self.set_accept(accept)
 
     def close(self):
         if getattr(self, 'h', None) is not None:
@@ -115,15 +121,41 @@ class RunningBest:
         self._check(self.lib.elfihip_reject_reset(self.h))
         self.n_pushed = 0
 
-    def push(self, X, y, row_base=None):
+    def set_accept(self, threshold):
+        """Acceptance threshold (None removes it); before the first push or after reset()."""
+        self._check(self.lib.elfihip_reject_set_accept(self.h, 0 if threshold is None else 1,
+                                                       0.0 if threshold is None else float(threshold)))
+        self.accept = threshold
+
+    def push_distances(self, d, row_base=None):
+        """Fold a batch whose distances exist already (host array (n,) or nested (n, K): ranked by the last column)."""
+        d = np.ascontiguousarray(d, dtype=np.float64)
+        if d.ndim == 1:
+            d = d.reshape(-1, 1)
+        elif d.ndim != 2:
+            raise ValueError('distances must be (n,) or (n, K)')
+        n, K = d.shape
+        base = self.n_pushed if row_base is None else int(row_base)
+        self._check(self.lib.elfihip_reject_push(self.h, _lib.ptr(d), n, K, base))
+        self.n_pushed += n
+
+    def meta(self):
+        """(k-th distance so far (+inf while fewer than k rows are in), rows accepted since the previous call, in total)."""
+        kth = C.c_double()
+        last, total = C.c_int64(), C.c_int64()
+        self._check(self.lib.elfihip_reject_meta(self.h, C.byref(kth), None, C.byref(last), C.byref(total)))
+        return kth.value, last.value, total.value
+
+    def push(self, X, y, row_base=None, return_distances=True):
         """Distances of the rows of X (n, m) to y (1, m) -- returned, shape (n,) -- with the state updated on the way.
-        row_base: global number of the batch's first row (default: the rows pushed so far)."""
+        row_base: global number of the batch's first row (default: the rows pushed so far).  return_distances=False:
+        nothing but the state's k rows ever leaves the GPU (returns None)."""
         X = np.ascontiguousarray(X, dtype=np.float64)
         y = np.ascontiguousarray(y, dtype=np.float64).reshape(-1)
         if X.ndim != 2 or X.shape[1] != y.shape[0]:
             raise ValueError('X must be (n, m) and y (1, m)')
         n, m = X.shape
-        out = np.empty(n, dtype=np.float64)
+        out = np.empty(n, dtype=np.float64) if return_distances else None
         base = self.n_pushed if row_base is None else int(row_base)
         self._check(self.lib.elfihip_reject_push_rows(self.h, self.metric, _lib.ptr(X), n, m, m, _lib.ptr(y),
                                                       _lib.ptr(self.aux), self.p, _lib.ptr(out), base))

@@ -153,15 +153,20 @@ int elfihip_topk_smallest_dev(elfihip_ctx* ctx, const double* dD, int64_t n, int
  * distances seen so far and their GLOBAL row numbers (row_base + row inside the batch; ties go to the earlier row) in
  * device memory, ascending.  A push computes a batch's distances (written to dout / out, as the Distance node must
  * return them) and folds the batch in during the same pass: once the state is full its k-th distance is a threshold and
- * the distance kernel itself lists the rows below it; a one-workgroup merge keeps the k best.  k <= 2048.
+ * the distance kernel itself lists the rows below it; a one-workgroup merge keeps the k best.
+ * k <= 2048: the state lives on the device, pushes are asynchronous.  2048 < k <= 2^20 ("host-merge" states): the few
+ * candidates of every push are merged into a sorted host copy, the k-th distance goes back as the device threshold
+ * (a push synchronises).
  * _dev forms are asynchronous (distance pass on the context's stream); elfihip_reject_result synchronises and copies the state out
- * (vals, rows: k entries; *count = how many are real, i.e. min(k, rows pushed)); it fails with ELFIHIP_ERR_STATE if a
- * batch offered more than 65536 rows below the threshold (reset the state between SMC rounds).  Nested distances
- * (n, K) are ranked by their last column (samplers.py:233). */
+ * (vals, rows: k entries; *count = how many are real).  A state never fails for valid input: the candidate list holds
+ * 8 x the largest batch pushed and is merged every 8th push at the latest; a push that would offer very many
+ * candidates (a small first batch, a new SMC round without reset) takes the radix selection of its k best instead.
+ * Nested distances (n, K) are ranked by their last column (samplers.py:233). */
 typedef struct elfihip_reject elfihip_reject;
 int elfihip_reject_create(elfihip_ctx* ctx, int64_t k, elfihip_reject** out);
 int elfihip_reject_free(elfihip_reject* h);
 int elfihip_reject_reset(elfihip_reject* h);
+/* out may be NULL: the batch's distances are not copied back (only the k best rows ever leave the GPU) */
 int elfihip_reject_push_rows(elfihip_reject* h, int metric, const double* X, int64_t n, int m, int64_t ldx,
                              const double* y, const double* aux, double p, double* out, int64_t row_base);
 int elfihip_reject_push_rows_dev(elfihip_reject* h, int metric, const double* dX, int64_t n, int m, int64_t ldx,
@@ -170,6 +175,19 @@ int elfihip_reject_push_multiw_dev(elfihip_reject* h, const double* dX, int64_t 
                                    const double* dW, int K, double* dout, int64_t row_base);
 /* distances that exist already (any Distance / Discrepancy node): dD[i * stride], i < n */
 int elfihip_reject_push_dev(elfihip_reject* h, const double* dD, int64_t n, int64_t stride, int64_t row_base);
+/* ... in host memory: D (n, ncols) row-major, ncols >= 1 nested columns, ranked by the last one -- what
+ * Rejection._merge_batch receives as batch[discrepancy_name] (samplers.py:209-237).  Synchronises. */
+int elfihip_reject_push(elfihip_reject* h, const double* D, int64_t n, int ncols, int64_t row_base);
+/* The acceptance condition of a threshold objective (samplers.py:219-225: Rejection.sample(threshold=...)): a row takes
+ * part only if EVERY one of its nested columns is <= threshold (pushes of (n, ncols) distances: elfihip_reject_push,
+ * _push_multiw_dev; single-column pushes test their one column).  Set before the first push or after a reset;
+ * enable = 0 removes it.  Accepted rows are counted on the device (elfihip_reject_meta). */
+int elfihip_reject_set_accept(elfihip_reject* h, int enable, double threshold);
+/* What Rejection._update_state_meta / _update_objective_n_batches read after every batch (samplers.py:239-271): the
+ * current k-th distance (+inf while fewer than k rows are in; it is the sampler's `threshold` state), rows accepted by
+ * the pushes since the previous call and in total (acceptance threshold set).  in_use: entries of a host-merge state
+ * (-1 for device states: elfihip_reject_result reports it).  Merges what is pending and synchronises; any output may be NULL. */
+int elfihip_reject_meta(elfihip_reject* h, double* kth, int64_t* in_use, int64_t* accepted_last, int64_t* accepted_total);
 /* device pointers to the state (k values ascending, k rows), e.g. as the send buffers of a gather */
 int elfihip_reject_state_dev(elfihip_reject* h, double** dvals, int64_t** drows);
 /* From the next merge on, every merge also leaves the state as one packed device buffer at ddst -- k doubles (values)
@@ -278,10 +296,12 @@ int elfihip_gp_set_schedule(elfihip_gp* gp, int schedule, int panel_group);
  * one point per call, gpy_regression.py:98-147,179-223; bo/utils.py:97-103 runs its starts one after the other).  Calls
  * with fewer than min_points query points stream the factor once per <= 128 points through (row block, k chunk)
  * workgroups -- HBM-bound, right for the 10 starts of the default LCBSC; calls with at least min_points points (default
- * 96: the 256 parallel starts of BASELINE configs[4], many-chain sampling) run both products as dense 64 x 64 MFMA
+ * 112: the 256 parallel starts of BASELINE configs[4], many-chain sampling) run both products as dense 64 x 64 MFMA
  * tiles with full-k accumulation -- matrix-pipe-bound (csrc/gp_dense.hip).  min_points <= 0 restores the default;
- * a huge value keeps every call on the streaming form.  Results agree to rounding; each form is deterministic. */
-int elfihip_gp_set_dense_threshold(elfihip_gp* gp, int64_t min_points);
+ * a huge value keeps every call on the streaming form.  tile_rows: rows of the factor per output tile of the dense form,
+ * 0 = by size (the tallest of 64 / 32 / 16 that still gives about one workgroup per CU), else 64, 32 or 16.  Results agree
+ * to rounding; each form is deterministic. */
+int elfihip_gp_set_dense_threshold(elfihip_gp* gp, int64_t min_points, int tile_rows);
 /* Device time per phase, for roofline accounting (bench.py; no reference counterpart).  While enabled, HIP events on the
  * GP's stream bracket the phases of elfihip_gp_factorize (Gram matrix | sweep | alpha + log-determinant), of single-group
  * prediction calls -- elfihip_gp_predict / _predict_grad / _lcb and every step of elfihip_gp_lcb_minimize -- (kernel row |

@@ -48,7 +48,7 @@ if what in ('dense', 'all'):
     for n, d in ((4096, 10), (8192, 20)):
         gp = fitted(n, d)
         res = {}
-        for S in (64, 96, 128, 192, 256, 512):
+        for S in (64, 96, 128, 160, 192, 256, 512):
             xs = np.random.RandomState(S).uniform(-2, 2, (S, d))
             row = {}
             for name, thr in (("stream", 1 << 40), ("dense", 1)):

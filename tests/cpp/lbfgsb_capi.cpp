@@ -22,3 +22,28 @@ void lb_result(void* h, double* x, double* f, int* it, int* nfev, int* status, i
 }
 void lb_free(void* h) { delete static_cast<Lbfgsb*>(h); }
 }
+
+
+// ---- the host-thread pool of the multi-start search (elfi_amd/csrc/round_pool.hpp)
+#include "../../elfi_amd/csrc/round_pool.hpp"
+extern "C" long long pool_rounds_check(int nthreads, int rounds, long long n) {
+  // every round: item i adds i + round to slot i exactly once; returns the number of slots with a wrong total
+  elfihip::RoundPool pool(nthreads);
+  std::vector<long long> slot((size_t)n, 0);
+  long long expect_extra = 0;
+  for (int r = 0; r < rounds; ++r) {
+    const long long m = (r % 3 == 0) ? n : n / 2 + r % 7;     // changing sizes, some below the serial cut-off
+    pool.run(m, [&](int64_t i) { slot[(size_t)i] += i + r; });
+    (void)expect_extra;
+  }
+  long long bad = 0;
+  for (long long i = 0; i < n; ++i) {
+    long long want = 0;
+    for (int r = 0; r < rounds; ++r) {
+      const long long m = (r % 3 == 0) ? n : n / 2 + r % 7;
+      if (i < m) want += i + r;
+    }
+    bad += slot[(size_t)i] != want;
+  }
+  return bad;
+}

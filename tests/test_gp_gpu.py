@@ -352,9 +352,10 @@ def test_prior_kernel_matrix_is_gpys_kern_K(hip_ctx):
     np.testing.assert_allclose(m._gp.kern.K(X)[:5, :5], ref(X)[:5, :5], rtol=1e-13)
 
 
-@pytest.mark.parametrize('n,d,S', [(300, 2, 100), (1000, 10, 256), (2048, 10, 200), (4096, 10, 256), (4100, 3, 97),
-                                   (8192, 20, 256)])
-def test_dense_form_of_the_products_vs_streaming_form_and_oracle(hip_ctx, n, d, S):
+@pytest.mark.parametrize('n,d,S,tm', [(300, 2, 100, 0), (300, 2, 100, 64), (1000, 10, 256, 32), (1000, 10, 256, 16),
+                                      (2048, 10, 200, 0), (4096, 10, 256, 64), (4096, 10, 256, 0), (4100, 3, 97, 16),
+                                      (8192, 20, 256, 0), (8192, 20, 70, 0)])
+def test_dense_form_of_the_products_vs_streaming_form_and_oracle(hip_ctx, n, d, S, tm):
     """Calls with many points run both triangular products as dense 64 x 64 MFMA tiles (csrc/gp_dense.hip).  Same
     quantities as the streaming form: compared with it on the same GP (1e-11: two summation orders of one formula) and
     with the CPU posterior at the usual tolerances (gpy_regression.py:127-140,206-218)."""
@@ -367,7 +368,7 @@ def test_dense_form_of_the_products_vs_streaming_form_and_oracle(hip_ctx, n, d, 
     m0, v0, dm0, dv0 = gp.predict_grad(xs)
     val0, g0 = gp.lcb(xs, beta)
     mm0, vv0 = gp.predict(xs, noiseless=False)
-    gp.set_dense_threshold(64)                        # dense form
+    gp.set_dense_threshold(64, tm)                    # dense form, row tiles of tm (0: by size)
     m1, v1, dm1, dv1 = gp.predict_grad(xs)
     val1, g1 = gp.lcb(xs, beta)
     mm1, vv1 = gp.predict(xs, noiseless=False)

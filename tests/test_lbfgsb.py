@@ -25,7 +25,7 @@ DP = C.POINTER(C.c_double)
 @pytest.fixture(scope='module')
 def lb(tmp_path_factory):
     out = str(tmp_path_factory.mktemp('lbfgsb') / 'liblbfgsb_test.so')
-    subprocess.check_call(['g++', '-O2', '-std=c++17', '-shared', '-fPIC', '-o', out,
+    subprocess.check_call(['g++', '-O2', '-std=c++17', '-shared', '-fPIC', '-pthread', '-o', out,
                            os.path.join(HERE, 'cpp', 'lbfgsb_capi.cpp')])
     lib = C.CDLL(out)
     lib.lb_new.restype = C.c_void_p
@@ -133,3 +133,13 @@ def test_start_outside_the_box_and_degenerate_cases(lb):
     # a non-finite first value ends that start without iterating
     r = run(lb, lambda x: np.nan, grad, np.array([0.0, 0.5, 0.0]), bounds)
     assert r['nit'] == 0 and r['status'] == 4
+
+
+def test_round_pool_every_item_once_per_round(lb):
+    """The host-thread pool that advances the L-BFGS-B state machines of many starts between device evaluations
+    (elfi_amd/csrc/round_pool.hpp): every item of every round is run exactly once, for any thread count."""
+    lb.pool_rounds_check.restype = C.c_longlong
+    lb.pool_rounds_check.argtypes = [C.c_int, C.c_int, C.c_longlong]
+    for threads in (1, 2, 8):
+        assert lb.pool_rounds_check(threads, 300, 256) == 0
+    assert lb.pool_rounds_check(4, 50, 5000) == 0

@@ -205,3 +205,59 @@ def test_config2_bolfi_fit_4096_through_the_reference_loop(hip_ctx, elfi):
     dmu, dvar = gp.predictive_gradients(xs)
     rdmu, rdvar = post.predictive_gradients(xs)
     assert np.max(np.abs(dmu - rdmu)) <= 1e-6 * np.max(np.abs(rdmu)) and np.max(np.abs(dvar - rdvar)) <= 1e-6 * (np.max(np.abs(rdvar)) + 1)
+
+
+def test_hip_rejection_is_the_reference_rejection_sample_by_sample(hip_ctx, elfi):
+    """elfi_amd.HipRejection (a subclass of the running ELFI's Rejection with _init_samples_lazy / _merge_batch /
+    _update_distances on the device state, samplers.py:180-237,279-299) next to elfi.Rejection on BASELINE configs[0]
+    (MA2, batch_size=1000): every objective form, sample by sample."""
+    import elfi_amd
+    from elfi.examples import ma2
+    for kwargs in (dict(n_sim=100000), dict(quantile=0.01), dict(threshold=0.25)):
+        ref = elfi.Rejection(ma2.get_model(seed_obs=4)['d'], batch_size=1000, seed=1).sample(1000, bar=False, **kwargs)
+        got = elfi_amd.HipRejection(ma2.get_model(seed_obs=4)['d'], batch_size=1000, seed=1).sample(1000, bar=False, **kwargs)
+        assert got.n_sim == ref.n_sim, kwargs
+        assert got.threshold == ref.threshold
+        assert np.array_equal(got.discrepancies, ref.discrepancies)
+        for k in ('t1', 't2'):
+            assert np.array_equal(got.samples[k], ref.samples[k])
+    # the tutorial's known answers (docs/usage/tutorial.rst:386,396,450,461-463) through the device state
+    m, d = _tutorial_model(elfi, hip=True)
+    res = elfi_amd.HipRejection(d, batch_size=10000, seed=20170530).sample(1000, quantile=0.01, bar=False)
+    assert repr(float(res.threshold)) == '0.116859716394976' and res.n_sim == 100000
+    res3 = elfi_amd.HipRejection(d, batch_size=10000, seed=20170530).sample(1000, threshold=0.2, bar=False)
+    assert res3.n_sim == 40000 and abs(res3.threshold - 0.185) < 5e-4
+    # n_samples beyond the device-resident merge
+    ref = elfi.Rejection(ma2.get_model(seed_obs=4)['d'], batch_size=10000, seed=3).sample(5000, n_sim=60000, bar=False)
+    got = elfi_amd.HipRejection(ma2.get_model(seed_obs=4)['d'], batch_size=10000, seed=3).sample(5000, n_sim=60000, bar=False)
+    assert np.array_equal(got.discrepancies, ref.discrepancies) and np.array_equal(got.samples['t1'], ref.samples['t1'])
+
+
+def test_hip_rejection_inside_adaptive_distance_smc_rounds(hip_ctx, elfi):
+    """_update_distances (samplers.py:279-299): an adaptive-distance Rejection re-ranks its sample under the updated
+    distance.  The reference's AdaptiveDistanceSMC builds its own Rejection objects, so the method is exercised
+    directly: same model, same seed, reference class against the device subclass."""
+    import elfi_amd
+    import scipy.stats as ss
+
+    def sim(mu, batch_size=1, random_state=None):
+        rs = random_state or np.random
+        return np.column_stack([rs.normal(mu, 1.0, batch_size), rs.normal(mu, 30.0, batch_size)])
+
+    def make():
+        m = elfi.new_model()
+        mu = elfi.Prior(ss.uniform, 0, 40, model=m, name='mu')
+        Y = elfi.Simulator(sim, mu, observed=np.array([[20.0, 20.0]]), name='Y')
+        S1 = elfi.Summary(lambda y: y[:, 0], Y, name='S1')
+        S2 = elfi.Summary(lambda y: y[:, 1], Y, name='S2')
+        return elfi.AdaptiveDistance(S1, S2, name='d')
+    out = []
+    for cls in (elfi.Rejection, elfi_amd.HipRejection):
+        d = make()
+        rej = cls(d, batch_size=2000, seed=7, output_names=['S1', 'S2'])
+        assert rej.adaptive
+        res = rej.sample(300, n_sim=20000, bar=False)
+        out.append(res)
+    a, b = out
+    assert a.n_sim == b.n_sim == 20000
+    assert np.array_equal(a.samples['mu'], b.samples['mu']) and np.array_equal(a.discrepancies, b.discrepancies)

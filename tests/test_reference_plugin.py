@@ -115,4 +115,4 @@ def test_gpu_client_reproduces_the_native_client(elfi):
     assert got.threshold == ref.threshold
     for k in ('t1', 't2'):
         assert np.array_equal(got.samples[k], ref.samples[k])
-    assert client.num_cores == 2
+    assert client.num_gpus == 2 and client.num_cores == 4     # two batches in flight per GPU

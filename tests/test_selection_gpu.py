@@ -174,12 +174,12 @@ def test_running_best_ties_and_explicit_row_numbers(hip_ctx):
     vals, rows = rb.result()
     assert np.array_equal(vals, d[order]) and np.array_equal(rows, r[order])
     with pytest.raises(ValueError):
-        elfi_amd.RunningBest(5000)
+        elfi_amd.RunningBest((1 << 20) + 1)
 
 
 def test_running_best_device_batches_nested_and_overflow(hip_ctx):
-    """Device-resident batches: nested (n, K) distances ranked by the last column; a batch that floods the candidate
-    list is reported, loudly, by result()."""
+    """Device-resident batches: nested (n, K) distances ranked by the last column; a batch in which far more rows beat the
+    threshold than round 2's fixed candidate list held is simply merged (the reference never fails there)."""
     import ctypes as C
     import torch
     import elfi_amd
@@ -212,11 +212,15 @@ def test_running_best_device_batches_nested_and_overflow(hip_ctx):
     assert lib.elfihip_reject_result(h, _lib.ptr(vals), _lib.ptr(rows), C.byref(cnt)) == 0 and cnt.value == k
     dv, dr = _best_ref(np.concatenate(cols), k)
     assert np.array_equal(vals, dv) and np.array_equal(rows, dr)
-    # distances that exist already, then a batch in which far more than 65536 rows beat the threshold
-    d2 = torch.from_numpy(np.concatenate(cols)[: 2 * n] * 1e-3).cuda()
+    # distances that exist already, then a batch in which far more than 65536 rows beat the threshold (every one of
+    # its 600 000 rows does): no reset needed, the state is the best k of everything pushed
+    d2h = np.concatenate(cols)[: 2 * n] * 1e-3
+    d2 = torch.from_numpy(d2h).cuda()
     torch.cuda.synchronize()
     assert lib.elfihip_reject_push_dev(h, d2.data_ptr(), 2 * n, 1, 10 * n) == 0
-    assert lib.elfihip_reject_result(h, _lib.ptr(vals), _lib.ptr(rows), C.byref(cnt)) == _lib.ERR_STATE
+    assert lib.elfihip_reject_result(h, _lib.ptr(vals), _lib.ptr(rows), C.byref(cnt)) == 0 and cnt.value == k
+    dv, dr = _best_ref(d2h, k)
+    assert np.array_equal(vals, dv) and np.array_equal(rows, dr + 10 * n)
     assert lib.elfihip_reject_reset(h) == 0
     assert lib.elfihip_reject_push_dev(h, d2.data_ptr(), 2 * n, 1, 0) == 0
     assert lib.elfihip_reject_result(h, _lib.ptr(vals), _lib.ptr(rows), C.byref(cnt)) == 0
@@ -248,3 +252,67 @@ def test_running_best_ignores_nan_distances(hip_ctx):
         order = np.lexsort((np.arange(len(alld)), np.where(np.isnan(alld), np.inf, alld), np.isnan(alld)))[:50]
         v, r = rb.result()
         assert np.array_equal(r, order) and np.array_equal(v, alld[order])
+
+
+def test_running_best_small_first_batch_then_large_ones(hip_ctx):
+    """The case that lost a whole run in round 2: a first batch of exactly k rows leaves a threshold every row of the
+    next batches beats.  Pushes of 200 000 rows follow: each takes the radix selection while n k / rows_seen is large,
+    the candidate list afterwards -- exact throughout."""
+    import elfi_amd
+    rs = np.random.RandomState(5)
+    k = 500
+    rb = elfi_amd.RunningBest(k)
+    y = np.zeros((1, 8))
+    seen = [rb.push(rs.randn(k, 8) * 3.0, y)]
+    for n in (200000, 200000, 50000, 200000, 200000, 200000):
+        seen.append(rb.push(rs.randn(n, 8), y))
+        vals, rows = rb.result()
+        dv, dr = _best_ref(np.concatenate(seen), k)
+        assert np.array_equal(vals, dv) and np.array_equal(rows, dr)
+    # without reset, a "new round" whose every row beats the state (an SMC round change)
+    seen.append(rb.push(rs.randn(300000, 8) * 1e-3, y))
+    vals, rows = rb.result()
+    dv, dr = _best_ref(np.concatenate(seen), k)
+    assert np.array_equal(vals, dv) and np.array_equal(rows, dr)
+    assert rb.push(rs.randn(1000, 8), y, return_distances=False) is None     # nothing but the state leaves the GPU
+
+
+@pytest.mark.parametrize('k', [3000, 10000])
+def test_running_best_large_k_host_merge(hip_ctx, k):
+    """n_samples beyond the device-resident merge (k > 2048): same contract, candidates merged on the host."""
+    import elfi_amd
+    rs = np.random.RandomState(k)
+    rb = elfi_amd.RunningBest(k, metric='euclidean')
+    y = rs.randn(1, 5)
+    seen = []
+    for n in (1500, 40000, 40000, 7, 100000, 40000):
+        seen.append(rb.push(rs.randn(n, 5), y))
+        vals, rows = rb.result()
+        dv, dr = _best_ref(np.concatenate(seen), k)
+        assert np.array_equal(vals, dv) and np.array_equal(rows, dr), (n, len(vals))
+    kth, _, _ = rb.meta()
+    assert kth == dv[k - 1]
+
+
+def test_running_best_acceptance_threshold_nested(hip_ctx):
+    """Threshold objective (samplers.py:219-225): a row of nested distances (n, K) takes part only if EVERY column is
+    <= threshold; the state ranks the accepted rows by the last column; accepted rows are counted per push."""
+    import elfi_amd
+    rs = np.random.RandomState(9)
+    k, K, thr = 200, 3, 1.2
+    rb = elfi_amd.RunningBest(k, accept=thr)
+    alld, total = [], 0
+    for n in (5000, 20000, 100, 20000):
+        d = np.abs(rs.randn(n, K)) + 0.05 * np.arange(K)
+        rb.push_distances(d)
+        alld.append(d)
+        D = np.concatenate(alld)
+        ok = np.all(D <= thr, axis=1)
+        key = np.where(ok, D[:, -1], np.inf)
+        order = np.lexsort((np.arange(len(D)), key))[:min(k, int(ok.sum()))]
+        vals, rows = rb.result()
+        assert np.array_equal(rows, order) and np.array_equal(vals, D[order, -1])
+        kth, last, tot = rb.meta()
+        total += int(np.all(d <= thr, axis=1).sum())
+        assert last == int(np.all(d <= thr, axis=1).sum()) and tot == total
+        assert kth == (vals[k - 1] if len(vals) == k else np.inf)
