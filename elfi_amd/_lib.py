@@ -97,6 +97,8 @@ PROTOTYPES = {
                                        C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
     "elfihip_ma2_distance_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_void_p,
                                            C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "elfihip_ma2_draw_distance_dev": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int64, C.c_int, C.c_void_p, C.c_void_p,
+                                       C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
     "elfihip_gp_kernel_matrix": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
     "elfihip_comm_unique_id": (C.c_int, [C.c_void_p, C.c_void_p]),
     "elfihip_comm_init_rank": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, c_void_pp]),

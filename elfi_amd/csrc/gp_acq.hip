@@ -28,7 +28,8 @@
 namespace elfihip {
 
 // Host threads for the quasi-Newton algebra of many starts (256 starts x a few microseconds per state-machine step is
-// as long as the device evaluation of the round): ELFIHIP_HOST_THREADS, default min(8, hardware threads).
+// as long as the device evaluation of the round): ELFIHIP_HOST_THREADS, default min(8, hardware threads)
+// (16 measured noisier and no faster under the GPU box's 16-CPU quota).
 static int host_threads() {
   static const int v = [] {
     const char* e = std::getenv("ELFIHIP_HOST_THREADS");

@@ -302,9 +302,12 @@ static int dense_launch(elfihip_gp* gp, DenseArgs D, int mode, const double* kbt
   return ELFIHIP_OK;
 }
 
-// Row-tile height: the tallest of 64 / 32 / 16 that still gives about one workgroup per CU (pairs x column blocks).
+// Row-tile height: the tallest of 64 / 32 / 16 that gives at least one workgroup per CU (pairs x column blocks).
+// Measured (ms per call, n = 8192 / 4096, S = 128 / 192 / 256; profiles/r03_dense.md): a grid below the CU count loses
+// in proportion (S = 128 at n = 8192: 0.79 with 128 workgroups of 64 rows, 0.51 with 256 of 32), above it the shorter
+// tiles are within 4-11 % of the taller ones either way.
 static int dense_tile_rows(const elfihip_gp* gp, int ncb) {
-  const int64_t want = (int64_t)gp->ctx->cu_count * 3 / 4;
+  const int64_t want = (int64_t)gp->ctx->cu_count;
   for (int tm : {64, 32})
     if ((int64_t)ncb * (gp->np / tm / 2) >= want) return tm;
   return 16;

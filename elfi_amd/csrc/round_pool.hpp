@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdint>
 #include <functional>
@@ -13,9 +14,12 @@
 namespace elfihip {
 
 // Workers that live for ONE lcb_minimize call.  Each round the caller publishes a job (an index count and a function of
-// the index) as a new GENERATION; every worker takes part in every generation exactly once -- it pulls index chunks from
-// a shared counter until none are left and then checks out -- and the caller, which pulls chunks as well, returns when
-// all have checked out.  (A wake-up through the condition variable costs some 10 us per round against rounds of 1 ms.)
+// the index) as a new GENERATION; every worker takes part in every generation exactly once -- it pulls indices from a
+// shared counter until none are left and then checks out -- and the caller, which pulls indices as well, returns when
+// all have checked out, so no worker is ever inside a job that is being replaced.  Between rounds (the device evaluates
+// the points: a few hundred microseconds) workers poll the generation for up to a millisecond before they block on the
+// condition variable: a wake-up through the kernel costs 50-100 us per round and thread, as long as the round's work
+// (measured: 256 starts, 8 threads, 0.145 ms of host time per round against 0.06 ms of work).
 class RoundPool {
  public:
   explicit RoundPool(int nthreads) {
@@ -24,7 +28,7 @@ class RoundPool {
   ~RoundPool() {
     {
       std::lock_guard<std::mutex> lock(mu_);
-      stop_ = true;
+      stop_.store(true, std::memory_order_release);
     }
     cv_go_.notify_all();
     for (auto& t : th_) t.join();
@@ -35,54 +39,69 @@ class RoundPool {
       for (int64_t i = 0; i < n; ++i) f(i);
       return;
     }
+    fn_ = [&f](int64_t i) { f(i); };
+    n_ = n;
+    next_.store(0, std::memory_order_relaxed);
+    busy_.store((int)th_.size(), std::memory_order_relaxed);
+    gen_.fetch_add(1, std::memory_order_release);
     {
-      std::lock_guard<std::mutex> lock(mu_);
-      fn_ = [&f](int64_t i) { f(i); };
-      n_ = n;
-      next_.store(0, std::memory_order_relaxed);
-      busy_ = (int)th_.size();
-      ++gen_;
+      std::lock_guard<std::mutex> lock(mu_);   // (a worker about to block re-checks the generation under this lock)
+      if (sleepers_ > 0) cv_go_.notify_all();
     }
-    cv_go_.notify_all();
     work();
-    std::unique_lock<std::mutex> lock(mu_);
-    cv_done_.wait(lock, [this] { return busy_ == 0; });
+    for (unsigned spin = 0; busy_.load(std::memory_order_acquire) != 0; ++spin)
+      if ((spin & 63u) == 63u) std::this_thread::yield();
   }
 
  private:
   void work() {
+    // one item per pull: items differ by an order of magnitude (a state machine that starts a new quasi-Newton
+    // iteration against one that takes a line-search step), chunks of eight left threads idle at the end of a round
     for (;;) {
-      const int64_t i0 = next_.fetch_add(8, std::memory_order_relaxed);
-      if (i0 >= n_) return;
-      const int64_t i1 = std::min<int64_t>(i0 + 8, n_);
-      for (int64_t i = i0; i < i1; ++i) fn_(i);
+      const int64_t i = next_.fetch_add(1, std::memory_order_relaxed);
+      if (i >= n_) return;
+      fn_(i);
     }
   }
   void loop() {
     unsigned long long seen = 0;
     for (;;) {
-      {
+      // poll for about a millisecond, then block
+      const auto t0 = std::chrono::steady_clock::now();
+      bool go = false;
+      for (unsigned spin = 0;; ++spin) {
+        if (gen_.load(std::memory_order_acquire) != seen) {
+          go = true;
+          break;
+        }
+        if (stop_.load(std::memory_order_acquire)) return;
+        if ((spin & 255u) == 255u) {
+          if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(1000)) break;
+          std::this_thread::yield();
+        }
+      }
+      if (!go) {
         std::unique_lock<std::mutex> lock(mu_);
-        cv_go_.wait(lock, [&] { return stop_ || gen_ != seen; });
-        if (stop_) return;
-        seen = gen_;
+        ++sleepers_;
+        cv_go_.wait(lock, [&] { return stop_.load(std::memory_order_acquire) || gen_.load(std::memory_order_acquire) != seen; });
+        --sleepers_;
+        if (gen_.load(std::memory_order_acquire) == seen) return;   // stop
       }
+      seen = gen_.load(std::memory_order_acquire);
       work();
-      {
-        std::lock_guard<std::mutex> lock(mu_);
-        if (--busy_ == 0) cv_done_.notify_one();
-      }
+      busy_.fetch_sub(1, std::memory_order_release);
     }
   }
   std::vector<std::thread> th_;
   std::mutex mu_;
-  std::condition_variable cv_go_, cv_done_;
+  std::condition_variable cv_go_;
   std::function<void(int64_t)> fn_;
   int64_t n_ = 0;
   std::atomic<int64_t> next_{0};
-  unsigned long long gen_ = 0;
-  int busy_ = 0;
-  bool stop_ = false;
+  std::atomic<unsigned long long> gen_{0};
+  std::atomic<int> busy_{0};
+  std::atomic<bool> stop_{false};
+  int sleepers_ = 0;   // guarded by mu_
 };
 
 }  // namespace elfihip

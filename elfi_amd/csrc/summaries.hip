@@ -19,6 +19,7 @@
 #include "common.hpp"
 #include <cstdlib>
 
+#include "philox.hpp"
 #include "tile_stream.hpp"
 
 #pragma clang fp contract(off)
@@ -94,6 +95,9 @@ struct SumArgs {
   double* out1;     // MEAN/VAR/AUTOCOV: result; MA2: S1
   double* out2;     // MA2: S2
   double* out3;     // MA2: distance
+  // MA2 with the white noise DRAWN HERE (R.X == NULL): element e of the row-major (n, L) noise matrix is normal number e
+  // of the stream (seed, stream) of philox.hpp -- what elfihip_randn_dev would have written to memory
+  uint64_t seed, stream;
 };
 
 template <int KIND, int U, bool PIPE>
@@ -105,12 +109,28 @@ __global__ __launch_bounds__(256) void row_summary_kernel(SumArgs S) {
   const int64_t ntiles = (A.n + Rt - 1) / Rt;
   double2 v[U];
   int64_t t = blockIdx.x;
-  if (PIPE && t < ntiles) tile_fetch<U>(A, t * Rt, (int)((A.n - t * Rt) < Rt ? (A.n - t * Rt) : Rt), v);
+  const bool draw = KIND == SUM_MA2 && A.X == nullptr;
+  if (PIPE && !draw && t < ntiles) tile_fetch<U>(A, t * Rt, (int)((A.n - t * Rt) < Rt ? (A.n - t * Rt) : Rt), v);
   for (; t < ntiles; t += gridDim.x) {
     const int64_t row0 = t * Rt;
     const int rows = (int)((A.n - row0) < Rt ? (A.n - row0) : Rt);
     __syncthreads();
-    if (PIPE) {
+    if (draw) {
+      // elements [e0, e1) of the noise matrix; pairs that straddle the tile's ends are drawn by both tiles
+      const int64_t e0 = row0 * L, e1 = e0 + (int64_t)rows * L;
+      for (int64_t p = e0 / 2 + tid; 2 * p < e1; p += blockDim.x) {
+        double z[2];
+        normal_pair(S.seed, S.stream, (uint64_t)p, z[0], z[1]);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int64_t e = 2 * p + h;
+          if (e >= e0 && e < e1) {
+            const int r = (int)((e - e0) / L), i = (int)((e - e0) - (int64_t)r * L);
+            tile[r * A.mp + i] = z[h];
+          }
+        }
+      }
+    } else if (PIPE) {
       tile_commit<U>(A, tile, rows, v);
       const int64_t tn = t + gridDim.x;
       if (tn < ntiles) tile_fetch<U>(A, tn * Rt, (int)((A.n - tn * Rt) < Rt ? (A.n - tn * Rt) : Rt), v);
@@ -205,7 +225,7 @@ template <int KIND>
 static int launch_summary(elfihip_ctx* ctx, SumArgs S) {
   RowArgs& A = S.R;
   const int L = A.m;
-  const bool pipe = A.vec2 && L <= 128;
+  const bool pipe = (A.vec2 || (KIND == SUM_MA2 && A.X == nullptr)) && L <= 128;   // (noise drawn in the kernel: no loads to vectorise)
   // 8 KiB in flight per workgroup (128 threads x 4 x 16 bytes), eight workgroups per CU: measured best for these
   // streaming kernels (L = 100: mean 5.6 TB/s against 4.9 with 32 KiB tiles and 4.5 with 4 KiB)
   int T;
@@ -295,13 +315,17 @@ static int summary_dev_impl(elfihip_ctx* ctx, int kind, const double* dX, int64_
 }
 
 static int ma2_dev_impl(elfihip_ctx* ctx, const double* dW, int64_t n, int n_obs, int64_t ldw, const double* dt1,
-                        const double* dt2, double obs1, double obs2, double* dS1, double* dS2, double* dD) {
+                        const double* dt2, double obs1, double obs2, double* dS1, double* dS2, double* dD,
+                        bool draw = false, uint64_t seed = 0, uint64_t stream = 0) {
   ELFIHIP_REQUIRE(ctx, n >= 0 && n_obs >= 3 && ldw >= n_obs + 2, "bad shape n=%lld n_obs=%d ldw=%lld", (long long)n,
                   n_obs, (long long)ldw);
-  ELFIHIP_REQUIRE(ctx, n == 0 || (dW && dt1 && dt2 && dS1 && dS2 && dD), "NULL data pointer");
+  ELFIHIP_REQUIRE(ctx, n == 0 || ((dW || draw) && dt1 && dt2 && dS1 && dS2 && dD), "NULL data pointer");
+  ELFIHIP_REQUIRE(ctx, !draw || n_obs + 2 <= 128, "the drawing form handles up to 126 observations per simulation");
   if (n == 0) return ELFIHIP_OK;
   SumArgs S;
-  S.R = summary_row_args(dW, n, n_obs + 2, ldw);
+  S.R = summary_row_args(draw ? nullptr : dW, n, n_obs + 2, ldw);
+  S.seed = seed;
+  S.stream = stream;
   S.lag = 0;
   S.t1 = dt1;
   S.t2 = dt2;
@@ -349,6 +373,13 @@ int elfihip_ma2_distance_dev(elfihip_ctx* ctx, const double* dW, int64_t n, int 
   if (!ctx) return fail(nullptr, ELFIHIP_ERR_ARG, "ctx is NULL");
   DeviceGuard g(ctx->device);
   return ma2_dev_impl(ctx, dW, n, n_obs, ldw, dt1, dt2, obs1, obs2, dS1, dS2, dD);
+}
+
+int elfihip_ma2_draw_distance_dev(elfihip_ctx* ctx, uint64_t seed, uint64_t stream, int64_t n, int n_obs, const double* dt1,
+                                  const double* dt2, double obs1, double obs2, double* dS1, double* dS2, double* dD) {
+  if (!ctx) return fail(nullptr, ELFIHIP_ERR_ARG, "ctx is NULL");
+  DeviceGuard g(ctx->device);
+  return ma2_dev_impl(ctx, nullptr, n, n_obs, n_obs + 2, dt1, dt2, obs1, obs2, dS1, dS2, dD, true, seed, stream);
 }
 
 int elfihip_ma2_distance(elfihip_ctx* ctx, const double* W, int64_t n, int n_obs, const double* t1, const double* t2,

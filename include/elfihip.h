@@ -244,6 +244,13 @@ int elfihip_ma2_distance(elfihip_ctx* ctx, const double* W, int64_t n, int n_obs
                          double obs1, double obs2, double* S1, double* S2, double* D);
 int elfihip_ma2_distance_dev(elfihip_ctx* ctx, const double* dW, int64_t n, int n_obs, int64_t ldw, const double* dt1,
                              const double* dt2, double obs1, double obs2, double* dS1, double* dS2, double* dD);
+/* The same with the white noise DRAWN IN THE KERNEL (synthetic-throughput runs; the reference draws it from MT19937 on the
+ * host, examples/ma2.py:31-33: bit parity with a reference run needs that stream, so parity runs hand W in): element e
+ * of the row-major (n, n_obs + 2) noise matrix is normal number e of the stream (seed, stream) of elfihip_randn_dev, so
+ * the results equal elfihip_randn_dev + elfihip_ma2_distance_dev bit for bit while the noise never exists in memory.
+ * n_obs <= 126. */
+int elfihip_ma2_draw_distance_dev(elfihip_ctx* ctx, uint64_t seed, uint64_t stream, int64_t n, int n_obs, const double* dt1,
+                                  const double* dt2, double obs1, double obs2, double* dS1, double* dS2, double* dD);
 
 /* The Gaussian example model, fused (elfi/examples/gauss.py:11-35 gauss, :142-173 ss_mean / ss_var, :133
  * elfi.Distance('euclidean', ss_mean, ss_var)): y = z * sigma + mu for n simulations of n_obs observations (what

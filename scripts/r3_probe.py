@@ -72,6 +72,22 @@ if what in ('dense', 'all'):
         out["dense_n%d_d%d" % (n, d)] = res
         gp.close()
 
+if what in ('tiles',):
+    for n, d in ((8192, 20), (4096, 10)):
+        gp = fitted(n, d)
+        res = {}
+        for S in (128, 192, 256):
+            xs = np.random.RandomState(S).uniform(-2, 2, (S, d))
+            for tm in (64, 32, 16):
+                gp.set_dense_threshold(1, tm)
+                gp.lcb(xs, 3.0)
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    gp.lcb(xs, 3.0)
+                res["S%d_tm%d_ms" % (S, tm)] = 1e3 * (time.perf_counter() - t0) / 5
+        out["tiles_n%d" % n] = res
+        gp.close()
+
 if what in ('cfg5',):
     out["cfg5"] = bolfi_bench.cfg5_leg()
 

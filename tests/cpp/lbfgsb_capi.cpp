@@ -35,6 +35,7 @@ extern "C" long long pool_rounds_check(int nthreads, int rounds, long long n) {
     const long long m = (r % 3 == 0) ? n : n / 2 + r % 7;     // changing sizes, some below the serial cut-off
     pool.run(m, [&](int64_t i) { slot[(size_t)i] += i + r; });
     (void)expect_extra;
+    if (r % 40 == 39) std::this_thread::sleep_for(std::chrono::milliseconds(3));   // workers give up polling and block
   }
   long long bad = 0;
   for (long long i = 0; i < n; ++i) {

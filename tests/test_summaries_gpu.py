@@ -77,3 +77,37 @@ def test_ma2_tutorial_golden_through_summaries_and_distance(hip_ctx, golden_dir)
     assert np.array_equal(d[:len(g['d0'])], g['d0'])
     thr = np.sort(d)[999]
     assert repr(float(thr)) == '0.116859716394976'
+
+
+@pytest.mark.parametrize('n,n_obs', [(1, 100), (777, 100), (50000, 100), (4096, 37), (1000, 126)])
+def test_ma2_with_the_noise_drawn_in_the_kernel(hip_ctx, n, n_obs):
+    """elfihip_ma2_draw_distance_dev (synthetic-throughput form of examples/ma2.py:11-59): the white noise never exists
+    in memory, yet S1, S2 and the distance equal -- bit for bit -- the fused path run on the matrix elfihip_randn_dev
+    writes for the same (seed, stream), which in turn is bit-identical to NumPy on those values
+    (test_fused_ma2_path_bit_exact)."""
+    import ctypes as C
+    import torch
+    lib = hip_ctx.lib
+    L = n_obs + 2
+    rs = np.random.RandomState(n)
+    t1 = torch.from_numpy(rs.uniform(-1, 1, n)).cuda()
+    t2 = torch.from_numpy(rs.uniform(-0.5, 0.5, n)).cuda()
+    W = torch.empty(n, L, dtype=torch.float64, device='cuda')
+    out = [torch.empty(n, dtype=torch.float64, device='cuda') for _ in range(6)]
+    torch.cuda.synchronize()
+    seed, stream = C.c_uint64(2024), C.c_uint64(5)
+    assert lib.elfihip_randn_dev(hip_ctx.handle, seed, stream, n * L, C.c_double(0.0), C.c_double(1.0), W.data_ptr()) == 0
+    assert lib.elfihip_ma2_distance_dev(hip_ctx.handle, W.data_ptr(), n, n_obs, L, t1.data_ptr(), t2.data_ptr(),
+                                        C.c_double(0.3), C.c_double(0.1), out[0].data_ptr(), out[1].data_ptr(),
+                                        out[2].data_ptr()) == 0
+    assert lib.elfihip_ma2_draw_distance_dev(hip_ctx.handle, seed, stream, n, n_obs, t1.data_ptr(), t2.data_ptr(),
+                                             C.c_double(0.3), C.c_double(0.1), out[3].data_ptr(), out[4].data_ptr(),
+                                             out[5].data_ptr()) == 0
+    hip_ctx.synchronize()
+    for a, b in zip(out[:3], out[3:]):
+        assert np.array_equal(a.cpu().numpy(), b.cpu().numpy())
+    # and against NumPy on the drawn noise
+    w = W.cpu().numpy()
+    x = w[:, 2:] + t1.cpu().numpy()[:, None] * w[:, 1:-1] + t2.cpu().numpy()[:, None] * w[:, :-2]
+    s1 = np.mean(x[:, 1:] * x[:, :-1], axis=1)
+    assert np.array_equal(out[3].cpu().numpy(), s1)
