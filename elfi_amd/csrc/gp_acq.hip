@@ -27,16 +27,23 @@
 
 namespace elfihip {
 
-// Host threads for the quasi-Newton algebra of many starts (256 starts x a few microseconds per state-machine step is
-// as long as the device evaluation of the round): ELFIHIP_HOST_THREADS, default min(8, hardware threads)
-// (16 measured noisier and no faster under the GPU box's 16-CPU quota).
+// Host threads for the quasi-Newton algebra of many starts (256 starts x 5 us per state-machine step is longer than the
+// device evaluation of the round): ELFIHIP_HOST_THREADS, default min(16, hardware threads, CPUs the cgroup grants).
+// Measured at configs[4] (n = 8192, 256 starts, 16-CPU quota): host part of one acquisition 44 ms with 1 thread, 10.6 with
+// 8, 8.1 with 16; 24 threads run into the quota (17-37 ms).
 static int host_threads() {
   static const int v = [] {
     const char* e = std::getenv("ELFIHIP_HOST_THREADS");
     int t = e ? std::atoi(e) : 0;
     if (t <= 0) {
       const unsigned hc = std::thread::hardware_concurrency();
-      t = (int)std::min<unsigned>(8u, hc ? hc : 1u);
+      t = (int)std::min<unsigned>(16u, hc ? hc : 1u);
+      // cgroup v2 CPU quota ("max" or "<quota> <period>")
+      if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        long long q = 0, p = 0;
+        if (std::fscanf(f, "%lld %lld", &q, &p) == 2 && q > 0 && p > 0) t = (int)std::min<long long>(t, std::max<long long>(1, q / p));
+        std::fclose(f);
+      }
     }
     return t < 1 ? 1 : (t > 64 ? 64 : t);
   }();
@@ -57,7 +64,8 @@ static int lcb_minimize_impl(elfihip_gp* gp, const double* starts, int64_t S, co
   who.reserve((size_t)S);
   for (int64_t i = 0; i < S; ++i) opt[(size_t)i].init(dim, lo, hi, starts + i * dim, maxiter);
   RoundPool pool(S >= 64 ? host_threads() : 1);
-  static const bool trace = std::getenv("ELFIHIP_ACQ_TRACE") != nullptr;
+  static const int trace = std::getenv("ELFIHIP_ACQ_TRACE") ? std::atoi(std::getenv("ELFIHIP_ACQ_TRACE")) : 0;
+  std::vector<std::pair<int, float>> per_round;
   double t_dev = 0.0, t_host = 0.0;
   int rounds = 0;
   int64_t n_eval = 0;
@@ -81,12 +89,18 @@ static int lcb_minimize_impl(elfihip_gp* gp, const double* starts, int64_t S, co
     const auto t3 = std::chrono::steady_clock::now();
     t_dev += std::chrono::duration<double>(t2 - t1).count();
     t_host += std::chrono::duration<double>(t1 - t0).count() + std::chrono::duration<double>(t3 - t2).count();
+    if (trace >= 2) per_round.emplace_back((int)A, (float)(1e3 * std::chrono::duration<double>(t2 - t1).count()));
     ++rounds;
   }
   if (trace)
     std::fprintf(stderr, "[elfihip acq] S=%lld n=%lld rounds=%d evals=%lld device %.3f ms host %.3f ms (threads %d)\n",
                  (long long)S, (long long)gp->n, rounds, (long long)n_eval, 1e3 * t_dev, 1e3 * t_host,
                  S >= 64 ? host_threads() : 1);
+  if (trace >= 2) {
+    std::fprintf(stderr, "[elfihip acq rounds] (active points: device ms)");
+    for (auto& pr : per_round) std::fprintf(stderr, " %d:%.3f", pr.first, pr.second);
+    std::fprintf(stderr, "\n");
+  }
   for (int64_t i = 0; i < S; ++i) {
     const Lbfgsb& o = opt[(size_t)i];
     for (int c = 0; c < dim; ++c) x_out[i * dim + c] = o.best_x()[c];

@@ -62,85 +62,103 @@ struct DenseAcc {
   v4d c[DenseShape<TM>::MI][DenseShape<TM>::NJ];
 };
 
+// One k-tile of both operands in flight per register SET: thread t carries k pair 2 (t & 15) of rows (t >> 4) + 16 j
+// (j < TM / 16 of A, j < 4 of B).  Plain local scalars named by token pasting: a struct passed by reference, or an array
+// captured by a lambda, is sent to scratch memory by this compiler (272 bytes per lane measured) and the loads serialise.
+#define DENSE_DECL(S) double2 S##a0 = {0.0, 0.0}, S##a1 = {0.0, 0.0}, S##a2 = {0.0, 0.0}, S##a3 = {0.0, 0.0}, S##b0, S##b1, S##b2, S##b3
+#define DENSE_ISSUE(S, a_, b_)                                                        \
+  do {                                                                                \
+    const double* ia_ = (a_);                                                         \
+    const double* ib_ = (b_);                                                         \
+    S##a0 = *reinterpret_cast<const double2*>(ia_);                                   \
+    if (TM >= 32) S##a1 = *reinterpret_cast<const double2*>(ia_ + (int64_t)16 * lda); \
+    if (TM >= 64) S##a2 = *reinterpret_cast<const double2*>(ia_ + (int64_t)32 * lda); \
+    if (TM >= 64) S##a3 = *reinterpret_cast<const double2*>(ia_ + (int64_t)48 * lda); \
+    S##b0 = *reinterpret_cast<const double2*>(ib_);                                   \
+    S##b1 = *reinterpret_cast<const double2*>(ib_ + (int64_t)16 * ldb);               \
+    S##b2 = *reinterpret_cast<const double2*>(ib_ + (int64_t)32 * ldb);               \
+    S##b3 = *reinterpret_cast<const double2*>(ib_ + (int64_t)48 * ldb);               \
+  } while (0)
+#define DENSE_STAGE(S, sb_)                                                           \
+  do {                                                                                \
+    double* sp_ = (sb_);                                                              \
+    *reinterpret_cast<double2*>(sp_) = S##a0;                                         \
+    if (TM >= 32) *reinterpret_cast<double2*>(sp_ + 16 * DLP) = S##a1;                \
+    if (TM >= 64) *reinterpret_cast<double2*>(sp_ + 32 * DLP) = S##a2;                \
+    if (TM >= 64) *reinterpret_cast<double2*>(sp_ + 48 * DLP) = S##a3;                \
+    *reinterpret_cast<double2*>(sp_ + TM * DLP) = S##b0;                              \
+    *reinterpret_cast<double2*>(sp_ + (TM + 16) * DLP) = S##b1;                       \
+    *reinterpret_cast<double2*>(sp_ + (TM + 32) * DLP) = S##b2;                       \
+    *reinterpret_cast<double2*>(sp_ + (TM + 48) * DLP) = S##b3;                       \
+  } while (0)
+
+template <int TM>
+__device__ __forceinline__ void dense_mma(DenseAcc<TM>& acc, const double* fa, const double* fb) {
+  typedef DenseShape<TM> SH;
+#pragma unroll
+  for (int h = 0; h < 4; ++h) {
+    double2 a[SH::MI], b[SH::NJ];
+#pragma unroll
+    for (int i = 0; i < SH::MI; ++i) a[i] = *reinterpret_cast<const double2*>(fa + i * 16 * DLP + 8 * h);
+#pragma unroll
+    for (int j = 0; j < SH::NJ; ++j) b[j] = *reinterpret_cast<const double2*>(fb + j * 16 * DLP + 8 * h);
+#pragma unroll
+    for (int i = 0; i < SH::MI; ++i)
+#pragma unroll
+      for (int j = 0; j < SH::NJ; ++j) {
+        acc.c[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].x, b[j].x, acc.c[i][j], 0, 0, 0);
+        acc.c[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].y, b[j].y, acc.c[i][j], 0, 0, 0);
+      }
+  }
+}
+
 // acc += A(TM x K) B(64 x K)^T for k in [kbeg, kend), multiples of 32.  256 threads.  Two LDS stages, one barrier per
-// k-tile: while stage p is multiplied the next k-tile (in registers since the previous step) is written to stage p ^ 1
-// and the loads of the one after it are issued.
+// k-tile, and TWO register sets: the loads of k-tile j are issued two k-tiles before it is written to its stage (a
+// k-tile is about 1 us of matrix-pipe time at TM = 64, less than a loaded memory round trip: with one set in flight the
+// waves waited at the stage write -- tri_first at n = 8192, S = 256: 0.341 ms with one set).
 template <int TM>
 __device__ __forceinline__ void gemm_tm_nt(DenseAcc<TM>& acc, const double* __restrict__ A, int64_t lda,
                                            const double* __restrict__ B, int64_t ldb, int kbeg, int kend, double* sm) {
   typedef DenseShape<TM> SH;
   const int t = threadIdx.x, l = t & 63, w = t >> 6;
   const int wr = w / SH::WAVES_C, wc = w % SH::WAVES_C;
-  // global -> LDS: thread t carries k pair 2 (t & 15) of rows (t >> 4) + 16 j  (j < TM / 16 for A, j < 4 for B)
   const double* pa = A + (int64_t)(t >> 4) * lda + 2 * (t & 15) + kbeg;
   const double* pb = B + (int64_t)(t >> 4) * ldb + 2 * (t & 15) + kbeg;
-  const int doff = (t >> 4) * DLP + 2 * (t & 15);
+  double* s0 = sm + (t >> 4) * DLP + 2 * (t & 15);
+  double* s1 = s0 + SH::STAGE;
   const int faoff = (wr * SH::WROWS + (l & 15)) * DLP + 2 * (l >> 4);
   const int fboff = (TM + wc * SH::WCOLS + (l & 15)) * DLP + 2 * (l >> 4);
-  // (plain scalars and macros: a lambda capturing a register array sends the array to scratch memory)
-  double2 ra0, ra1 = {0.0, 0.0}, ra2 = {0.0, 0.0}, ra3 = {0.0, 0.0}, rb0, rb1, rb2, rb3;
-#define DENSE_ISSUE(a_, b_)                                                    \
-  do {                                                                         \
-    const double* ia_ = (a_);                                                  \
-    const double* ib_ = (b_);                                                  \
-    ra0 = *reinterpret_cast<const double2*>(ia_);                              \
-    if (TM >= 32) ra1 = *reinterpret_cast<const double2*>(ia_ + (int64_t)16 * lda); \
-    if (TM >= 64) ra2 = *reinterpret_cast<const double2*>(ia_ + (int64_t)32 * lda); \
-    if (TM >= 64) ra3 = *reinterpret_cast<const double2*>(ia_ + (int64_t)48 * lda); \
-    rb0 = *reinterpret_cast<const double2*>(ib_);                              \
-    rb1 = *reinterpret_cast<const double2*>(ib_ + (int64_t)16 * ldb);          \
-    rb2 = *reinterpret_cast<const double2*>(ib_ + (int64_t)32 * ldb);          \
-    rb3 = *reinterpret_cast<const double2*>(ib_ + (int64_t)48 * ldb);          \
-  } while (0)
-#define DENSE_STAGE(buf_)                                                      \
-  do {                                                                         \
-    double* sb_ = (buf_) + doff;                                               \
-    *reinterpret_cast<double2*>(sb_) = ra0;                                    \
-    if (TM >= 32) *reinterpret_cast<double2*>(sb_ + 16 * DLP) = ra1;           \
-    if (TM >= 64) *reinterpret_cast<double2*>(sb_ + 32 * DLP) = ra2;           \
-    if (TM >= 64) *reinterpret_cast<double2*>(sb_ + 48 * DLP) = ra3;           \
-    *reinterpret_cast<double2*>(sb_ + TM * DLP) = rb0;                         \
-    *reinterpret_cast<double2*>(sb_ + (TM + 16) * DLP) = rb1;                  \
-    *reinterpret_cast<double2*>(sb_ + (TM + 32) * DLP) = rb2;                  \
-    *reinterpret_cast<double2*>(sb_ + (TM + 48) * DLP) = rb3;                  \
-  } while (0)
   const int nkt = (kend - kbeg) / DK;
-  DENSE_ISSUE(pa, pb);
+  DENSE_DECL(r0);
+  DENSE_DECL(r1);
+  DENSE_ISSUE(r0, pa, pb);
+  if (nkt > 1) DENSE_ISSUE(r1, pa + DK, pb + DK);
   __syncthreads();   // whoever used the staging area before (previous tile's epilogue) is done
-  DENSE_STAGE(sm);
-  if (nkt > 1) DENSE_ISSUE(pa + DK, pb + DK);
+  DENSE_STAGE(r0, s0);
+  if (nkt > 2) DENSE_ISSUE(r0, pa + 2 * DK, pb + 2 * DK);
   __syncthreads();
-  int p = 0;
 #pragma unroll 1
-  for (int kt = 0; kt < nkt; ++kt) {
-    const double* buf = sm + p * SH::STAGE;
+  for (int kt = 0; kt < nkt; kt += 2) {
+    // even k-tile in stage 0; k-tile kt + 1 (set 1) goes to stage 1, set 1 is refilled with k-tile kt + 3
     if (kt + 1 < nkt) {
-      DENSE_STAGE(sm + (p ^ 1) * SH::STAGE);
-      if (kt + 2 < nkt) DENSE_ISSUE(pa + (int64_t)(kt + 2) * DK, pb + (int64_t)(kt + 2) * DK);
+      DENSE_STAGE(r1, s1);
+      if (kt + 3 < nkt) DENSE_ISSUE(r1, pa + (int64_t)(kt + 3) * DK, pb + (int64_t)(kt + 3) * DK);
     }
-    const double* fa = buf + faoff;
-    const double* fb = buf + fboff;
-#pragma unroll
-    for (int h = 0; h < 4; ++h) {
-      double2 a[SH::MI], b[SH::NJ];
-#pragma unroll
-      for (int i = 0; i < SH::MI; ++i) a[i] = *reinterpret_cast<const double2*>(fa + i * 16 * DLP + 8 * h);
-#pragma unroll
-      for (int j = 0; j < SH::NJ; ++j) b[j] = *reinterpret_cast<const double2*>(fb + j * 16 * DLP + 8 * h);
-#pragma unroll
-      for (int i = 0; i < SH::MI; ++i)
-#pragma unroll
-        for (int j = 0; j < SH::NJ; ++j) {
-          acc.c[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].x, b[j].x, acc.c[i][j], 0, 0, 0);
-          acc.c[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].y, b[j].y, acc.c[i][j], 0, 0, 0);
-        }
-    }
+    dense_mma<TM>(acc, sm + faoff, sm + fboff);
     __syncthreads();
-    p ^= 1;
+    if (kt + 1 >= nkt) break;
+    // odd k-tile in stage 1; k-tile kt + 2 (set 0) goes to stage 0, set 0 is refilled with k-tile kt + 4
+    if (kt + 2 < nkt) {
+      DENSE_STAGE(r0, s0);
+      if (kt + 4 < nkt) DENSE_ISSUE(r0, pa + (int64_t)(kt + 4) * DK, pb + (int64_t)(kt + 4) * DK);
+    }
+    dense_mma<TM>(acc, sm + SH::STAGE + faoff, sm + SH::STAGE + fboff);
+    __syncthreads();
   }
+}
+#undef DENSE_DECL
 #undef DENSE_ISSUE
 #undef DENSE_STAGE
-}
 
 struct DenseArgs {
   const double* W;      // WL (first product) or WT (second)
@@ -302,12 +320,14 @@ static int dense_launch(elfihip_gp* gp, DenseArgs D, int mode, const double* kbt
   return ELFIHIP_OK;
 }
 
-// Row-tile height: the tallest of 64 / 32 / 16 that gives at least one workgroup per CU (pairs x column blocks).
-// Measured (ms per call, n = 8192 / 4096, S = 128 / 192 / 256; profiles/r03_dense.md): a grid below the CU count loses
-// in proportion (S = 128 at n = 8192: 0.79 with 128 workgroups of 64 rows, 0.51 with 256 of 32), above it the shorter
-// tiles are within 4-11 % of the taller ones either way.
+// Row-tile height: the tallest of 64 / 32 / 16 that gives at least TWO workgroups per CU (pairs x column blocks): two
+// co-resident workgroups cover each other's barriers and epilogues.  Measured (ms per call incl. kernel rows, assembly
+// and copies; tile rows 64 / 32 / 16; profiles/r03_dense.md):
+//   n = 8192: S = 128: 0.79 / 0.51 / 0.51   S = 192: 0.78 / 0.75 / 0.67   S = 256: 0.795 / 0.765 / 0.88
+//   n = 4096: S = 128: 0.41 / 0.27 / 0.19   S = 192: 0.42 / 0.28 / 0.28   S = 256: 0.42 / 0.29 / 0.29
+// -- the rule picks the fastest (or a tie) in every one of these cases.
 static int dense_tile_rows(const elfihip_gp* gp, int ncb) {
-  const int64_t want = (int64_t)gp->ctx->cu_count;
+  const int64_t want = (int64_t)2 * gp->ctx->cu_count;
   for (int tm : {64, 32})
     if ((int64_t)ncb * (gp->np / tm / 2) >= want) return tm;
   return 16;
