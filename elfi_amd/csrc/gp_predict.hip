@@ -200,6 +200,9 @@ __global__ __launch_bounds__(256, 3) void tri_apply_kernel(TriArgs T) {   // thr
   };
   load_b(0);
   // uniform row base + 32-bit lane offset
+  // (a tiled copy of the matrix -- every workgroup's 64 KiB one contiguous run -- was measured through this kernel's
+  // addressing alone and changes nothing: 21.7 / 25.2 us per fused product at n = 4096 either way; the products are
+  // bound by launch ramp + one memory round trip per workgroup + the last arriver's epilogue, not by DRAM locality)
   const double* wbase = T.W + k0 * T.lda + i0;
   const unsigned lane_off = (unsigned)(4 * w + (l >> 4)) * (unsigned)T.lda + 2u * (l & 15);
 #pragma unroll
@@ -476,10 +479,19 @@ __global__ __launch_bounds__(256) void finish_kernel(const double* mu_part, int 
   q = ((red[4] + red[5]) + red[6]) + red[7];
   double v = prior_var - q;
   v = v > 1e-15 ? v : 1e-15;  // [GPy-upstream] predict clips the variance at 1e-15
+  // copy-free calls: the same values go to pinned host memory straight from the registers (re-reading `out` first cost
+  // a store -> load round trip through memory at the very end of every lock-step); every writer is in wave 0
+  double* hout = host_out ? host_out + (int64_t)blockIdx.y * (3 * PC + 3 * PC * dp) : nullptr;
   if (t == 0) {
+    const double vv = v + noise_add, lc = m - sqrt(beta * v);
     mu[s] = m;
-    var[s] = v + noise_add;
-    val[s] = m - sqrt(beta * v);
+    var[s] = vv;
+    val[s] = lc;
+    if (hout) {
+      hout[s] = m;
+      hout[PC + s] = vv;
+      hout[2 * PC + s] = lc;
+    }
   }
   if (with_grad) {
     // 32 values of the 2 dp gradient sums at a time: thread (value t & 31, slice t >> 5) adds chunks slice, slice + 8,
@@ -514,25 +526,26 @@ __global__ __launch_bounds__(256) void finish_kernel(const double* mu_part, int 
     for (int a = t; a < dp; a += 256) {
       const double dm = -inv_ls2 * gtot[a];
       const double dv = 2.0 * inv_ls2 * gtot[dp + a];  // -2 * sum u_i dk_i, dk_i = -(k/l^2)(x - X_i)
+      const double gr = dm - 0.5 * dv * sc;
       dmu[s * dp + a] = dm;
       dvar[s * dp + a] = dv;
-      grad[s * dp + a] = dm - 0.5 * dv * sc;
+      grad[s * dp + a] = gr;
+      if (hout) {
+        hout[3 * PC + s * dp + a] = dm;
+        hout[3 * PC + PC * dp + s * dp + a] = dv;
+        hout[3 * PC + 2 * PC * dp + s * dp + a] = gr;
+      }
     }
   }
   if (host_out) {
-    // copy-free call: one wave copies this column's results to pinned host memory, makes them visible to the
-    // host and raises the column's flag (the host polls the flags of the columns it asked for)
-    host_out += (int64_t)blockIdx.y * (3 * PC + 3 * PC * dp);
+    // one wave makes the column's results visible to the host and raises the column's flag (the host polls the flags
+    // of the columns it asked for); dp <= 64: every store above came from wave 0
     done_flags += (int64_t)blockIdx.y * PC;
-    __syncthreads();
+    if (dp > 64) {   // (writers beyond wave 0: each makes its own stores visible, then the flag)
+      __threadfence_system();
+      __syncthreads();
+    }
     if (t < 64) {
-      if (t < 3) host_out[t * PC + s] = out[t * PC + s];
-      if (with_grad)
-        for (int e = t; e < 3 * dp; e += 64) {
-          const int which = e / dp, a = e - which * dp;
-          const int o = 3 * PC + which * PC * dp + s * dp + a;
-          host_out[o] = out[o];
-        }
       __threadfence_system();
       if (t == 0) __hip_atomic_store(done_flags + s, done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
