@@ -275,20 +275,26 @@ struct SelWork {
   unsigned int err;
 };
 
+// Grid barrier WITHOUT cache-maintenance fences.  Everything the workgroups exchange goes through agent-scope accesses on
+// both sides -- histogram bins and counters by device-scope atomics, candidate keys and per-workgroup counts by
+// write-through (sc1) stores, every reader by sc1 loads (__hip_atomic_load relaxed / agent), which never hit the CU's L1
+// -- so an arrival only has to wait for the wave's own memory operations (s_waitcnt vmcnt(0): stores, atomics) and bump
+// the counter.  MI355X_MICROARCH.md's price list: a counter barrier between two __threadfence() (this kernel until round
+// 2: buffer_wbl2 + buffer_inv of a whole L2 / L1 per workgroup and barrier) 9-9.3 us, against 3-4.5 us for the
+// fan-in + broadcast alone; five of them per selection.
 __device__ __forceinline__ void sel_grid_barrier(SelWork* w, unsigned int target) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // EVERY wave: its write-through stores and atomics have landed
   __syncthreads();
   if (threadIdx.x == 0) {
-    __threadfence();
-    atomicAdd(&w->bar, 1u);
+    __hip_atomic_fetch_add(&w->bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned int spins = 0;
     while (__hip_atomic_load(&w->bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      __builtin_amdgcn_s_sleep(2);
+      __builtin_amdgcn_s_sleep(1);
       if (++spins > (1u << 24)) {
         atomicExch(&w->err, 1u);
         break;
       }
     }
-    __threadfence();
   }
   __syncthreads();
 }
@@ -417,7 +423,8 @@ __global__ __launch_bounds__(SEL_NT) void sel_persistent_kernel(const double* d,
         for (int u = 0; u < U; ++u) {
           const int64_t i = i0 + u * SEL_NT + tid;
           const unsigned long long kk = key_of(v[u]);
-          if (i < hi && (kk & cmask) == prefix) w->cand[atomicAdd(&w->ncand, 1u)] = kk;
+          if (i < hi && (kk & cmask) == prefix)   // write-through store: visible to the other XCDs without a fence
+            __hip_atomic_store(&w->cand[atomicAdd(&w->ncand, 1u)], kk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
       sel_grid_barrier(w, G * ++bar_no);
@@ -459,7 +466,7 @@ __global__ __launch_bounds__(SEL_NT) void sel_persistent_kernel(const double* d,
     if (lt) atomicAdd(&base[0], lt);
     if (eq) atomicAdd(&base[1], eq);
     __syncthreads();
-    if (tid < 2) w->counts[2 * blockIdx.x + tid] = base[tid];
+    if (tid < 2) __hip_atomic_store(&w->counts[2 * blockIdx.x + tid], base[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   sel_grid_barrier(w, G * ++bar_no);
   {

@@ -203,16 +203,39 @@ def scg(f, gradf, x, maxiters=50, xtol=1e-6, ftol=1e-6, gtol=1e-5):
     return x, flog, function_eval, status
 
 
+def _scipy_search(name, obj, phi0, max_iters):
+    """The other optimisers GPy's `model.optimize(optimizer=...)` accepts ([GPy-upstream] paramz
+    optimization.get_optimizer: 'lbfgsb' / 'lbfgs' / 'org-bfgs' -> fmin_l_bfgs_b, 'bfgs' / 'org-bfgs', 'tnc', 'simplex'),
+    with the arguments paramz passes: the same objective and gradient on the transformed parameters, max_iters as the
+    iteration / evaluation cap.  Parity unpinned (no reference test or print-out uses them)."""
+    import scipy.optimize as so
+    fg = lambda x: (obj.f(x), obj.grad(x))
+    if name in ('lbfgsb', 'lbfgs', 'lbfgsb-ps'):
+        x, f, d = so.fmin_l_bfgs_b(fg, phi0, maxfun=max_iters, maxiter=max_iters)
+        return x, [f], d.get('funcalls', 0), d.get('task', '')
+    if name in ('bfgs', 'org-bfgs'):
+        r = so.fmin_bfgs(obj.f, phi0, obj.grad, maxiter=max_iters, disp=False, full_output=True)
+        return r[0], [r[1]], r[4], 'warnflag %d' % r[6]
+    if name == 'tnc':
+        x, nfev, rc = so.fmin_tnc(fg, phi0, messages=0, maxfun=max_iters)
+        return x, [obj.f(x)], nfev, 'rc %d' % rc
+    if name == 'simplex':
+        r = so.fmin(obj.f, phi0, disp=False, maxfun=max_iters, full_output=True)
+        return r[0], [r[1]], r[3], 'warnflag %d' % r[4]
+    raise ValueError("optimizer %r: expected one of 'scg' (the reference's default, gpy_regression.py:30), 'lbfgsb', "
+                     "'bfgs', 'tnc', 'simplex'" % (name,))
+
+
 def optimize_hyperparameters(model, max_iters=50):
     """MAP hyper-parameters for `model` (a fitted HipGPRegression); refits it at the optimum."""
-    if model.optimizer != 'scg':
-        raise NotImplementedError("optimizer %r: only 'scg' (the reference's default, "
-                                  "gpy_regression.py:30) is implemented" % (model.optimizer,))
     h0 = dict(model._hyper)
     obj = MarginalObjective(model)
     phi0 = logexp_inv(np.array([h0[k] for k in NAMES]))
     try:
-        phi, flog, nfev, status = scg(obj.f, obj.grad, phi0, maxiters=max_iters)
+        if model.optimizer == 'scg':
+            phi, flog, nfev, status = scg(obj.f, obj.grad, phi0, maxiters=max_iters)
+        else:
+            phi, flog, nfev, status = _scipy_search(str(model.optimizer).lower(), obj, phi0, max_iters)
     except Exception:
         # whatever ended the search (LinAlgError, or the ValueError / ZeroDivisionError the objective re-raises after
         # ten failed evaluations in a row): the device GP holds the last TRIAL hyper-parameters, possibly

@@ -81,9 +81,6 @@ class HipLCBSC:
 
     def __init__(self, model, prior=None, n_inits=10, max_opt_iters=1000, noise_var=None,
                  exploration_rate=10, seed=None, constraints=None, delta=None, additive_cost=None):
-        if constraints is not None or additive_cost is not None:
-            raise NotImplementedError('constraints / additive_cost need the reference LCBSC (SLSQP / '
-                                      'user callbacks on the host); it accepts HipGPRegression as model')
         if delta is not None:
             if delta <= 0 or delta >= 1:
                 logger.warning('Parameter delta should be in the interval (0,1)')
@@ -92,8 +89,11 @@ class HipLCBSC:
         self.prior = prior
         self.n_inits = int(n_inits)
         self.max_opt_iters = int(max_opt_iters)
-        self.constraints = None
-        self.additive_cost = None
+        # constraints: scipy constraint definitions, as the reference hands them to SLSQP (acquisition.py:159-160);
+        # additive_cost: an object with evaluate(x) / evaluate_gradient(x) added to the criterion (acquisition.py:278-279,
+        # 299-300) -- host callbacks of the user; the GP part of every evaluation still runs on the device
+        self.constraints = constraints
+        self.additive_cost = additive_cost
         self.noise_var = None if noise_var is None else self._noise_spec(noise_var)
         self.exploration_rate = exploration_rate
         self.random_state = np.random if seed is None else np.random.RandomState(seed)
@@ -140,12 +140,50 @@ class HipLCBSC:
     # -- point-wise interface (plots, tests, other optimisers): acquisition.py:262-301
     def evaluate(self, x, t=None):
         mean, var = self.model.predict(x, noiseless=True)
-        return mean - np.sqrt(self._beta(t) * var)
+        value = mean - np.sqrt(self._beta(t) * var)
+        if self.additive_cost is not None:
+            value += self.additive_cost.evaluate(x)
+        return value
 
     def evaluate_gradient(self, x, t=None):
         mean, var = self.model.predict(x, noiseless=True)
         grad_mean, grad_var = self.model.predictive_gradients(x)
-        return grad_mean - 0.5 * grad_var * np.sqrt(self._beta(t) / var)
+        value = grad_mean - 0.5 * grad_var * np.sqrt(self._beta(t) / var)
+        if self.additive_cost is not None:
+            value += self.additive_cost.evaluate_gradient(x)
+        return value
+
+    def _value_and_gradient(self, X, t):
+        """Criterion and gradient at the rows of X: ONE batched device call for the GP part + the user's cost."""
+        val, grad = self.model.lcb(X, self._beta(t), with_grad=True)
+        val, grad = val.reshape(-1), np.array(grad, dtype=float)
+        if self.additive_cost is not None:
+            val = val + np.asarray(self.additive_cost.evaluate(X), dtype=float).reshape(-1)
+            grad = grad + np.asarray(self.additive_cost.evaluate_gradient(X), dtype=float).reshape(grad.shape)
+        return val, grad
+
+    def _minimize_on_host(self, t, start_points):
+        """The two forms whose search cannot stay inside the library.  additive_cost: the library's L-BFGS-B state
+        machines in reverse-communication form (multistart.py), every round one batched device evaluation + the cost.
+        constraints: scipy's SLSQP from every start in turn, as the reference does (bo/utils.py:97-103 with
+        method='SLSQP', acquisition.py:159), each evaluation one device call."""
+        bounds = self.model.bounds
+        if self.constraints is None:
+            from .multistart import minimize_lockstep
+            res = minimize_lockstep(lambda X: self._value_and_gradient(X, t), start_points, bounds,
+                                    maxiter=self.max_opt_iters)
+            return res['locs'], res['vals'], res['iters'], None
+        import scipy.optimize
+        locs, vals, iters = [], np.empty(len(start_points)), np.empty(len(start_points), dtype=np.int32)
+        fun = lambda x: float(self._value_and_gradient(x[None, :], t)[0][0])
+        jac = lambda x: self._value_and_gradient(x[None, :], t)[1][0]
+        for i, x0 in enumerate(start_points):
+            r = scipy.optimize.minimize(fun, x0, method='SLSQP', jac=jac, bounds=bounds, constraints=self.constraints,
+                                        options={'maxiter': self.max_opt_iters})
+            locs.append(r['x'])
+            vals[i] = r['fun']
+            iters[i] = r.get('nit', 0)
+        return np.array(locs), vals, iters, None
 
     def _start_points(self):
         return draw_start_points(self.model.bounds, self.n_inits, self.prior, self.random_state)
@@ -161,7 +199,9 @@ class HipLCBSC:
             return np.array(start_points[0], dtype=float), float(-np.sqrt(self._beta(t)))
         rank, world = _dist_rank_world() if self.shard_starts else (0, 1)
         mine = np.arange(rank, len(start_points), world)     # start s belongs to rank s % world
-        if len(mine):
+        if len(mine) and (self.constraints is not None or self.additive_cost is not None):
+            locs, vals, iters, n_eval = self._minimize_on_host(t, start_points[mine])
+        elif len(mine):
             locs, vals, iters, n_eval = self.model._handle.lcb_minimize(start_points[mine], bounds, self._beta(t),
                                                                        maxiter=self.max_opt_iters)
         else:

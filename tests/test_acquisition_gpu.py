@@ -159,3 +159,51 @@ def test_against_the_reference_recorded_acquisition(hip_ctx):
         k_ref = int(np.argmin(g['vals_' + tag]))
         if np.max(np.abs(info['locs'][info['ind_min']] - g['locs_' + tag][k_ref])) <= 1e-3:
             np.testing.assert_allclose(x_acq, g['x_acq_' + tag], rtol=0, atol=1e-3)
+
+
+class _QuadraticCost:
+    """additive_cost of acquisition.py:278-279,299-300: evaluate(x) (n, 1), evaluate_gradient(x) (n, d)."""
+
+    def __init__(self, centre, weight):
+        self.c, self.w = np.asarray(centre, dtype=float), float(weight)
+
+    def evaluate(self, x):
+        x = np.atleast_2d(x)
+        return self.w * np.sum((x - self.c) ** 2, axis=1, keepdims=True)
+
+    def evaluate_gradient(self, x):
+        x = np.atleast_2d(x)
+        return 2.0 * self.w * (x - self.c)
+
+
+def test_additive_cost_and_constraints_like_the_reference_rule(hip_ctx):
+    """HipLCBSC(additive_cost=...) / HipLCBSC(constraints=...): what the reference's LCBSC does with these arguments
+    (acquisition.py:146-172,256-301: criterion + cost; SLSQP under the constraints, bo/utils.py:97-103), the GP part of
+    every evaluation on the device.  Checked against scipy on the CPU posterior from the same start points."""
+    import scipy.optimize
+    from elfi_amd import HipLCBSC
+    m, ref, bounds = _setup(400, 2, seed=21)
+    t = 5
+    cost = _QuadraticCost([1.5, -1.0], 0.7)
+    acq = HipLCBSC(m, n_inits=8, seed=3, additive_cost=cost)
+    xs = np.random.RandomState(0).uniform(-2, 2, (6, 2))
+    scale = np.max(np.abs(G.lcb_evaluate(ref, xs, t))) + 1.0
+    np.testing.assert_allclose(acq.evaluate(xs, t), G.lcb_evaluate(ref, xs, t) + cost.evaluate(xs), rtol=0, atol=1e-8 * scale)
+    np.testing.assert_allclose(acq.evaluate_gradient(xs, t), G.lcb_evaluate_gradient(ref, xs, t) + cost.evaluate_gradient(xs),
+                               rtol=0, atol=1e-7 * scale)
+    starts = np.random.RandomState(1).uniform(-2, 2, (8, 2))
+    xhat, val = acq.minimize(t, start_points=starts)
+    fun = lambda x: float(G.lcb_evaluate(ref, x, t)[0, 0] + cost.evaluate(x)[0, 0])
+    grad = lambda x: G.lcb_evaluate_gradient(ref, x, t)[0] + cost.evaluate_gradient(x)[0]
+    best = min(scipy.optimize.minimize(fun, x0, method='L-BFGS-B', jac=grad, bounds=bounds).fun for x0 in starts)
+    assert val <= best + 1e-6 * scale and abs(fun(xhat) - val) <= 1e-8 * scale
+    assert acq.acquire(3, t=t).shape == (3, 2)
+    # a linear inequality constraint x0 + x1 <= -0.5, handed over as scipy's dict form
+    cons = {'type': 'ineq', 'fun': lambda x: -0.5 - x[0] - x[1], 'jac': lambda x: np.array([-1.0, -1.0])}
+    acq2 = HipLCBSC(m, n_inits=8, seed=3, constraints=cons)
+    xhat2, val2 = acq2.minimize(t, start_points=starts)
+    assert xhat2[0] + xhat2[1] <= -0.5 + 1e-6
+    f2 = lambda x: float(G.lcb_evaluate(ref, x, t)[0, 0])
+    g2 = lambda x: G.lcb_evaluate_gradient(ref, x, t)[0]
+    best2 = min(scipy.optimize.minimize(f2, x0, method='SLSQP', jac=g2, bounds=bounds, constraints=cons).fun for x0 in starts)
+    assert abs(val2 - best2) <= 1e-5 * scale

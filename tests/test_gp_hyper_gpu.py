@@ -140,3 +140,31 @@ def test_map_search_reaches_the_reference_s_published_optimum(hip_ctx):
     np.testing.assert_allclose(got[2], printed[2], rtol=5e-2)          # the flat bias direction
     # and the gradient of the device objective vanishes at the printed optimum to the search's own tolerance
     assert np.max(np.abs(obj.grad(H.logexp_inv(printed)))) <= 5e-3
+
+
+@pytest.mark.parametrize('optimizer', ['lbfgsb', 'bfgs', 'tnc', 'simplex'])
+def test_other_optimizers_reach_the_map_objective(hip_ctx, optimizer):
+    """GPyRegression(optimizer=...) hands the name to GPy's model.optimize (gpy_regression.py:30,321); besides 'scg' the
+    SciPy-backed searches run on the same device objective.  They must improve the MAP objective and -- given enough
+    iterations -- end at (or below) the optimum the default search finds."""
+    from elfi_amd import HipGPRegression
+    X, y, bounds = G.synthetic_gp_problem(200, 2, seed=5)
+    names = ['t1', 't2']
+    ref_m = HipGPRegression(names, bounds=dict(zip(names, bounds)), max_opt_iters=200)
+    ref_m.update(X, y, optimize=True)
+    f_scg = ref_m._opt_info['objective'][-1]
+    m = HipGPRegression(names, bounds=dict(zip(names, bounds)), optimizer=optimizer,
+                        max_opt_iters=2000 if optimizer == 'simplex' else 400)
+    m.update(X, y)
+    from elfi_amd import hyperopt as H
+    f0 = H.MarginalObjective(m).f(H.logexp_inv(np.array([m._hyper[k] for k in H.NAMES])))
+    m.optimize()
+    f1 = m._opt_info['objective'][-1]
+    assert f1 < f0 - 1.0
+    assert f1 <= f_scg + 1e-3 * abs(f_scg), (optimizer, f1, f_scg)
+    post = G.Posterior(X, y, **m._hyper)                       # refitted at the optimum
+    xs = np.random.RandomState(0).uniform(-2, 2, (5, 2))
+    np.testing.assert_allclose(m.predict(xs)[0], post.predict(xs)[0], rtol=1e-7)
+    with pytest.raises(ValueError):
+        bad = HipGPRegression(names, bounds=dict(zip(names, bounds)), optimizer='nope')
+        bad.update(X, y, optimize=True)
