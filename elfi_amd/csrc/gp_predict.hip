@@ -158,7 +158,7 @@ __device__ __forceinline__ void grad_rows(const double* __restrict__ X, const do
                                           int nchunks, int64_t i0, int64_t n, int64_t np, int dp, double (*red)[PC][32]);
 
 template <int MODE, bool FUSE>
-__global__ __launch_bounds__(256, 3) void tri_apply_kernel(TriArgs T) {   // three workgroups per CU: <= 168 registers
+__global__ __launch_bounds__(256, 3) void tri_apply_kernel(TriArgs T) {   // three workgroups per CU: <= 168 registers (four = 128 registers spills: 61 -> 74 us per lock-step)
   // No LDS staging of the matrix: a lane's 16-byte load IS its MFMA operand.  Lane (kq = l >> 4, ip = l & 15)
   // of wave w loads W[k][i0 + 2 ip .. + 1] for k = k0 + 16 q + 4 w + kq, q = 0 .. len/16: one instruction covers
   // 4 rows x 256 contiguous bytes, and its two doubles feed two v_mfma_f64_16x16x4 (even rows i / odd rows i)
