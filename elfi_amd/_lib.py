@@ -125,6 +125,7 @@ PROTOTYPES = {
     "elfihip_gp_profile": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "elfihip_gp_set_schedule": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "elfihip_gp_set_dense_threshold": (C.c_int, [C.c_void_p, C.c_int64, C.c_int]),
+    "elfihip_gp_set_lockstep_form": (C.c_int, [C.c_void_p, C.c_int]),
     "elfihip_gp_nlml_grad": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_void_p]),
     "elfihip_gp_form_kinv": (C.c_int, [C.c_void_p]),
     "elfihip_gp_extend": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_double)]),

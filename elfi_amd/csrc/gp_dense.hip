@@ -333,15 +333,7 @@ static int dense_tile_rows(const elfihip_gp* gp, int ncb) {
   return 16;
 }
 
-int64_t dense_min_points(const elfihip_gp* gp) {
-  if (gp->dense_min > 0) return gp->dense_min;
-  static const int64_t v = [] {
-    const char* e = std::getenv("ELFIHIP_DENSE_MIN");   // process-wide default, for experiments
-    const long long x = e ? std::atoll(e) : 0;
-    return (int64_t)(x > 0 ? x : 112);
-  }();
-  return v;
-}
+int64_t dense_min_points(const elfihip_gp* gp) { return gp->dense_min > 0 ? gp->dense_min : 112; }
 
 // mode: 0 = mean / variance, 1 = + gradients (and LCB); same outputs as predict_impl.
 int predict_dense_impl(elfihip_gp* gp, const double* Xs, int64_t S, int mode, int noiseless, double beta, double* mu,

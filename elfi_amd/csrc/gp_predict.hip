@@ -724,15 +724,9 @@ static void launch_tri(const elfihip_gp* gp, const PredictWs& W, bool lower, con
     hipLaunchKernelGGL((tri_apply_kernel<0, false>), grid, dim3(256), 0, gp->ctx->stream, T);
 }
 
-// The fused lock-step (four launches instead of six) is the default; ELFIHIP_LOCKSTEP_FUSE=0 keeps the six-launch form
-// (same numbers for mean / variance, gradient sums in 64-row instead of 32-row chunks).
-static bool lockstep_fused() {
-  static const bool v = [] {
-    const char* e = std::getenv("ELFIHIP_LOCKSTEP_FUSE");
-    return !(e && e[0] == '0');
-  }();
-  return v;
-}
+// The fused lock-step (four launches instead of six) is the default; elfihip_gp_set_lockstep_form(gp, 1) keeps the
+// six-launch form (same numbers for mean / variance, gradient sums in 64-row instead of 32-row chunks).
+static bool lockstep_fused(const elfihip_gp* gp) { return gp->lockstep_form == 0; }
 
 static int ensure_tri_counters(elfihip_gp* gp) {
   if (gp->tri_cnt) return ELFIHIP_OK;
@@ -749,7 +743,7 @@ static int ensure_ws(elfihip_gp* gp, PredictWs* W, int64_t npass) {
   W->nblk_k = (int)((np + 255) / 256);
   W->nkc = (nb + KCH - 1) / KCH;
   // gradient chunks: 64-row workgroups of grad_kernel, or the 32-row blocks of the fused second product
-  W->ngc = lockstep_fused() ? (int)(np / RB) : (int)((gp->n + GR - 1) / GR);
+  W->ngc = lockstep_fused(gp) ? (int)(np / RB) : (int)((gp->n + GR - 1) / GR);
   size_t off = 0;
   auto take = [&](size_t doubles) {
     size_t o = off;
@@ -853,7 +847,7 @@ int predict_enqueue(elfihip_gp* gp, const PredictPlan& P, int64_t S_active, int 
   // W.xs and W.xs2 are adjacent in the workspace (PC * dp is a multiple of the 16-double granule)
   if (!P.direct) ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(W.xs, P.hx, P.n_in * sizeof(double), hipMemcpyHostToDevice, st));
   if (mode == 1) ELFIHIP_TRY(ensure_wl(gp));
-  const bool fused = lockstep_fused();
+  const bool fused = lockstep_fused(gp);
   if (fused) ELFIHIP_TRY(ensure_tri_counters(gp));
   const int rblocks = (int)(np * PC / 256);
   static thread_local QueryArgs qa;  // only filled (and read by the kernel) for single-pass calls
@@ -1276,6 +1270,13 @@ static int cross_cov_impl(elfihip_gp* gp, const double* Q, int64_t S, double* co
 using namespace elfihip;
 
 extern "C" {
+
+int elfihip_gp_set_lockstep_form(elfihip_gp* gp, int form) {
+  if (!gp) return fail(nullptr, ELFIHIP_ERR_ARG, "gp is NULL");
+  ELFIHIP_REQUIRE(gp->ctx, form == 0 || form == 1, "form must be 0 (four launches, fused epilogues) or 1 (six launches)");
+  gp->lockstep_form = form;
+  return ELFIHIP_OK;
+}
 
 int elfihip_gp_predict(elfihip_gp* gp, const double* Xs, int64_t S, int noiseless, double* mu, double* var) {
   if (!gp) return fail(nullptr, ELFIHIP_ERR_ARG, "gp is NULL");

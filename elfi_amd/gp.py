@@ -92,6 +92,10 @@ class GPHandle:
         (include/elfihip.h: elfihip_gp_set_dense_threshold); 0 = default.  tile_rows: 0 = by size, else 64 / 32 / 16."""
         self._check(self.lib.elfihip_gp_set_dense_threshold(self.h, int(min_points), int(tile_rows)))
 
+    def set_lockstep_form(self, form=0):
+        """0: four launches per small prediction call (fused epilogues, default); 1: the six-launch form."""
+        self._check(self.lib.elfihip_gp_set_lockstep_form(self.h, int(form)))
+
     PHASES = ('gram', 'sweep', 'alpha', 'kstar', 'tri_first', 'tri_second', 'grad_finish', 'kinv_grad')
 
     def profile(self, enable=-1):

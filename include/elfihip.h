@@ -309,6 +309,13 @@ int elfihip_gp_set_schedule(elfihip_gp* gp, int schedule, int panel_group);
  * 0 = by size (the tallest of 64 / 32 / 16 that still gives about one workgroup per CU), else 64, 32 or 16.  Results agree
  * to rounding; each form is deterministic. */
 int elfihip_gp_set_dense_threshold(elfihip_gp* gp, int64_t min_points, int tile_rows);
+/* How a prediction call with few points (every step of the multi-start search, bo/utils.py:97-103) is launched:
+ * form 0 (default) = four launches -- kernel rows | first triangular product | second | assembly -- the reduction of the
+ * first product's chunk partials and the gradient sums of the second run as epilogues of the LAST workgroup to arrive at
+ * each 32-row block (write-through partials, one relaxed device-scope arrival per workgroup, one acquire by the last
+ * arriver); form 1 = the six launches of round 2 (product, reduction, product, gradient sums as kernels of their own).
+ * Mean / variance are bit-identical between the forms, gradients agree to rounding (32- against 64-row chunks). */
+int elfihip_gp_set_lockstep_form(elfihip_gp* gp, int form);
 /* Device time per phase, for roofline accounting (bench.py; no reference counterpart).  While enabled, HIP events on the
  * GP's stream bracket the phases of elfihip_gp_factorize (Gram matrix | sweep | alpha + log-determinant), of single-group
  * prediction calls -- elfihip_gp_predict / _predict_grad / _lcb and every step of elfihip_gp_lcb_minimize -- (kernel row |

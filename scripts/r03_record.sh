@@ -10,7 +10,7 @@ R=$PWD
 ( time timeout 600 python bench.py ) > $OUT/bench_default.json 2> $OUT/bench_default.err
 tail -c 300 $OUT/bench_default.err
 timeout 200 python scripts/r3_probe.py lockstep > $OUT/probe_lockstep_fused.json 2>/dev/null
-ELFIHIP_LOCKSTEP_FUSE=0 timeout 200 python scripts/r3_probe.py lockstep > $OUT/probe_lockstep_six.json 2>/dev/null
+R3_LOCKSTEP_FORM=1 timeout 200 python scripts/r3_probe.py lockstep > $OUT/probe_lockstep_six.json 2>/dev/null
 timeout 200 python scripts/r3_probe.py dense > $OUT/probe_dense.json 2>/dev/null
 timeout 200 python scripts/r3_probe.py tiles > $OUT/probe_tiles.json 2>/dev/null
 ELFIHIP_ACQ_TRACE=2 timeout 200 python scripts/r3_probe.py cfg5 > $OUT/probe_cfg5.json 2> $OUT/probe_cfg5.err

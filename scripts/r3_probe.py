@@ -1,4 +1,4 @@
-"""Round-3 developer probe (GPU): lock-step (fused / six-launch by ELFIHIP_LOCKSTEP_FUSE), dense / streaming form of the
+"""Round-3 developer probe (GPU): lock-step (fused / six-launch by R3_LOCKSTEP_FORM -> elfihip_gp_set_lockstep_form), dense / streaming form of the
 many-point products, the configs[4] acquisition.  python scripts/r3_probe.py [lockstep|dense|cfg5|all]"""
 import json
 import os
@@ -13,7 +13,8 @@ from elfi_amd import bolfi_bench
 from elfi_amd.gp import GPHandle
 
 what = sys.argv[1] if len(sys.argv) > 1 else 'all'
-out = {"fuse_env": os.environ.get("ELFIHIP_LOCKSTEP_FUSE", "(default on)")}
+FORM = int(os.environ.get("R3_LOCKSTEP_FORM", "0"))      # 0 fused (default), 1 six launches
+out = {"lockstep_form": FORM}
 
 
 def fitted(n, d):
@@ -23,6 +24,7 @@ def fitted(n, d):
     gp.set_hyper(h['var'], h['ls'], h['bias'], h['noise'])
     gp.set_data(X, y)
     gp.factorize()
+    gp.set_lockstep_form(FORM)
     return gp
 
 

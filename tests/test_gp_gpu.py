@@ -387,3 +387,28 @@ def test_dense_form_of_the_products_vs_streaming_form_and_oracle(hip_ctx, n, d, 
         _close(dm1, gmu, 1e-8, 'grad mu')
         _close(dv1, gvar, 1e-7, 'grad var')
     gp.set_dense_threshold(0)
+
+
+@pytest.mark.parametrize('n,d,S', [(700, 5, 10), (2100, 2, 16), (4096, 10, 10), (1000, 20, 40)])
+def test_fused_lockstep_form_equals_the_six_launch_form(hip_ctx, n, d, S):
+    """elfihip_gp_set_lockstep_form: the reduction of the first product's partials and the gradient sums of the second as
+    epilogues of the last workgroup to arrive at a row block (write-through partials, relaxed arrival, one acquire) against
+    the same work as kernels of their own.  Mean / variance / LCB value: bit for bit (same summation order); gradients to
+    rounding (32- against 64-row chunks).  Many calls in a row: a stale read of another workgroup's partials would show."""
+    X, y, bounds = _problem(n, d, seed=n + S)
+    gp, _, ref = _fit(X, y, bounds)
+    rs = np.random.RandomState(1)
+    for rep in range(25):
+        xs = rs.uniform(-2, 2, (S, d))
+        gp.set_lockstep_form(1)
+        m0, v0, dm0, dv0 = gp.predict_grad(xs)
+        val0, g0 = gp.lcb(xs, 3.0)
+        gp.set_lockstep_form(0)
+        m1, v1, dm1, dv1 = gp.predict_grad(xs)
+        val1, g1 = gp.lcb(xs, 3.0)
+        assert np.array_equal(m0, m1) and np.array_equal(v0, v1) and np.array_equal(val0, val1), rep
+        _close(dm1, dm0, 1e-12, 'grad mu')
+        _close(dv1, dv0, 1e-11, 'grad var')
+        _close(g1, g0, 1e-11, 'lcb grad')
+    rmu, rvar = ref.predict(xs, noiseless=True)
+    _close(m1, rmu, 1e-8, 'mu')
