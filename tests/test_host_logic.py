@@ -108,8 +108,10 @@ def test_lcbsc_arguments_and_beta():
         HipLCBSC(_Model(), noise_var={'a': 0.1, 'b': -0.2})
     with pytest.raises(ValueError):
         HipLCBSC(_Model(), noise_var='x')
-    with pytest.raises(NotImplementedError):
-        HipLCBSC(_Model(), constraints=[{}])
+    # constraints / additive_cost are accepted as the reference accepts them (acquisition.py:24-73); what they do is
+    # tested on the GPU (tests/test_acquisition_gpu.py)
+    cons = [{'type': 'ineq', 'fun': lambda x: x[0]}]
+    assert HipLCBSC(_Model(), constraints=cons).constraints is cons
 
 
 def test_lcbsc_random_number_consumption_matches_the_reference_recipe():
