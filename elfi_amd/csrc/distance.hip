@@ -77,9 +77,14 @@ struct Op {
   __device__ static __forceinline__ double finish(double s, double inv_p) {
     if constexpr (METRIC == ELFIHIP_EUCLIDEAN || METRIC == ELFIHIP_SEUCLIDEAN)
       return sqrt(s);
-    else if constexpr (METRIC == ELFIHIP_MINKOWSKI)
+    else if constexpr (METRIC == ELFIHIP_MINKOWSKI) {
+      // the root of the integer orders 3 and 4 without pow() (SciPy takes pow(s, 1.0 / p), whose exponent is itself
+      // rounded: cbrt / sqrt(sqrt) agree with it to 1-2 ulp, inside the 1e-14 the general orders are held to); at
+      // m = 2 the pow() per ROW was what the kernel spent its time on (4 10^6 rows: 0.058 ms against 0.018 for euclidean)
+      if (inv_p == 1.0 / 3.0) return cbrt(s);
+      if (inv_p == 0.25) return sqrt(sqrt(s));
       return pow(s, inv_p);
-    else
+    } else
       return s;
   }
 };
