@@ -111,7 +111,10 @@ class Lbfgsb {
       return;
     }
     const double fold = fk_;
-    std::vector<double> s(n_), y(n_);
+    std::vector<double>& s = snew_;   // (member scratch: a step of 256 state machines is a few thousand allocations otherwise)
+    std::vector<double>& y = ynew_;
+    s.resize(n_);
+    y.resize(n_);
     double dr = 0.0, ddum = 0.0;  // s^T y and -g_k^T s
     for (int i = 0; i < n_; ++i) {
       s[i] = x_[i] - xk_[i];
@@ -145,9 +148,32 @@ class Lbfgsb {
       if (static_cast<int>(S_.size()) == MEM) {
         S_.erase(S_.begin());
         Y_.erase(Y_.begin());
+        for (int i = 1; i < MEM; ++i)      // the cached inner products move with their pairs
+          for (int j = 1; j < MEM; ++j) {
+            sy_[(i - 1) * MEM + (j - 1)] = sy_[i * MEM + j];
+            ss_[(i - 1) * MEM + (j - 1)] = ss_[i * MEM + j];
+          }
       }
       S_.push_back(s);
       Y_.push_back(y);
+      {
+        // S_i . Y_j and S_i . S_j involving the new pair (index c - 1): every entry is the same left-to-right sum
+        // build_middle used to recompute for all c^2 pairs in every iteration
+        const int c = cols(), a = c - 1;
+        for (int j = 0; j < c; ++j) {
+          double sy_aj = 0.0, sy_ja = 0.0, ss_aj = 0.0, ss_ja = 0.0;
+          for (int q = 0; q < n_; ++q) {
+            sy_aj += S_[a][q] * Y_[j][q];
+            sy_ja += S_[j][q] * Y_[a][q];
+            ss_aj += S_[a][q] * S_[j][q];
+            ss_ja += S_[j][q] * S_[a][q];
+          }
+          sy_[a * MEM + j] = sy_aj;
+          sy_[j * MEM + a] = sy_ja;
+          ss_[a * MEM + j] = ss_aj;
+          ss_[j * MEM + a] = ss_ja;
+        }
+      }
       theta_ = rr / dr;
       if (!build_middle()) reset_memory();
     }
@@ -326,6 +352,32 @@ class Lbfgsb {
     }
   }
 
+  // The same solve for the m columns of B (k x m, row-major) at once: every entry goes through exactly the operations
+  // lu_solve applies to its column, in the same order; the loops run along the rows of B (contiguous), so the compiler
+  // vectorises what k separate calls walked with stride k.
+  static void lu_solve_multi(const std::vector<double>& a, const std::vector<int>& piv, int k, std::vector<double>& B, int m) {
+    for (int c = 0; c < k; ++c)
+      if (piv[c] != c)
+        for (int j = 0; j < m; ++j) std::swap(B[c * m + j], B[piv[c] * m + j]);
+    for (int c = 0; c < k; ++c)
+      for (int r = c + 1; r < k; ++r) {
+        const double arc = a[r * k + c];
+        double* br = &B[r * m];
+        const double* bc = &B[c * m];
+        for (int j = 0; j < m; ++j) br[j] -= arc * bc[j];
+      }
+    for (int c = k - 1; c >= 0; --c) {
+      double* bc = &B[c * m];
+      for (int q = c + 1; q < k; ++q) {
+        const double acq = a[c * k + q];
+        const double* bq = &B[q * m];
+        for (int j = 0; j < m; ++j) bc[j] -= acq * bq[j];
+      }
+      const double acc = a[c * k + c];
+      for (int j = 0; j < m; ++j) bc[j] /= acc;
+    }
+  }
+
   int cols() const { return static_cast<int>(S_.size()); }
   // row i of W = [Y, theta S]  (2c entries)
   void w_row(int i, double* w) const {
@@ -343,11 +395,7 @@ class Lbfgsb {
     mid_lu_.assign(static_cast<size_t>(k) * k, 0.0);
     for (int i = 0; i < c; ++i)
       for (int j = 0; j < c; ++j) {
-        double sy = 0.0, ss = 0.0;
-        for (int q = 0; q < n_; ++q) {
-          sy += S_[i][q] * Y_[j][q];
-          ss += S_[i][q] * S_[j][q];
-        }
+        const double sy = sy_[i * MEM + j], ss = ss_[i * MEM + j];   // S_i . Y_j, S_i . S_j (cached in feed())
         if (i == j) mid_lu_[i * k + j] = -sy;            // -D
         if (i > j) {
           mid_lu_[(c + i) * k + j] = sy;                 // L
@@ -376,10 +424,16 @@ class Lbfgsb {
   // ---- generalised Cauchy point ([BLNZ95] Algorithm CP): z_ <- x^c, c_ <- W^T (x^c - x), free_ -------
   void cauchy() {
     const int c = cols(), k = 2 * c;
-    std::vector<double> t(n_), dd(n_), p(k, 0.0), w(k), tmp(k);
+    std::vector<double>&t = t_, &dd = dd_, &p = p_, &w = w_, &tmp = tmp_;
+    t.resize(n_);
+    dd.resize(n_);
+    p.assign(k, 0.0);
+    w.resize(k);
+    tmp.resize(k);
     c_.assign(k, 0.0);
     z_ = xk_;
-    std::vector<int> order;
+    std::vector<int>& order = order_;
+    order.clear();
     const double inf = std::numeric_limits<double>::infinity();
     for (int i = 0; i < n_; ++i) {
       const double g = gk_[i];
@@ -463,7 +517,11 @@ class Lbfgsb {
   void subspace() {
     const int c = cols(), k = 2 * c, nf = static_cast<int>(free_.size());
     if (k == 0 || nf == 0) return;
-    std::vector<double> mc = c_, r(nf), v(k, 0.0), w(k);
+    std::vector<double>&mc = mc_, &r = r_, &v = v_, &w = w_;
+    mc = c_;
+    r.resize(nf);
+    v.assign(k, 0.0);
+    w.resize(k);
     apply_M(mc);
     for (int q = 0; q < nf; ++q) {
       const int i = free_[q];
@@ -475,21 +533,27 @@ class Lbfgsb {
     }
     apply_M(v);
     // N = I - M (W_F^T W_F) / theta ;  v <- N^-1 v
-    std::vector<double> wtw(static_cast<size_t>(k) * k, 0.0), nmat(static_cast<size_t>(k) * k, 0.0), col(k);
+    std::vector<double>&wtw = wtw_, &nmat = nmat_, &col = col_;
+    wtw.assign(static_cast<size_t>(k) * k, 0.0);
+    nmat.assign(static_cast<size_t>(k) * k, 0.0);
+    col.resize(k);
     for (int q = 0; q < nf; ++q) {
       w_row(free_[q], w.data());
       for (int a = 0; a < k; ++a)
-        for (int b = 0; b < k; ++b) wtw[a * k + b] += w[a] * w[b];
+        for (int b = a; b < k; ++b) wtw[a * k + b] += w[a] * w[b];   // upper triangle: w[a] w[b] = w[b] w[a] exactly
     }
-    for (int b = 0; b < k; ++b) {
-      for (int a = 0; a < k; ++a) col[a] = wtw[a * k + b] / theta_;
-      apply_M(col);
-      for (int a = 0; a < k; ++a) nmat[a * k + b] = (a == b ? 1.0 : 0.0) - col[a];
-    }
-    std::vector<int> piv;
+    for (int a = 0; a < k; ++a)
+      for (int b = 0; b < a; ++b) wtw[a * k + b] = wtw[b * k + a];
+    // N = I - M (W_F^T W_F / theta): all k columns through the factorised middle matrix at once
+    for (int e = 0; e < k * k; ++e) nmat[e] = wtw[e] / theta_;
+    lu_solve_multi(mid_lu_, mid_piv_, k, nmat, k);
+    for (int a = 0; a < k; ++a)
+      for (int b = 0; b < k; ++b) nmat[a * k + b] = (a == b ? 1.0 : 0.0) - nmat[a * k + b];
+    std::vector<int>& piv = piv_;
     if (!lu_factor(nmat, piv, k)) return;  // keep the Cauchy point
     lu_solve(nmat, piv, k, v);
-    std::vector<double> du(nf);
+    std::vector<double>& du = du_;
+    du.resize(nf);
     for (int q = 0; q < nf; ++q) {
       w_row(free_[q], w.data());
       double wv = 0.0;
@@ -499,7 +563,8 @@ class Lbfgsb {
     }
     // projected subspace minimiser [MN11]; if that is not a descent direction fall back to the
     // largest feasible step along du from the Cauchy point [BLNZ95]
-    std::vector<double> zc = z_;
+    std::vector<double>& zc = zc_;
+    zc = z_;
     bool clipped = false;
     for (int q = 0; q < nf; ++q) {
       const int i = free_[q];
@@ -614,6 +679,10 @@ class Lbfgsb {
   std::vector<std::vector<double>> S_, Y_;
   std::vector<double> mid_lu_;
   std::vector<int> mid_piv_, free_;
+  double sy_[MEM * MEM] = {}, ss_[MEM * MEM] = {};   // S_i . Y_j, S_i . S_j of the stored pairs
+  // scratch of feed / cauchy / subspace (sized on use, kept between calls)
+  std::vector<double> snew_, ynew_, t_, dd_, p_, w_, tmp_, mc_, r_, v_, wtw_, nmat_, col_, du_, zc_;
+  std::vector<int> order_, piv_;
   LineSearch ls_;
 };
 
