@@ -181,8 +181,10 @@ static int hyper_grad_impl(elfihip_gp* gp, bool store_kinv, double* grad) {
   for (int64_t ti = 0; ti < nt; ++ti) depth += (ti + 1) * (np - ti * NB);
   // measured (nlml_grad, ms): n=2048: 0.40 uncut, 0.26 with chunks of 512; n=4096: 0.83 uncut, 0.66 with 1024;
   // n=8192: 3.3 uncut, 3.6-3.9 with 2048-1024 (enough tiles to balance; every extra chunk repeats the epilogue)
-  int64_t kchunk = round_up(depth / ((int64_t)ctx->cu_count * 3) + 1, 2 * NB);
-  if (kchunk < 4 * NB) kchunk = 4 * NB;
+  // (round 3: chunks down to 128 deep -- at the sizes a BOLFI run spends most of its searches on, n <= 2048, chunks of
+  // 512 left 10-200 workgroups with one long tile each: 0.095 / 0.105 / 0.119 ms at n = 512 / 1024 / 2048)
+  int64_t kchunk = round_up(depth / ((int64_t)ctx->cu_count * 3) + 1, NB);
+  if (kchunk < NB) kchunk = NB;
   if (store_kinv || kchunk > np) kchunk = np;
   for (int64_t ti = 0; ti < nt && !cached; ++ti)
     for (int64_t tj = 0; tj <= ti; ++tj) {
