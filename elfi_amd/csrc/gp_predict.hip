@@ -501,14 +501,14 @@ __global__ __launch_bounds__(256) void finish_kernel(const double* mu_part, int 
       const int idx = a0 + (t & 31), cs = t >> 5;
       double acc = 0.0;
       if (idx < 2 * dp) {
-        // eight chunk values in flight per round (the loop with one load per iteration waits a memory round trip per
+        // sixteen chunk values in flight per round (the loop with one load per iteration waits a memory round trip per
         // chunk: 16 of them at n = 4096), added in chunk order
-        for (int c = cs; c < ngc; c += 64) {
-          double gv[8];
+        for (int c = cs; c < ngc; c += 128) {   // (n = 4096: 128 chunks = ONE round trip for all of a thread's 16 values)
+          double gv[16];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) gv[u] = (c + 8 * u < ngc) ? gp1[(int64_t)(c + 8 * u) * 2 * dp + idx] : 0.0;
+          for (int u = 0; u < 16; ++u) gv[u] = (c + 8 * u < ngc) ? gp1[(int64_t)(c + 8 * u) * 2 * dp + idx] : 0.0;
 #pragma unroll
-          for (int u = 0; u < 8; ++u) acc += gv[u];
+          for (int u = 0; u < 16; ++u) acc += gv[u];
         }
       }
       __syncthreads();
