@@ -47,12 +47,11 @@ class _SurfaceRule:
             if not callable(getattr(model, needed, None)):
                 raise TypeError('model must evaluate the acquisition surfaces itself (elfi_amd.HipGPRegression); '
                                 'missing: %s' % needed)
-        if constraints is not None:
-            raise NotImplementedError('constraints need the reference rule (SLSQP on the host); it accepts '
-                                      'HipGPRegression as model')
         self.model, self.prior = model, prior
         self.n_inits, self.max_opt_iters = int(n_inits), int(max_opt_iters)
-        self.constraints = None
+        # stored as AcquisitionBase stores it (acquisition.py:65); this family's acquire() never hands it to its search
+        # (acquisition.py:378-384 calls minimize() without constraints), so neither does this one
+        self.constraints = constraints
         # kept as attributes; this family never jitters its acquisitions
         self.noise_var, self.exploration_rate = noise_var, exploration_rate
         self.seed, self.random_state = (0, np.random) if seed is None else (seed, np.random.RandomState(seed))
