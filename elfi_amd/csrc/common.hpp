@@ -62,7 +62,7 @@ struct elfihip_ctx {
   hipEvent_t ev_u[4] = {nullptr, nullptr, nullptr, nullptr};  // look-ahead window columns of the next panel group
   int cu_count = 0;
   int topk_form = 0;                  // 0: resident selection with the nine-launch form as fallback; 1: nine-launch form
-  bool dense_lds_enabled = false;     // dense_tri_kernel's dynamic-LDS limit has been raised (gp_dense.hip)
+  unsigned dense_lds_mask = 0;        // dense_tri_kernel<.,64/32/16>: dynamic-LDS limit raised (gp_dense.hip)
   bool step_lds_enabled = false;      // step_kernel's dynamic-LDS limit has been raised (gp_fit.hip)
   std::string err;
   // staging buffers for the host entry points

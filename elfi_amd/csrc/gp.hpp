@@ -77,6 +77,8 @@ struct elfihip_gp {
   elfihip::DevBuf ws_dense;
   double* h_dense = nullptr;
   size_t hd_cap = 0;  // doubles
+  size_t hd_flags = 0;               // flag words initialised so far
+  unsigned long long hd_seq = 0;     // value the flags of the latest dense call take
 };
 
 namespace elfihip {
@@ -146,5 +148,5 @@ void launch_kstar_passes(elfihip_gp* gp, const double* xs, const double* xs2, do
                          int nblk_k, unsigned npass);
 void launch_finish_passes(elfihip_gp* gp, const double* mu_part, int nblk_k, const double* var_part, int nblk_v,
                           const double* g_part, int ngc, double* out, int s_left, int noiseless, double beta, int mode,
-                          unsigned npass);
+                          unsigned npass, double* host_out, unsigned long long* done_flags, unsigned long long done_value);
 }  // namespace elfihip

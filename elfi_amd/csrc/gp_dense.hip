@@ -27,6 +27,7 @@
 #include "gp.hpp"
 #include "mfma_f64.hpp"
 
+#include <chrono>
 #include <cstdlib>
 
 namespace elfihip {
@@ -295,13 +296,13 @@ static int dense_launch(elfihip_gp* gp, DenseArgs D, int mode, const double* kbt
   elfihip_ctx* ctx = gp->ctx;
   hipStream_t st = ctx->stream;
   constexpr size_t lds = dense_lds_bytes(TM);
-  static bool enabled = false;   // per process; the attribute belongs to the function, not to a device object
-  if (!enabled) {
+  const unsigned bit = TM == 64 ? 1u : (TM == 32 ? 2u : 4u);   // per context (= per device of this process)
+  if (!(ctx->dense_lds_mask & bit)) {
     ELFIHIP_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(dense_tri_kernel<0, TM>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ELFIHIP_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(dense_tri_kernel<1, TM>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    enabled = true;
+    ctx->dense_lds_mask |= bit;
   }
   D.nrb = (int)(D.np / TM);
   const unsigned grid = (unsigned)round_up((int64_t)D.ncb * (D.nrb / 2), 8);
@@ -366,15 +367,28 @@ int predict_dense_impl(elfihip_gp* gp, const double* Xs, int64_t S, int mode, in
   double* base = gp->ws_dense.as<double>();
   // pinned staging: points + norms up, results down (one copy each way)
   const size_t n_in = (size_t)S_pad * dp + (size_t)S_pad, n_out = (size_t)npass * outsz;
-  if (gp->hd_cap < n_in + n_out) {
+  // [completion flags, one per point | points + norms | results]: pinned, device-visible, coherent -- the input upload stays
+  // one copy (the dense products read the points many times), the RESULTS are written to host memory by the assembly kernel
+  // itself, which raises a flag per point the host polls: no download, no stream wait (a blocking stream wait wakes up
+  // some 10-20 us late on this stack, once per round of the multi-start search)
+  const size_t n_flags = (size_t)S_pad;
+  if (gp->hd_cap < n_flags + n_in + n_out) {
     if (gp->h_dense) ELFIHIP_CHECK_HIP(ctx, hipHostFree(gp->h_dense));
     gp->h_dense = nullptr;
     gp->hd_cap = 0;
-    const size_t want = 2 * (n_in + n_out) + 1024;
-    ELFIHIP_CHECK_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&gp->h_dense), want * sizeof(double), hipHostMallocDefault));
+    const size_t want = 2 * (n_flags + n_in + n_out) + 1024;
+    ELFIHIP_CHECK_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&gp->h_dense), want * sizeof(double),
+                                         hipHostMallocMapped | hipHostMallocCoherent));
     gp->hd_cap = want;
+    gp->hd_flags = 0;
+    gp->hd_seq = 0;
   }
-  double* hx = gp->h_dense;
+  if (gp->hd_flags < n_flags) {   // a larger call than any before: its new flag words start from zero
+    for (size_t f = gp->hd_flags; f < n_flags; ++f) reinterpret_cast<unsigned long long*>(gp->h_dense)[f] = 0;
+    gp->hd_flags = n_flags;
+  }
+  unsigned long long* hflag = reinterpret_cast<unsigned long long*>(gp->h_dense);
+  double* hx = gp->h_dense + n_flags;
   double* hout = hx + n_in;
   std::fill(hx, hx + n_in, 0.0);
   for (int64_t s = 0; s < S; ++s) {
@@ -412,11 +426,26 @@ int predict_dense_impl(elfihip_gp* gp, const double* Xs, int64_t S, int mode, in
     case 32: ELFIHIP_TRY(dense_launch<32>(gp, D, mode, base + o_kbt, base + o_vt)); break;
     default: ELFIHIP_TRY(dense_launch<16>(gp, D, mode, base + o_kbt, base + o_vt)); break;
   }
+  const unsigned long long seq = ++gp->hd_seq;
   launch_finish_passes(gp, base + o_mu, nblk_k, base + o_var, nrb, base + o_g, nrb, base + o_out, (int)S, noiseless, beta, mode,
-                       (unsigned)npass);
+                       (unsigned)npass, hout, hflag, seq);
   ELFIHIP_TRY(launch_status(ctx, "dense prediction"));
-  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(hout, base + o_out, n_out * sizeof(double), hipMemcpyDeviceToHost, st));
-  ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(st));
+  {
+    // poll the points' flags (the assembly workgroup of a point writes its results, fences, then raises the flag);
+    // if they do not arrive within the budget the stream wait takes over and reports whatever went wrong
+    const auto t0 = std::chrono::steady_clock::now();
+    int64_t done = 0;
+    bool ok = false;
+    for (unsigned spin = 0;; ++spin) {
+      while (done < S && __atomic_load_n(hflag + done, __ATOMIC_ACQUIRE) == seq) ++done;
+      if (done == S) {
+        ok = true;
+        break;
+      }
+      if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(500)) break;
+    }
+    if (!ok) ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(st));
+  }
   if (prof) {
     prof_add(gp, ELFIHIP_PHASE_TRI_FIRST, 0, 1);
     if (mode == 1) prof_add(gp, ELFIHIP_PHASE_TRI_SECOND, 1, 2);

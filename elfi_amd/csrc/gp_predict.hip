@@ -682,11 +682,11 @@ void launch_kstar_passes(elfihip_gp* gp, const double* xs, const double* xs2, do
 
 void launch_finish_passes(elfihip_gp* gp, const double* mu_part, int nblk_k, const double* var_part, int nblk_v,
                           const double* g_part, int ngc, double* out, int s_left, int noiseless, double beta, int mode,
-                          unsigned npass) {
+                          unsigned npass, double* host_out, unsigned long long* done_flags, unsigned long long done_value) {
   const double inv_ls2 = 1.0 / (gp->ls * gp->ls);
   hipLaunchKernelGGL(finish_kernel, dim3(PC, npass), dim3(256), 0, gp->ctx->stream, mu_part, nblk_k, var_part, nblk_v, g_part,
                      ngc, out, gp->dp, s_left, gp->var + gp->bias, noiseless ? 0.0 : gp->noise, inv_ls2, beta, mode,
-                     (double*)nullptr, (unsigned long long*)nullptr, 0ull);
+                     host_out, done_flags, done_value);
 }
 
 // One triangular product for `g` passes: part[pass][kc][i][s] from bin[pass][k][s].
