@@ -157,3 +157,42 @@ def test_hip_objects_pickle_without_device_state():
     st = elfi_amd.AdaptiveDistanceState()
     st2 = pickle.loads(pickle.dumps(st))
     assert st2.state['w'] == [None]
+
+
+def test_loop_timers_split_update_search_and_acquire():
+    """elfi_amd.loop_timing.instrument: wraps exactly the three calls the reference's BOLFI loop makes into the device
+    objects (bolfi.py:219,247: target_model.update(..., optimize) and acquisition_method.acquire) and takes itself out again."""
+    import time
+    from elfi_amd.loop_timing import instrument
+
+    class _GP:
+        n_evidence = 0
+        _opt_info = None
+
+        def update(self, x, y, optimize=False):
+            time.sleep(0.002)
+            self.n_evidence += 1
+            if optimize:
+                self.optimize()
+
+        def optimize(self):
+            time.sleep(0.004)
+            self._opt_info = dict(n_fits=7, status='ok')
+
+    class _Acq:
+        def acquire(self, n, t=None):
+            time.sleep(0.001)
+            return np.zeros((n, 1))
+
+    gp, acq = _GP(), _Acq()
+    T = instrument(gp, acq)
+    for i in range(6):
+        gp.update(None, None, optimize=(i % 3 == 2))
+        acq.acquire(1, t=i)
+    T.restore()
+    assert T.updates == 6 and T.acquires == 6 and len(T.searches) == 2
+    assert T.searches[0][0] == 3 and T.searches[0][2] == 7
+    assert 0.010 <= T.fit_s < 0.030 and 0.007 <= T.search_s < 0.020 and 0.005 <= T.acquire_s < 0.015
+    assert 'update' not in gp.__dict__ and 'acquire' not in acq.__dict__
+    s = T.summary(0.05, 6)
+    assert abs(sum(s['share'].values()) - 1.0) < 1e-9 and s['rebuilds_in_searches'] == 14
