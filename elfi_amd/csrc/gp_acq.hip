@@ -15,6 +15,7 @@
 // number of lock-steps of a call is the largest evaluation count any single start needs
 // (typically 10-25 at the BASELINE shapes).
 #include <chrono>
+#include <memory>
 #include <thread>
 #include <cmath>
 #include <cstdio>
@@ -63,7 +64,12 @@ static int lcb_minimize_impl(elfihip_gp* gp, const double* starts, int64_t S, co
   std::vector<int64_t> who;
   who.reserve((size_t)S);
   for (int64_t i = 0; i < S; ++i) opt[(size_t)i].init(dim, lo, hi, starts + i * dim, maxiter);
-  RoundPool pool(S >= 64 ? host_threads() : 1);
+  // the worker threads outlive the call (one pool per calling thread: starting 15 threads costs about half a millisecond,
+  // a tenth of a short 64-start search); between calls they sleep on the pool's condition variable
+  static thread_local RoundPool serial_pool(1);
+  static thread_local std::unique_ptr<RoundPool> wide_pool;
+  if (S >= 64 && !wide_pool) wide_pool.reset(new RoundPool(host_threads()));
+  RoundPool& pool = S >= 64 ? *wide_pool : serial_pool;
   static const int trace = std::getenv("ELFIHIP_ACQ_TRACE") ? std::atoi(std::getenv("ELFIHIP_ACQ_TRACE")) : 0;
   std::vector<std::pair<int, float>> per_round;
   double t_dev = 0.0, t_host = 0.0;
