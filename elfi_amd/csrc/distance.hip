@@ -30,6 +30,26 @@ namespace elfihip {
 constexpr int kMaxTileM = 299;  // widest row the LDS-tile kernel takes (64 rows * 301 * 8 B < 160 KiB)
 constexpr int kMaxK = 64;
 
+// Cube root for the order-3 Minkowski distance: exponent split by frexp, a single-precision seed (exp2 / log2, ~1e-6) and
+// ONE Halley step (cubic: ~1e-18) -- some sixty instructions against the several hundred of pow(s, 1.0 / 3.0); within
+// 1 ulp of the correctly rounded root, inside the 1e-14 the general orders are held to against SciPy's pow().
+// (The device library's cbrt() measured SLOWER than pow() here: 1.25 10^6 x 64 rows 0.128 -> 0.205 ms.)
+__device__ __forceinline__ double cbrt_halley(double s) {
+  if (!(s > 0.0) || !(s < __builtin_huge_val())) return s;   // 0, NaN, +inf (negative sums do not occur)
+  int e;
+  double mant = frexp(s, &e);                 // s = mant 2^e, mant in [0.5, 1)
+  int q = e / 3, r = e - 3 * q;
+  if (r < 0) {
+    r += 3;
+    q -= 1;
+  }
+  mant = ldexp(mant, r);                      // in [0.5, 4)
+  double y = (double)__builtin_exp2f(__builtin_log2f((float)mant) * (1.0f / 3.0f));
+  const double y3 = y * y * y;
+  y = y * ((y3 + 2.0 * mant) / (2.0 * y3 + mant));
+  return ldexp(y, q);
+}
+
 // ---- per-metric term / finish --------------------------------------------------
 template <int METRIC, bool W>
 struct Op {
@@ -79,9 +99,9 @@ struct Op {
       return sqrt(s);
     else if constexpr (METRIC == ELFIHIP_MINKOWSKI) {
       // the root of the integer orders 3 and 4 without pow() (SciPy takes pow(s, 1.0 / p), whose exponent is itself
-      // rounded: cbrt / sqrt(sqrt) agree with it to 1-2 ulp, inside the 1e-14 the general orders are held to); at
+      // rounded: the roots below agree with it to 1-2 ulp, inside the 1e-14 the general orders are held to); at
       // m = 2 the pow() per ROW was what the kernel spent its time on (4 10^6 rows: 0.058 ms against 0.018 for euclidean)
-      if (inv_p == 1.0 / 3.0) return cbrt(s);
+      if (inv_p == 1.0 / 3.0) return cbrt_halley(s);
       if (inv_p == 0.25) return sqrt(sqrt(s));
       return pow(s, inv_p);
     } else
@@ -606,6 +626,82 @@ static RowArgs make_row_args(const double* dX, int64_t n, int m, int64_t ldx, co
   return A;
 }
 
+// The same product with VI in REGISTERS and the rows streamed like the other distance kernels (round 3: the LDS form above
+// re-read its B operand from LDS for every MFMA and filled its tile with 8-byte loads behind an integer division --
+// 0.59 ms for 1.25 10^6 x 64, 0.14 of the HBM roofline and an eighth of what the matrix pipes allow).  VI does not change
+// between tiles: lane l keeps VI[4 s + (l >> 4)][16 j + (l & 15)] for every k step s and column tile j (KC = 4: 64
+// doubles) from the first tile to the last; the rows arrive by the software-pipelined 16-byte loads of tile_stream.hpp
+// (next tile in flight while this one is multiplied) as RAW x, and x - y is formed when an operand is read.
+// KC = 16-column tiles of the padded row (the k extent is padded to the same 16 KC; padded entries are exact zeros).
+template <int KC>
+__global__ __launch_bounds__(256, 2) void dist_rows_mahalanobis_reg_kernel(RowArgs A) {   // two workgroups per CU: <= 256 registers
+  extern __shared__ __align__(16) double lds[];
+  constexpr int U = 8;   // 256 threads x 8 x 16 bytes = one 64 x 64 tile
+  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, m = A.m, mp = A.mp;
+  double* tile = lds;    // MAHA_ROWS x mp raw rows (+ 64 doubles of zeros behind: operand reads beyond the last row)
+  double* ys = tile + MAHA_ROWS * mp + 64;   // y padded to 16 KC entries (in LDS: 16 KC registers fewer per lane)
+  for (int e = tid; e < 64; e += 256) tile[MAHA_ROWS * mp + e] = 0.0;
+  for (int e = tid; e < 16 * KC; e += 256) ys[e] = e < m ? A.y[e] : 0.0;
+  double b[4 * KC][KC], yc[KC];
+#pragma unroll
+  for (int s_ = 0; s_ < 4 * KC; ++s_) {
+    const int k = 4 * s_ + (l >> 4);
+#pragma unroll
+    for (int j = 0; j < KC; ++j) {
+      const int c = 16 * j + (l & 15);
+      b[s_][j] = (k < m && c < m) ? A.aux[(size_t)k * m + c] : 0.0;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < KC; ++j) yc[j] = (16 * j + (l & 15)) < m ? A.y[16 * j + (l & 15)] : 0.0;
+  const int64_t ntiles = (A.n + MAHA_ROWS - 1) / MAHA_ROWS;
+  double2 v[U];
+  int64_t t = blockIdx.x;
+  if (t < ntiles) tile_fetch<U>(A, t * MAHA_ROWS, (int)((A.n - t * MAHA_ROWS) < MAHA_ROWS ? (A.n - t * MAHA_ROWS) : MAHA_ROWS), v);
+  for (; t < ntiles; t += gridDim.x) {
+    const int64_t row0 = t * MAHA_ROWS;
+    const int rows = (int)((A.n - row0) < MAHA_ROWS ? (A.n - row0) : MAHA_ROWS);
+    __syncthreads();   // tile free
+    tile_commit<U>(A, tile, rows, v);
+    const int64_t tn = t + gridDim.x;
+    if (tn < ntiles) tile_fetch<U>(A, tn * MAHA_ROWS, (int)((A.n - tn * MAHA_ROWS) < MAHA_ROWS ? (A.n - tn * MAHA_ROWS) : MAHA_ROWS), v);
+    __syncthreads();
+    // rows >= `rows` of a short last tile hold the previous tile's values: finite or not, they only reach their own
+    // (discarded) results -- every lane's operand is its own row's
+    const double* xa = tile + (16 * w + (l & 15)) * mp + (l >> 4);   // A operand: row l & 15, k = 4 s + (l >> 4)
+    // one column tile at a time (ONE accumulator tile live: with all KC of them the KC = 4 instance spills beside its 64
+    // registers of VI); the A operand is re-read from LDS per column tile, 16 KC ds_read_b64 against 4 KC^2 MFMAs
+    double part[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int j = 0; j < KC; ++j) {
+      v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s_ = 0; s_ < 4 * KC; ++s_) {
+        const int k = 4 * s_ + (l >> 4);
+        const double a = k < m ? xa[4 * s_] - ys[k] : 0.0;    // (masked: the padding must not carry a neighbour's NaN)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[s_][j], acc, 0, 0, 0);
+      }
+      // fold with delta: accumulator element i of lane l is T[row (l >> 4) + 4 i][column 16 j + (l & 15)]
+      const int c = 16 * j + (l & 15);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const double dlt = c < m ? tile[(16 * w + (l >> 4) + 4 * i) * mp + c] - yc[j] : 0.0;
+        part[i] += acc[i] * dlt;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      double q = part[i];
+      q += __shfl_xor(q, 1, 64);
+      q += __shfl_xor(q, 2, 64);
+      q += __shfl_xor(q, 4, 64);
+      q += __shfl_xor(q, 8, 64);
+      const int r = 16 * w + (l >> 4) + 4 * i;
+      if ((l & 15) == 0 && r < rows) A.out[row0 + r] = sqrt(q);
+    }
+  }
+}
+
 // F / filtered: fused selection (reject.hip).  *filtered tells the caller whether the kernel that ran offered the
 // candidates itself; otherwise the caller filters dout in a separate pass.
 int dist_rows_dev_impl(elfihip_ctx* ctx, int metric, const double* dX, int64_t n, int m, int64_t ldx, const double* dy,
@@ -622,6 +718,18 @@ int dist_rows_dev_impl(elfihip_ctx* ctx, int metric, const double* dX, int64_t n
   const bool w = daux != nullptr;
   if (cm == ELFIHIP_MAHALANOBIS) {
     ELFIHIP_REQUIRE(ctx, m <= kMaxTileM, "mahalanobis supports m <= %d", kMaxTileM);
+    if (m >= 8 && m <= 64 && A.vec2) {   // even m, 16-byte aligned rows: VI in registers, pipelined row loads
+      const int kc = (m + 15) / 16;
+      const size_t lb = ((size_t)MAHA_ROWS * A.mp + 64 + 64) * sizeof(double);
+      const int g = grid_for(ctx, (n + MAHA_ROWS - 1) / MAHA_ROWS, lb, 256);
+      switch (kc) {
+        case 1: hipLaunchKernelGGL((dist_rows_mahalanobis_reg_kernel<1>), dim3(g), dim3(256), lb, ctx->stream, A); break;
+        case 2: hipLaunchKernelGGL((dist_rows_mahalanobis_reg_kernel<2>), dim3(g), dim3(256), lb, ctx->stream, A); break;
+        case 3: hipLaunchKernelGGL((dist_rows_mahalanobis_reg_kernel<3>), dim3(g), dim3(256), lb, ctx->stream, A); break;
+        default: hipLaunchKernelGGL((dist_rows_mahalanobis_reg_kernel<4>), dim3(g), dim3(256), lb, ctx->stream, A); break;
+      }
+      return launch_status(ctx, "dist_rows_mahalanobis_reg_kernel");
+    }
     if (m >= 8 && m <= 64) {   // narrower rows: the padding to the 16-wide tile costs more than the lane-per-row form
       const int mk = (m + 3) & ~3, mc = (m + 15) & ~15;
       const size_t lb = ((size_t)MAHA_ROWS * (mc | 1) + (size_t)mk * mc) * sizeof(double);
