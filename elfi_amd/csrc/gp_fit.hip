@@ -146,45 +146,56 @@ __device__ __forceinline__ void sqrt_rsqrt(double p, double& s, double& y) {
   y = fma(e2, y, y);
 }
 
-constexpr int PP = 18;    // pitch of the dense copy of the solved 16-wide panel
-
-// The 128 x 128 working block holds two triangles at once: entries (i, c <= i) are the block of Ky being turned into
-// L11; entries (r, c > r) are the rows of the appended identity being turned into L11^-T.  Eliminating 16 columns at a
-// time ("phase A"): every row that has entries in the panel -- the 16 rows of the diagonal tile, the rows below it and
-// the identity rows above -- is held by ONE LANE (16 doubles in registers).  Eliminating column j is then the same
-// three vector instructions for every row: scale entry j by 1/sqrt(pivot), subtract entry j times l_cj from entry c.
-// The pivot and the l_cj come from the tile rows by v_readlane (SGPR broadcast); each wave keeps its own copy of the
-// tile rows in lanes 0-15 (redundant, so no cross-wave traffic or barrier inside the panel).  This factors the tile,
-// solves the panel below it and carries the identity rows along in one go.  The rank-16 update of everything right
-// of the panel runs on 16 x 16 f64 MFMA tiles.
-
-// The trailing tiles of the block live in REGISTERS: the 128 x 128 working block (both triangles, as above) is 8 x 8
-// tiles of 16 x 16.  (With the block in LDS every rank-16 update reads and rewrites its tiles there -- eight times per
-// tile -- and that traffic, not the elimination, made up the 41-56 us of the LDS-resident predecessors of this kernel.)
-//   * waves 3.. ("update waves") own the 64 tiles, dealt round-robin along tile columns; a tile lives in the MFMA
-//     accumulator layout in 4 registers per lane from the first load to the moment its column is eliminated;
-//   * waves 0-2 run phase A of panel p exactly as above (one lane per row), reading the tile column from a small LDS
-//     panel PB (128 x 16) and writing the solved panel (i) densely into P2 (double-buffered) for the updates and
-//     (ii) straight to global memory -- L11, L11^-T and W11 = L11^-1 entries are final once their column is eliminated,
-//     so there is no write-out pass and no global store on the critical path (barriers wait for LDS traffic only);
-//   * after phase A(p) the owners of tile column p+1 apply panel p and publish their tiles into PB (U1, one tile per
-//     wave), then phase A(p+1) starts while the update waves apply panel p to the remaining tiles (U2).
-// LDS: PB 17 KiB + P2 37 KiB; per panel about 120 KiB of LDS traffic instead of about 370 KiB-equivalents.
-constexpr int PBP = 17;  // pitch of the tile-column panel PB
-constexpr int POTF2T_LDS_DOUBLES = NB * PBP + 2 * NB * PP + 2 * 16 * PBP;
+// The 128 x 128 diagonal block of [Ky ; I] -> [L11 ; L11^-T], 16 columns ("panel") at a time, with every tile in
+// REGISTERS.
+//
+// Wave R (of eight "tile waves") owns row block R of both halves: slot C <= R holds tile (R, C) of the block of Ky, slot
+// C > R tile (R, C) of the identity rows (zero until panel R has been eliminated; tile (R, R) of the identity never
+// exists as data).  A tile X lives TRANSPOSED in the f64 16x16x4 MFMA accumulator layout (lane (lr, lc), register r:
+// X^T[4 r + lr][lc] = X[lc][4 r + lr]) -- which is at the same time the layout of MFMA operand B (k slice r) of X^T and
+// of operand A (k slice r) of X.  Hence, with M = L_pp^-1 (16 x 16) of the panel's diagonal tile:
+//   * panel solve  P = X L_pp^-T,  P^T = M X^T:  four MFMAs with A = M (from LDS) and B = the tile's registers as they
+//     are; the result P^T is again in the accumulator layout;
+//   * rank-16 update  X(R, C) -= P(R) P(C)^T,  X^T -= P(C) P(R)^T:  A = -P(C)^T registers of wave C (through LDS, already
+//     negated), B = P(R)^T registers of the wave itself -- no layout conversion anywhere, and the DIAGONAL tile (R, R)
+//     takes both operands from the wave's own registers.
+// So the chain from one diagonal tile to the next never waits for another wave's panel.  Per panel p:
+//   factor wave (the ninth; it holds no tiles, so its sixteen row registers do not compete with the slots):
+//                  tile (p, p), one lane per row, rows 16-31 carrying the identity: elimination in registers
+//                  -> M into LDS -> barrier B(p)
+//   tile wave R:   [U(p-1) on tile (R, p)] -> P(R)^T = M X(R, p)^T -> publish -P(R)^T -> U(p) on its own diagonal tile
+//                  -> (wave p+1: diagonal tile into LDS for the factor wave, which polls a flag word for it)
+//                  -> U(p-1) on its remaining tiles, the panel to global memory -> barrier B(p+1)
+// U(q) of an off-diagonal tile needs another wave's panel and is therefore applied one panel late (at panel q+1), which
+// is early enough: tile (R, C) is first READ at panel C.  LDS: M (2 x 2 KiB), the negated panels (2 x 16 KiB), 2 KiB for
+// the diagonal tile on its way to one lane per row.
+// Round 2's form (three elimination waves holding one row of the whole 144-row panel per lane, thirteen update waves,
+// two LDS round trips per panel) took 35 us per block, 40 % of it elimination; this one has the elimination of ONE
+// 16 x 16 tile (with its identity rows), 12 MFMAs, one LDS flag and one barrier on the chain.
+constexpr int PT_MA = 0;                        // 2 x 256: MA[16 t + c] = M[c][t]
+constexpr int PT_NP = 2 * 256;                  // 2 x 8 x 256: [parity][C][register][lane]
+constexpr int PT_CV = PT_NP + 2 * 8 * 256;      // 32 x 17: the diagonal tile, below it (written once) the identity
+constexpr int PT_FLAG = PT_CV + 32 * 17;         // one word: the diagonal tile in CV belongs to panel <flag>
+constexpr int PT_ST = PT_FLAG + 2;              // 9 x (16 x 18): a wave's solved tile, row-major, on its way to coalesced stores
+constexpr int POTF2T_LDS_DOUBLES = PT_ST + 9 * 16 * 18;
+constexpr int POTF2T_THREADS = 11 * 64;
+constexpr int WAIT_VMCNT0 = 0x0F70;   // s_waitcnt vmcnt(0) alone (gfx9 encoding: expcnt 7, lgkmcnt 15 = no wait)
 
 __device__ __forceinline__ void lds_barrier() {
   // s_barrier that waits for this wave's LDS traffic only: global stores stay in flight (__syncthreads would drain them)
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-typedef __attribute__((address_space(1))) double gdouble;    // global memory, said explicitly: inside the out-of-line
+typedef __attribute__((address_space(1))) double gdouble;    // global memory and LDS, said explicitly: inside the
+typedef __attribute__((address_space(3))) double ldouble;    // out-of-line instance below generic pointers would become
+typedef __attribute__((address_space(3))) int lint;          // FLAT accesses (which count on vmcnt AND lgkmcnt)
 typedef double v2d_t __attribute__((ext_vector_type(2)));
-typedef __attribute__((address_space(1))) v2d_t gdouble2;   // instance below generic pointers would become FLAT accesses
+typedef __attribute__((address_space(3))) v2d_t ldouble2;
+typedef __attribute__((address_space(1))) v2d_t gdouble2;
 
 #ifdef ELFIHIP_POTF2_STAMP   // developer probe (scripts/native/potf2_probe.hip): cycle stamps per wave, panel and phase
 __device__ long long g_potf2_stamp[16 * 8 * 8];
-#define STAMP(p, slot) do { if ((threadIdx.x & 63) == 0) g_potf2_stamp[((threadIdx.x >> 6) * 8 + (p)) * 8 + (slot)] = __builtin_readcyclecounter(); } while (0)
+#define STAMP(p, slot) do { if ((threadIdx.x & 63) == 0) g_potf2_stamp[(R * 8 + (p)) * 8 + (slot)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define STAMP(p, slot) do { } while (0)
 #endif
@@ -192,210 +203,68 @@ __device__ long long g_potf2_stamp[16 * 8 * 8];
 template <int NT>
 __device__ __forceinline__ void potf2_tiles_body(double* Akk_, int64_t lda, double* Wkk_, int64_t ldw, double* W11_, int* info,
                                                  int kblock, double* sm) {
+  static_assert(NT >= POTF2T_THREADS, "eleven wave slots");
+  // Waves are dealt to the four SIMDs of the CU in turn (wave w -> SIMD class w mod 4).  Wave 3 factors and has its SIMD
+  // to itself (waves 7, 11, ... leave at once; a finished wave no longer counts at s_barrier): beside waves that keep
+  // the SIMD's matrix pipe busy the elimination wave is hardly issued at all (measured: no progress during the 3 000
+  // cycles of a panel's deferred updates).  The eight row blocks go to the other three classes so that the MFMA work of
+  // every panel is as even as a fixed assignment allows (rows {0, 7}, {1, 3, 4}, {2, 5, 6}: the matrix tiles of the late
+  // rows are busy in the early panels, the identity tiles of the early rows in the late ones).
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (wid >= 11 || wid == 7 || wid == 8) return;
+  //                      wid:  0  1  2  3  4  5  6  7  8  9  10
+  constexpr unsigned long long ROW_OF_WAVE = 0x6'4'f'f'5'3'7'8'2'1'0ull;   // nibbles; 8: the factor wave
+  const int R = (int)((ROW_OF_WAVE >> (4 * wid)) & 15);
+  constexpr unsigned CLASS_OF_ROW = 0x0'2'2'1'1'2'1'0u;                     // nibble R: SIMD class of row block R's wave
   gdouble* Akk = (gdouble*)Akk_;
   gdouble* Wkk = (gdouble*)Wkk_;
   gdouble* W11 = (gdouble*)W11_;
-  constexpr int NA = 3;              // phase-A waves
-  constexpr int NU = NT / 64 - NA;   // update waves
-  constexpr int NS = (64 + NU - 1) / NU;  // tile slots per update wave
-  double* PB = sm;
-  double* P2 = PB + NB * PBP;
-  double* TB = P2 + 2 * NB * PP;  // 2 x (16 x PBP): the tile rows of the solved panel
-  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
-  const bool upd = w >= NA;
-  const int u = w - NA;
-  const int lr = l >> 4, lc = l & 15;
-  v4d x[NS];
-  // tile t = u + NU s of this wave: column C = t >> 3, row R = t & 7
-  auto publish = [&](const v4d& v, int R) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) PB[(16 * R + lr + 4 * r) * PBP + lc] = v[r];
-  };
-  // x(R, C) -= panel_q(R) panel_q(C)^T for an active tile: C > q and (R >= C (Cholesky part) or R <= q (L^-T part))
-  auto apply = [&](v4d& v, int R, int C, int q, const double* P2q) {
-    const int arow = (R >= C) ? 16 * (R - q - 1) : (NB - 16 - 16 * q) + 16 * R;
-    const int brow = 16 * (C - q - 1);
-    double am[4], bv[4];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      am[kk] = -P2q[(arow + lc) * PP + 4 * kk + lr];
-      bv[kk] = P2q[(brow + lc) * PP + 4 * kk + lr];
-    }
-    v4d n = v;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) n = __builtin_amdgcn_mfma_f64_16x16x4f64(am[kk], bv[kk], n, 0, 0, 0);
-    if (R == C) {  // diagonal tile: its strict upper part belongs to the L^-T rows of a later panel
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = (lc <= lr + 4 * r) ? n[r] : v[r];
-    } else {
-      v = n;
-    }
-  };
-  // Solved panel q -> global memory, by the update waves, off the critical path (coalesced: 8 rows x 128 bytes per
-  // instruction; a lane-per-row store from phase A costs 64 cache lines per instruction, 1.5 us per panel).
-  //   rows below the tile: L11 entries;  L^-T rows r < 16 q + 16: entries (r, j >= r) into WT's diagonal block and,
-  //   transposed, into W11 = L11^-1;  tile rows: lower triangle of the diagonal tile of L11.
-  auto write_out = [&](int q) {
-    const int c0 = 16 * q, ntop = NB - 16 - c0, naug = c0 + 16;
-    const double* P2q = P2 + (q & 1) * NB * PP;
-    const double* tb = TB + (q & 1) * 16 * PBP;
-    const int sub = l >> 3, pair = l & 7;
-    const int j0 = u, nj = NU;
-    // items are dealt round-robin and taken four at a time: four LDS reads in flight, then four stores
-    // (a) rows below the tile, 8 rows x 128 bytes per item
-    for (int b0 = j0; 8 * b0 < ntop; b0 += 4 * nj) {
-      double2 v[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int o = 8 * (b0 + e * nj) + sub;
-        v[e] = *reinterpret_cast<const double2*>(P2q + (o < ntop ? o : 0) * PP + 2 * pair);
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int o = 8 * (b0 + e * nj) + sub;
-        if (o < ntop) *reinterpret_cast<gdouble2*>(Akk + ((int64_t)(c0 + 16 + o) * lda + c0 + 2 * pair)) = (v2d_t){v[e].x, v[e].y};
-      }
-    }
-    // (b) L^-T rows r < naug: entries (r, j >= r) of WT's diagonal block
-    for (int b0 = j0; 8 * b0 < naug; b0 += 4 * nj) {
-      double2 v[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int r = 8 * (b0 + e * nj) + sub;
-        v[e] = *reinterpret_cast<const double2*>(P2q + (ntop + (r < naug ? r : 0)) * PP + 2 * pair);
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int r = 8 * (b0 + e * nj) + sub;
-        gdouble* dst = Wkk + ((int64_t)r * ldw + c0 + 2 * pair);
-        const int j = c0 + 2 * pair;
-        if (r < naug) {
-          if (j >= r)
-            *reinterpret_cast<gdouble2*>(dst) = (v2d_t){v[e].x, v[e].y};
-          else if (j + 1 >= r)
-            dst[1] = v[e].y;
-        }
-      }
-    }
-    // (c) the same entries transposed into W11 = L11^-1: item = (column c, 64 rows)
-    const int nh = (naug + 63) >> 6;
-    for (int b0 = j0; b0 < 16 * nh; b0 += 4 * nj) {
-      double v[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int idx = b0 + e * nj;
-        const int c = nh == 1 ? idx : idx >> 1, r = (nh == 1 ? 0 : 64 * (idx & 1)) + l;
-        v[e] = P2q[(ntop + (r < naug ? r : 0)) * PP + (c & 15)];
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int idx = b0 + e * nj;
-        const int c = nh == 1 ? idx : idx >> 1, r = (nh == 1 ? 0 : 64 * (idx & 1)) + l;
-        if (idx < 16 * nh && r < naug && c0 + c >= r) W11[(c0 + c) * NB + r] = v[e];
-      }
-    }
-    // (d) the tile rows: lower triangle of the diagonal tile of L11
-    if (j0 == nj - 1) {
-      const int i = l >> 2;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int c = 4 * (l & 3) + e;
-        if (c <= i) Akk[(int64_t)(c0 + i) * lda + c0 + c] = tb[i * PBP + c];
-      }
-    }
-  };
-  int bad = 0;
-  // the two roles are separate loops (not one loop with a branch inside) so that the registers of one role are not
-  // live in the other: same number of barriers on both sides
-  if (upd) {
-#pragma unroll
-    for (int s_ = 0; s_ < NS; ++s_) {
-      const int t = u + NU * s_;
-      x[s_] = (v4d){0.0, 0.0, 0.0, 0.0};
-      if (t < 64) {
-        const int C = t >> 3, R = t & 7;
-        if (C <= R) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = lr + 4 * r;
-            const double v = Akk[(int64_t)(16 * R + row) * lda + 16 * C + lc];
-            x[s_][r] = (R != C || lc <= row) ? v : 0.0;
-          }
-        }
-        if (C == 0) publish(x[s_], R);
-      }
-    }
-    lds_barrier();
-    for (int p = 0; p < NB / 16; ++p) {
-      double* P2w = P2 + (p & 1) * NB * PP;
-      STAMP(p, 0);
-      // U2 of the previous panel on the waves of the SIMD without a phase-A wave: every tile right of column p (column p
-      // itself was brought up to date in U1)
-      if (p > 0) {
-        const double* P2r = P2 + ((p - 1) & 1) * NB * PP;
-#pragma unroll
-        for (int s_ = 0; s_ < NS; ++s_) {
-          const int t = u + NU * s_;
-          const int C = t >> 3, R = t & 7;
-          if (t < 64 && C > p && (R >= C || R <= p - 1)) apply(x[s_], R, C, p - 1, P2r);
-        }
-        STAMP(p, 1);
-        write_out(p - 1);
-      }
-      STAMP(p, 2);
-      lds_barrier();
-      STAMP(p, 3);
-      // U1: tile column p+1 receives panel p and goes to PB for the next phase A
-      if (p + 1 < NB / 16) {
-#pragma unroll
-        for (int s_ = 0; s_ < NS; ++s_) {
-          const int t = u + NU * s_;
-          const int C = t >> 3, R = t & 7;
-          if (t < 64 && C == p + 1) {
-            apply(x[s_], R, C, p, P2w);
-            publish(x[s_], R);
-          }
-        }
-      }
-      STAMP(p, 4);
-      lds_barrier();
-      STAMP(p, 5);
-    }
-    write_out(NB / 16 - 1);
-    STAMP(7, 6);
-  } else {
-#ifdef POTF2_PRIO
-    __builtin_amdgcn_s_setprio(3);
+  const int l = threadIdx.x & 63;
+#ifdef ELFIHIP_POTF2_STAMP
+  if ((threadIdx.x & 63) == 0) g_potf2_stamp[(R * 8 + 0) * 8 + 7] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID
 #endif
-    lds_barrier();
+  ldouble* MA = (ldouble*)sm + PT_MA;
+  ldouble* NP = (ldouble*)sm + PT_NP;
+  ldouble* CV = (ldouble*)sm + PT_CV;
+  volatile lint* flag = (volatile lint*)((ldouble*)sm + PT_FLAG);
+  if (R == 8) {
+    // ================================================================== the factor wave
+    const int trow = l & 15;
+    const bool is_tile = l < 16, is_aug = l >= 16 && l < 32;
+    if (l == 0) *flag = 0;
+    int bad = 0;
+    // tile (0, 0) straight from global memory.  The explicit wait tells the compiler's wait-count pass that no load is
+    // outstanding when the loop is entered: otherwise it guards the first use of these registers in the loop with
+    // s_waitcnt vmcnt(0), which also drains the global STORES of the previous panel -- a memory round trip per panel
+    double a[16];
+    {
+      gdouble* src = Akk + (int64_t)trow * lda;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const double v = src[c];
+        a[c] = is_tile ? v : ((is_aug && c == trow) ? 1.0 : 0.0);   // (entries right of the diagonal are never read)
+      }
+      if (is_aug) {   // rows 16-31 of CV: the identity rows every later tile is eliminated with
+#pragma unroll
+        for (int c = 0; c < 16; ++c) CV[(16 + trow) * 17 + c] = c == trow ? 1.0 : 0.0;
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);
+#pragma unroll 1
     for (int p = 0; p < NB / 16; ++p) {
-      const int c0 = 16 * p;
-      const int ntop = NB - 16 - c0;  // rows below the tile
-      double* P2w = P2 + (p & 1) * NB * PP;
+      ldouble* MAp = MA + (p & 1) * 256;
       STAMP(p, 0);
-      // ---- phase A (see above): one lane per row of the tile column, elimination in registers
-      const bool is_tile = l < 16;
-      const int o = 48 * w + (l - 16);
-      const bool is_other = l >= 16 && o < NB;
-      const bool below = is_other && o < ntop;
-      const int srow = is_tile ? c0 + l : (below ? c0 + 16 + o : o - ntop);
-      const bool is_aug = is_other && !below;
-      const bool live = is_tile || is_other;
-      const int rrow = live ? srow : 0;
-      const int t = srow - c0;
-      const unsigned upto_l = (2u << (l & 15)) - 1u;
-      const unsigned right_of_diag = t < 0 ? 0xFFFFu : (t >= 15 ? 0u : (0xFFFFu & ~((2u << (t & 15)) - 1u)));
-      const unsigned keep_r = is_tile ? upto_l : (below ? 0xFFFFu : (is_aug ? right_of_diag : 0u));
-      const unsigned diag_m = (is_aug && t >= 0 && t < 16) ? (1u << (t & 15)) : 0u;
-      const double* rp = PB + rrow * PBP;
-      double a[16];
+      if (p > 0) {
+        // wave p has put its diagonal tile into CV and then raised the flag (LDS operations of one wave complete in
+        // order); polling it instead of a barrier keeps the other waves' panel solves off this chain
+        int spins = 0;
+        while (*flag != p && ++spins < (1 << 22)) {
+        }
+        if (spins >= (1 << 22) && bad == 0) bad = kblock * NB + 16 * p + 1;   // cannot happen: a pivot report, not a hang
+        STAMP(p, 5);
 #pragma unroll
-      for (int c = 0; c < 16; ++c) a[c] = rp[c];
-      asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
-                        "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]),
-                        "+v"(a[15]));
-#pragma unroll
-      for (int c = 0; c < 16; ++c) a[c] = ((keep_r >> c) & 1u) ? a[c] : (((diag_m >> c) & 1u) ? 1.0 : 0.0);
+        for (int c = 0; c < 16; ++c) a[c] = CV[(l & 31) * 17 + c];   // no masks: tile rows, then the identity rows
+      }
       STAMP(p, 1);
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
@@ -418,29 +287,182 @@ __device__ __forceinline__ void potf2_tiles_body(double* Akk_, int64_t lda, doub
         const double tc_ = pc * y0;
         const double ec = fma(-tc_, y0, 1.0);
         const double sc_ = fma(0.375, ec, 0.5);
-        if (!(pc > 0.0) && bad == 0) bad = kblock * NB + c0 + c + 1;
+        if (!(pc > 0.0) && bad == 0) bad = kblock * NB + 16 * p + c + 1;
         a[c] = fma(ay0 * ec, sc_, ay0);  // on tile row c this is p / sqrt(p): the diagonal of the factor
       }
       STAMP(p, 2);
-      // the solved panel: densely into P2 for the updates ...
-      if (is_other) {
-        double* pp = P2w + o * PP;
+      // M for everybody: identity row t = l - 16 holds L^-T[t][c] = M[c][t]
+      if (is_aug) {
+        ldouble* mrow = MAp + 16 * trow;
 #pragma unroll
-        for (int c = 0; c < 16; c += 2) *reinterpret_cast<double2*>(pp + c) = make_double2(a[c], a[c + 1]);
-      }
-      if (is_tile && w == 0) {  // ... and the tile rows next to it (the update waves carry both to global memory)
-        double* tb = TB + (p & 1) * 16 * PBP + l * PBP;
-#pragma unroll
-        for (int c = 0; c < 16; ++c) tb[c] = a[c];
+        for (int c = 0; c < 16; c += 2) *(ldouble2*)(mrow + c) = (v2d_t){a[c], a[c + 1]};
       }
       STAMP(p, 3);
-      lds_barrier();
+      lds_barrier();   // B(p)
       STAMP(p, 4);
-      lds_barrier();
-      STAMP(p, 5);
+      // off the chain: the diagonal tile of L11 (lower triangle) to global memory, through LDS so that a store
+      // instruction covers 8 rows x 128 bytes (one lane per row: 16 partial lines per instruction, and the CU's
+      // memory pipe, not the elimination, sets the pace -- 1.5 us per panel)
+      {
+        ldouble* LT = (ldouble*)sm + PT_ST + 8 * 16 * 18;
+        if (is_tile) {
+#pragma unroll
+          for (int c = 0; c < 16; c += 2) *(ldouble2*)(LT + trow * 18 + c) = (v2d_t){a[c], a[c + 1]};
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        const int sj = l & 7;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int i = (l >> 3) + 8 * h;
+          const v2d_t v = *(ldouble2*)(LT + i * 18 + 2 * sj);
+          gdouble* dst = Akk + (int64_t)(16 * p + i) * lda + 16 * p + 2 * sj;
+          if (2 * sj + 1 <= i)
+            *(gdouble2*)dst = v;
+          else if (2 * sj <= i)
+            dst[0] = v.x;
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    if (bad != 0 && l == 0) atomicCAS(info, 0, bad);
+    return;
+  }
+  // ==================================================================== the tile waves
+  // Register slots RELATIVE to the panel: `cur` = tile (R, p), q[j] = tile (R, p + 1 + j), rotated after every panel, and
+  // the diagonal tile (R, R) in registers of its own (its q slot stays zero: tile (R, R) of the identity is never data).
+  // Every panel therefore runs the SAME instructions (a slot chosen by `if (p == C)` copies was eight pieces of code
+  // each executed once per launch: instruction-cache misses at ~100 cycles per instruction, 6 000 cycles per panel).
+  const int lr = l >> 4, lc = l & 15;
+  v4d cur = (v4d){0.0, 0.0, 0.0, 0.0}, dg = cur;
+  v4d q[7];
+  {
+    gdouble* row = Akk + (int64_t)(16 * R + lc) * lda;
+    if (R > 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        cur[r] = row[4 * r + lr];
+        const int j = 4 * r + lr;   // symmetric fill from the lower triangle
+        dg[r] = j <= lc ? row[16 * R + j] : Akk[(int64_t)(16 * R + j) * lda + 16 * R + lc];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      q[j] = (v4d){0.0, 0.0, 0.0, 0.0};
+      if (1 + j < R) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) q[j][r] = row[16 * (1 + j) + 4 * r + lr];
+      }
     }
   }
-  if (bad != 0 && tid == 0) atomicCAS(info, 0, bad);
+  v4d yp = (v4d){0.0, 0.0, 0.0, 0.0};   // P_{p-1}(R)^T
+  __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);   // (as in the factor wave: nothing but stores outstanding inside the loop)
+  lds_barrier();                        // B(0)
+#pragma unroll 1
+  for (int p = 0; p < NB / 16; ++p) {
+    const ldouble* MAp = MA + (p & 1) * 256;
+    const ldouble* NPr = NP + ((p - 1) & 1) * 8 * 256;   // panels of step p-1
+    ldouble* NPw = NP + (p & 1) * 8 * 256;
+    STAMP(p, 0);
+    // ---- on the chain: U(p-1) on tile (R, p), the panel solve, U(p) on the wave's own diagonal tile
+    // (the wave whose diagonal tile is factored next goes first at the SIMD's matrix pipe, which it shares with two
+    // other waves and their deferred updates)
+    if (R != p + 1 && p + 1 < NB / 16 && ((CLASS_OF_ROW >> (4 * R)) & 15) == ((CLASS_OF_ROW >> (4 * (p + 1))) & 15)) {
+      // the wave whose diagonal tile is factored next has its SIMD's matrix pipe to itself until it has handed the tile
+      // over (beside the deferred updates of the waves it shares the SIMD with, its twelve MFMAs took 3 000 cycles)
+      int spins = 0;
+      while (*flag != p + 1 && ++spins < (1 << 22)) {
+      }
+    }
+    v4d y;
+    if (R == p) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) y[r] = MAp[16 * lc + 4 * r + lr];   // P(p)^T of the identity rows = M
+    } else {
+      double ma[4];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) ma[kk] = MAp[64 * kk + l];
+      if (p > 0) {
+        double na[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) na[kk] = NPr[p * 256 + 64 * kk + l];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) cur = __builtin_amdgcn_mfma_f64_16x16x4f64(na[kk], yp[kk], cur, 0, 0, 0);
+      }
+      y = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) y = __builtin_amdgcn_mfma_f64_16x16x4f64(ma[kk], cur[kk], y, 0, 0, 0);
+    }
+    if (R > p) {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) dg = __builtin_amdgcn_mfma_f64_16x16x4f64(-y[kk], y[kk], dg, 0, 0, 0);
+      if (R == p + 1) {   // complete: to the factor wave, one row per lane there
+#pragma unroll
+        for (int r = 0; r < 4; ++r) CV[(4 * r + lr) * 17 + lc] = dg[r];
+        asm volatile("" ::: "memory");
+        if (l == 0) *flag = p + 1;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) NPw[R * 256 + 64 * r + l] = -y[r];
+    }
+    STAMP(p, 1);
+    // ---- off the chain: U(p-1) on the remaining tiles right of column p (matrix tiles C < R; identity tiles C > R
+    // once panel R has been eliminated, i.e. R <= p-1)
+    if (p > 0) {
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        const int C = p + 1 + j;
+        if (C < 8 && C != R && (C < R || R <= p - 1)) {
+          const ldouble* np = NPr + C * 256 + l;
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) q[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(np[64 * kk], yp[kk], q[j], 0, 0, 0);
+        }
+      }
+    }
+    STAMP(p, 2);
+    // ---- the solved panel to global memory: L11 rows (R > p); L^-T rows (R <= p) into WT's diagonal block and,
+    // transposed, into W11 = L11^-1 (entries on and right of the diagonal only).  Row-major destinations go through the
+    // wave's LDS staging tile: 8 rows x 128 bytes per store instruction instead of 16 rows x 32 bytes.
+    {
+      ldouble* ST = (ldouble*)sm + PT_ST + R * (16 * 18);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ST[lc * 18 + 4 * r + lr] = y[r];
+      if (R <= p) {   // W11[col][row]: the accumulator layout is already coalesced along the rows
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int gcol = 16 * p + 4 * r + lr, grow = 16 * R + lc;
+          if (gcol >= grow) W11[gcol * NB + grow] = y[r];
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      const int sj = l & 7;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int i = (l >> 3) + 8 * h;
+        const v2d_t v = *(ldouble2*)(ST + i * 18 + 2 * sj);
+        const int grow = 16 * R + i, gcol = 16 * p + 2 * sj;
+        if (R > p) {
+          *(gdouble2*)(Akk + (int64_t)grow * lda + gcol) = v;
+        } else {
+          gdouble* dst = Wkk + (int64_t)grow * ldw + gcol;
+          if (gcol >= grow)
+            *(gdouble2*)dst = v;
+          else if (gcol + 1 >= grow)
+            dst[1] = v.y;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    // ---- next panel: rotate the slots
+    yp = y;
+    cur = q[0];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) q[j] = q[j + 1];
+    q[6] = (v4d){0.0, 0.0, 0.0, 0.0};
+    STAMP(p, 3);
+    if (p + 1 < NB / 16) lds_barrier();   // B(p+1)
+  }
 }
 
 template <int NT>
