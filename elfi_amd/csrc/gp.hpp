@@ -33,10 +33,11 @@ struct elfihip_gp {
   double* WL = nullptr;     // (cap, lda): L^-1 = WT^T (lower), mirrored from WT on first use after a factorisation
                             //             (wl_valid); the second triangular product of the predictor reads it row-wise
   double* Kinv = nullptr;   // (cap, lda): K^-1 (lower tiles), only for the hyper-parameter gradient
-  double* W11 = nullptr;    // (NB, NB) inverse of the diagonal block being eliminated (lower)
+  double* W11 = nullptr;    // 2 x (NB, NB): inverse of the diagonal block being eliminated (lower), alternating
   double* alpha = nullptr;  // (cap) K^-1 y
   double* red = nullptr;    // small reduction scratch
-  int* info = nullptr;      // device: 1-based index of the first non-positive pivot, 0 if none
+  int* info = nullptr;      // device: 1-based index of the first non-positive pivot, 0 if none; from word 4 on the
+  int ninfo = 0;            // arrival counters of the fused sweep's steps (four words each); ninfo words in all
   double* h_fit = nullptr;  // pinned, device-visible: sum log L_ii, z'z and the pivot report of the latest rebuild
   // integration points of ExpIntVar (elfihip_gp_set_integration_points): V_P = L^-1 K(X, P) stored k-major
   double* VP = nullptr;     // (np, m_pad)
@@ -56,6 +57,7 @@ struct elfihip_gp {
   const void* sched_heads = nullptr;
   std::vector<int> sched_step_off, sched_step_nwg;   // per step: first offset entry, workgroups with work
   int sched_nb = 0, sched_nwg = 0;
+  bool sched_far_first = false;   // a workgroup's units by descending column (the chained form of the step launch)
   // per-phase device timing (elfihip_gp_profile): HIP events around the phases of a fit / prediction / gradient call
   // while enabled; sums in milliseconds and call counts per phase (indices: ELFIHIP_PHASE_* in include/elfihip.h)
   bool profile = false;

@@ -41,7 +41,8 @@ struct GramArgs {
   int64_t lda, n, np;
   int dp;
   double var, neg_half_inv_ls2, bias, diag_add;
-  int* info;   // the factorisation's pivot report: cleared here, by the first kernel of a rebuild
+  int* info;   // the factorisation's pivot report and the fused sweep's arrival counters behind it: cleared here, by
+  int ninfo;   // the first kernel of a rebuild
 };
 
 __global__ __launch_bounds__(256) void gram_kernel(GramArgs G) {
@@ -52,7 +53,8 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs G) {
   // decode lower-triangular tile pair (ti >= tj) from the linear block index
   const int64_t nt = G.np / 64;
   int64_t b = blockIdx.x;
-  if (b == 0 && threadIdx.x == 0) *G.info = 0;
+  if (b == 0)
+    for (int i = threadIdx.x; i < G.ninfo; i += 256) G.info[i] = 0;
   int64_t ti = (int64_t)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
   while (ti * (ti + 1) / 2 > b) --ti;
   while ((ti + 1) * (ti + 2) / 2 <= b) ++ti;
@@ -795,13 +797,18 @@ __device__ __noinline__ void potf2_tiles_call(double* Akk, int64_t lda, double* 
 // PERSISTENT -- one per CU beside workgroup 0 -- and walk their list with the next unit's first operand loads and old
 // C values in flight while the current unit is multiplied.
 struct StepArgs {
-  PanelArgs P;
-  double* W11;
+  PanelArgs P;              // P.k: the panel this launch solves (P.W11 = the inverse of diagonal block k) and applies
+  double* W11;              // where the diagonal block k+1 puts ITS inverse (the other of the two buffers; NULL: the
+                            // update alone, scripts/native/step_probe.hip)
   int* info;
   const SweepUnit* units;   // the schedule's unit table (all steps)
   const int32_t* wg_off;    // this step: offset of every update workgroup's first unit in `units`
   const SweepUnit* heads;   // this step: every update workgroup's first unit again (pad = its unit count), so that the
                             // first operand addresses are one load away from the workgroup number
+  unsigned* cnt;            // this step's arrival counters {panel solved, strip (k+1, k) solved, tile (k+1, k+1) updated};
+                            // NULL: round 2's form -- panel solve and diagonal tile are launches of their own
+  int nmini;                // 16-row pieces of panel k (8 per row block)
+  int nwg;                  // update workgroups launched
 };
 
 struct StepUnit {
@@ -810,6 +817,7 @@ struct StepUnit {
   double* C;          // unit's rows of the tile
   double keep;        // 1: C -= P P^T, 0: C = -P P^T (the unit that creates an L^-T tile)
   int nkt;            // 32-deep k-tiles: K / 32
+  int kt0;            // the first of them
 };
 
 __device__ __forceinline__ StepUnit step_decode(const StepArgs& S, const int4 r) {
@@ -823,6 +831,7 @@ __device__ __forceinline__ StepUnit step_decode(const StepArgs& S, const int4 r)
   U.Bp = P.A + ((int64_t)c * NB) * P.lda + (int64_t)kt0 * GK2;
   U.keep = keep ? 1.0 : 0.0;
   U.nkt = nkt;
+  U.kt0 = kt0;
   return U;
 }
 
@@ -830,15 +839,199 @@ __device__ __forceinline__ StepUnit step_unit(const StepArgs& S, int i) {
   return step_decode(S, *reinterpret_cast<const int4*>(S.units + i));
 }
 
-__global__ __launch_bounds__(1024) void step_kernel(StepArgs S) {
+#ifdef ELFIHIP_STEP_STAMP   // developer probe (scripts/native/step_timeline_probe.hip): shader-clock stamps of ONE step
+__device__ long long g_step_stamp[1024 * 8];
+__device__ int g_step_stamp_k = 16;
+#define SSTAMP(slot) do { if (threadIdx.x == 0 && S.P.k == g_step_stamp_k) g_step_stamp[blockIdx.x * 8 + (slot)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define SSTAMP(slot) do { } while (0)
+#endif
+
+// ---- hand-offs inside the fused step launch (guide: write-through stores, every storing wave drains, ONE relaxed
+// device-scope arrival per workgroup, ONE agent-scope acquire by the consumer -- no release fence anywhere)
+typedef __attribute__((address_space(1))) unsigned long long gu64_fit_t;
+__device__ __forceinline__ void store_wt_f64(double* p, double v) {
+  __hip_atomic_store((gu64_fit_t*)(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+constexpr int STEP_SPIN_LIMIT = 1 << 22;   // polls (a few seconds): a hand-off that never comes is reported, not waited for
+constexpr int STEP_INFO_TIMEOUT = -1;      // pivot report of a launch whose workgroups were not all resident
+
+// every thread of the workgroup: wait until *c >= target, then acquire
+__device__ __forceinline__ void step_wait(const unsigned* c, unsigned target, int* info) {
+  int spins = 0;
+  while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    if (++spins >= STEP_SPIN_LIMIT) {
+      if (threadIdx.x == 0) atomicCAS(info, 0, STEP_INFO_TIMEOUT);
+      break;
+    }
+    __builtin_amdgcn_s_sleep(2);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+// after the workgroup's write-through stores: drain, meet, one arrival (at one or two counters)
+__device__ __forceinline__ void step_arrive(unsigned* c, unsigned n, unsigned* c2 = nullptr) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(c, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (c2) __hip_atomic_fetch_add(c2, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// One 16-row piece of panel k, P <- P W11^T in place, by the sixteen waves of a step workgroup: wave (h, T) takes
+// column tile T and the k octets [8 h, 8 h + 8) of the 2 (T + 1) the lower-triangular W11 leaves it (as trsm16_wave,
+// whose single round trip this keeps: every operand is loaded before the first wait); the two halves meet in LDS.
+// Stores are write-through: other workgroups of the SAME launch read the solved panel.
+__device__ __forceinline__ void step_solve_piece(const PanelArgs& P, int piece, double* sm) {
+  double* Pb = panel_block(P, piece >> 3) + (int64_t)(piece & 7) * 16 * P.lda;
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int h = w >> 3, T = w & 7;
+  const int O = 2 * (T + 1);
+  const int q2 = 2 * (l >> 4);
+  const double* pa = Pb + (int64_t)(l & 15) * P.lda + q2 + 64 * h;
+  const double* pb = P.W11 + (int64_t)(16 * T + (l & 15)) * NB + q2 + 64 * h;
+  double2 a[8], b[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    a[j] = (double2){0.0, 0.0};
+    b[j] = (double2){0.0, 0.0};
+    if (8 * h + j < O) {
+      a[j] = *reinterpret_cast<const double2*>(pa + 8 * j);
+      b[j] = *reinterpret_cast<const double2*>(pb + 8 * j);
+    }
+  }
+  v4d c = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    if (8 * h + j < O) {
+      c = __builtin_amdgcn_mfma_f64_16x16x4f64(a[j].x, b[j].x, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f64_16x16x4f64(a[j].y, b[j].y, c, 0, 0, 0);
+    }
+  double* part = sm + (T * 64 + l) * 4;
+  if (h == 1) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) part[r] = c[r];
+  }
+  __syncthreads();   // every wave holds its part of the strip: it may be overwritten
+  if (h == 0) {
+    double* po = Pb + (int64_t)(l >> 4) * P.lda + (l & 15) + 16 * T;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) store_wt_f64(po + (int64_t)(4 * r) * P.lda, c[r] + part[r]);
+  }
+  __syncthreads();   // LDS free for the next piece
+}
+
+// Two of the sixteen 32 x 32 pieces of tile (k+1, k+1) -= P P^T (P = the solved strip (k+1, k)) by waves 0-7 of a step
+// workgroup (lookahead_tile_kernel<1> for the diagonal tile only: four waves per piece, 32 of the 128 k each, partial
+// sums through LDS); write-through stores: the launch's first workgroup factors the tile next.
+__device__ __forceinline__ void step_tile_pieces(const PanelArgs& P, int pair, double* sm) {
+  const int t = threadIdx.x & 255, l = t & 63, w = t >> 6;
+  const int g = threadIdx.x >> 8;                  // piece of the pair (waves 8-15: none)
+  const int lb = 2 * pair + (g & 1);
+  const int sub = (lb >> 2) & 3, cs = lb & 3;
+  const int cblk = P.k + 1;
+  constexpr int TP = 33;                           // pitch of a 32 x 32 partial in LDS
+  double* lds = sm + (g & 1) * 4 * 32 * TP;
+  const bool on = g < 2;
+  const double* Ap = P.A + ((int64_t)cblk * NB + sub * 32) * P.lda + (int64_t)P.k * NB;
+  const double* Bp = P.A + ((int64_t)cblk * NB + cs * 32) * P.lda + (int64_t)P.k * NB;
+  double* C = P.A + ((int64_t)cblk * NB + sub * 32) * P.lda + (int64_t)cblk * NB + cs * 32;
+  double cv[4];
+  if (on) {
+    const int kb = w * 32 + 2 * (l >> 4);
+    const double* pa = Ap + (int64_t)(l & 15) * P.lda + kb;
+    const double* pb = Bp + (int64_t)(l & 15) * P.lda + kb;
+    double2 a[2][4], b[2][4];
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        a[i][o] = *reinterpret_cast<const double2*>(pa + (int64_t)i * 16 * P.lda + 8 * o);
+        b[i][o] = *reinterpret_cast<const double2*>(pb + (int64_t)i * 16 * P.lda + 8 * o);
+      }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = t + 256 * u;
+      cv[u] = C[(int64_t)(e >> 5) * P.lda + (e & 31)];
+    }
+    v4d acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][o].x, b[j][o].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][o].y, b[j][o].y, acc[i][j], 0, 0, 0);
+        }
+    double* part = lds + w * 32 * TP;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[(i * 16 + (l >> 4) + 4 * r) * TP + j * 16 + (l & 15)] = acc[i][j][r];
+  }
+  __syncthreads();
+  if (on) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = t + 256 * u;
+      const int o = (e >> 5) * TP + (e & 31);
+      const double sres = ((lds[o] + lds[32 * TP + o]) + lds[2 * 32 * TP + o]) + lds[3 * 32 * TP + o];
+      store_wt_f64(C + (int64_t)(e >> 5) * P.lda + (e & 31), cv[u] - sres);
+    }
+  }
+}
+
+// CHAINED: panel solve and diagonal tile inside this launch (S.cnt != NULL); the two forms are separate kernels so that
+// the three-launch form's update loop compiles exactly as it did without the other's roles around it
+template <bool CHAINED>
+__device__ __forceinline__ void step_body(const StepArgs& S) {
   extern __shared__ __align__(16) double sm[];
   const PanelArgs& P = S.P;
+  constexpr bool chained = CHAINED;
+  SSTAMP(0);
   if (blockIdx.x == 0) {
     const int kk = P.k + 1;
     double* Akk = P.A + ((int64_t)kk * NB) * P.lda + (int64_t)kk * NB;
     double* Wkk = P.WT + ((int64_t)kk * NB) * P.lda + (int64_t)kk * NB;
+    if (chained) step_wait(S.cnt + 2, 8u, S.info);   // tile (k+1, k+1) complete (eight workgroups, two pieces each)
+    SSTAMP(1);
     if (S.W11) potf2_tiles_call(Akk, P.lda, Wkk, P.lda, S.W11, S.info, kk, sm);   // (NULL: the update alone, scripts/native/step_probe.hip)
+    SSTAMP(2);
     return;
+  }
+  const int idx = blockIdx.x - 1;
+  if (chained) {
+    // ---- the panel solve, dealt over the update workgroups; the first eight take strip (k+1, k) and then the diagonal
+    // tile: the chain to the next diagonal block is solve -> hop -> tile -> hop -> block, beside everybody's updates
+    const int lead = S.nwg >= 16 ? 8 : 0;   // workgroups that keep out of the rest of the panel
+    if (idx < 8) {
+      step_solve_piece(P, idx, sm);
+      step_arrive(S.cnt + 1, 1u, S.cnt);
+      SSTAMP(1);
+    }
+    unsigned done = 0;
+    if (idx >= lead)
+      for (int e = 8 + (idx - lead); e < S.nmini; e += S.nwg - lead) {
+        step_solve_piece(P, e, sm);
+        ++done;
+      }
+    if (done) step_arrive(S.cnt, done);
+    if (idx >= 8) SSTAMP(1);
+    if (idx < 8) {
+      step_wait(S.cnt + 1, 8u, S.info);
+      SSTAMP(2);
+      step_tile_pieces(P, idx, sm);
+      step_arrive(S.cnt + 2, 1u);
+      SSTAMP(3);
+    }
   }
   constexpr int RT = 1;                 // 16-row MFMA tiles per wave along the rows
   constexpr int ROWS = 64 * RT;         // rows of a unit
@@ -862,6 +1055,18 @@ __global__ __launch_bounds__(1024) void step_kernel(StepArgs S) {
   // multiplied, the next element (in registers since the previous step) is written to stage p^1 and the loads of the
   // element after it are issued -- one barrier per k-tile, and the LDS stores overlap other waves' MFMAs.
   StepUnit cur = step_decode(S, head);
+  // k-tiles from 4 k on belong to the panel this launch solves: before the first of them is requested, the whole panel
+  // must have arrived (a workgroup's units are ordered so that those come last)
+  const int kt_new = chained ? 4 * P.k : (1 << 30);
+  bool ready = !chained;
+  auto need_panel = [&](const StepUnit& U, int kt) {
+    if (chained && !ready && U.kt0 + kt >= kt_new) {
+      SSTAMP(4);
+      step_wait(S.cnt, (unsigned)S.nmini, S.info);
+      SSTAMP(5);
+      ready = true;
+    }
+  };
   double2 pa0, pa1, pb0, pb1;
   auto issue = [&](const double* A_, const double* B_) {
     pa0 = *reinterpret_cast<const double2*>(A_ + goff);
@@ -877,6 +1082,7 @@ __global__ __launch_bounds__(1024) void step_kernel(StepArgs S) {
     *reinterpret_cast<double2*>(da + (ROWS + 64) * GLP2) = pb1;
   };
   pa1 = (double2){0.0, 0.0};
+  need_panel(cur, 1);   // (the first two k-tiles are requested before the loop)
   issue(cur.Ap, cur.Bp);
   v4d cv[RT][2];
 #pragma unroll
@@ -904,10 +1110,13 @@ __global__ __launch_bounds__(1024) void step_kernel(StepArgs S) {
       if (kt + 1 < cur.nkt || more) {
         stage(sm + (p ^ 1) * BUF);                       // element e+1: this unit's next k-tile or the next unit's first
         const int k2 = kt + 2 - cur.nkt;                 // element e+2
-        if (k2 < 0)
+        if (k2 < 0) {
+          need_panel(cur, kt + 2);
           issue(cur.Ap + (kt + 2) * GK2, cur.Bp + (kt + 2) * GK2);
-        else if (more)
+        } else if (more) {
+          need_panel(nxt, k2);
           issue(nxt.Ap + k2 * GK2, nxt.Bp + k2 * GK2);
+        }
       }
       const double* fa = buf + faoff;
       const double* fb = buf + fboff;
@@ -937,7 +1146,10 @@ __global__ __launch_bounds__(1024) void step_kernel(StepArgs S) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           cp[(int64_t)(i * 16 + 4 * r) * lda + j * 16] = cur.keep * cv[i][j][r] - acc[i][j][r];
-    if (!more) break;
+    if (!more) {
+      SSTAMP(6);
+      break;
+    }
     // the next unit's old values: in flight during its k loop
     const double* cn = nxt.C + coff;
 #pragma unroll
@@ -950,6 +1162,9 @@ __global__ __launch_bounds__(1024) void step_kernel(StepArgs S) {
     u = un;
   }
 }
+
+__global__ __launch_bounds__(1024) void step_kernel(StepArgs S) { step_body<false>(S); }
+__global__ __launch_bounds__(1024) void step_chain_kernel(StepArgs S) { step_body<true>(S); }
 
 constexpr size_t STEP_LDS_BYTES = 2 * (64 + 128) * GLP2 * sizeof(double);  // two stages of a unit (> the diagonal block's)
 static_assert(STEP_LDS_BYTES >= POTF2T_LDS_DOUBLES * sizeof(double) && STEP_LDS_BYTES <= 160 * 1024, "LDS budget");
@@ -1029,21 +1244,21 @@ static int enable_lds(elfihip_ctx* ctx, K k, size_t bytes) {
 static std::mutex g_sched_mutex;
 static std::map<std::pair<int, int>, std::shared_ptr<const SweepSchedule>> g_sched_cache;
 
-static std::shared_ptr<const SweepSchedule> sweep_schedule_for(int nb, int nwg) {
+static std::shared_ptr<const SweepSchedule> sweep_schedule_for(int nb, int nwg, bool far_first) {
   std::lock_guard<std::mutex> lock(g_sched_mutex);
-  auto key = std::make_pair(nb, nwg);
+  auto key = std::make_pair(nb, far_first ? -nwg : nwg);
   auto it = g_sched_cache.find(key);
   if (it != g_sched_cache.end()) return it->second;
   auto S = std::make_shared<SweepSchedule>();
-  sweep_build(nb, nwg, S.get());
+  sweep_build(nb, nwg, S.get(), far_first);
   g_sched_cache[key] = S;
   return S;
 }
 
-static int sweep_plan(elfihip_gp* gp, int nb, int nwg, hipStream_t st) {
-  if (gp->sched_nb == nb && gp->sched_nwg == nwg) return ELFIHIP_OK;
+static int sweep_plan(elfihip_gp* gp, int nb, int nwg, bool far_first, hipStream_t st) {
+  if (gp->sched_nb == nb && gp->sched_nwg == nwg && gp->sched_far_first == far_first) return ELFIHIP_OK;
   elfihip_ctx* ctx = gp->ctx;
-  std::shared_ptr<const SweepSchedule> S = sweep_schedule_for(nb, nwg);
+  std::shared_ptr<const SweepSchedule> S = sweep_schedule_for(nb, nwg, far_first);
   // every workgroup's first unit of every step once more, contiguous per step (an empty workgroup: count 0)
   std::vector<SweepUnit> heads;
   for (const SweepStep& x : S->steps)
@@ -1074,42 +1289,53 @@ static int sweep_plan(elfihip_gp* gp, int nb, int nwg, hipStream_t st) {
   }
   gp->sched_nb = nb;
   gp->sched_nwg = nwg;
+  gp->sched_far_first = far_first;
   return ELFIHIP_OK;
 }
 
-static int sweep_fused(elfihip_gp* gp, int nb, hipStream_t st) {
+static int sweep_fused(elfihip_gp* gp, int nb, hipStream_t st, bool chained) {
   elfihip_ctx* ctx = gp->ctx;
   if (!ctx->step_lds_enabled) {
     ELFIHIP_TRY(enable_lds(ctx, step_kernel, STEP_LDS_BYTES));
+    ELFIHIP_TRY(enable_lds(ctx, step_chain_kernel, STEP_LDS_BYTES));
     ctx->step_lds_enabled = true;
   }
   const int nwg = std::max(8, ctx->cu_count - 1);   // update workgroups: one per CU beside the diagonal block
-  ELFIHIP_TRY(sweep_plan(gp, nb, nwg, st));
+  ELFIHIP_TRY(sweep_plan(gp, nb, nwg, chained, st));
+  double* const W11buf[2] = {gp->W11, gp->W11 + (size_t)NB * NB};
   PanelArgs P;
   P.A = gp->A;
   P.WT = gp->WT;
-  P.W11 = gp->W11;
   P.lda = gp->lda;
   P.nb = nb;
   P.kun = 1;
   hipLaunchKernelGGL(potf2_tiles_kernel<1024>, dim3(1), dim3(1024), POTF2T_LDS_DOUBLES * sizeof(double), st, gp->A,
-                     gp->lda, gp->WT, gp->lda, gp->W11, gp->info, 0);
+                     gp->lda, gp->WT, gp->lda, W11buf[0], gp->info, 0);
   for (int k = 0; k < nb; ++k) {
     P.k = k;
     P.ku0 = k;
+    P.W11 = W11buf[k & 1];
     const int nrows = (nb - 1 - k) + 1 + k;  // below + y block + L^-T rows above
-    hipLaunchKernelGGL(trsm16_kernel, dim3(8 * nrows), dim3(256), 0, st, P);
     const int m = nb - 1 - k;
+    if (!chained || m == 0) hipLaunchKernelGGL(trsm16_kernel, dim3(8 * nrows), dim3(256), 0, st, P);
     if (m == 0) break;
-    hipLaunchKernelGGL(lookahead_tile_kernel<1>, dim3(16), dim3(256), LOOKAHEAD_TILE_LDS, st, P, k + 1);
+    if (!chained) hipLaunchKernelGGL(lookahead_tile_kernel<1>, dim3(16), dim3(256), LOOKAHEAD_TILE_LDS, st, P, k + 1);
     StepArgs S;
     S.P = P;
-    S.W11 = gp->W11;
+    S.W11 = W11buf[(k + 1) & 1];
     S.info = gp->info;
     S.units = reinterpret_cast<const SweepUnit*>(gp->sched_units);
     S.wg_off = reinterpret_cast<const int32_t*>(gp->sched_wgoff) + gp->sched_step_off[k];
     S.heads = reinterpret_cast<const SweepUnit*>(gp->sched_heads) + (size_t)k * nwg;
-    hipLaunchKernelGGL(step_kernel, dim3(1 + gp->sched_step_nwg[k]), dim3(1024), STEP_LDS_BYTES, st, S);
+    S.cnt = chained ? reinterpret_cast<unsigned*>(gp->info) + 4 + 4 * k : nullptr;
+    S.nmini = 8 * nrows;
+    S.nwg = nwg;
+    // chained: every update workgroup has its share of the panel solve, with or without units
+    const int grid = 1 + (chained ? nwg : gp->sched_step_nwg[k]);
+    if (chained)
+      hipLaunchKernelGGL(step_chain_kernel, dim3(grid), dim3(1024), STEP_LDS_BYTES, st, S);
+    else
+      hipLaunchKernelGGL(step_kernel, dim3(grid), dim3(1024), STEP_LDS_BYTES, st, S);
   }
   return launch_status(ctx, "cholesky sweep (fused steps)");
 }
@@ -1248,16 +1474,19 @@ int gp_factorize_impl(elfihip_gp* gp) {
     G.bias = gp->bias;
     G.diag_add = gp->noise + GP_JITTER;
     G.info = gp->info;
+    G.ninfo = gp->ninfo;
     const int64_t nt = np / 64;
     const size_t lds = 2 * 64 * (size_t)(gp->dp + 1) * sizeof(double);
     hipLaunchKernelGGL(gram_kernel, dim3((unsigned)(nt * (nt + 1) / 2)), dim3(256), lds, st, G);
     ELFIHIP_TRY(launch_status(ctx, "gram_kernel"));
   }
   prof_mark(gp, 1);
-  // schedule of the sweep: gp->schedule 1 = streams, 2 = fused steps, 0 = by size (elfihip_gp_set_schedule)
-  const bool fused = gp->schedule == 2 || (gp->schedule == 0 && nb < FUSED_BELOW_NB);
+  // schedule of the sweep: gp->schedule 1 = streams, 2 = fused steps (panel solve | diagonal tile | step launch per block
+  // column), 3 = fused steps chained inside ONE launch per block column (measured slower: DESIGN.md section 7), 0 = by
+  // size (elfihip_gp_set_schedule)
+  const bool fused = gp->schedule == 2 || gp->schedule == 3 || (gp->schedule == 0 && nb < FUSED_BELOW_NB);
   if (fused)
-    ELFIHIP_TRY(sweep_fused(gp, nb, st));
+    ELFIHIP_TRY(sweep_fused(gp, nb, st, gp->schedule == 3));
   else
     ELFIHIP_TRY(sweep_streams(gp, nb, st));
   prof_mark(gp, 2);
@@ -1272,6 +1501,11 @@ int gp_factorize_impl(elfihip_gp* gp) {
   prof_add(gp, ELFIHIP_PHASE_GRAM, 0, 1);
   prof_add(gp, ELFIHIP_PHASE_SWEEP, 1, 2);
   prof_add(gp, ELFIHIP_PHASE_ALPHA, 2, 3);
+  if (info == STEP_INFO_TIMEOUT) {
+    gp->factored = false;
+    return fail(ctx, ELFIHIP_ERR_HIP, "factorisation sweep: a hand-off inside a step launch timed out (the launch's "
+                "workgroups were not all resident: another kernel holds compute units of this device)");
+  }
   if (info != 0) {
     gp->factored = false;
     return fail(ctx, ELFIHIP_ERR_NOT_PD, "covariance matrix is not positive definite (pivot %d <= 0)", info);
@@ -1316,11 +1550,12 @@ int elfihip_gp_create(elfihip_ctx* ctx, int d, int64_t capacity, elfihip_gp** ou
   alloc(&gp->A, (size_t)(gp->cap + NB) * mat);
   alloc(&gp->WT, (size_t)gp->cap * mat);
   alloc(&gp->WL, (size_t)gp->cap * mat);
-  alloc(&gp->W11, ((size_t)NB * NB + 64) * sizeof(double));
+  alloc(&gp->W11, (2 * (size_t)NB * NB + 64) * sizeof(double));   // two: block k's is read while block k+1's is written
   alloc(&gp->alpha, (size_t)gp->cap * sizeof(double));
   alloc(&gp->red, 64 * sizeof(double));
-  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&gp->info), sizeof(int));
-  if (e == hipSuccess) e = hipMemsetAsync(gp->info, 0, sizeof(int), ctx->stream);
+  gp->ninfo = 4 + 4 * (int)(gp->cap / NB);   // pivot report; four counter words per step of the fused sweep
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&gp->info), gp->ninfo * sizeof(int));
+  if (e == hipSuccess) e = hipMemsetAsync(gp->info, 0, gp->ninfo * sizeof(int), ctx->stream);
   if (e == hipSuccess)
     e = hipHostMalloc(reinterpret_cast<void**>(&gp->h_fit), 8 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -1463,7 +1698,7 @@ int elfihip_gp_profile(elfihip_gp* gp, int enable, double* phase_ms, int64_t* ph
 
 int elfihip_gp_set_schedule(elfihip_gp* gp, int schedule, int panel_group) {
   if (!gp) return fail(nullptr, ELFIHIP_ERR_ARG, "gp is NULL");
-  ELFIHIP_REQUIRE(gp->ctx, schedule >= 0 && schedule <= 2, "schedule %d outside {0, 1, 2}", schedule);
+  ELFIHIP_REQUIRE(gp->ctx, schedule >= 0 && schedule <= 3, "schedule %d outside {0, 1, 2, 3}", schedule);
   ELFIHIP_REQUIRE(gp->ctx, panel_group == 0 || panel_group == 1 || panel_group == 2 || panel_group == 4,
                   "panel_group %d outside {0, 1, 2, 4}", panel_group);
   gp->schedule = schedule;

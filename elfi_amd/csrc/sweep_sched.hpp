@@ -139,7 +139,7 @@ inline int sweep_bins_needed(const std::vector<int>& count, int max_nkt, double 
 
 // One construction of the sweep's schedule: steps of length T, no touch deeper than ktmax k-tiles (mandatory ones
 // excepted).  Returns the predicted time; fills `S` when given.
-inline double sweep_simulate(int nb, int nwg, double T, int ktmax, SweepSchedule* S) {
+inline double sweep_simulate(int nb, int nwg, double T, int ktmax, SweepSchedule* S, bool far_first = false) {
   std::vector<int> rem(nb + 2, 0), take(nb + 2, 0);
   for (int c = 2; c < nb; ++c) rem[c] = 4 * (c - 1);
   const int nsteps = std::max(0, nb - 1);
@@ -254,7 +254,9 @@ inline double sweep_simulate(int nb, int nwg, double T, int ktmax, SweepSchedule
     makespan[k] = worst;
     total += std::max(SWEEP_POTF2_US, worst) + SWEEP_CHAIN_US;
     if (S) {
-      // the longest workgroups first, empty ones last; a workgroup's units by column, row, half: neighbours share operands
+      // the longest workgroups first, empty ones last; a workgroup's units by column, row, half: neighbours share
+      // operands.  far_first (the chained form of the step launch): the LAST columns first -- the units of column k+1
+      // and k+2 read the panel solved inside the same launch and may have to wait for it
       std::vector<int> wgs(nwg);
       for (int w = 0; w < nwg; ++w) wgs[w] = w;
       std::stable_sort(wgs.begin(), wgs.end(), [&](int a, int b) { return loads[a] > loads[b]; });
@@ -265,7 +267,7 @@ inline double sweep_simulate(int nb, int nwg, double T, int ktmax, SweepSchedule
         std::vector<int>& m = mine[w];
         std::sort(m.begin(), m.end(), [&](int a, int b) {
           const SweepUnit &x = units[a], &y = units[b];
-          if (x.c != y.c) return x.c < y.c;
+          if (x.c != y.c) return far_first ? x.c > y.c : x.c < y.c;
           if (x.row != y.row) return x.row < y.row;
           return x.half < y.half;
         });
@@ -304,7 +306,7 @@ inline double sweep_simulate(int nb, int nwg, double T, int ktmax, SweepSchedule
 
 // The schedule for nb block columns on nwg update workgroups: the best T of a few by predicted time, from the longer of
 // the diagonal block's time and the average update time per step upwards; ktmax = the deepest unit that fits into T.
-inline void sweep_build(int nb, int nwg, SweepSchedule* S) {
+inline void sweep_build(int nb, int nwg, SweepSchedule* S, bool far_first = false) {
   double work = 0.0;   // k-tiles of half-tile units
   for (int c = 1; c < nb; ++c) {
     work += 2.0 * ((double)(nb - c + 1) * 4 * c - 4);
@@ -328,7 +330,7 @@ inline void sweep_build(int nb, int nwg, SweepSchedule* S) {
       bk = big;
     }
   }
-  sweep_simulate(nb, nwg, bT, bk, S);
+  sweep_simulate(nb, nwg, bT, bk, S, far_first);
 }
 // Replay a schedule symbolically; returns 0 when every tile half receives exactly the k range it must, in order, in
 // time, created once, and no two workgroups touch the same tile half in one step.  (tests)

@@ -84,7 +84,8 @@ class GPHandle:
         return lz.value
 
     def set_schedule(self, schedule=0, panel_group=0):
-        """Sweep schedule of factorize(): 0 by size, 1 two-stream look-ahead, 2 fused steps (include/elfihip.h)."""
+        """Sweep schedule of factorize(): 0 by size, 1 two-stream look-ahead, 2 fused steps, 3 fused steps chained inside
+        one launch per block column (include/elfihip.h)."""
         self._check(self.lib.elfihip_gp_set_schedule(self.h, int(schedule), int(panel_group)))
 
     def set_dense_threshold(self, min_points=0, tile_rows=0):

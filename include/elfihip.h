@@ -295,7 +295,10 @@ int elfihip_gp_append(elfihip_gp* gp, const double* X_new, const double* y_new, 
 int elfihip_gp_factorize(elfihip_gp* gp, double* log_marginal);
 /* How elfihip_gp_factorize schedules its sweep over the 128-wide block columns (no reference counterpart: GPy hands
  * the factorisation to LAPACK).  schedule 0 = chosen by size (default), 1 = two-stream look-ahead with panel groups,
- * 2 = fused steps on the caller's stream (the next diagonal block factored beside the trailing update, one launch);
+ * 2 = fused steps on the caller's stream (panel solve, diagonal tile, then ONE launch with the next diagonal block
+ * beside the trailing update: three launches per block column), 3 = the same chained by arrival counters inside ONE
+ * launch per block column (kept for measurement: the in-launch hand-offs cost more than the two launches they replace;
+ * needs all of the launch's workgroups resident, i.e. the device to itself);
  * panel_group 0 = by size, else 1 / 2 / 4 panels per pass over the trailing matrix (schedule 1).  Results agree to
  * rounding between schedules; each is deterministic. */
 int elfihip_gp_set_schedule(elfihip_gp* gp, int schedule, int panel_group);

@@ -21,7 +21,7 @@ for n, d in shapes:
     gp.set_data(X, y)
     flops = 2.0 * n * n * d + 2.0 * n ** 3 / 3.0
     ref = None
-    for name, sched, group in (("streams (auto group)", 1, 0), ("streams G=1", 1, 1), ("fused steps", 2, 0)):
+    for name, sched, group in (("streams (auto group)", 1, 0), ("fused steps", 2, 0), ("fused steps, chained", 3, 0)):
         gp.set_schedule(sched, group)
         lz = gp.factorize()
         if ref is None:

@@ -265,13 +265,14 @@ def _fit_with_schedule(X, y, h, schedule, group=0):
     return gp, gp.factorize()
 
 
-# schedule 1 = two-stream look-ahead with panel groups, 2 = fused steps (include/elfihip.h: elfihip_gp_set_schedule);
-# 0 = the size-dependent default.  Block columns nb = ceil(n / 128): every branch of the stream schedule's group / pass
+# schedule 1 = two-stream look-ahead with panel groups, 2 = fused steps, 3 = fused steps chained inside one launch per
+# block column (include/elfihip.h: elfihip_gp_set_schedule); 0 = the size-dependent default.  Block columns nb = ceil(n / 128): every branch of the stream schedule's group / pass
 # selection (nb < 30: single panels, fine pass; 30..39: groups of 4, square tiles; 40..47: groups of 2, fine pass;
 # >= 48: groups of 4, fine pass) and the fused schedule on both sides of its default range are in the list.
 @pytest.mark.parametrize('n,d,schedule,group', [
     (100, 2, 1, 0), (100, 2, 2, 0), (129, 3, 1, 0), (129, 3, 2, 0), (700, 5, 1, 2), (700, 5, 2, 0),
-    (1500, 10, 1, 4), (1500, 10, 2, 0), (2500, 4, 1, 0), (2500, 4, 2, 0)])
+    (1500, 10, 1, 4), (1500, 10, 2, 0), (2500, 4, 1, 0), (2500, 4, 2, 0),
+    (100, 2, 3, 0), (129, 3, 3, 0), (700, 5, 3, 0), (2500, 4, 3, 0)])
 def test_both_sweep_schedules_vs_oracle(hip_ctx, n, d, schedule, group):
     X, y, bounds, h, post = _oracle_for(n, d)
     gp, logz = _fit_with_schedule(X, y, h, schedule, group)
@@ -282,10 +283,10 @@ def test_both_sweep_schedules_vs_oracle(hip_ctx, n, d, schedule, group):
 
 
 @pytest.mark.parametrize('n,d,schedule', [
-    (4096, 10, 0), (4096, 10, 1), (4096, 10, 2),      # cfg3 metric shape: nb = 32
+    (4096, 10, 0), (4096, 10, 1), (4096, 10, 2), (4096, 10, 3),   # cfg3 metric shape: nb = 32
     (5120, 10, 0), (5120, 10, 1), (5120, 10, 2),      # nb = 40: stream schedule switches to groups of 2 + fine pass
     (6144, 10, 1), (6144, 10, 2),                     # nb = 48: groups of 4 + fine pass
-    (8192, 20, 0), (8192, 20, 1), (8192, 20, 2),      # cfg5 shape: nb = 64
+    (8192, 20, 0), (8192, 20, 1), (8192, 20, 2), (8192, 20, 3),   # cfg5 shape: nb = 64
     (10240, 10, 0)])                                  # nb = 80: the fused schedule's largest sizes (default up to 96)
 def test_large_n_full_matrix_parity(hip_ctx, n, d, schedule):
     """Every entry of L, L^-T, alpha and the log marginal at the sizes of BASELINE.json configs[2] / configs[4], plus
