@@ -12,7 +12,7 @@
 //     and no triangular solves, whose 32-step dependency chain is what makes the
 //     reference's per-point predict an O(n^2) BLAS-2 affair.
 //   * per block column: (1) potf2_tiles: one workgroup factors the 128x128 diagonal block and
-//     its inverse in LDS; (2) trsm: every row block below / above multiplies its panel by
+//     its inverse, every 16x16 tile in registers; (2) trsm: every row block below / above multiplies its panel by
 //     W11^T on the matrix cores (a 128x128x128 GEMM per workgroup); (3) update: one launch
 //     of 128x128 f64-MFMA tiles does the SYRK on the trailing lower triangle AND the GEMM
 //     on the y row and on the growing L^-T rows.

@@ -44,7 +44,7 @@ int main() {
       CK(hipMemcpy(dU, U.data(), U.size() * 16, hipMemcpyHostToDevice));
       CK(hipMemcpy(dO, O.data(), O.size() * 4, hipMemcpyHostToDevice));
       CK(hipMemcpy(dH, H.data(), H.size() * 16, hipMemcpyHostToDevice));
-      StepArgs S;
+      StepArgs S = {};
       S.P.A = A; S.P.WT = WT; S.P.W11 = nullptr; S.P.lda = lda; S.P.k = 0; S.P.nb = nb; S.P.ku0 = 0; S.P.kun = 1;
       S.W11 = nullptr; S.info = nullptr; S.units = dU; S.wg_off = dO; S.heads = dH;
       float best = 1e9f;
