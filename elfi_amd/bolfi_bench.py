@@ -166,6 +166,8 @@ def run(n=4096, d=10, S=10, iters=50, warm=3):
                                 "HBM-bound: %.0f MB per update" % (2 * 8.0 * n * n / 2 / 1e6)},
     }
     out["fit_large"] = fit_only(8192, 20)
+    # the sizes a real run's hyper-parameter searches rebuild at (configs[2]: 512 ... 4096): chain-bound, not MFMA-bound
+    out["fit_small"] = {str(m): fit_only(m, d) for m in (1024, 2048)}
     out["cfg5"] = cfg5_leg()
     return out
 
