@@ -196,3 +196,27 @@ def test_loop_timers_split_update_search_and_acquire():
     assert 'update' not in gp.__dict__ and 'acquire' not in acq.__dict__
     s = T.summary(0.05, 6)
     assert abs(sum(s['share'].values()) - 1.0) < 1e-9 and s['rebuilds_in_searches'] == 14
+
+
+def test_truncnorm_draw_is_the_public_call_bit_for_bit():
+    """lcb_acquisition.truncnorm_draw (the jitter of acquire(), acquisition.py:174-191): same values and same generator
+    state as ss.truncnorm.rvs, through the direct form and through the fall-backs."""
+    import scipy.stats as ss
+    import elfi_amd.lcb_acquisition as L
+    rs1, rs2 = np.random.RandomState(3), np.random.RandomState(3)
+    std = np.sqrt(0.1)
+    for k in range(300):
+        lo, hi = (0.0, 2.0) if k % 3 else (-1.0, 0.5)
+        c = np.array([rs1.uniform(lo, hi)])
+        assert rs2.uniform(lo, hi) == c[0]
+        a, b = (lo - c) / std, (hi - c) / std
+        x1 = ss.truncnorm.rvs(a, b, loc=c, scale=std, size=1, random_state=rs1)
+        x2 = L.truncnorm_draw(a, b, c, std, 1, rs2)
+        assert np.array_equal(x1, x2)
+    assert L._TRUNCNORM_DIRECT in (True, False)
+    # batches of several points take the public call
+    c = np.array([0.3, 1.1, 1.9])
+    x1 = ss.truncnorm.rvs((0 - c) / std, (2 - c) / std, loc=c, scale=std, size=3, random_state=rs1)
+    x2 = L.truncnorm_draw((0 - c) / std, (2 - c) / std, c, std, 3, rs2)
+    assert np.array_equal(x1, x2)
+    assert np.array_equal(rs1.get_state()[1], rs2.get_state()[1]) and rs1.get_state()[2] == rs2.get_state()[2]
