@@ -59,13 +59,58 @@ def _allgather_starts(locs, vals, iters, n_starts, world, device):
 _TRUNCNORM_DIRECT = None   # None: not yet checked in this process; True / False: the direct form reproduces the public call
 
 
+_PPF_LEAN = None       # None: being checked against SciPy's _ppf call by call; True: trusted; False: not used
+_PPF_LEAN_CHECKS = 0
+
+
+def _logsumexp2(p, q):
+    """scipy.special.logsumexp([p, q], axis=0) for two real 1-element arrays, operation by operation as
+    scipy/special/_logsumexp.py forms it (the maximum is taken out, log1p of the rest over the multiplicity, then
+    + log(multiplicity) + maximum) -- without the array-namespace machinery that makes up its 45 us per call."""
+    if p[0] == q[0]:
+        return np.log1p(np.zeros(1)) + np.log(np.full(1, 2.0)) + p
+    hi, lo = (p, q) if p[0] > q[0] else (q, p)
+    return np.log1p(np.exp(lo - hi)) + np.log(np.ones(1)) + hi
+
+
+def _truncnorm_ppf_lean(q, a, b):
+    """truncnorm_gen._ppf(q, a, b) (scipy/stats/_continuous_distns.py) for 1-element arrays whose interval contains 0
+    (a <= 0 <= b, not both 0 -- the jitter of a point inside or on its bounds): the same special functions in the same
+    order.  None where SciPy takes its complex-valued branch (an interval on one side of 0)."""
+    import scipy.special as sc
+    if not (a[0] <= 0.0 <= b[0]) or b[0] <= 0.0:
+        return None
+    log_mass = sc.log1p(-sc.ndtr(a) - sc.ndtr(-b))
+    if a[0] < 0.0:
+        return sc.ndtri_exp(_logsumexp2(sc.log_ndtr(a), np.log(q) + log_mass))
+    return -sc.ndtri_exp(_logsumexp2(sc.log_ndtr(-b), np.log1p(-q) + log_mass))
+
+
 def _truncnorm_direct(a, b, loc, scale, random_state):
     """One truncated-normal draw the way `ss.truncnorm.rvs(a, b, loc=loc, scale=scale, size=1, random_state=...)` makes
     it (scipy/stats/_continuous_distns.py, truncnorm_gen._rvs_scalar: U = random_state.uniform(0, 1, N), then the
     distribution's own _ppf, then * scale + loc) without rv_continuous.rvs' argument machinery in front of it
-    (350 us per call on this box against 200; a BOLFI acquisition makes one call per parameter)."""
+    (350 us per call on this box against 200; a BOLFI acquisition makes one call per parameter).  The quantile itself
+    through the lean restatement above (15 us against 100) once that has agreed with SciPy's _ppf bit for bit on its
+    first 64 uses in this process."""
+    global _PPF_LEAN, _PPF_LEAN_CHECKS
     U = random_state.uniform(low=0, high=1, size=1)
-    return ss.truncnorm._ppf(U, a, b) * scale + loc
+    x = None
+    if _PPF_LEAN is not False:
+        a1, b1 = np.asarray(a, dtype=float).reshape(1), np.asarray(b, dtype=float).reshape(1)
+        x = _truncnorm_ppf_lean(U, a1, b1)
+        if x is not None and _PPF_LEAN is None:
+            ref = ss.truncnorm._ppf(U, a, b)
+            if np.shape(ref) != np.shape(x) or not np.array_equal(ref, x):
+                _PPF_LEAN = False
+            else:
+                _PPF_LEAN_CHECKS += 1
+                if _PPF_LEAN_CHECKS >= 64:
+                    _PPF_LEAN = True
+            x = ref
+    if x is None:
+        x = ss.truncnorm._ppf(U, a, b)
+    return x * scale + loc
 
 
 def truncnorm_draw(a, b, loc, scale, size, random_state):

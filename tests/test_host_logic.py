@@ -220,3 +220,32 @@ def test_truncnorm_draw_is_the_public_call_bit_for_bit():
     x2 = L.truncnorm_draw((0 - c) / std, (2 - c) / std, c, std, 3, rs2)
     assert np.array_equal(x1, x2)
     assert np.array_equal(rs1.get_state()[1], rs2.get_state()[1]) and rs1.get_state()[2] == rs2.get_state()[2]
+
+
+def test_lean_truncnorm_quantile_is_scipys_bit_for_bit():
+    """The restatement of truncnorm_gen._ppf that acquire()'s jitter uses after its run-time check: every branch it
+    accepts, against SciPy's own function, bit for bit (declines intervals on one side of 0)."""
+    import scipy.stats as ss
+    import elfi_amd.lcb_acquisition as L
+    rs = np.random.RandomState(0)
+    n_checked = 0
+    for k in range(20000):
+        q = rs.uniform(size=1)
+        if k % 7 == 0:
+            q = np.array([rs.choice([1e-300, 1e-17, 0.5, 1 - 1e-16, 1e-8])])
+        lo, hi = sorted(rs.uniform(-40, 40, 2))
+        if k % 3 == 0:
+            lo, hi = -abs(lo) - 1e-3, abs(hi) + 1e-3
+        if k % 11 == 0:
+            lo, hi = 0.0, abs(hi) + 0.1
+        if k % 13 == 0:
+            lo, hi = -abs(lo) - 0.1, 0.0
+        a, b = np.array([lo]), np.array([hi])
+        x = L._truncnorm_ppf_lean(q, a, b)
+        if x is None:
+            assert not (lo <= 0.0 < hi)
+            continue
+        ref = ss.truncnorm._ppf(q, a, b)
+        assert np.array_equal(ref, x) or (np.isnan(ref).all() and np.isnan(x).all()), (q, a, b, ref, x)
+        n_checked += 1
+    assert n_checked > 5000
