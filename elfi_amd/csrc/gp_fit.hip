@@ -210,14 +210,15 @@ __device__ __forceinline__ void potf2_tiles_body(double* Akk_, int64_t lda, doub
   // to itself (waves 7, 11, ... leave at once; a finished wave no longer counts at s_barrier): beside waves that keep
   // the SIMD's matrix pipe busy the elimination wave is hardly issued at all (measured: no progress during the 3 000
   // cycles of a panel's deferred updates).  The eight row blocks go to the other three classes so that the MFMA work of
-  // every panel is as even as a fixed assignment allows (rows {0, 7}, {1, 3, 4}, {2, 5, 6}: the matrix tiles of the late
+  // every panel is as even as a fixed assignment allows, counting the 1 500 cycles the class of the next diagonal tile's
+  // wave waits for it (rows {0, 7}, {1, 2, 6}, {3, 4, 5}: the matrix tiles of the late
   // rows are busy in the early panels, the identity tiles of the early rows in the late ones).
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (wid >= 11 || wid == 7 || wid == 8) return;
   //                      wid:  0  1  2  3  4  5  6  7  8  9  10
-  constexpr unsigned long long ROW_OF_WAVE = 0x6'4'f'f'5'3'7'8'2'1'0ull;   // nibbles; 8: the factor wave
+  constexpr unsigned long long ROW_OF_WAVE = 0x5'6'f'f'4'2'7'8'3'1'0ull;   // nibbles; 8: the factor wave
   const int R = (int)((ROW_OF_WAVE >> (4 * wid)) & 15);
-  constexpr unsigned CLASS_OF_ROW = 0x0'2'2'1'1'2'1'0u;                     // nibble R: SIMD class of row block R's wave
+  constexpr unsigned CLASS_OF_ROW = 0x0'1'2'2'2'1'1'0u;                     // nibble R: SIMD class of row block R's wave
   gdouble* Akk = (gdouble*)Akk_;
   gdouble* Wkk = (gdouble*)Wkk_;
   gdouble* W11 = (gdouble*)W11_;
