@@ -169,8 +169,10 @@ __device__ __forceinline__ void sqrt_rsqrt(double p, double& s, double& y) {
 //                  -> (wave p+1: diagonal tile into LDS for the factor wave, which polls a flag word for it)
 //                  -> U(p-1) on its remaining tiles, the panel to global memory -> barrier B(p+1)
 // U(q) of an off-diagonal tile needs another wave's panel and is therefore applied one panel late (at panel q+1), which
-// is early enough: tile (R, C) is first READ at panel C.  LDS: M (2 x 2 KiB), the negated panels (2 x 16 KiB), 2 KiB for
-// the diagonal tile on its way to one lane per row.
+// is early enough: tile (R, C) is first READ at panel C.  (In the code the slots are RELATIVE to the panel and rotate, so
+// that every panel runs the same instructions; waves that share a SIMD with the wave of the next diagonal tile let it
+// finish its twelve MFMAs first.)  LDS: M (2 x 2 KiB), the negated panels (2 x 16 KiB), 4 KiB for the diagonal tile on
+// its way to one lane per row above the identity rows, 21 KiB of staging tiles for the stores to global memory.
 // Round 2's form (three elimination waves holding one row of the whole 144-row panel per lane, thirteen update waves,
 // two LDS round trips per panel) took 35 us per block, 40 % of it elimination; this one has the elimination of ONE
 // 16 x 16 tile (with its identity rows), 12 MFMAs, one LDS flag and one barrier on the chain.
