@@ -21,10 +21,20 @@ from .weighted import weighted_sample_quantile, weighted_var  # noqa: F401
 from .gp import GPHandle, HipGPRegression  # noqa: F401
 from .selection import RunningBest, merge_batch, smallest_k  # noqa: F401
 from .sampler import HipRejection, hip_rejection_class  # noqa: F401
+from .distance import adaptive_batch  # noqa: F401
+from .adaptive import hip_adaptive_distance_class  # noqa: F401
+from .smc import HipAdaptiveDistanceSMC, HipAdaptiveThresholdSMC, HipSMC, hip_smc_class  # noqa: F401
 from .summaries import autocov, ma2_distance, ss_mean, ss_var  # noqa: F401
 from .lcb_acquisition import HipLCBSC  # noqa: F401
 from .posterior import HipBolfiPosterior, sample_posterior  # noqa: F401
 from . import chains, multistart  # noqa: F401
 from .maxvar_acquisition import HipExpIntVar, HipMaxVar, HipRandMaxVar  # noqa: F401
+
+
+
+def HipAdaptiveDistance(*summaries, **kwargs):
+    """elfi.AdaptiveDistance(*summaries, **kwargs) with the node's arithmetic on the GPU (elfi_amd/adaptive.py)."""
+    return hip_adaptive_distance_class()(*summaries, **kwargs)
+
 
 __version__ = "0.1.0"

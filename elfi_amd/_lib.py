@@ -79,6 +79,12 @@ PROTOTYPES = {
     "elfihip_reject_push_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64]),
     "elfihip_reject_push": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int64]),
     "elfihip_reject_set_accept": (C.c_int, [C.c_void_p, C.c_int, C.c_double]),
+    "elfihip_reject_set_accept_cols": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "elfihip_adaptive_push_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_void_p,
+                                           C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64]),
+    "elfihip_adaptive_push": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_void_p,
+                                       C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.c_void_p, C.c_void_p,
+                                       C.c_int64]),
     "elfihip_reject_meta": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "elfihip_reject_state_dev": (C.c_int, [C.c_void_p, c_void_pp, c_void_pp]),
     "elfihip_reject_export_dev": (C.c_int, [C.c_void_p, C.c_void_p]),

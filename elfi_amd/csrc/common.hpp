@@ -67,6 +67,7 @@ struct elfihip_ctx {
   std::string err;
   // staging buffers for the host entry points
   elfihip::DevBuf in, out, par, scratch;
+  elfihip::DevBuf stat;   // workgroup partials of the fused adaptive-distance pass (adaptive.hip; topk.hip owns `scratch`)
 };
 
 namespace elfihip {

@@ -89,6 +89,7 @@ int elfihip_ctx_destroy(elfihip_ctx* ctx) {
     ctx->out.release();
     ctx->par.release();
     ctx->scratch.release();
+    ctx->stat.release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->ev_a) (void)hipEventDestroy(ctx->ev_a);

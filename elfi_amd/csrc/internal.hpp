@@ -25,4 +25,19 @@ elfihip_ctx* reject_ctx(elfihip_reject* h);
 int reject_push_rows_impl(elfihip_reject* h, int metric, const double* dX, int64_t n, int m, int64_t ldx,
                           const double* dy, const double* daux, double p, double* dout, int64_t row_base);
 
+
+// welford.hip: AdaptiveDistance.add_data in the reference's own (two-pass) form, into dstate (1 + 2m)
+int welford_dev_impl(elfihip_ctx* ctx, const double* dX, int64_t n, int m, int64_t ldx, double* dstate);
+
+// adaptive.hip: the fused pass of an adaptive-distance batch (K nested distances + column statistics + selection)
+bool adaptive_pass_supported(const double* dX, int m, int64_t ldx, int K);
+int adaptive_max_parts(const elfihip_ctx* ctx);
+int adaptive_pass_impl(elfihip_ctx* ctx, const double* dX, int64_t n, int m, int64_t ldx, const double* dy,
+                       const double* dW, int K, double* dout, const RejectFilter* F, const double* dacc,
+                       unsigned long long* dacc_count, double* partial, int* nparts);
+int adaptive_stats_finish(elfihip_ctx* ctx, const double* partial, int nparts, int m, double* bst, double* dstate);
+// reject.hip: the batch against a sampler state (h may be NULL: distances and statistics only)
+int adaptive_push_impl(elfihip_ctx* ctx, elfihip_reject* h, const double* dX, int64_t n, int m, int64_t ldx,
+                       const double* dy, const double* dW, int K, double* dout, double* dwelford, int64_t row_base);
+
 }  // namespace elfihip

@@ -55,6 +55,9 @@ struct elfihip_reject {
   // acceptance threshold (samplers.py:219-225)
   bool has_accept = false;
   double accept = 0.0;
+  int acc_ncols = 0;                         // > 0: one threshold per nested column (AdaptiveDistanceSMC, samplers.py:657-660)
+  elfihip::DevBuf acc_mem;                   // REJ_ACC_COLS thresholds on the device (a scalar threshold fills them all)
+  double* acc_dev = nullptr;
   unsigned long long* acc_count = nullptr;   // device: rows accepted so far
   unsigned long long acc_seen = 0;           // ... as of the previous meta() read
   // k > REJ_MAX_K: sorted host copy of the state, merged on the host after every push
@@ -71,6 +74,10 @@ constexpr int REJ_MERGE_EVERY = 8;        // pushes per merge
 constexpr unsigned int REJ_CAP = 1u << 16;   // smallest candidate list
 constexpr int64_t REJ_MAX_K_HOST = 1 << 20;  // host-merge states
 constexpr double REJ_HEAVY = 8192.0;         // expected candidates from which a push takes the radix selection
+constexpr int REJ_ACC_COLS = 64;             // nested columns an acceptance condition can cover (= kMaxK of distance.hip)
+// provisional threshold of a large first batch (adaptive_push_impl)
+constexpr int64_t REJ_PROV_MIN_ROWS = 1 << 20;
+constexpr unsigned int REJ_PROV_MAX_CAND = 1u << 16;
 
 __device__ __forceinline__ bool rej_less(double av, long long ar, double bv, long long br) {
   return av < bv || (av == bv && ar < br);
@@ -234,7 +241,7 @@ __global__ __launch_bounds__(1024) void reject_merge_kernel(RejArgs S) {
 // column = the last of `ncols` nested columns) against the threshold.  accept != NULL: a row takes part only if EVERY
 // one of its columns is <= *accept (samplers.py:219-225), and the rows that do are counted.
 __global__ __launch_bounds__(256) void reject_filter_kernel(const double* d, int64_t n, int64_t stride, int ncols,
-                                                            RejectFilter F, int use_accept, double accept,
+                                                            RejectFilter F, int use_accept, const double* acc,
                                                             unsigned long long* acc_count) {
   const double thr = *F.thr;
   const int64_t nround = (n + (int64_t)gridDim.x * 256 - 1) / ((int64_t)gridDim.x * 256);
@@ -244,7 +251,7 @@ __global__ __launch_bounds__(256) void reject_filter_kernel(const double* d, int
     const double v = i < n ? d[i * stride] : 0.0;
     bool ok = i < n;
     if (use_accept && ok)
-      for (int c = 0; c < ncols; ++c) ok = ok && d[i * stride - c] <= accept;
+      for (int c = 0; c < ncols; ++c) ok = ok && d[i * stride - c] <= acc[ncols - 1 - c];
     if (use_accept) mine += __popcll(__ballot(ok));   // uniform branch: every lane of the wave holds the wave's count
     reject_offer(F, ok && v < thr, v, F.row_base + i);
   }
@@ -458,10 +465,12 @@ static int reject_push(elfihip_reject* h, int64_t n, const double* dsel, int64_t
     int g = (int)((n + 255) / 256);
     if (g > ctx->cu_count * 8) g = ctx->cu_count * 8;
     hipLaunchKernelGGL(reject_filter_kernel, dim3(g), dim3(256), 0, st, dsel, n, stride, ncols, F, h->has_accept ? 1 : 0,
-                       h->accept, h->acc_count);
+                       h->acc_dev, h->acc_count);
   }
   h->pending_rows += n;
-  if (!full) h->filled = h->filled + n < h->k ? h->filled + n : h->k;   // (acceptance mode fills through the list)
+  // rows that ENTERED the state: every offered row without an acceptance condition; with one, the accepted rows -- the
+  // count elfihip_reject_meta reads back (until then the state keeps merging after every push, which is always correct)
+  if (!full && !h->has_accept) h->filled = h->filled + n < h->k ? h->filled + n : h->k;
   // Merge interval: the p-th push after the state became full offers about k / p candidates (batches of one
   // distribution), so merging every p / 2 pushes -- at most every REJ_MERGE_EVERY-th -- keeps a merge at about k / 2
   // candidates: early on, while the threshold still falls quickly, after every push.  Host-merge states and states
@@ -484,6 +493,182 @@ int reject_push_rows_impl(elfihip_reject* h, int metric, const double* dX, int64
   });
 }
 
+// ---- one AdaptiveDistance batch: distances + column statistics + selection in one read (adaptive.hip) -------------
+// The j best rows of a batch's prefix sit at the head of the candidate list with batch-local row numbers: make the
+// numbers global, make the j-th distance the threshold of the pass over the rest, and let the list continue behind them.
+__global__ void reject_seed_kernel(double* thr, unsigned int* count, const double* cand_val, long long* cand_row, int j,
+                                   long long row_base) {
+  for (int e = threadIdx.x; e < j; e += blockDim.x) cand_row[e] += row_base;
+  if (threadIdx.x == 0) {
+    *thr = cand_val[j - 1];
+    *count = (unsigned int)j;
+  }
+}
+
+__global__ void reject_unseed_kernel(double* thr, unsigned int* count, const double* best_val, int k) {
+  *thr = best_val[k - 1];
+  *count = 0u;
+}
+
+// h == nullptr: distances and statistics only (what the AdaptiveDistance node computes when a batch is generated).
+// dwelford: the running (count, mean, M2) store of add_data, 1 + 2m doubles on the device (nullptr: no statistics).
+// dout: (n, K) or nullptr (the distances are then kept only as far as the selection needs them).
+int adaptive_push_impl(elfihip_ctx* ctx, elfihip_reject* h, const double* dX, int64_t n, int m, int64_t ldx,
+                       const double* dy, const double* dW, int K, double* dout, double* dwelford, int64_t row_base) {
+  hipStream_t st = ctx->stream;
+  const bool fused = adaptive_pass_supported(dX, m, ldx, K);
+  const size_t ns = 1 + 2 * (size_t)m;
+  const int maxp = adaptive_max_parts(ctx);
+  double *partial = nullptr, *bst = nullptr;
+  if (dwelford && fused) {
+    ELFIHIP_CHECK_HIP(ctx, ctx->stat.reserve((2 * (size_t)maxp * ns + ns) * sizeof(double)));
+    partial = ctx->stat.as<double>();
+    bst = partial + 2 * (size_t)maxp * ns;
+  }
+  int nparts = 0;
+  // the pass over rows [lo, hi): distances to o (may be nullptr when fused), statistics into the next partial slots
+  auto pass = [&](int64_t lo, int64_t hi, const RejectFilter* F, bool with_acc, double* o) -> int {
+    const double* X = dX + lo * ldx;
+    if (fused) {
+      int np = 0;
+      ELFIHIP_TRY(adaptive_pass_impl(ctx, X, hi - lo, m, ldx, dy, dW, K, o, F, with_acc ? h->acc_dev : nullptr,
+                                     with_acc ? h->acc_count : nullptr, partial ? partial + (size_t)nparts * ns : nullptr,
+                                     &np));
+      nparts += np;
+      return ELFIHIP_OK;
+    }
+    return dist_multiw_dev_impl(ctx, X, hi - lo, m, ldx, dy, dW, K, o, nullptr, nullptr);
+  };
+  auto finish_stats = [&]() -> int {
+    if (!dwelford) return ELFIHIP_OK;
+    if (fused) return adaptive_stats_finish(ctx, partial, nparts, m, bst, dwelford);
+    return welford_dev_impl(ctx, dX, n, m, ldx, dwelford);   // (odd m, wide rows, many weight vectors: the two-pass form)
+  };
+  // distances the selection can read when the caller keeps none
+  auto scratch_out = [&](int64_t rows, double** o) -> int {
+    ELFIHIP_CHECK_HIP(ctx, ctx->out.reserve((size_t)rows * K * sizeof(double)));
+    *o = ctx->out.as<double>();
+    return ELFIHIP_OK;
+  };
+  if (!h) {
+    double* o = dout;
+    if (!fused && !o) ELFIHIP_TRY(scratch_out(n, &o));
+    ELFIHIP_TRY(pass(0, n, nullptr, false, o));
+    return finish_stats();
+  }
+  ELFIHIP_REQUIRE(ctx, h->acc_ncols == 0 || h->acc_ncols == K, "%d acceptance thresholds but K = %d nested distances",
+                  h->acc_ncols, K);
+  ELFIHIP_TRY(ensure_cap(h, n));
+  const bool full = h->host_mode ? (int64_t)h->hval.size() >= h->k : h->filled >= h->k;
+  if (!fused) {
+    // distances first, then the state's own candidate pass over them
+    double* o = dout;
+    if (!o) ELFIHIP_TRY(scratch_out(n, &o));
+    ELFIHIP_TRY(pass(0, n, nullptr, false, o));
+    ELFIHIP_TRY(reject_push(h, n, o + (K - 1), K, K, (long long)row_base, [&](const RejectFilter*, bool* filtered) {
+      *filtered = false;
+      return ELFIHIP_OK;
+    }));
+    return finish_stats();
+  }
+  const double expect = full ? (double)n * (double)h->k / (double)std::max<int64_t>(h->rows_seen, 1) : 1e300;
+  const bool select = !h->has_accept && (!full || expect > REJ_HEAVY);
+  h->rows_seen += n;
+  auto merge_list = [&](int ncand, long long row_offset) -> int {
+    if (h->host_mode) return host_merge(h, ncand < 0 ? ~0u : (unsigned int)ncand, row_offset);
+    hipLaunchKernelGGL(reject_merge_kernel, dim3(1), dim3(1024), REJ_MERGE_LDS, st, merge_args(h, ncand, row_offset));
+    return launch_status(ctx, "reject_merge_kernel");
+  };
+  if (select && !full && n >= REJ_PROV_MIN_ROWS && 64 * h->k <= n) {
+    // A large first batch (an SMC round starts from an empty state: samplers.py:474-487).  Every row could enter, so
+    // there is no threshold for the kernel to filter with, and a radix selection over all n distances costs as much
+    // as the pass itself (10^7 x 3: 0.65 ms).  Instead: the j-th smallest distance T of a PREFIX of s rows (j a few
+    // standard deviations above the k s / n of the batch's k best that fall into the prefix of exchangeable rows) is
+    // with overwhelming probability above the batch's k-th smallest, and then the prefix's j best + the rows of the
+    // rest below T -- about j n / s of them -- contain the batch's k best.  That is CHECKED (the list's length is read
+    // back): if fewer than k rows qualified (the rows were not exchangeable: sorted input), or far too many, the
+    // selection of all n distances runs instead.  Exact either way.
+    ELFIHIP_TRY(reject_flush(h));
+    const int64_t s = std::min<int64_t>(std::max<int64_t>(n / 32, 16384), n / 2);
+    const double mu = (double)h->k * (double)s / (double)n;
+    int64_t j = (int64_t)std::ceil(mu + 6.0 * std::sqrt(mu) + 8.0);
+    if (j > h->k) j = h->k;
+    double* pre = dout;
+    if (!pre) ELFIHIP_TRY(scratch_out(s, &pre));
+    ELFIHIP_TRY(pass(0, s, nullptr, false, pre));
+    ELFIHIP_TRY(topk_dev_impl(ctx, pre + (K - 1), s, K, j, h->cand_val, reinterpret_cast<int64_t*>(h->cand_row), true));
+    hipLaunchKernelGGL(reject_seed_kernel, dim3(1), dim3(256), 0, st, h->thr, h->count, h->cand_val, h->cand_row, (int)j,
+                       (long long)row_base);
+    RejectFilter F;
+    F.thr = h->thr;
+    F.cval = h->cand_val;
+    F.crow = h->cand_row;
+    F.count = h->count;
+    F.cap = h->cap;
+    F.row_base = (long long)row_base + s;
+    ELFIHIP_TRY(pass(s, n, &F, false, dout ? dout + s * K : nullptr));
+    unsigned int c = 0;
+    ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(&c, h->count, sizeof c, hipMemcpyDeviceToHost, st));
+    ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(st));
+    if ((int64_t)c >= h->k && (int64_t)c <= std::max<int64_t>(REJ_PROV_MAX_CAND, 64 * j) && c <= h->cap) {
+      ELFIHIP_TRY(merge_list(-1, 0));
+    } else {
+      // the prefix did not represent the batch: selection over all n distances (recomputed when the caller kept none)
+      hipLaunchKernelGGL(reject_unseed_kernel, dim3(1), dim3(1), 0, st, h->thr, h->count, h->best_val,
+                         (int)std::min<int64_t>(h->k, REJ_MAX_K));
+      if (h->host_mode) {
+        const double inf = std::numeric_limits<double>::infinity();
+        const double thr = (int64_t)h->hval.size() >= h->k ? h->hval[h->k - 1] : inf;
+        ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(h->thr, &thr, sizeof thr, hipMemcpyHostToDevice, st));
+        ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(st));
+      }
+      double* all = dout;
+      if (!all) {
+        ELFIHIP_TRY(scratch_out(n, &all));
+        ELFIHIP_TRY(dist_multiw_dev_impl(ctx, dX, n, m, ldx, dy, dW, K, all, nullptr, nullptr));
+      }
+      const int64_t kb = n < h->k ? n : h->k;
+      ELFIHIP_TRY(topk_dev_impl(ctx, all + (K - 1), n, K, kb, h->cand_val, reinterpret_cast<int64_t*>(h->cand_row), true));
+      ELFIHIP_TRY(merge_list((int)kb, (long long)row_base));
+    }
+    h->filled = h->k;
+    h->unmerged = 0;
+    h->pending_rows = 0;
+    return finish_stats();
+  }
+  if (select) {
+    // (as reject_push: the state is still filling up, or very many rows would qualify) plain pass, radix selection of
+    // the batch's k best, merge
+    ELFIHIP_TRY(reject_flush(h));
+    double* o = dout;
+    if (!o) ELFIHIP_TRY(scratch_out(n, &o));
+    ELFIHIP_TRY(pass(0, n, nullptr, false, o));
+    const int64_t kb = n < h->k ? n : h->k;
+    ELFIHIP_TRY(topk_dev_impl(ctx, o + (K - 1), n, K, kb, h->cand_val, reinterpret_cast<int64_t*>(h->cand_row), true));
+    ELFIHIP_TRY(merge_list((int)kb, (long long)row_base));
+    h->filled = h->filled + n < h->k ? h->filled + n : h->k;
+    return finish_stats();
+  }
+  // the kernel lists the acceptable rows below the state's k-th distance itself
+  if (h->pending_rows + n > (int64_t)h->cap) ELFIHIP_TRY(reject_flush(h));
+  RejectFilter F;
+  F.thr = h->thr;
+  F.cval = h->cand_val;
+  F.crow = h->cand_row;
+  F.count = h->count;
+  F.cap = h->cap;
+  F.row_base = (long long)row_base;
+  ELFIHIP_TRY(pass(0, n, &F, h->has_accept, dout));
+  h->pending_rows += n;
+  if (!full && !h->has_accept) h->filled = h->filled + n < h->k ? h->filled + n : h->k;
+  ++h->armed_pushes;
+  int64_t interval = h->armed_pushes / 2;
+  interval = interval < 1 ? 1 : (interval > REJ_MERGE_EVERY ? REJ_MERGE_EVERY : interval);
+  if (h->host_mode || !full) interval = 1;
+  if (++h->unmerged >= interval) ELFIHIP_TRY(reject_flush(h));
+  return finish_stats();
+}
+
 }  // namespace elfihip
 
 using namespace elfihip;
@@ -496,6 +681,7 @@ int elfihip_reject_free(elfihip_reject* h) {
   (void)hipStreamSynchronize(h->ctx->stream);
   h->mem.release();
   h->cand_mem.release();
+  h->acc_mem.release();
   delete h;
   return ELFIHIP_OK;
 }
@@ -519,8 +705,10 @@ int elfihip_reject_create(elfihip_ctx* ctx, int64_t k, elfihip_reject** out) {
   const size_t bytes = (size_t)k * 16 + 64;
   hipError_t e = h->mem.reserve(bytes);
   if (e == hipSuccess) e = h->cand_mem.reserve((size_t)REJ_CAP * 16);
+  if (e == hipSuccess) e = h->acc_mem.reserve(REJ_ACC_COLS * sizeof(double));
   if (e != hipSuccess) {
     h->mem.release();
+    h->cand_mem.release();
     delete h;
     return fail(ctx, ELFIHIP_ERR_NOMEM, "sampler state allocation failed: %s", hipGetErrorString(e));
   }
@@ -536,6 +724,7 @@ int elfihip_reject_create(elfihip_ctx* ctx, int64_t k, elfihip_reject** out) {
   h->cap = (unsigned int)std::min<size_t>(h->cand_mem.cap / 16, 0x7fffffffu);
   h->cand_val = h->cand_mem.as<double>();
   h->cand_row = reinterpret_cast<long long*>(h->cand_val + h->cap);
+  h->acc_dev = h->acc_mem.as<double>();
   int rc = reject_reset_impl(h);
   if (rc != ELFIHIP_OK) {
     elfihip_reject_free(h);
@@ -644,6 +833,32 @@ int elfihip_reject_set_accept(elfihip_reject* h, int enable, double threshold) {
   ELFIHIP_REQUIRE(h->ctx, h->rows_seen == 0, "set the acceptance threshold before the first push (or after a reset)");
   h->has_accept = enable != 0;
   h->accept = threshold;
+  h->acc_ncols = 0;
+  if (h->has_accept) {
+    DeviceGuard g(h->ctx->device);
+    double v[REJ_ACC_COLS];
+    for (double& x : v) x = threshold;
+    ELFIHIP_CHECK_HIP(h->ctx, hipMemcpyAsync(h->acc_dev, v, sizeof v, hipMemcpyHostToDevice, h->ctx->stream));
+    ELFIHIP_CHECK_HIP(h->ctx, hipStreamSynchronize(h->ctx->stream));   // `v` is a stack array
+  }
+  return ELFIHIP_OK;
+}
+
+int elfihip_reject_set_accept_cols(elfihip_reject* h, int ncols, const double* thresholds) {
+  if (!h) return fail(nullptr, ELFIHIP_ERR_ARG, "state is NULL");
+  ELFIHIP_REQUIRE(h->ctx, ncols >= 1 && ncols <= REJ_ACC_COLS && thresholds, "ncols = %d outside [1, %d]", ncols, REJ_ACC_COLS);
+  ELFIHIP_REQUIRE(h->ctx, h->rows_seen == 0, "set the acceptance thresholds before the first push (or after a reset)");
+  double v[REJ_ACC_COLS];
+  for (int c = 0; c < REJ_ACC_COLS; ++c) {
+    v[c] = c < ncols ? thresholds[c] : std::numeric_limits<double>::infinity();
+    ELFIHIP_REQUIRE(h->ctx, v[c] == v[c], "acceptance threshold %d is NaN", c);
+  }
+  DeviceGuard g(h->ctx->device);
+  ELFIHIP_CHECK_HIP(h->ctx, hipMemcpyAsync(h->acc_dev, v, sizeof v, hipMemcpyHostToDevice, h->ctx->stream));
+  ELFIHIP_CHECK_HIP(h->ctx, hipStreamSynchronize(h->ctx->stream));
+  h->has_accept = true;
+  h->accept = thresholds[ncols - 1];
+  h->acc_ncols = ncols;
   return ELFIHIP_OK;
 }
 
@@ -651,6 +866,9 @@ int elfihip_reject_push(elfihip_reject* h, const double* D, int64_t n, int ncols
   if (!h) return fail(nullptr, ELFIHIP_ERR_ARG, "state is NULL");
   elfihip_ctx* ctx = h->ctx;
   ELFIHIP_REQUIRE(ctx, n >= 0 && ncols >= 1 && (n == 0 || D), "bad arguments");
+  ELFIHIP_REQUIRE(ctx, ncols <= REJ_ACC_COLS, "ncols = %d above %d", ncols, REJ_ACC_COLS);
+  ELFIHIP_REQUIRE(ctx, h->acc_ncols == 0 || h->acc_ncols == ncols, "%d acceptance thresholds but %d nested columns",
+                  h->acc_ncols, ncols);
   if (n == 0) return ELFIHIP_OK;
   DeviceGuard g(ctx->device);
   const size_t bytes = (size_t)n * ncols * sizeof(double);
@@ -681,6 +899,7 @@ int elfihip_reject_meta(elfihip_reject* h, double* kth, int64_t* in_use, int64_t
   if (accepted_last) *accepted_last = (int64_t)(acc - h->acc_seen);
   if (accepted_total) *accepted_total = (int64_t)acc;
   h->acc_seen = acc;
+  if (h->has_accept && !h->host_mode) h->filled = (int64_t)acc < h->k ? (int64_t)acc : h->k;
   return ELFIHIP_OK;
 }
 

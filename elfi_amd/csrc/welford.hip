@@ -11,6 +11,7 @@
 // a workgroup, then workgroups by index) -- no atomics, so repeated runs and different
 // grid schedules of the same launch shape give identical bits.
 #include "common.hpp"
+#include "internal.hpp"
 
 #pragma clang fp contract(off)
 
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(256) void welford_finish_kernel(const double* parti
   }
 }
 
-static int welford_dev_impl(elfihip_ctx* ctx, const double* dX, int64_t n, int m, int64_t ldx, double* dstate) {
+int welford_dev_impl(elfihip_ctx* ctx, const double* dX, int64_t n, int m, int64_t ldx, double* dstate) {
   ELFIHIP_REQUIRE(ctx, n >= 0 && m >= 1 && ldx >= m, "bad shape n=%lld m=%d ldx=%lld", (long long)n, m,
                   (long long)ldx);
   ELFIHIP_REQUIRE(ctx, dstate && (n == 0 || dX), "NULL data pointer");

@@ -167,6 +167,42 @@ def welford_update(X, count, mean, M2, ctx=None):
     return cnt.value, mean, M2
 
 
+def adaptive_batch(X, y, W, store=None, state=None, row_base=0, distances=True, ctx=None):
+    """One AdaptiveDistance batch in ONE read of its rows on the GPU (csrc/adaptive.hip): the (n, K) nested distances
+    under the weight rows W (K, m) (AdaptiveDistance.nested_distance, elfi/model/elfi_model.py:1135-1151), the batch
+    folded into the running column statistics `store` = (count, mean, M2) (AdaptiveDistance.add_data, :1104-1125) and,
+    with `state` (a selection.RunningBest), what Rejection._merge_batch keeps of the batch
+    (elfi/methods/inference/samplers.py:209-237).  Returns (distances or None, new store or None)."""
+    X = np.asarray(X)
+    if X.ndim != 2:
+        raise ValueError('XA must be a 2-dimensional array.')
+    n, m = X.shape
+    if X.dtype != np.float64 or X.strides[1] != 8 or X.strides[0] % 8 or X.strides[0] < 8 * m:
+        X = _as_f64(X)
+    ldx = X.strides[0] // 8 if n > 1 else m
+    y = _as_f64(y).reshape(-1)
+    if y.shape[0] != m:
+        raise ValueError('XA and XB must have the same number of columns '
+                         '(i.e. feature dimension.)')
+    W = _as_f64(W)
+    if W.ndim != 2 or W.shape[1] != m:
+        raise ValueError('W must be (K, %d)' % m)
+    K = W.shape[0]
+    out = np.empty((n, K), dtype=np.float64) if distances else None
+    cnt = mean = M2 = None
+    if store is not None:
+        cnt = C.c_int64(int(store[0]))
+        mean = np.array(np.broadcast_to(np.asarray(store[1], dtype=np.float64), (m,)))
+        M2 = np.array(np.broadcast_to(np.asarray(store[2], dtype=np.float64), (m,)))
+    ctx = ctx or (state.ctx if state is not None else _lib.default_context())
+    ctx.call("elfihip_adaptive_push", state.h if state is not None else None, _lib.ptr(X), n, m, ldx, _lib.ptr(y),
+             _lib.ptr(W), K, _lib.ptr(out), C.byref(cnt) if store is not None else None, _lib.ptr(mean), _lib.ptr(M2),
+             int(row_base))
+    if state is not None:
+        state.n_pushed += n
+    return out, ((cnt.value, mean, M2) if store is not None else None)
+
+
 class HipDistance:
     """Callable `dist(X (n,m), Y (1,m)) -> (n,)`: what elfi.Distance accepts as a callable
     metric (elfi/model/elfi_model.py:987-991).  Use as

@@ -122,9 +122,15 @@ class RunningBest:
         self.n_pushed = 0
 
     def set_accept(self, threshold):
-        """Acceptance threshold (None removes it); before the first push or after reset()."""
-        self._check(self.lib.elfihip_reject_set_accept(self.h, 0 if threshold is None else 1,
-                                                       0.0 if threshold is None else float(threshold)))
+        """Acceptance threshold (None removes it); before the first push or after reset().  A sequence is one threshold
+        per nested column -- what AdaptiveDistanceSMC hands its Rejection (samplers.py:657-660: [inf, threshold of
+        population 1, ...], compared column by column, samplers.py:222-223)."""
+        if threshold is not None and np.ndim(threshold) > 0:
+            t = np.ascontiguousarray(threshold, dtype=np.float64).reshape(-1)
+            self._check(self.lib.elfihip_reject_set_accept_cols(self.h, t.shape[0], _lib.ptr(t)))
+        else:
+            self._check(self.lib.elfihip_reject_set_accept(self.h, 0 if threshold is None else 1,
+                                                           0.0 if threshold is None else float(threshold)))
         self.accept = threshold
 
     def push_distances(self, d, row_base=None):

@@ -183,6 +183,11 @@ int elfihip_reject_push(elfihip_reject* h, const double* D, int64_t n, int ncols
  * _push_multiw_dev; single-column pushes test their one column).  Set before the first push or after a reset;
  * enable = 0 removes it.  Accepted rows are counted on the device (elfihip_reject_meta). */
 int elfihip_reject_set_accept(elfihip_reject* h, int enable, double threshold);
+/* The same condition with ONE THRESHOLD PER NESTED COLUMN: what AdaptiveDistanceSMC hands its Rejection as `threshold`
+ * -- the list [inf, threshold of population 1, ...] (samplers.py:657-660), compared column by column by
+ * `batch[d] <= threshold` (samplers.py:222-223).  thresholds: ncols values, +inf allowed; every later push must carry
+ * ncols nested columns. */
+int elfihip_reject_set_accept_cols(elfihip_reject* h, int ncols, const double* thresholds);
 /* What Rejection._update_state_meta / _update_objective_n_batches read after every batch (samplers.py:239-271): the
  * current k-th distance (+inf while fewer than k rows are in; it is the sampler's `threshold` state), rows accepted by
  * the pushes since the previous call and in total (acceptance threshold set).  in_use: entries of a host-merge state
@@ -203,6 +208,31 @@ int elfihip_reject_flush(elfihip_reject* h);
  * would list such rows last, after every finite distance): while fewer than k finite distances have been seen, count is
  * their number. */
 int elfihip_reject_result(elfihip_reject* h, double* vals, int64_t* rows, int64_t* count);
+
+/* ------------------------------------------------------------------ one adaptive-distance batch in one read
+ * Everything the reference does with a batch of an AdaptiveDistance round while its rows are read ONCE:
+ *   - AdaptiveDistance.nested_distance (elfi/model/elfi_model.py:1135-1151): the K weighted euclidean distances under
+ *     the weights of the EARLIER rounds (W (K, m): cdist weights, a row of ones for the unweighted first function) ->
+ *     dout / out (n, K), bit-identical to elfihip_dist_multiw; dout / out may be NULL (nothing but the state's k rows
+ *     leaves the GPU);
+ *   - AdaptiveDistance.add_data (elfi_model.py:1104-1125), which Rejection._merge_batch calls for every batch
+ *     (elfi/methods/inference/samplers.py:213-216): the batch folded into the running column statistics [N, mean (m),
+ *     M2 (m)] that the NEXT update_distance turns into weights -- dwelford (device, 1 + 2m doubles, in place) or
+ *     count / mean / M2 (host, in place); NULL: no statistics.  Tile-local two-pass sums merged with Chan's pairwise
+ *     update in a fixed order: equal to the reference's batched Welford update up to rounding, bit-reproducible;
+ *   - Rejection._merge_batch (samplers.py:218-237) against `state` (may be NULL): acceptance of every nested column
+ *     (elfihip_reject_set_accept / _set_accept_cols), ranking by the last one, rows numbered row_base + row.  A first
+ *     batch of >= 2^20 rows is selected against a provisional threshold taken from a prefix of the batch and verified
+ *     (see csrc/reject.hip); the result is exact in every case.
+ * Rows narrower than 129 doubles with even m / ldx and 16-byte aligned dX take the fused kernel (csrc/adaptive.hip);
+ * other shapes run the separate passes (elfihip_welford_update_dev, elfihip_dist_multiw_dev, candidate pass).
+ * _dev: asynchronous on the context's stream, except for the first-batch check, which reads four bytes back. */
+int elfihip_adaptive_push_dev(elfihip_ctx* ctx, elfihip_reject* state, const double* dX, int64_t n, int m, int64_t ldx,
+                              const double* dy, const double* dW, int K, double* dout, double* dwelford,
+                              int64_t row_base);
+int elfihip_adaptive_push(elfihip_ctx* ctx, elfihip_reject* state, const double* X, int64_t n, int m, int64_t ldx,
+                          const double* y, const double* W, int K, double* out, int64_t* count, double* mean,
+                          double* M2, int64_t row_base);
 
 /* ------------------------------------------------------------------ SMC proposal density
  * GMDistribution.pdf (elfi/methods/utils.py:142-183): density of a Gaussian mixture with shared
