@@ -167,12 +167,13 @@ def welford_update(X, count, mean, M2, ctx=None):
     return cnt.value, mean, M2
 
 
-def adaptive_batch(X, y, W, store=None, state=None, row_base=0, distances=True, ctx=None):
+def adaptive_batch(X, y, W, store=None, state=None, row_base=None, distances=True, ctx=None):
     """One AdaptiveDistance batch in ONE read of its rows on the GPU (csrc/adaptive.hip): the (n, K) nested distances
     under the weight rows W (K, m) (AdaptiveDistance.nested_distance, elfi/model/elfi_model.py:1135-1151), the batch
     folded into the running column statistics `store` = (count, mean, M2) (AdaptiveDistance.add_data, :1104-1125) and,
     with `state` (a selection.RunningBest), what Rejection._merge_batch keeps of the batch
-    (elfi/methods/inference/samplers.py:209-237).  Returns (distances or None, new store or None)."""
+    (elfi/methods/inference/samplers.py:209-237; rows numbered row_base + row, default: the rows pushed so far).
+    Returns (distances or None, new store or None)."""
     X = np.asarray(X)
     if X.ndim != 2:
         raise ValueError('XA must be a 2-dimensional array.')
@@ -197,7 +198,7 @@ def adaptive_batch(X, y, W, store=None, state=None, row_base=0, distances=True, 
     ctx = ctx or (state.ctx if state is not None else _lib.default_context())
     ctx.call("elfihip_adaptive_push", state.h if state is not None else None, _lib.ptr(X), n, m, ldx, _lib.ptr(y),
              _lib.ptr(W), K, _lib.ptr(out), C.byref(cnt) if store is not None else None, _lib.ptr(mean), _lib.ptr(M2),
-             int(row_base))
+             int(row_base if row_base is not None else (state.n_pushed if state is not None else 0)))
     if state is not None:
         state.n_pushed += n
     return out, ((cnt.value, mean, M2) if store is not None else None)

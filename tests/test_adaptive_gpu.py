@@ -28,10 +28,12 @@ def _exact_stats(X):
     return len(X), mean, ((Xl - mean) ** 2).sum(axis=0)
 
 
-def _check_stats(store, X, merges=4096):
+def _check_stats(store, X, fused=True):
     """(count, mean, M2) of the device against the exact two-pass values.  A-priori bounds: every Chan update rounds
     the running mean once (half an ulp of |mean|; chains are tens of updates long) and the mean of a tile carries
-    1e-16 x the spread; M2 is a sum of non-negative terms (relative error ~ depth x eps) plus n (error of the mean)^2."""
+    1e-16 x the spread; M2 is a sum of non-negative terms (relative error ~ depth x eps) plus n (error of the mean)^2.
+    fused=False: the shapes that take welford.hip, which follows the reference's own formula (first batch: sum of
+    x (x - mean) about a zero mean) -- its terms, not M2, set the scale of the rounding."""
     n, mean, M2 = _exact_stats(X)
     cnt, dm, dq = store
     assert cnt == n
@@ -40,6 +42,8 @@ def _check_stats(store, X, merges=4096):
     err = np.abs((dm.astype(np.longdouble) - mean).astype(float))
     assert np.all(err <= tol_mean), (err.max(), tol_mean[np.argmax(err / tol_mean)])
     tol_m2 = 2e-13 * M2.astype(float) + 4 * n * tol_mean ** 2 + 4 * np.spacing(M2.astype(float))
+    if not fused:
+        tol_m2 = tol_m2 + 2e-13 * np.sum(np.abs(X * (X - mean.astype(float))), axis=0)
     e2 = np.abs((dq.astype(np.longdouble) - M2).astype(float))
     assert np.all(e2 <= tol_m2), (e2.max(), tol_m2[np.argmax(e2 / tol_m2)])
 
@@ -58,7 +62,7 @@ def test_distances_and_statistics_vs_oracle(hip_ctx, n, m, K):
     assert np.array_equal(d, _nested_ref(X, y, W))
     assert np.array_equal(d, elfi_amd.nested_weighted_euclidean(X, y, W))
     if n > 1:
-        _check_stats(store, X)
+        _check_stats(store, X, fused=(m % 2 == 0 and m <= 128))
     else:
         assert store[0] == 1 and np.array_equal(store[1], X[0]) and np.all(store[2] == 0)
     # no statistics / no distances requested
