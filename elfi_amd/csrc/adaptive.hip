@@ -35,8 +35,12 @@
 
 namespace elfihip {
 
-constexpr int ADA_T = 128;      // threads per workgroup (two waves), as dist_multiw_pipe_kernel
-constexpr int ADA_U = 16;       // 16-byte loads per thread and tile
+constexpr int ADA_T = 256;      // threads per workgroup: four waves
+constexpr int ADA_U = 8;        // 16-byte loads per thread and tile (generic streaming path)
+constexpr int ADA_RMAX = 128;   // rows per tile at most (two waves of row owners)
+#ifndef ADA_OCC
+#define ADA_OCC 4                // waves per SIMD the register allocation aims at (<= 128 registers: four workgroups per CU)
+#endif
 
 struct AdaptArgs {
   RowArgs A;                         // rows, observed y, W (K, m) in aux, out (n, K) or NULL, the selection filter
@@ -48,6 +52,19 @@ struct AdaptArgs {
 struct ColStat {
   double n, mean, M2;
 };
+
+#ifdef ELFIHIP_ADA_STAMP   // developer probe (scripts/native/ada_probe.hip): shader-clock stamps per wave, tile and phase
+__device__ long long g_ada_stamp[8 * 4 * 16 * 8];
+#define ADA_STAMP(slot)                                                                                   \
+  do {                                                                                                    \
+    if (blockIdx.x < 8 && iter >= 64 && iter < 80 && (threadIdx.x & 63) == 0)                             \
+      g_ada_stamp[((blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + iter - 64) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define ADA_STAMP(slot) \
+  do {                  \
+  } while (0)
+#endif
 
 // Chan et al.: (n, mean, M2) <- (n, mean, M2) U (nb, mb, qb); the operations and their order are those of
 // welford_merge_kernel (welford.hip) and elfi_amd/sharding.py:merge_welford.
@@ -67,113 +84,333 @@ __device__ __forceinline__ void chan_merge(ColStat& a, double nb, double mb, dou
   a.n = tot;
 }
 
-template <int U>
-__global__ __launch_bounds__(ADA_T) void adaptive_pass_kernel(AdaptArgs P) {
+// Uniform operands of the row sums (the weights w_kj, the observed y_j: the same for every lane) come through the
+// constant address space, i.e. scalar loads into SGPRs that the f64 VALU instructions take directly, in blocks of B
+// elements with the next block requested before the current one is summed (scalar loads return out of order: a wait is a
+// wait for all of them, so a block is requested right after the wait that delivered its predecessor; two blocks of
+// B = 16 doubles are 64 of a wave's 102 SGPRs).  Measured per tile of 64 x 64 and ONE column
+// (scripts/native/ada_probe.hip, cycles): broadcast ds_reads of y_j / w_kj as distance.hip's kernels do 5700 (the LDS
+// round trip of every unrolled group of four); scalar loads, four elements per wait 5400 (a ~300-cycle round trip per
+// four elements); operands spread over the lanes + v_readlane 8400 (the SGPR hand-over stalls the VALU).
+typedef const double __attribute__((address_space(4))) * cdptr;
+__device__ __forceinline__ cdptr as_constant(const double* p) { return (cdptr) reinterpret_cast<uintptr_t>(p); }
+
+// sqrt(sum_j w_j d_j^2), left to right (cdist's order; multiply and add round separately).  PRE: `row` holds the
+// differences d_j = x_j - y_j (formed once, when the tile was written); otherwise x_j, and y comes with the weights.
+// The row's elements are read from LDS four at a time, one group ahead of their use (the read past the row's last
+// group lands in LDS the workgroup owns and is never used).
+template <int B, bool PRE>
+__device__ __forceinline__ double row_distance(const double* row, cdptr ys, cdptr w, int m) {
+  double s = 0.0;
+  double wn[B], yn[PRE ? 1 : B];
+#pragma unroll
+  for (int i = 0; i < B; ++i) {
+    wn[i] = w[i];
+    if constexpr (!PRE) yn[i] = ys[i];
+  }
+  double xn[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) xn[i] = row[i];
+  int j0 = 0;
+  for (; j0 + B <= m; j0 += B) {
+    double wc[B], yc[PRE ? 1 : B];
+#pragma unroll
+    for (int i = 0; i < B; ++i) {
+      wc[i] = wn[i];
+      if constexpr (!PRE) yc[i] = yn[i];
+    }
+    const int jn = j0 + 2 * B <= m ? j0 + B : j0;   // (the last block re-requests itself: nothing is read beyond y / W)
+#pragma unroll
+    for (int i = 0; i < B; ++i) {
+      wn[i] = w[jn + i];
+      if constexpr (!PRE) yn[i] = ys[jn + i];
+    }
+#pragma unroll
+    for (int i0 = 0; i0 < B; i0 += 4) {
+      double x[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) x[i] = xn[i];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xn[i] = row[j0 + i0 + 4 + i];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        double d = x[i];
+        if constexpr (!PRE) d = d - yc[i0 + i];
+        const double d2 = d * d;
+        s = s + wc[i0 + i] * d2;
+      }
+    }
+  }
+  for (int j = j0; j < m; ++j) {   // m not a multiple of the block
+    double d = row[j];
+    if constexpr (!PRE) d = d - ys[j];
+    const double d2 = d * d;
+    s = s + w[j] * d2;
+  }
+  return sqrt(s);
+}
+
+// Column statistics of CH rows (p[0], p[step], ...) held in registers: sum -> mean (CH is a power of two: the scaling is
+// exact) -> sum of squared deviations about it; fixed association.
+template <int CH>
+__device__ __forceinline__ void chunk_stats(const double (&x)[CH], double& mean, double& q) {
+  if constexpr (CH >= 4) {
+    double a[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < CH; i += 4) {
+      a[0] += x[i];
+      a[1] += x[i + 1];
+      a[2] += x[i + 2];
+      a[3] += x[i + 3];
+    }
+    mean = ((a[0] + a[1]) + (a[2] + a[3])) * (1.0 / CH);
+    double b[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < CH; i += 4) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const double e = x[i + u] - mean;
+        b[u] += e * e;
+      }
+    }
+    q = (b[0] + b[1]) + (b[2] + b[3]);
+  } else {
+    double a = 0.0;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) a += x[i];
+    mean = a * (1.0 / CH);
+    q = 0.0;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const double e = x[i] - mean;
+      q += e * e;
+    }
+  }
+}
+
+// Two groups of the same count n: Chan's update without the division (f = 1/2).
+__device__ __forceinline__ void merge_equal(double n, double& ma, double& qa, double mb, double qb) {
+  const double delta = mb - ma;
+  qa = qa + qb + delta * delta * (n * 0.5);
+  ma = ma + delta * 0.5;
+}
+
+// NU > 0: m / 2 divides the workgroup size, so load u of a thread is the same element pair QS rows further down and a
+// tile is exactly NU loads per thread -- source and LDS offsets are one add per load, and the loads of a full tile carry
+// no predicate (one straight run of NU global_load_dwordx4).  A thread then holds NU rows of the SAME two columns of every
+// tile in registers when it writes them to LDS: it subtracts the observed pair once (the tile holds d = x - y) and takes
+// the two columns' statistics from those registers -- two-pass sums of the NU values, Chan's update of its running
+// triples -- so the statistics cost no LDS read at all.  NU == 0: any even m through the generic tile_fetch /
+// tile_commit of tile_stream.hpp (an integer division per load and tile, ADA_U predicated loads); the tile holds x, the
+// statistics make their two passes over LDS.
+//
+// Work split (measured with scripts/native/ada_probe.hip; round 4): with the whole row's K distances in one lane the
+// wave that owned the rows was the critical path of a two-wave workgroup (K = 3: 1.35 ms per 10^7 x 64 against 1.03 at
+// K = 1), and its time was operand latency, not arithmetic.  Four waves per workgroup: lane r of a wave owns row r (or
+// r + 64: tiles of 128 rows have two row blocks), the K columns are dealt out over the 4 (2) waves of a row block, so
+// every sum keeps cdist's order and a wave sweeps its row once per column it holds.  The verdicts of the waves on their
+// columns (acceptance) meet in LDS.
+template <int NU>
+__global__ __launch_bounds__(ADA_T, ADA_OCC) void adaptive_pass_kernel(AdaptArgs P) {
   extern __shared__ __align__(16) double lds[];
+  constexpr int U = NU > 0 ? NU : ADA_U;
+  constexpr bool POW2 = NU > 0;
   const RowArgs& A = P.A;
   const int T = ADA_T, tid = threadIdx.x, m = A.m, K = A.K, R = A.R, mp = A.mp;
   double* tile = lds;
-  const int tile_doubles = R * mp > 3 * T ? R * mp : 3 * T;   // the tile doubles as the end-of-kernel reduction space
-  double* ys = tile + tile_doubles;
-  double* ws = ys + m;        // (K, m)
-  double* accs = ws + (size_t)K * m;   // (K)
-  for (int j = tid; j < m; j += T) ys[j] = A.y[j];
-  for (int j = tid; j < K * m; j += T) ws[j] = A.aux[j];
+  const int tile_doubles = R * mp > 6 * T ? R * mp : 6 * T;   // the tile doubles as the end-of-kernel reduction space
+  double* accs = tile + tile_doubles + 8;   // (K) acceptance thresholds (8 doubles of slack behind the tile: row_distance reads ahead)
+  int* flag = reinterpret_cast<int*>(accs + K);   // (4, 128) acceptance of a column group's columns, row by row
+  const cdptr ys = as_constant(A.y), ws = as_constant(A.aux);   // (m), (K, m): uniform operands through the scalar cache
   if (P.acc)
     for (int j = tid; j < K; j += T) accs[j] = P.acc[j];
   const int64_t ntiles = (A.n + R - 1) / R;
   const double inf = __longlong_as_double(0x7ff0000000000000ll);
   const double thr = A.F.thr ? *A.F.thr : inf;
-  // column statistics: thread (g, c)
-  const int G = T / m;                    // row groups (the launcher guarantees m <= T)
-  const int g = tid / m, c = tid - g * m;
-  const bool sact = P.partial != nullptr && g < G;
-  ColStat st = {0.0, 0.0, 0.0};
+  // (wave-uniform values the compiler must see as uniform: they select the wave's columns, whose weights are scalar loads)
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int RB = R > 64 ? 2 : 1;           // row blocks of 64
+  const int CG = 4 / RB;                   // column groups: waves per row block
+  const int rb = wave % RB, cg = wave / RB;
+  const int rl = rb * 64 + (tid & 63);     // the row this lane owns
+  const bool owner = cg == (K - 1) % CG;   // this wave holds the LAST column of its rows: it counts and offers
   unsigned long long nacc = 0;
+  // strided streaming: element pair jj0 (columns 2 jj0, 2 jj0 + 1) of row q0 + u QS
+  const int h = m >> 1;
+  const int q0 = POW2 ? tid / h : 0, jj0 = POW2 ? tid - q0 * h : 0, QS = POW2 ? T / h : 1;
+  const int64_t soff = (int64_t)q0 * A.ldx + 2 * jj0, sstep = (int64_t)QS * A.ldx;
+  const int doff = q0 * mp + 2 * jj0, dstep = QS * mp;
+  double2 yp = make_double2(0.0, 0.0);     // the observed pair of this thread's columns
+  if constexpr (POW2) yp = make_double2(A.y[2 * jj0], A.y[2 * jj0 + 1]);
+  // column statistics.  POW2: this thread's two columns (st0, st1), from registers.  Generic: thread (g, c) = column c,
+  // rows g, g + G, ... of every tile, from LDS (st0).
+  const int G = T / m;          // row groups (the launcher guarantees m <= T / 2)
+  const int g = tid / m, c = tid - g * m;
+  const bool stats = P.partial != nullptr;
+  ColStat st0 = {0.0, 0.0, 0.0}, st1 = {0.0, 0.0, 0.0};
   double2 v[U];
+  auto fetch = [&](int64_t row0, int rows) {
+    if constexpr (POW2) {
+      const double* __restrict__ src = A.X + row0 * A.ldx + soff;
+      if (rows == R) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = *reinterpret_cast<const double2*>(src + u * sstep);
+      } else {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          v[u] = make_double2(0.0, 0.0);
+          if (q0 + u * QS < rows) v[u] = *reinterpret_cast<const double2*>(src + u * sstep);
+        }
+      }
+    } else {
+      tile_fetch<U>(A, row0, rows, v);
+    }
+  };
+  // tile <- the registers (POW2: as differences from the observed pair), statistics of the registers on the way
+  auto commit = [&](int rows) {
+    if constexpr (POW2) {
+      if (rows == R) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          double* dst = tile + doff + u * dstep;
+          dst[0] = v[u].x - yp.x;
+          dst[1] = v[u].y - yp.y;
+        }
+        if (stats) {
+          double a[U], b[U], ma, qa, mb, qb;
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            a[u] = v[u].x;
+            b[u] = v[u].y;
+          }
+          chunk_stats<U>(a, ma, qa);
+          chunk_stats<U>(b, mb, qb);
+          chan_merge(st0, (double)U, ma, qa);
+          chan_merge(st1, (double)U, mb, qb);
+        }
+      } else {
+        int cnt = 0;
+        double sa = 0.0, sb = 0.0;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (q0 + u * QS < rows) {
+            double* dst = tile + doff + u * dstep;
+            dst[0] = v[u].x - yp.x;
+            dst[1] = v[u].y - yp.y;
+            sa += v[u].x;
+            sb += v[u].y;
+            ++cnt;
+          }
+        if (stats && cnt > 0) {
+          const double ma = sa / (double)cnt, mb = sb / (double)cnt;
+          double qa = 0.0, qb = 0.0;
+#pragma unroll
+          for (int u = 0; u < U; ++u)
+            if (q0 + u * QS < rows) {
+              const double ea = v[u].x - ma, eb = v[u].y - mb;
+              qa += ea * ea;
+              qb += eb * eb;
+            }
+          chan_merge(st0, (double)cnt, ma, qa);
+          chan_merge(st1, (double)cnt, mb, qb);
+        }
+      }
+    } else {
+      tile_commit<U>(A, tile, rows, v);
+    }
+  };
   int64_t t = blockIdx.x;
-  if (t < ntiles) tile_fetch<U>(A, t * R, (int)((A.n - t * R) < R ? (A.n - t * R) : R), v);
+  if (t < ntiles) fetch(t * R, (int)((A.n - t * R) < R ? (A.n - t * R) : R));
+#ifdef ELFIHIP_ADA_STAMP
+  int iter = -1;
+#endif
   for (; t < ntiles; t += gridDim.x) {
+#ifdef ELFIHIP_ADA_STAMP
+    ++iter;
+#endif
     const int64_t row0 = t * R;
     const int rows = (int)((A.n - row0) < R ? (A.n - row0) : R);
-    __syncthreads();   // tile free (every reader of the previous one is done); ys / ws / accs visible on the first trip
-    tile_commit<U>(A, tile, rows, v);
+    ADA_STAMP(0);
+    __syncthreads();   // tile free (every reader of the previous one is done); accs visible on the first trip
+    ADA_STAMP(1);
+    commit(rows);
+    ADA_STAMP(2);
     const int64_t tn = t + gridDim.x;
-    if (tn < ntiles) tile_fetch<U>(A, tn * R, (int)((A.n - tn * R) < R ? (A.n - tn * R) : R), v);
+    if (tn < ntiles) fetch(tn * R, (int)((A.n - tn * R) < R ? (A.n - tn * R) : R));
+    ADA_STAMP(3);
     __syncthreads();
-    // ---- nested distances: lane r owns row r (cdist's left-to-right order per weight vector)
+    ADA_STAMP(4);
+    // ---- nested distances of this lane's row under its wave's columns cg, cg + CG, ...
     double dlast = 0.0;
-    bool ok = tid < rows;
-    if (tid < rows) {
-      const double* row = tile + (size_t)tid * mp;
-      for (int k0 = 0; k0 < K; k0 += 4) {
-        const int kn = K - k0 < 4 ? K - k0 : 4;
-        const double* w0 = ws + (size_t)k0 * m;
-        const double* w1 = ws + (size_t)(k0 + (kn > 1 ? 1 : 0)) * m;
-        const double* w2 = ws + (size_t)(k0 + (kn > 2 ? 2 : 0)) * m;
-        const double* w3 = ws + (size_t)(k0 + (kn > 3 ? 3 : 0)) * m;
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-#pragma unroll 4
-        for (int j = 0; j < m; ++j) {
-          const double d = row[j] - ys[j];
-          const double d2 = d * d;
-          s0 = s0 + w0[j] * d2;
-          s1 = s1 + w1[j] * d2;
-          s2 = s2 + w2[j] * d2;
-          s3 = s3 + w3[j] * d2;
-        }
-        const double r0 = sqrt(s0), r1 = sqrt(s1), r2 = sqrt(s2), r3 = sqrt(s3);
-        if (A.out) {
-          double* o = A.out + (row0 + tid) * K + k0;
-          o[0] = r0;
-          if (kn > 1) o[1] = r1;
-          if (kn > 2) o[2] = r2;
-          if (kn > 3) o[3] = r3;
-        }
-        if (P.acc) {   // samplers.py:219-225: every nested column against its threshold (a NaN distance is not accepted)
-          ok = ok && r0 <= accs[k0];
-          if (kn > 1) ok = ok && r1 <= accs[k0 + 1];
-          if (kn > 2) ok = ok && r2 <= accs[k0 + 2];
-          if (kn > 3) ok = ok && r3 <= accs[k0 + 3];
-        }
-        dlast = kn > 3 ? r3 : (kn > 2 ? r2 : (kn > 1 ? r1 : r0));
+    bool ok = rl < rows;
+    if (rl < rows) {
+      const double* row = tile + (size_t)rl * mp;
+      for (int k = cg; k < K; k += CG) {
+        double r;
+        if constexpr (POW2)
+          r = row_distance<16, true>(row, ys, ws + (size_t)k * m, m);
+        else
+          r = row_distance<8, false>(row, ys, ws + (size_t)k * m, m);
+        if (A.out) A.out[(row0 + rl) * K + k] = r;
+        if (P.acc) ok = ok && r <= accs[k];   // samplers.py:219-225: every nested column against its threshold (a NaN distance is not accepted)
+        dlast = r;   // (the owner's last column is K - 1)
       }
     }
-    if (P.acc) nacc += (unsigned long long)__popcll(__ballot(ok));   // wave-uniform
-    if (A.F.thr) reject_offer(A.F, ok && dlast < thr, dlast, A.F.row_base + row0 + tid);
-    // ---- column statistics of the tile: two passes over this thread's rows in LDS, then Chan's update
-    if (sact && g < rows) {
-      const double* col = tile + c;
-      double s = 0.0;
-      int cnt = 0;
-#pragma unroll 8
-      for (int r = g; r < rows; r += G) {
-        s += col[(size_t)r * mp];
-        ++cnt;
+    if (P.acc && K > 1) {   // the other column groups' verdicts on this row (uniform branch: all threads arrive)
+      if (!owner) flag[cg * ADA_RMAX + rl] = ok ? 1 : 0;
+      __syncthreads();
+      if (owner) {
+        const int ng = K < CG ? K : CG;   // groups that hold columns
+        for (int q = 0; q < ng; ++q)
+          if (q != cg) ok = ok && flag[q * ADA_RMAX + rl] != 0;
       }
-      const double mt = s / (double)cnt;
-      double q = 0.0;
-#pragma unroll 8
-      for (int r = g; r < rows; r += G) {
-        const double e = col[(size_t)r * mp] - mt;
-        q += e * e;
-      }
-      chan_merge(st, (double)cnt, mt, q);
     }
+    if (owner) {
+      if (P.acc) nacc += (unsigned long long)__popcll(__ballot(ok));   // wave-uniform
+      if (A.F.thr) reject_offer(A.F, ok && dlast < thr, dlast, A.F.row_base + row0 + rl);
+    }
+    ADA_STAMP(5);
+    if constexpr (!POW2) {
+      // ---- column statistics of the tile: two passes over this thread's rows in LDS, then Chan's update
+      if (stats && g < G && g < rows) {
+        const double* col = tile + c;
+        double sum = 0.0;
+        int cnt = 0;
+#pragma unroll 8
+        for (int r = g; r < rows; r += G) {
+          sum += col[(size_t)r * mp];
+          ++cnt;
+        }
+        const double mt = sum / (double)cnt;
+        double q = 0.0;
+#pragma unroll 8
+        for (int r = g; r < rows; r += G) {
+          const double e = col[(size_t)r * mp] - mt;
+          q += e * e;
+        }
+        chan_merge(st0, (double)cnt, mt, q);
+      }
+    }
+    ADA_STAMP(6);
   }
-  if (P.partial) {
-    __syncthreads();   // the tile is free: its first 3 T doubles carry the row groups' triples
+  if (stats) {
+    __syncthreads();   // the tile is free: it carries the threads' triples, column by column
     double* red = tile;
-    if (sact) {
-      red[3 * tid] = st.n;
-      red[3 * tid + 1] = st.mean;
-      red[3 * tid + 2] = st.M2;
+    // entry (column col, slot sl): red[3 (sl * m + col) ..]; POW2: slot = q0 (QS per column), generic: slot = g (G per column)
+    const int nslot = POW2 ? QS : G;
+    if constexpr (POW2) {
+      double* e0 = red + 3 * ((size_t)q0 * m + 2 * jj0);
+      e0[0] = st0.n, e0[1] = st0.mean, e0[2] = st0.M2;
+      e0[3] = st1.n, e0[4] = st1.mean, e0[5] = st1.M2;
+    } else if (g < G) {
+      double* e0 = red + 3 * ((size_t)g * m + c);
+      e0[0] = st0.n, e0[1] = st0.mean, e0[2] = st0.M2;
     }
     __syncthreads();
     if (tid < m) {
       ColStat a = {0.0, 0.0, 0.0};
-      for (int gg = 0; gg < G; ++gg) {
-        const double* e = red + 3 * (gg * m + tid);
+      for (int sl = 0; sl < nslot; ++sl) {
+        const double* e = red + 3 * ((size_t)sl * m + tid);
         chan_merge(a, e[0], e[1], e[2]);
       }
       double* o = P.partial + (size_t)blockIdx.x * (1 + 2 * m);
@@ -234,17 +471,17 @@ static bool ada_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p
 
 static size_t ada_lds_bytes(int m, int K, int R) {
   const int mp = m | 1;
-  const size_t tile = std::max<size_t>((size_t)R * mp, 3 * (size_t)ADA_T);
-  return (tile + (size_t)m + (size_t)K * m + (size_t)K) * sizeof(double);
+  const size_t tile = std::max<size_t>((size_t)R * mp, 6 * (size_t)ADA_T);
+  return (tile + 8 + (size_t)K + 2 * ADA_RMAX) * sizeof(double);   // + read-ahead slack, K thresholds, 4 x 128 ints of acceptance flags
 }
 
 static int ada_rows_per_tile(int m) {
-  int R = 2 * ADA_T * ADA_U / m;
-  return R > ADA_T ? ADA_T : R;
+  int R = 2 * ADA_T * ADA_U / m;      // 32 KiB of rows
+  return R > ADA_RMAX ? ADA_RMAX : R;
 }
 
 bool adaptive_pass_supported(const double* dX, int m, int64_t ldx, int K) {
-  if (m < 1 || m > ADA_T || (m & 1) || (ldx & 1) || !ada_aligned16(dX)) return false;
+  if (m < 2 || m > ADA_T / 2 || (m & 1) || (ldx & 1) || !ada_aligned16(dX)) return false;
   return ada_lds_bytes(m, K, ada_rows_per_tile(m)) <= 64 * 1024;
 }
 
@@ -286,7 +523,18 @@ int adaptive_pass_impl(elfihip_ctx* ctx, const double* dX, int64_t n, int m, int
   int64_t g = (int64_t)ctx->cu_count * per_cu;
   if (g > ntiles) g = ntiles;
   if (g < 1) g = 1;
-  hipLaunchKernelGGL((adaptive_pass_kernel<ADA_U>), dim3((unsigned)g), dim3(ADA_T), lds, ctx->stream, P);
+  const int h = m / 2;
+  const int nu = (ADA_T % h == 0 && A.R % (ADA_T / h) == 0) ? A.R / (ADA_T / h) : 0;   // loads per thread and tile when m / 2 divides the workgroup
+#define ELFIHIP_ADA_LAUNCH(NU) \
+  hipLaunchKernelGGL((adaptive_pass_kernel<NU>), dim3((unsigned)g), dim3(ADA_T), lds, ctx->stream, P)
+  switch (nu) {
+    case 8: ELFIHIP_ADA_LAUNCH(8); break;
+    case 4: ELFIHIP_ADA_LAUNCH(4); break;
+    case 2: ELFIHIP_ADA_LAUNCH(2); break;
+    case 1: ELFIHIP_ADA_LAUNCH(1); break;
+    default: ELFIHIP_ADA_LAUNCH(0); break;
+  }
+#undef ELFIHIP_ADA_LAUNCH
   if (nparts && partial) *nparts = (int)g;
   return launch_status(ctx, "adaptive_pass_kernel");
 }

@@ -100,29 +100,26 @@ struct RejArgs {
   double* export_val;   // packed copy of the new state for the caller (may be NULL)
 };
 
-constexpr size_t REJ_MERGE_LDS = REJ_MAX_K * 16 + REJ_CHUNK * 16 + 2 * (REJ_MAX_K + 4) * 4 + REJ_CHUNK * 4 + 64 * 4;
+constexpr size_t REJ_MERGE_LDS = REJ_MAX_K * 16 + REJ_CHUNK * 16;
 
 __global__ __launch_bounds__(1024) void reject_merge_kernel(RejArgs S) {
-  // Merge by ranks, REJ_CHUNK candidates at a time: an element's place in the merged order is the number of elements
-  // before it.  A candidate x finds its SLOT by binary search (the state is sorted): slot(x) = number of state entries
-  // below x.  With cnt[s] = candidates in slot s and pre[s] = candidates in slots before s (one scan over the slots):
-  //   state entry e   moves to  e + pre[e + 1]                      (the candidates of slots <= e are exactly those below it)
-  //   candidate x     moves to  slot + pre[slot] + (candidates of the SAME slot below x)
-  // and the candidates of a slot are on a linked list (one atomic exchange each), so the last term costs the length
-  // of that list -- about one -- instead of a scan over the chunk.  (distance, row) is a strict order, rows being
-  // unique, so every place is taken once.  Candidates that are not below the current k-th entry take no part.
-  // History: a 4096-pair bitonic sort measured 50 us per merge; ranks by scanning the whole chunk for every element
-  // 30 us per chunk (92 us per merge on the bench's rotating batches, a fifth of the step rate).
+  // Merge by ranks, REJ_CHUNK candidates at a time.  (distance, row) is a strict total order (rows are unique), so an
+  // element's place in the merged sequence is the number of elements before it:
+  //   1. the chunk is sorted in LDS (bitonic network over the next power of two, +inf / max-row padding);
+  //   2. candidate i of the sorted chunk moves to  i + (state entries below it)      -- binary search in the state;
+  //      state entry e           moves to  e + (chunk candidates below it)           -- binary search in the chunk;
+  //   3. places >= k fall off.  Values travel in registers across the barrier, the scatter is in place.
+  // History: a 4096-pair bitonic sort of state + candidates together measured 50 us per merge; ranks of the candidates
+  // of one state slot through a linked list (rounds 2-3) cost one dependent LDS round trip per candidate of the slot --
+  // about one when a full state meets a few candidates, but the whole chunk when the state is still empty: every
+  // candidate falls into slot 0, 1024 list steps each, 57 us per chunk (round 4: 171 us for the 2400 candidates of an SMC
+  // round's first batch).  Sorting the 1024-chunk alone is 55 compare-exchange steps whatever the state holds.
   extern __shared__ __align__(16) unsigned char rej_sm[];
   double* bv = reinterpret_cast<double*>(rej_sm);
   long long* br = reinterpret_cast<long long*>(bv + REJ_MAX_K);
   double* cv = reinterpret_cast<double*>(br + REJ_MAX_K);
   long long* cr = reinterpret_cast<long long*>(cv + REJ_CHUNK);
-  int* pre = reinterpret_cast<int*>(cr + REJ_CHUNK);   // (k + 2): counts per slot, then their exclusive prefix sums
-  int* head = pre + REJ_MAX_K + 4;                      // (k + 1): first candidate of the slot's list, -1 = none
-  int* nxt = head + REJ_MAX_K + 4;                      // (chunk)
-  int* wsum = nxt + REJ_CHUNK;                          // (16) per-wave totals of the scan
-  const int t = threadIdx.x, k = S.k, lane = t & 63, w = t >> 6;
+  const int t = threadIdx.x, k = S.k;
   unsigned int c = S.ncand >= 0 ? (unsigned int)S.ncand : *S.count;
   if (c > S.cap) {
     if (t == 0) atomicOr(S.status, 1u);   // the list is incomplete: the state can no longer be trusted (reported by result)
@@ -132,63 +129,46 @@ __global__ __launch_bounds__(1024) void reject_merge_kernel(RejArgs S) {
     bv[e] = S.best_val[e];
     br[e] = S.best_row[e];
   }
-  constexpr int SPT = (REJ_MAX_K + 2 + 1023) / 1024;   // slots per thread in the scan (consecutive)
+  const double inf = __longlong_as_double(0x7ff0000000000000ll);
+  const long long maxrow = 0x7fffffffffffffffll;
   for (unsigned int c0 = 0; c0 < c; c0 += REJ_CHUNK) {
     const int nc = (int)min((unsigned int)REJ_CHUNK, c - c0);
-    for (int e = t; e < k + 2; e += 1024) {
-      pre[e] = 0;
-      head[e < k + 1 ? e : 0] = -1;
-    }
-    __syncthreads();   // also: the state of the previous round is in place
-    double xv = 0.0;
-    long long xr = 0;
-    int slot = -1;
-    if (t < nc) {
-      xv = S.cand_val[c0 + t];
-      xr = S.cand_row[c0 + t] + S.row_offset;
+    int P = 1;
+    while (P < nc) P <<= 1;
+    __syncthreads();   // the state of the previous round is in place; the chunk buffers are free
+    if (t < P) {
+      double xv = inf;
+      long long xr = maxrow;
+      if (t < nc) {
+        xv = S.cand_val[c0 + t];
+        xr = S.cand_row[c0 + t] + S.row_offset;
+        if (!(xv == xv)) {   // a NaN never enters the state
+          xv = inf;
+          xr = maxrow;
+        }
+      }
       cv[t] = xv;
       cr[t] = xr;
-      if (rej_less(xv, xr, bv[k - 1], br[k - 1])) {
-        int lo = 0, hi = k - 1;   // first state entry that is not below x (entry k-1 is not)
-        while (lo < hi) {
-          const int mid = (lo + hi) >> 1;
-          if (rej_less(bv[mid], br[mid], xv, xr))
-            lo = mid + 1;
-          else
-            hi = mid;
+    }
+    for (int size = 2; size <= P; size <<= 1) {
+      for (int stride = size >> 1; stride > 0; stride >>= 1) {
+        __syncthreads();
+        if (t < (P >> 1)) {
+          const int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
+          const bool up = (lo & size) == 0;
+          const double av = cv[lo], bvv = cv[hi];
+          const long long ar = cr[lo], brr = cr[hi];
+          if (rej_less(bvv, brr, av, ar) == up) {
+            cv[lo] = bvv;
+            cr[lo] = brr;
+            cv[hi] = av;
+            cr[hi] = ar;
+          }
         }
-        slot = lo;
-        atomicAdd(&pre[slot], 1);
-        nxt[t] = atomicExch(&head[slot], t);
       }
     }
     __syncthreads();
-    // exclusive scan of pre[0 .. k+1] (SPT consecutive slots per thread, wave scan, wave totals)
-    int loc[SPT], sum = 0;
-#pragma unroll
-    for (int i = 0; i < SPT; ++i) {
-      const int e = SPT * t + i;
-      loc[i] = e < k + 2 ? pre[e] : 0;
-      sum += loc[i];
-    }
-    int inc = sum;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int o = __shfl_up(inc, d, 64);
-      if (lane >= d) inc += o;
-    }
-    if (lane == 63) wsum[w] = inc;
-    __syncthreads();
-    int base = inc - sum;
-    for (int j = 0; j < w; ++j) base += wsum[j];
-#pragma unroll
-    for (int i = 0; i < SPT; ++i) {
-      const int e = SPT * t + i;
-      if (e < k + 2) pre[e] = base;
-      base += loc[i];
-    }
-    __syncthreads();
-    // places: values travel in registers across the barrier, the scatter is in place
+    // places
     double sv[2];
     long long sr[2];
     int sp[2];
@@ -201,14 +181,34 @@ __global__ __launch_bounds__(1024) void reject_merge_kernel(RejArgs S) {
       if (e < k) {
         sv[u] = bv[e];
         sr[u] = br[e];
-        sp[u] = e + pre[e + 1];
+        int lo = 0, hi = nc;   // candidates below this entry: first candidate that is not below it
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (rej_less(cv[mid], cr[mid], sv[u], sr[u]))
+            lo = mid + 1;
+          else
+            hi = mid;
+        }
+        sp[u] = e + lo;
       }
     }
     int cp = k;
-    if (slot >= 0) {
-      int below = 0;
-      for (int j = head[slot]; j >= 0; j = nxt[j]) below += (j != t && rej_less(cv[j], cr[j], xv, xr)) ? 1 : 0;
-      cp = slot + pre[slot] + below;
+    double xv = 0.0;
+    long long xr = 0;
+    if (t < nc) {
+      xv = cv[t];
+      xr = cr[t];
+      if (xr != maxrow || xv != inf) {   // (padding and NaN candidates sort last and take no part)
+        int lo = 0, hi = k;   // state entries below this candidate
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (rej_less(bv[mid], br[mid], xv, xr))
+            lo = mid + 1;
+          else
+            hi = mid;
+        }
+        cp = t + lo;
+      }
     }
     __syncthreads();
 #pragma unroll
@@ -691,13 +691,7 @@ int elfihip_reject_create(elfihip_ctx* ctx, int64_t k, elfihip_reject** out) {
   *out = nullptr;
   ELFIHIP_REQUIRE(ctx, k >= 1 && k <= REJ_MAX_K_HOST, "k = %lld outside [1, %lld]", (long long)k, (long long)REJ_MAX_K_HOST);
   DeviceGuard g(ctx->device);
-  // the merge kernel keeps the state, a chunk of candidates and its rank tables in 69,920 bytes of LDS: more than the
-  // 64 KiB of earlier CDNA parts -- this library is built for gfx950 (160 KiB per CU) only
-  hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(reject_merge_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)REJ_MERGE_LDS);
-  if (ea != hipSuccess)
-    return fail(ctx, ELFIHIP_ERR_HIP, "the sampler state's merge kernel needs %zu bytes of LDS per workgroup (gfx950): %s",
-                REJ_MERGE_LDS, hipGetErrorString(ea));
+  // (the merge kernel keeps the state and a chunk of candidates in REJ_MERGE_LDS = 48 KiB of dynamic LDS: no attribute needed)
   elfihip_reject* h = new elfihip_reject();
   h->ctx = ctx;
   h->k = k;
