@@ -24,10 +24,10 @@ from .sampler import HipRejection, hip_rejection_class  # noqa: F401
 from .distance import adaptive_batch  # noqa: F401
 from .adaptive import hip_adaptive_distance_class  # noqa: F401
 from .smc import HipAdaptiveDistanceSMC, HipAdaptiveThresholdSMC, HipSMC, hip_smc_class  # noqa: F401
-from .summaries import autocov, ma2_distance, ss_mean, ss_var  # noqa: F401
+from .summaries import autocov, gauss_distance, ma2_distance, ma2_draw_distance, ss_mean, ss_var  # noqa: F401
 from .lcb_acquisition import HipLCBSC  # noqa: F401
 from .posterior import HipBolfiPosterior, sample_posterior  # noqa: F401
-from . import chains, multistart  # noqa: F401
+from . import chains, fused_models, multistart  # noqa: F401
 from .maxvar_acquisition import HipExpIntVar, HipMaxVar, HipRandMaxVar  # noqa: F401
 
 

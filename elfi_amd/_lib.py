@@ -11,6 +11,7 @@ elfi/model/utils.py:42-49 re-raises), non-PD Cholesky -> numpy.linalg.LinAlgErro
 import ctypes as C
 import os
 import threading
+import weakref
 
 import numpy as np
 
@@ -85,6 +86,10 @@ PROTOTYPES = {
     "elfihip_adaptive_push": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_void_p,
                                        C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.c_void_p, C.c_void_p,
                                        C.c_int64]),
+    "elfihip_kept_distances": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
+    "elfihip_reject_push_kept": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64]),
+    "elfihip_ma2_draw_distance": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int64, C.c_int, C.c_void_p, C.c_void_p,
+                                           C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
     "elfihip_reject_meta": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "elfihip_reject_state_dev": (C.c_int, [C.c_void_p, c_void_pp, c_void_pp]),
     "elfihip_reject_export_dev": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -267,6 +272,12 @@ class Context:
         return dict(cu_count=cu.value, clock_khz=clk.value, mem_clock_khz=mclk.value,
                     mem_bus_bits=bus.value, total_mem=mem.value, name=name.value.decode())
 
+    def kept_epoch(self):
+        """Counter of the host-form distance calls on this context: names the device copy of what the last one returned."""
+        ep = C.c_uint64()
+        self.call("elfihip_kept_distances", C.byref(ep), None, None)
+        return ep.value
+
     def timer_start(self):
         self.call("elfihip_timer_start")
 
@@ -274,6 +285,44 @@ class Context:
         ms = C.c_float()
         self.call("elfihip_timer_stop", C.byref(ms))
         return ms.value
+
+
+# Distances that are still on the device: id(array a distance call returned) -> (weak reference, context, epoch).  The
+# sampler state asks for the entry of the array it is handed (selection.RunningBest.push_distances) and skips the upload
+# when the context still keeps that call's copy (include/elfihip.h: elfihip_kept_distances).
+_KEPT = {}
+
+
+def remember_kept(arr, ctx):
+    if len(_KEPT) > 32:
+        for key in [k for k, (ref, _, _) in _KEPT.items() if ref() is None]:
+            del _KEPT[key]
+        while len(_KEPT) > 32:
+            del _KEPT[next(iter(_KEPT))]
+    try:
+        _KEPT[id(arr)] = (weakref.ref(arr), ctx, ctx.kept_epoch())
+    except TypeError:
+        pass
+    return arr
+
+
+def alias_kept(new, old):
+    """`new` (a reshaped view of `old`) is what the caller will hand on: it names the same device copy."""
+    ent = _KEPT.get(id(old))
+    if ent is not None and ent[0]() is old:
+        try:
+            _KEPT[id(new)] = (weakref.ref(new), ent[1], ent[2])
+        except TypeError:
+            pass
+    return new
+
+
+def kept_epoch_of(arr, ctx):
+    """Epoch of the device copy of `arr` on `ctx`, or None."""
+    ent = _KEPT.get(id(arr))
+    if ent is None or ent[0]() is not arr or ent[1] is not ctx:
+        return None
+    return ent[2]
 
 
 _ctx_by_device = {}

@@ -118,7 +118,7 @@ def hip_adaptive_distance_class():
                 raise ValueError(_SHAPE_HINT.format(e))
             self._remember(summaries, (cnt, mean, M2))
             if d.ndim == 2 and d.shape[1] == 1:
-                d = d.reshape(-1)
+                d = _lib.alias_kept(d.reshape(-1), d)   # (the view is what the sampler will see)
             return d
 
         def _remember(self, summaries, stats):

@@ -606,7 +606,10 @@ int elfihip_adaptive_push(elfihip_ctx* ctx, elfihip_reject* state, const double*
     dout = ctx->out.as<double>();
   }
   ELFIHIP_TRY(adaptive_push_impl(ctx, state, dX, n, m, ldd, dy, dW, K, dout, count ? dstate : nullptr, row_base));
-  if (out) ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(out, dout, (size_t)n * K * sizeof(double), hipMemcpyDeviceToHost, st));
+  if (out) {
+    ELFIHIP_TRY(keep_distances(ctx, dout, n, K));
+    ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(out, dout, (size_t)n * K * sizeof(double), hipMemcpyDeviceToHost, st));
+  }
   if (count) ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(hst.data(), dstate, ns * sizeof(double), hipMemcpyDeviceToHost, st));
   ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(st));
   if (count) {

@@ -68,6 +68,12 @@ struct elfihip_ctx {
   // staging buffers for the host entry points
   elfihip::DevBuf in, out, par, scratch;
   elfihip::DevBuf stat;   // workgroup partials of the fused adaptive-distance pass (adaptive.hip; topk.hip owns `scratch`)
+  // the distances the last host-form distance call returned, kept on the device for the sampler state
+  // (elfihip_kept_distances / elfihip_reject_push_kept): (keep_n, keep_cols) row-major; the epoch names the call
+  elfihip::DevBuf keep;
+  uint64_t keep_epoch = 0;
+  int64_t keep_n = 0;
+  int keep_cols = 0;
 };
 
 namespace elfihip {
@@ -124,6 +130,18 @@ struct DeviceGuard {
 };
 
 int ctx_aux(elfihip_ctx* ctx);  // ctx.hip: lazily creates hi_stream / ev_a / ev_b
+
+// Host-form distance calls leave a device copy of what they return (n x cols doubles at dsrc, on the context's stream).
+inline int keep_distances(elfihip_ctx* ctx, const double* dsrc, int64_t n, int cols) {
+  ++ctx->keep_epoch;
+  ctx->keep_n = 0;
+  ctx->keep_cols = cols;
+  if (n <= 0) return ELFIHIP_OK;
+  if (ctx->keep.reserve((size_t)n * cols * sizeof(double)) != hipSuccess) return ELFIHIP_OK;   // (no copy kept: the sampler uploads)
+  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(ctx->keep.p, dsrc, (size_t)n * cols * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  ctx->keep_n = n;
+  return ELFIHIP_OK;
+}
 
 inline int launch_status(elfihip_ctx* ctx, const char* what) {
   hipError_t e = hipGetLastError();

@@ -30,6 +30,14 @@ extern "C" {
 
 int elfihip_version(void) { return ELFIHIP_VERSION; }
 
+int elfihip_kept_distances(elfihip_ctx* ctx, uint64_t* epoch, int64_t* n, int* ncols) {
+  if (!ctx) return fail(nullptr, ELFIHIP_ERR_ARG, "ctx is NULL");
+  if (epoch) *epoch = ctx->keep_epoch;
+  if (n) *n = ctx->keep_n;
+  if (ncols) *ncols = ctx->keep_cols;
+  return ELFIHIP_OK;
+}
+
 int elfihip_device_count(int* count) {
   if (!count) return fail(nullptr, ELFIHIP_ERR_ARG, "count is NULL");
   int n = 0;
@@ -90,6 +98,7 @@ int elfihip_ctx_destroy(elfihip_ctx* ctx) {
     ctx->par.release();
     ctx->scratch.release();
     ctx->stat.release();
+    ctx->keep.release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->ev_a) (void)hipEventDestroy(ctx->ev_a);

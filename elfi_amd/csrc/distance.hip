@@ -901,6 +901,7 @@ int elfihip_dist_rows(elfihip_ctx* ctx, int metric, const double* X, int64_t n, 
   ELFIHIP_TRY(stage_rows(ctx, X, n, m, ldx, &dX));
   ELFIHIP_CHECK_HIP(ctx, ctx->out.reserve((size_t)(n ? n : 1) * sizeof(double)));
   ELFIHIP_TRY(dist_rows_dev_impl(ctx, metric, dX, n, m, m, dy, daux, p, ctx->out.as<double>(), nullptr, nullptr));
+  ELFIHIP_TRY(keep_distances(ctx, ctx->out.as<double>(), n, 1));
   if (n)
     ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(out, ctx->out.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -947,6 +948,7 @@ int elfihip_dist_cols(elfihip_ctx* ctx, int metric, const double* const* cols, i
   }
   ELFIHIP_CHECK_HIP(ctx, ctx->out.reserve((size_t)(ldc ? ldc : 2) * sizeof(double)));
   ELFIHIP_TRY(dist_cols_dev_impl(ctx, metric, dC, n, m, ldc ? ldc : 2, dy, daux, p, ctx->out.as<double>()));
+  ELFIHIP_TRY(keep_distances(ctx, ctx->out.as<double>(), n, 1));
   if (n)
     ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(out, ctx->out.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -966,6 +968,7 @@ int elfihip_dist_multiw(elfihip_ctx* ctx, const double* X, int64_t n, int m, int
   ELFIHIP_TRY(stage_rows(ctx, X, n, m, ldx, &dX));
   ELFIHIP_CHECK_HIP(ctx, ctx->out.reserve((size_t)(n ? n : 1) * K * sizeof(double)));
   ELFIHIP_TRY(dist_multiw_dev_impl(ctx, dX, n, m, m, dy, dW, K, ctx->out.as<double>(), nullptr, nullptr));
+  ELFIHIP_TRY(keep_distances(ctx, ctx->out.as<double>(), n, K));
   if (n)
     ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(out, ctx->out.p, (size_t)n * K * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));

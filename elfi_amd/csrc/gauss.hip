@@ -276,6 +276,7 @@ int elfihip_gauss_distance(elfihip_ctx* ctx, const double* Z, uint64_t seed, uin
   ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(dsg, sigma, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   ELFIHIP_TRY(gauss_dev_impl(ctx, Z ? dZ : nullptr, n_obs, seed, stream, n, n_obs, dmu, dsg, obs_mean, obs_var,
                              Y ? dY : nullptr, dS, dS + n, dS + 2 * n));
+  ELFIHIP_TRY(keep_distances(ctx, dS + 2 * n, n, 1));
   ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(S1, dS, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(S2, dS + n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(D, dS + 2 * n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));

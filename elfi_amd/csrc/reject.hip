@@ -773,6 +773,28 @@ int elfihip_reject_push_dev(elfihip_reject* h, const double* dD, int64_t n, int6
   });
 }
 
+int elfihip_reject_push_kept(elfihip_reject* h, uint64_t epoch, int64_t row_base) {
+  if (!h) return fail(nullptr, ELFIHIP_ERR_ARG, "state is NULL");
+  elfihip_ctx* ctx = h->ctx;
+  if (epoch != ctx->keep_epoch || (ctx->keep_n > 0 && !ctx->keep.p))
+    return fail(ctx, ELFIHIP_ERR_STATE, "the kept distances are those of a later call (epoch %llu, asked for %llu)",
+                (unsigned long long)ctx->keep_epoch, (unsigned long long)epoch);
+  const int64_t n = ctx->keep_n;
+  const int K = ctx->keep_cols;
+  ELFIHIP_REQUIRE(ctx, K >= 1 && K <= REJ_ACC_COLS, "ncols = %d outside [1, %d]", K, REJ_ACC_COLS);
+  ELFIHIP_REQUIRE(ctx, h->acc_ncols == 0 || h->acc_ncols == K, "%d acceptance thresholds but %d nested columns",
+                  h->acc_ncols, K);
+  if (n == 0) return ELFIHIP_OK;
+  DeviceGuard g(ctx->device);
+  const double* dD = ctx->keep.as<double>();
+  ELFIHIP_TRY(reject_push(h, n, dD + (K - 1), K, K, (long long)row_base, [&](const RejectFilter*, bool* filtered) {
+    *filtered = false;
+    return ELFIHIP_OK;
+  }));
+  // the kept copy belongs to the context: what reads it is queued before the next distance call can replace it (same stream)
+  return ELFIHIP_OK;
+}
+
 int elfihip_reject_state_dev(elfihip_reject* h, double** dvals, int64_t** drows) {
   if (!h) return fail(nullptr, ELFIHIP_ERR_ARG, "state is NULL");
   DeviceGuard g(h->ctx->device);

@@ -382,29 +382,47 @@ int elfihip_ma2_draw_distance_dev(elfihip_ctx* ctx, uint64_t seed, uint64_t stre
   return ma2_dev_impl(ctx, nullptr, n, n_obs, n_obs + 2, dt1, dt2, obs1, obs2, dS1, dS2, dD, true, seed, stream);
 }
 
-int elfihip_ma2_distance(elfihip_ctx* ctx, const double* W, int64_t n, int n_obs, const double* t1, const double* t2,
-                         double obs1, double obs2, double* S1, double* S2, double* D) {
-  if (!ctx) return fail(nullptr, ELFIHIP_ERR_ARG, "ctx is NULL");
+// host forms: W != NULL reads the caller's white noise, W == NULL draws it in the kernel (seed, stream)
+static int ma2_host(elfihip_ctx* ctx, const double* W, uint64_t seed, uint64_t stream, int64_t n, int n_obs, const double* t1,
+                    const double* t2, double obs1, double obs2, double* S1, double* S2, double* D) {
   ELFIHIP_REQUIRE(ctx, n >= 0 && n_obs >= 3, "bad shape n=%lld n_obs=%d", (long long)n, n_obs);
-  ELFIHIP_REQUIRE(ctx, n == 0 || (W && t1 && t2 && S1 && S2 && D), "NULL data pointer");
+  ELFIHIP_REQUIRE(ctx, n == 0 || (t1 && t2 && S1 && S2 && D), "NULL data pointer");
   if (n == 0) return ELFIHIP_OK;
   DeviceGuard g(ctx->device);
   const int L = n_obs + 2;
-  ELFIHIP_CHECK_HIP(ctx, ctx->in.reserve(((size_t)n * L + 2 * (size_t)n) * sizeof(double)));
+  const size_t nw = W ? (size_t)n * L : 0;
+  ELFIHIP_CHECK_HIP(ctx, ctx->in.reserve((nw + 2 * (size_t)n) * sizeof(double)));
   ELFIHIP_CHECK_HIP(ctx, ctx->out.reserve(3 * (size_t)n * sizeof(double)));
   double* dW = ctx->in.as<double>();
-  double* dt1 = dW + (size_t)n * L;
+  double* dt1 = dW + nw;
   double* dt2 = dt1 + n;
   double* dS = ctx->out.as<double>();
-  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(dW, W, (size_t)n * L * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  if (W) ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(dW, W, nw * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(dt1, t1, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(dt2, t2, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  ELFIHIP_TRY(ma2_dev_impl(ctx, dW, n, n_obs, L, dt1, dt2, obs1, obs2, dS, dS + n, dS + 2 * n));
+  if (W)
+    ELFIHIP_TRY(ma2_dev_impl(ctx, dW, n, n_obs, L, dt1, dt2, obs1, obs2, dS, dS + n, dS + 2 * n));
+  else
+    ELFIHIP_TRY(ma2_dev_impl(ctx, nullptr, n, n_obs, L, dt1, dt2, obs1, obs2, dS, dS + n, dS + 2 * n, true, seed, stream));
+  ELFIHIP_TRY(keep_distances(ctx, dS + 2 * n, n, 1));
   ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(S1, dS, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(S2, dS + n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(D, dS + 2 * n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return ELFIHIP_OK;
+}
+
+int elfihip_ma2_distance(elfihip_ctx* ctx, const double* W, int64_t n, int n_obs, const double* t1, const double* t2,
+                         double obs1, double obs2, double* S1, double* S2, double* D) {
+  if (!ctx) return fail(nullptr, ELFIHIP_ERR_ARG, "ctx is NULL");
+  ELFIHIP_REQUIRE(ctx, n == 0 || W, "NULL data pointer");
+  return ma2_host(ctx, W, 0, 0, n, n_obs, t1, t2, obs1, obs2, S1, S2, D);
+}
+
+int elfihip_ma2_draw_distance(elfihip_ctx* ctx, uint64_t seed, uint64_t stream, int64_t n, int n_obs, const double* t1,
+                              const double* t2, double obs1, double obs2, double* S1, double* S2, double* D) {
+  if (!ctx) return fail(nullptr, ELFIHIP_ERR_ARG, "ctx is NULL");
+  return ma2_host(ctx, nullptr, seed, stream, n, n_obs, t1, t2, obs1, obs2, S1, S2, D);
 }
 
 }  // extern "C"

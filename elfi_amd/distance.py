@@ -99,7 +99,7 @@ def cdist_rows(X, y, metric='euclidean', p=2.0, w=None, V=None, VI=None, ctx=Non
     ctx = ctx or _lib.default_context()
     ctx.call("elfihip_dist_rows", mid, _lib.ptr(X), n, m, ldx, _lib.ptr(y), _lib.ptr(aux),
              C.c_double(p), _lib.ptr(out))
-    return out
+    return _lib.remember_kept(out, ctx)
 
 
 def cdist_cols(cols, y, metric='euclidean', p=2.0, w=None, V=None, ctx=None):
@@ -125,7 +125,7 @@ def cdist_cols(cols, y, metric='euclidean', p=2.0, w=None, V=None, ctx=None):
     ctx = ctx or _lib.default_context()
     ctx.call("elfihip_dist_cols", mid, arr, m, n, _lib.ptr(y), _lib.ptr(aux), C.c_double(p),
              _lib.ptr(out))
-    return out
+    return _lib.remember_kept(out, ctx)
 
 
 def nested_weighted_euclidean(X, y, W, ctx=None):
@@ -150,7 +150,7 @@ def nested_weighted_euclidean(X, y, W, ctx=None):
     out = np.empty((n, K), dtype=np.float64)
     ctx = ctx or _lib.default_context()
     ctx.call("elfihip_dist_multiw", _lib.ptr(X), n, m, m, _lib.ptr(y), _lib.ptr(W), K, _lib.ptr(out))
-    return out
+    return _lib.remember_kept(out, ctx)
 
 
 def welford_update(X, count, mean, M2, ctx=None):
@@ -201,6 +201,8 @@ def adaptive_batch(X, y, W, store=None, state=None, row_base=None, distances=Tru
              int(row_base if row_base is not None else (state.n_pushed if state is not None else 0)))
     if state is not None:
         state.n_pushed += n
+    if out is not None:
+        _lib.remember_kept(out, ctx)
     return out, ((cnt.value, mean, M2) if store is not None else None)
 
 

@@ -134,7 +134,19 @@ class RunningBest:
         self.accept = threshold
 
     def push_distances(self, d, row_base=None):
-        """Fold a batch whose distances exist already (host array (n,) or nested (n, K): ranked by the last column)."""
+        """Fold a batch whose distances exist already (host array (n,) or nested (n, K): ranked by the last column).  When
+        `d` is the very array a distance call on this context just returned, the device copy that call left is folded
+        in instead (no upload: include/elfihip.h, elfihip_reject_push_kept)."""
+        epoch = _lib.kept_epoch_of(d, self.ctx)
+        if epoch is not None:
+            base = self.n_pushed if row_base is None else int(row_base)
+            rc = self.lib.elfihip_reject_push_kept(self.h, epoch, base)
+            if rc == _lib.OK:
+                self.n_pushed += len(d)
+                self.kept_pushes = getattr(self, 'kept_pushes', 0) + 1
+                return
+            if rc != _lib.ERR_STATE:
+                self._check(rc)
         d = np.ascontiguousarray(d, dtype=np.float64)
         if d.ndim == 1:
             d = d.reshape(-1, 1)

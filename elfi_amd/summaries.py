@@ -78,7 +78,28 @@ def ma2_distance(w, t1, t2, observed, ctx=None):
     ctx = ctx or _lib.default_context()
     ctx.call("elfihip_ma2_distance", _lib.ptr(w), n, L - 2, _lib.ptr(t1), _lib.ptr(t2), C.c_double(o[0]),
              C.c_double(o[1]), _lib.ptr(S1), _lib.ptr(S2), _lib.ptr(D))
-    return S1, S2, D
+    return S1, S2, _lib.remember_kept(D, ctx)
+
+
+def ma2_draw_distance(t1, t2, observed, n_obs=100, seed=0, stream=0, ctx=None):
+    """The whole MA2 example as ONE device operation (elfi/examples/ma2.py:11-59 + Distance('euclidean', S1, S2)): the
+    white noise is drawn inside the kernel (Philox4x32-10 keyed by `seed`, counter stream `stream`), the series never
+    exists in memory.  t1, t2: (batch,); observed: the two observed summaries.  Returns (S1, S2, d), each (batch,)."""
+    t1 = np.asarray(t1, dtype=np.float64).reshape(-1)
+    t2 = np.asarray(t2, dtype=np.float64).reshape(-1)
+    n = max(t1.shape[0], t2.shape[0])
+    t1 = np.ascontiguousarray(np.broadcast_to(t1, (n,)))
+    t2 = np.ascontiguousarray(np.broadcast_to(t2, (n,)))
+    o = np.asarray(observed, dtype=np.float64).reshape(-1)
+    if o.shape[0] != 2:
+        raise ValueError('observed must hold the two observed summaries')
+    if int(n_obs) < 3:
+        raise ValueError('need n_obs >= 3')
+    S1, S2, D = np.empty(n), np.empty(n), np.empty(n)
+    ctx = ctx or _lib.default_context()
+    ctx.call("elfihip_ma2_draw_distance", C.c_uint64(int(seed)), C.c_uint64(int(stream)), n, int(n_obs), _lib.ptr(t1),
+             _lib.ptr(t2), C.c_double(o[0]), C.c_double(o[1]), _lib.ptr(S1), _lib.ptr(S2), _lib.ptr(D))
+    return S1, S2, _lib.remember_kept(D, ctx)
 
 
 def gauss_distance(mu, sigma, observed, n_obs=50, z=None, seed=0, stream=0, return_y=False, ctx=None):
@@ -108,4 +129,5 @@ def gauss_distance(mu, sigma, observed, n_obs=50, z=None, seed=0, stream=0, retu
     ctx.call("elfihip_gauss_distance", _lib.ptr(z), C.c_uint64(int(seed)), C.c_uint64(int(stream)), n, n_obs,
              _lib.ptr(mu), _lib.ptr(sigma), C.c_double(o[0]), C.c_double(o[1]), _lib.ptr(Y), _lib.ptr(S1), _lib.ptr(S2),
              _lib.ptr(D))
+    _lib.remember_kept(D, ctx)
     return (S1, S2, D, Y) if return_y else (S1, S2, D)

@@ -193,6 +193,15 @@ int elfihip_reject_set_accept_cols(elfihip_reject* h, int ncols, const double* t
  * the pushes since the previous call and in total (acceptance threshold set).  in_use: entries of a host-merge state
  * (-1 for device states: elfihip_reject_result reports it).  Merges what is pending and synchronises; any output may be NULL. */
 int elfihip_reject_meta(elfihip_reject* h, double* kth, int64_t* in_use, int64_t* accepted_last, int64_t* accepted_total);
+/* Distances that are still on the device.  Every HOST-form call that returns distances (elfihip_dist_rows, _dist_cols,
+ * _dist_multiw, _adaptive_push, _gauss_distance, _ma2_distance, _ma2_draw_distance) leaves a device copy of what it
+ * returned in the context -- (n, ncols) row-major -- until the next such call; elfihip_kept_distances names it (epoch: a
+ * counter of those calls).  elfihip_reject_push_kept folds that copy into the state as elfihip_reject_push would fold
+ * the host array (acceptance, ranking by the last column), without the upload: what Rejection._merge_batch receives as
+ * batch[discrepancy_name] (samplers.py:209-237) is the array the Distance node just returned.  Status ELFIHIP_ERR_STATE
+ * when a later call has replaced the copy (the caller then pushes the host array). */
+int elfihip_kept_distances(elfihip_ctx* ctx, uint64_t* epoch, int64_t* n, int* ncols);
+int elfihip_reject_push_kept(elfihip_reject* h, uint64_t epoch, int64_t row_base);
 /* device pointers to the state (k values ascending, k rows), e.g. as the send buffers of a gather */
 int elfihip_reject_state_dev(elfihip_reject* h, double** dvals, int64_t** drows);
 /* From the next merge on, every merge also leaves the state as one packed device buffer at ddst -- k doubles (values)
@@ -272,6 +281,10 @@ int elfihip_row_summary_dev(elfihip_ctx* ctx, int kind, const double* dX, int64_
  * NumPy/SciPy results, in one pass over W. */
 int elfihip_ma2_distance(elfihip_ctx* ctx, const double* W, int64_t n, int n_obs, const double* t1, const double* t2,
                          double obs1, double obs2, double* S1, double* S2, double* D);
+/* ... with the white noise drawn inside the kernel (Philox4x32-10, key `seed`, counter stream `stream`: the draws of
+ * elfihip_randn_dev), host parameters in, host results out: the whole example as ONE node operation. */
+int elfihip_ma2_draw_distance(elfihip_ctx* ctx, uint64_t seed, uint64_t stream, int64_t n, int n_obs, const double* t1,
+                              const double* t2, double obs1, double obs2, double* S1, double* S2, double* D);
 int elfihip_ma2_distance_dev(elfihip_ctx* ctx, const double* dW, int64_t n, int n_obs, int64_t ldw, const double* dt1,
                              const double* dt2, double obs1, double obs2, double* dS1, double* dS2, double* dD);
 /* The same with the white noise DRAWN IN THE KERNEL (synthetic-throughput runs; the reference draws it from MT19937 on the

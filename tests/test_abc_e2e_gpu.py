@@ -1,0 +1,114 @@
+"""GPU: ABC end to end through the reference's loop with the nodes on the device.
+
+  * the distances a Distance node returned are folded into the sampler state from the device copy the call left
+    (include/elfihip.h: elfihip_kept_distances / elfihip_reject_push_kept) -- same state as with the upload, and the
+    hand-over really happens inside elfi_amd.HipRejection;
+  * elfi_amd.fused_models: ELFI's MA2 / Gaussian example models whose Simulator node is the fused device kernel with
+    device draws, through elfi.Rejection and elfi_amd.HipRejection (elfi/methods/parameter_inference.py:283-292,
+    elfi/methods/inference/samplers.py:196-237).
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ORACLE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle')
+sys.path.insert(0, ORACLE)
+import ref_shim  # noqa: E402
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(not ref_shim.available(), reason='no reference package (run oracle/make_ref.sh)')]
+
+
+@pytest.fixture(scope='module')
+def elfi():
+    e = ref_shim.install()
+    import elfi.clients.native as native
+    native.set_as_default()
+    return e
+
+
+def test_kept_distances_hand_over(hip_ctx):
+    import elfi_amd
+    rs = np.random.RandomState(0)
+    X, y = rs.randn(50000, 8), rs.randn(1, 8)
+    a, b = elfi_amd.RunningBest(100), elfi_amd.RunningBest(100)
+    d1 = elfi_amd.cdist_rows(X, y)
+    a.push_distances(d1)                       # the array the call just returned: no upload
+    assert a.kept_pushes == 1
+    b.push_distances(d1.copy())                # any other array: uploaded
+    assert getattr(b, 'kept_pushes', 0) == 0
+    assert all(np.array_equal(p, q) for p, q in zip(a.result(), b.result()))
+    # a later distance call replaces the device copy: the earlier array is uploaded, the result is the same
+    d2 = elfi_amd.cdist_rows(X[::-1], y)
+    d3 = elfi_amd.cdist_rows(X * 0.5, y)
+    a.push_distances(d2)
+    b.push_distances(d2.copy())
+    assert a.kept_pushes == 1
+    a.push_distances(d3)
+    b.push_distances(d3.copy())
+    assert a.kept_pushes == 2
+    va, ra = a.result()
+    vb, rb = b.result()
+    assert np.array_equal(va, vb) and np.array_equal(ra, rb)
+    allv = np.concatenate([d1, d2, d3])
+    assert np.array_equal(va, np.sort(allv)[:100])
+    # nested distances with per-column acceptance
+    W = np.vstack([np.ones(8), rs.uniform(0.2, 2, 8)])
+    acc = [np.inf, 2.5]
+    c, e = elfi_amd.RunningBest(50, accept=acc), elfi_amd.RunningBest(50, accept=acc)
+    D = elfi_amd.nested_weighted_euclidean(X, y, W)
+    c.push_distances(D)
+    e.push_distances(D.copy())
+    assert c.kept_pushes == 1 and all(np.array_equal(p, q) for p, q in zip(c.result(), e.result()))
+    assert c.meta()[2] == int(np.sum(D[:, 1] <= 2.5))
+
+
+def test_hip_rejection_takes_the_device_copy(hip_ctx, elfi):
+    """Inside the real loop: every batch's distances reach the state without the upload, and the sample is the
+    reference's (configs[0]: MA2, batch_size=1000)."""
+    import elfi_amd
+    from elfi.examples import ma2
+    m = ma2.get_model(seed_obs=4)
+    m['d'].become(elfi.Distance(elfi_amd.HipDistance('euclidean'), m['S1'], m['S2'], model=m))
+    rej = elfi_amd.HipRejection(m['d'], batch_size=1000, seed=1)
+    got = rej.sample(500, n_sim=50000, bar=False)
+    assert rej._hip_best.kept_pushes == 50
+    ref = elfi.Rejection(ma2.get_model(seed_obs=4)['d'], batch_size=1000, seed=1).sample(500, n_sim=50000, bar=False)
+    assert np.array_equal(got.discrepancies, ref.discrepancies) and np.array_equal(got.samples['t1'], ref.samples['t1'])
+
+
+@pytest.mark.parametrize('name', ['ma2', 'gauss'])
+def test_fused_example_models_through_the_reference_loop(hip_ctx, elfi, name):
+    import elfi_amd
+    from elfi_amd import fused_models as F
+    make = F.ma2_model if name == 'ma2' else F.gauss_model
+    pars = ('t1', 't2') if name == 'ma2' else ('mu', 'sigma')
+    truth = (0.6, 0.2) if name == 'ma2' else (4.0, 0.4)
+    ref = elfi.Rejection(make(seed_obs=4)['d'], batch_size=20000, seed=7).sample(400, n_sim=200000, bar=False)
+    rej = elfi_amd.HipRejection(make(seed_obs=4)['d'], batch_size=20000, seed=7)
+    got = rej.sample(400, n_sim=200000, bar=False)
+    # the same seeds -> the same device draws: HipRejection == Rejection sample by sample, with the distances handed
+    # over on the device
+    assert got.n_sim == ref.n_sim == 200000 and rej._hip_best.kept_pushes == 10
+    assert np.array_equal(got.discrepancies, ref.discrepancies)
+    for p in pars:
+        assert np.array_equal(got.samples[p], ref.samples[p])
+    # the posterior sample sits where the reference's own test expects it (tests/functional/test_inference.py:58-76:
+    # means within 0.2 of the data-generating parameters) and agrees with the reference model's host simulation
+    host_model = (__import__('elfi.examples.ma2', fromlist=['x']) if name == 'ma2'
+                  else __import__('elfi.examples.gauss', fromlist=['x'])).get_model(seed_obs=4)
+    host = elfi.Rejection(host_model['d'], batch_size=20000, seed=7).sample(400, n_sim=200000, bar=False)
+    for p, tv in zip(pars, truth):
+        assert abs(got.sample_means[p] - tv) < 0.2
+        assert abs(got.sample_means[p] - host.sample_means[p]) < 0.1
+    assert abs(got.threshold - host.threshold) < 0.25 * host.threshold
+    # what the Simulator node returns is what the device operation returns for the node's seed
+    m = make(seed_obs=4)
+    out = m.generate(1000, outputs=['t1', 't2', 'MA2', 'S1', 'd'] if name == 'ma2' else ['mu', 'sigma', 'gauss', 'ss_mean', 'd'],
+                     seed=3)
+    sim = out['MA2' if name == 'ma2' else 'gauss']
+    assert sim.shape == (1000, 2) and np.array_equal(out['S1' if name == 'ma2' else 'ss_mean'], sim[:, 0])
+    obs = m.observed['MA2' if name == 'ma2' else 'gauss']
+    assert np.array_equal(out['d'], np.sqrt((sim[:, 0] - obs[0, 0]) ** 2 + (sim[:, 1] - obs[0, 1]) ** 2))
