@@ -261,3 +261,82 @@ def test_hip_rejection_inside_adaptive_distance_smc_rounds(hip_ctx, elfi):
     a, b = out
     assert a.n_sim == b.n_sim == 20000
     assert np.array_equal(a.samples['mu'], b.samples['mu']) and np.array_equal(a.discrepancies, b.discrepancies)
+
+
+def _bolfi_d(elfi, hip, d, n_initial, update_interval, n_inits, seed=1):
+    """BASELINE configs[4]'s shape: d elfi.Prior nodes, identity simulator with Gaussian noise, euclidean distance to the
+    origin, log discrepancy, elfi.BOLFI with the surrogate and the acquisition handed in (bolfi.py:103-137)."""
+    import elfi_amd
+    import scipy.stats as ss
+    from elfi.model.extensions import ModelPrior
+
+    def sim(*theta, batch_size=1, random_state=None):
+        rs = random_state or np.random
+        th = np.column_stack([np.asarray(t).reshape(-1) for t in theta])
+        return th + 0.3 * rs.standard_normal(th.shape)
+    m = elfi.new_model()
+    names = ['p%02d' % i for i in range(d)]
+    pri = [elfi.Prior(ss.uniform, -2, 4, model=m, name=nm) for nm in names]
+    Y = elfi.Simulator(sim, *pri, observed=np.zeros((1, d)), name='sim')
+    dist = elfi.Distance(elfi_amd.HipDistance('euclidean') if hip else 'euclidean', Y, name='d')
+    log_d = elfi.Operation(np.log, dist, name='log_d')
+    bounds = {nm: (-2, 2) for nm in names}
+    if hip:
+        gp = elfi_amd.HipGPRegression(names, bounds=bounds)
+        acq = elfi_amd.HipLCBSC(gp, prior=ModelPrior(m), n_inits=n_inits, noise_var=0.1, exploration_rate=10, seed=seed)
+    else:
+        from oracle_gp_model import OracleGPRegression
+        from elfi.methods.bo.acquisition import LCBSC
+        gp = OracleGPRegression(names, bounds=bounds)
+        acq = LCBSC(gp, prior=ModelPrior(m), n_inits=n_inits, noise_var=0.1, exploration_rate=10, seed=seed)
+    return elfi.BOLFI(log_d, batch_size=1, initial_evidence=n_initial, update_interval=update_interval, bounds=bounds,
+                      acq_noise_var=0.1, target_model=gp, acquisition_method=acq, seed=seed)
+
+
+@pytest.mark.timeout(1800)
+def test_config4_shape_bolfi_d20_through_the_reference_loop(hip_ctx, elfi):
+    """BASELINE.json configs[4] through its entry point: elfi.BOLFI over 20 elfi.Prior nodes with HipGPRegression +
+    HipLCBSC(n_inits=256), update_interval=64 (bolfi.py:103-137,201-254), a shortened run that crosses four refits
+    (initial_evidence=1792 -> fit(2048); the full 7936 -> 8192 runs in bench.py's cfg5_end_to_end leg, and here with
+    ELFI_AMD_FULL_CFG5=1)."""
+    from elfi_amd.loop_timing import instrument
+    full = os.environ.get('ELFI_AMD_FULL_CFG5') == '1'
+    d, interval, n_inits = 20, 64, 256
+    n0, n1 = (7936, 8192) if full else (1792, 2048)
+    hip = _bolfi_d(elfi, True, d, n0, interval, n_inits)
+    T = instrument(hip.target_model, hip.acquisition_method)
+    hip.fit(n_evidence=n1, bar=False)
+    T.restore()
+    gp = hip.target_model
+    assert gp.n_evidence == n1 and gp.X.shape == (n1, d) and np.all(np.isfinite(gp.Y))
+    assert T.acquires == n1 - n0 and len(T.searches) == 4
+    assert np.all(np.abs(gp.X) <= 2.0)
+    opt = hip.acquisition_method.last_opt
+    assert opt['starts'].shape == (n_inits, d) and opt['locs'].shape == (n_inits, d)
+    # the acquisitions concentrate where the discrepancy is small (the origin): mean norm of the acquired points below the
+    # prior draws' (uniform on [-2, 2]^20: ~5.2)
+    assert np.mean(np.linalg.norm(gp.X[n0:], axis=1)) < 0.8 * np.mean(np.linalg.norm(gp.X[:n0], axis=1))
+    # the surrogate the loop left behind = ONE CPU posterior of its evidence at its final hyper-parameters
+    import gp_oracle as G
+    post = G.Posterior(gp.X, gp.Y, **gp._hyper)
+    xs = np.random.RandomState(0).uniform(-2, 2, (8, d))
+    mu, var = gp.predict(xs, noiseless=True)
+    rmu, rvar = post.predict(xs, noiseless=True)
+    assert np.max(np.abs(mu - rmu)) <= 1e-7 * np.max(np.abs(rmu)) and np.max(np.abs(var - rvar)) <= 1e-7 * np.max(rvar + 1)
+
+
+@pytest.mark.timeout(1800)
+def test_d20_first_acquisitions_next_to_the_oracle_model(hip_ctx, elfi):
+    """The same 20-parameter loop with the CPU oracle model and the reference's own LCBSC + scipy L-BFGS-B: identical
+    initial evidence, and the first acquisitions (before any hyper-parameter search) agree to the accuracy L-BFGS-B
+    locates a minimiser in 20 dimensions."""
+    d, n0, interval, n_inits = 20, 256, 8, 10
+    hip = _bolfi_d(elfi, True, d, n0, interval, n_inits)
+    hip.fit(n_evidence=n0 + interval - 1, bar=False)
+    cpu = _bolfi_d(elfi, False, d, n0, interval, n_inits)
+    cpu.fit(n_evidence=n0 + interval - 1, bar=False)
+    Xh, Xc = hip.target_model.X, cpu.target_model.X
+    assert np.array_equal(Xh[:n0], Xc[:n0]) and np.array_equal(hip.target_model.Y[:n0], cpu.target_model.Y[:n0])
+    dev = np.max(np.abs(Xh[n0:] - Xc[n0:]), axis=1)
+    assert dev[0] <= 1e-4, dev
+    assert np.count_nonzero(dev <= 1e-3) >= len(dev) - 2, dev      # a flat 20-dimensional surface: a start may tip into another basin

@@ -224,3 +224,82 @@ def test_sharded_acquisition_starts(tmp_path):
     assert np.array_equal(a0, a1), 'every rank must acquire the same points'
     assert np.array_equal(a0, x1), 'sharding the starts must not change the acquisition'
     assert np.array_equal(np.load(tmp_path / 'vals_0.npy'), single.last_opt['vals'])
+
+
+# ---- the REAL elfi.BOLFI loop on two ranks, acquisition starts sharded (configs[4]'s split: every rank holds the same
+# evidence and surrogate, start s belongs to rank s % world, ONE all-gather of the optima per acquisition)
+class _OracleHandle:
+    """GPHandle.lcb_minimize on the CPU oracle: scipy L-BFGS-B from every start handed in (what the device state
+    machines do in lock-step), so that HipLCBSC's sharding logic runs in the reference's loop without a GPU."""
+
+    def __init__(self, model):
+        self.model = model
+
+    def lcb_minimize(self, starts, bounds, beta, maxiter=1000):
+        import gp_oracle as G
+        import scipy.optimize
+        post = self.model.instance
+        fun = lambda x: float(post.predict(x[None, :], noiseless=True)[0][0, 0]
+                              - np.sqrt(beta * post.predict(x[None, :], noiseless=True)[1][0, 0]))
+        locs, vals = [], []
+        for x0 in np.asarray(starts, float):
+            r = scipy.optimize.minimize(fun, x0, method='L-BFGS-B', bounds=bounds, options={'maxiter': maxiter})
+            locs.append(r.x)
+            vals.append(r.fun)
+        return np.array(locs), np.array(vals), np.zeros(len(locs), dtype=np.int32), 0
+
+
+def _bolfi_run(n_inits, shard):
+    import ref_shim
+    elfi = ref_shim.install()
+    import elfi.clients.native as native
+    native.set_as_default()
+    from elfi.examples import ma2
+    from elfi.model.extensions import ModelPrior
+    from elfi_amd import HipLCBSC
+    from oracle_gp_model import OracleGPRegression
+    m = ma2.get_model(seed_obs=4)
+    log_d = elfi.Operation(np.log, m['d'], name='log_d')
+    bounds = {'t1': (-2, 2), 't2': (-1, 1)}
+    gp = OracleGPRegression(['t1', 't2'], bounds=bounds)
+    gp._handle = _OracleHandle(gp)
+    acq = HipLCBSC(gp, prior=ModelPrior(m, parameter_names=['t1', 't2']), n_inits=n_inits, noise_var=0.1,
+                   exploration_rate=10, seed=1)
+    acq.shard_starts = shard
+    b = elfi.BOLFI(log_d, batch_size=1, initial_evidence=20, update_interval=5, bounds=bounds, acq_noise_var=0.1,
+                   target_model=gp, acquisition_method=acq, seed=1)
+    b.fit(n_evidence=32, bar=False)
+    return gp.X.copy(), gp.Y.copy()
+
+
+def _bolfi_worker(rank, world, port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, 'oracle'), os.path.join(ROOT, 'tests')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        X, Y = _bolfi_run(6, True)
+        np.save(os.path.join(out_dir, 'bolfi_X_%d.npy' % rank), X)
+        np.save(os.path.join(out_dir, 'bolfi_Y_%d.npy' % rank), Y)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_reference_bolfi_loop_with_sharded_starts(tmp_path):
+    """elfi.BOLFI(...).fit on two ranks (elfi/methods/inference/bolfi.py:201-254) with HipLCBSC(shard_starts=True): both
+    ranks acquire the same points as ONE process running all the starts -- the evidence stays identical on every rank,
+    which is what lets every rank rebuild the same surrogate without exchanging it."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import ref_shim
+    if not ref_shim.available():
+        pytest.skip('no reference package')
+    import torch.multiprocessing as mp
+    mp.spawn(_bolfi_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    X1, Y1 = _bolfi_run(6, False)
+    X0, Xb = np.load(tmp_path / 'bolfi_X_0.npy'), np.load(tmp_path / 'bolfi_X_1.npy')
+    assert X0.shape == (32, 2)
+    assert np.array_equal(X0, Xb) and np.array_equal(np.load(tmp_path / 'bolfi_Y_0.npy'), np.load(tmp_path / 'bolfi_Y_1.npy'))
+    assert np.array_equal(X0, X1) and np.array_equal(np.load(tmp_path / 'bolfi_Y_0.npy'), Y1)
