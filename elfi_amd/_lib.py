@@ -149,6 +149,7 @@ PROTOTYPES = {
     "elfihip_gp_lcb": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_void_p, C.c_void_p]),
     "elfihip_gp_lcb_minimize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_double,
                                           C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
+    "elfihip_gp_set_acq_options": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "elfihip_gp_set_integration_points": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "elfihip_gp_cross_cov": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "elfihip_gp_maxvar": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -73,6 +73,10 @@ struct elfihip_gp {
   unsigned long long done_seq = 0;  // value of the completion flag after the latest single-pass prediction
   // dense predictor (gp_dense.hip): workspace and pinned staging of calls with many points
   int lockstep_form = 0;         // 0: fused triangular products (four launches per prediction); 1: six launches
+  // acquisition search (gp_acq.hip, elfihip_gp_set_acq_options): host threads of the quasi-Newton algebra (0 = by the
+  // machine) and the trace level written to stderr (0 = none)
+  int acq_host_threads = 0;
+  int acq_trace = 0;
   unsigned* tri_cnt = nullptr;   // 2 x (cap / 32) arrival counters of the fused triangular products (gp_predict.hip)
   int dense_tm = 0;        // row-tile height of the dense form: 0 = by size, else 64 / 32 / 16 (ELFIHIP_DENSE_TM, tests)
   int64_t dense_min = 0;   // points from which a call takes the dense form; 0 = default (elfihip_gp_set_dense_threshold)

@@ -29,26 +29,26 @@
 namespace elfihip {
 
 // Host threads for the quasi-Newton algebra of many starts (256 starts x 5 us per state-machine step is longer than the
-// device evaluation of the round): ELFIHIP_HOST_THREADS, default min(16, hardware threads, CPUs the cgroup grants).
+// device evaluation of the round): elfihip_gp_set_acq_options, default min(16, hardware threads, CPUs the cgroup grants).
 // Measured at configs[4] (n = 8192, 256 starts, 16-CPU quota): host part of one acquisition 44 ms with 1 thread, 10.6 with
 // 8, 8.1 with 16; 24 threads run into the quota (17-37 ms).
-static int host_threads() {
+static int default_host_threads() {
   static const int v = [] {
-    const char* e = std::getenv("ELFIHIP_HOST_THREADS");
-    int t = e ? std::atoi(e) : 0;
-    if (t <= 0) {
-      const unsigned hc = std::thread::hardware_concurrency();
-      t = (int)std::min<unsigned>(16u, hc ? hc : 1u);
-      // cgroup v2 CPU quota ("max" or "<quota> <period>")
-      if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
-        long long q = 0, p = 0;
-        if (std::fscanf(f, "%lld %lld", &q, &p) == 2 && q > 0 && p > 0) t = (int)std::min<long long>(t, std::max<long long>(1, q / p));
-        std::fclose(f);
-      }
+    const unsigned hc = std::thread::hardware_concurrency();
+    int t = (int)std::min<unsigned>(16u, hc ? hc : 1u);
+    // cgroup v2 CPU quota ("max" or "<quota> <period>")
+    if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+      long long q = 0, p = 0;
+      if (std::fscanf(f, "%lld %lld", &q, &p) == 2 && q > 0 && p > 0) t = (int)std::min<long long>(t, std::max<long long>(1, q / p));
+      std::fclose(f);
     }
-    return t < 1 ? 1 : (t > 64 ? 64 : t);
+    return t < 1 ? 1 : t;
   }();
   return v;
+}
+static int host_threads(const elfihip_gp* gp) {
+  const int t = gp->acq_host_threads > 0 ? gp->acq_host_threads : default_host_threads();
+  return t < 1 ? 1 : (t > 64 ? 64 : t);
 }
 
 static int lcb_minimize_impl(elfihip_gp* gp, const double* starts, int64_t S, const double* lo, const double* hi,
@@ -66,11 +66,13 @@ static int lcb_minimize_impl(elfihip_gp* gp, const double* starts, int64_t S, co
   for (int64_t i = 0; i < S; ++i) opt[(size_t)i].init(dim, lo, hi, starts + i * dim, maxiter);
   // the worker threads outlive the call (one pool per calling thread: starting 15 threads costs about half a millisecond,
   // a tenth of a short 64-start search); between calls they sleep on the pool's condition variable
+  // (a pool made before a fork does not exist in the child, and one of another width is replaced)
   static thread_local RoundPool serial_pool(1);
   static thread_local std::unique_ptr<RoundPool> wide_pool;
-  if (S >= 64 && !wide_pool) wide_pool.reset(new RoundPool(host_threads()));
+  const int nth = host_threads(gp);
+  if (S >= 64 && (!wide_pool || !wide_pool->alive() || wide_pool->threads() != nth)) wide_pool.reset(new RoundPool(nth));
   RoundPool& pool = S >= 64 ? *wide_pool : serial_pool;
-  static const int trace = std::getenv("ELFIHIP_ACQ_TRACE") ? std::atoi(std::getenv("ELFIHIP_ACQ_TRACE")) : 0;
+  const int trace = gp->acq_trace;
   std::vector<std::pair<int, float>> per_round;
   double t_dev = 0.0, t_host = 0.0;
   int rounds = 0;
@@ -101,7 +103,7 @@ static int lcb_minimize_impl(elfihip_gp* gp, const double* starts, int64_t S, co
   if (trace)
     std::fprintf(stderr, "[elfihip acq] S=%lld n=%lld rounds=%d evals=%lld device %.3f ms host %.3f ms (threads %d)\n",
                  (long long)S, (long long)gp->n, rounds, (long long)n_eval, 1e3 * t_dev, 1e3 * t_host,
-                 S >= 64 ? host_threads() : 1);
+                 S >= 64 ? nth : 1);
   if (trace >= 2) {
     std::fprintf(stderr, "[elfihip acq rounds] (active points: device ms)");
     for (auto& pr : per_round) std::fprintf(stderr, " %d:%.3f", pr.first, pr.second);
@@ -130,7 +132,21 @@ int elfihip_gp_lcb_minimize(elfihip_gp* gp, const double* starts, int64_t S, con
   if (!gp->factored)
     return fail(gp->ctx, ELFIHIP_ERR_STATE, "GP is not factorised (call elfihip_gp_factorize first)");
   DeviceGuard g(gp->ctx->device);
-  return lcb_minimize_impl(gp, starts, S, lower, upper, beta, maxiter, x_out, f_out, iters_out, n_eval_out);
+  try {
+    return lcb_minimize_impl(gp, starts, S, lower, upper, beta, maxiter, x_out, f_out, iters_out, n_eval_out);
+  } catch (const std::bad_alloc&) {
+    return fail(gp->ctx, ELFIHIP_ERR_NOMEM, "out of host memory in the multi-start search (%lld starts)", (long long)S);
+  } catch (const std::exception& e) {
+    return fail(gp->ctx, ELFIHIP_ERR_STATE, "multi-start search failed: %s", e.what());
+  }
+}
+
+int elfihip_gp_set_acq_options(elfihip_gp* gp, int host_threads, int trace) {
+  if (!gp) return fail(nullptr, ELFIHIP_ERR_ARG, "gp is NULL");
+  ELFIHIP_REQUIRE(gp->ctx, host_threads >= 0 && host_threads <= 64 && trace >= 0, "host_threads in [0, 64], trace >= 0");
+  gp->acq_host_threads = host_threads;
+  gp->acq_trace = trace;
+  return ELFIHIP_OK;
 }
 
 // ---- reverse-communication form for objectives assembled on the host (include/elfihip.h) ----------

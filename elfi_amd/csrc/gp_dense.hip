@@ -336,9 +336,30 @@ static int dense_tile_rows(const elfihip_gp* gp, int ncb) {
 
 int64_t dense_min_points(const elfihip_gp* gp) { return gp->dense_min > 0 ? gp->dense_min : 112; }
 
-// mode: 0 = mean / variance, 1 = + gradients (and LCB); same outputs as predict_impl.
+static int predict_dense_round(elfihip_gp* gp, const double* Xs, int64_t S, int mode, int noiseless, double beta, double* mu,
+                               double* var, double* dmu, double* dvar, double* val, double* grad);
+
+// mode: 0 = mean / variance, 1 = + gradients (and LCB); same outputs as predict_impl.  Any number of points: rounds of at
+// most `cap` points reuse one workspace (3 np doubles per point: kr, kbt, VT -- 512 MiB at most) and one set of flags; a
+// round's grid stays far below the 65535-block limit of its y / z dimensions (a posterior evaluated on a 10^5-point grid
+// would otherwise ask for 5 GB of workspace, and 10^6 points for an illegal launch).
 int predict_dense_impl(elfihip_gp* gp, const double* Xs, int64_t S, int mode, int noiseless, double beta, double* mu,
                        double* var, double* dmu, double* dvar, double* val, double* grad) {
+  const int d = gp->d;
+  int64_t cap = ((int64_t)512 << 20) / (24 * (gp->np > 0 ? gp->np : 1));
+  cap = cap < 256 ? 256 : (cap > 4096 ? 4096 : cap);
+  cap -= cap % 64;
+  for (int64_t s0 = 0; s0 < S; s0 += cap) {
+    const int64_t sc = S - s0 < cap ? S - s0 : cap;
+    ELFIHIP_TRY(predict_dense_round(gp, Xs + s0 * d, sc, mode, noiseless, beta, mu ? mu + s0 : nullptr,
+                                    var ? var + s0 : nullptr, dmu ? dmu + s0 * d : nullptr, dvar ? dvar + s0 * d : nullptr,
+                                    val ? val + s0 : nullptr, grad ? grad + s0 * d : nullptr));
+  }
+  return ELFIHIP_OK;
+}
+
+static int predict_dense_round(elfihip_gp* gp, const double* Xs, int64_t S, int mode, int noiseless, double beta, double* mu,
+                               double* var, double* dmu, double* dvar, double* val, double* grad) {
   elfihip_ctx* ctx = gp->ctx;
   hipStream_t st = ctx->stream;
   if (!gp->factored)

@@ -28,6 +28,13 @@
 #include "mfma_f64.hpp"
 #include "special.hpp"
 
+
+// The hand-offs between workgroups in this file (write-through stores, s_waitcnt vmcnt(0), relaxed agent-scope atomics, one
+// acquire at the consumer) rely on the gfx9 family counting stores in vmcnt and on sc1 atomics writing through.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "built for gfx950 (MI355X): the cross-workgroup hand-offs here are not valid on this target"
+#endif
+
 namespace elfihip {
 
 constexpr int PC = 16;    // columns (query points) per pass

@@ -6,10 +6,13 @@
 #include <chrono>
 #include <condition_variable>
 #include <cstdint>
+#include <exception>
 #include <functional>
 #include <mutex>
 #include <thread>
 #include <vector>
+
+#include <unistd.h>
 
 namespace elfihip {
 
@@ -22,10 +25,14 @@ namespace elfihip {
 // (measured: 256 starts, 8 threads, 0.145 ms of host time per round against 0.06 ms of work).
 class RoundPool {
  public:
-  explicit RoundPool(int nthreads) {
+  explicit RoundPool(int nthreads) : pid_(getpid()), nthreads_(nthreads) {
     for (int i = 1; i < nthreads; ++i) th_.emplace_back([this] { loop(); });
   }
   ~RoundPool() {
+    if (getpid() != pid_) {   // a forked child inherited the thread OBJECTS, not the threads: nothing to stop or join
+      for (auto& t : th_) t.detach();
+      return;
+    }
     {
       std::lock_guard<std::mutex> lock(mu_);
       stop_.store(true, std::memory_order_release);
@@ -33,13 +40,29 @@ class RoundPool {
     cv_go_.notify_all();
     for (auto& t : th_) t.join();
   }
+  int threads() const { return nthreads_; }
+  // The pool was made by this process (a child forked after the pool's first use must not wait for workers it does not have).
+  bool alive() const { return getpid() == pid_; }
   template <class F>
   void run(int64_t n, F f) {
-    if (th_.empty() || n < 32) {
+    if (th_.empty() || n < 32 || !alive()) {
       for (int64_t i = 0; i < n; ++i) f(i);
       return;
     }
-    fn_ = [&f](int64_t i) { f(i); };
+    // an exception inside an item (bad_alloc in a state machine) is carried to the caller instead of ending the process
+    // from a worker thread; the remaining items of the round are skipped
+    failed_.store(false, std::memory_order_relaxed);
+    error_ = nullptr;
+    fn_ = [this, &f](int64_t i) {
+      if (failed_.load(std::memory_order_relaxed)) return;
+      try {
+        f(i);
+      } catch (...) {
+        std::lock_guard<std::mutex> lock(mu_);
+        if (!error_) error_ = std::current_exception();
+        failed_.store(true, std::memory_order_relaxed);
+      }
+    };
     n_ = n;
     next_.store(0, std::memory_order_relaxed);
     busy_.store((int)th_.size(), std::memory_order_relaxed);
@@ -51,6 +74,7 @@ class RoundPool {
     work();
     for (unsigned spin = 0; busy_.load(std::memory_order_acquire) != 0; ++spin)
       if ((spin & 63u) == 63u) std::this_thread::yield();
+    if (error_) std::rethrow_exception(error_);
   }
 
  private:
@@ -92,7 +116,11 @@ class RoundPool {
       busy_.fetch_sub(1, std::memory_order_release);
     }
   }
+  const pid_t pid_;
+  const int nthreads_;
   std::vector<std::thread> th_;
+  std::exception_ptr error_;
+  std::atomic<bool> failed_{false};
   std::mutex mu_;
   std::condition_variable cv_go_;
   std::function<void(int64_t)> fn_;

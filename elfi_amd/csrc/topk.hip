@@ -29,6 +29,13 @@
 #include "common.hpp"
 #include "internal.hpp"
 
+
+// The hand-offs between workgroups in this file (write-through stores, s_waitcnt vmcnt(0), relaxed agent-scope atomics, one
+// acquire at the consumer) rely on the gfx9 family counting stores in vmcnt and on sc1 atomics writing through.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "built for gfx950 (MI355X): the cross-workgroup hand-offs here are not valid on this target"
+#endif
+
 namespace elfihip {
 
 constexpr int SEL_BITS = 11, SEL_BINS = 1 << SEL_BITS, SEL_PASSES = 6;

@@ -97,6 +97,11 @@ class GPHandle:
         """0: four launches per small prediction call (fused epilogues, default); 1: the six-launch form."""
         self._check(self.lib.elfihip_gp_set_lockstep_form(self.h, int(form)))
 
+    def set_acq_options(self, host_threads=0, trace=0):
+        """Options of lcb_minimize (include/elfihip.h: elfihip_gp_set_acq_options): host threads of the multi-start
+        search's quasi-Newton algebra (0: by the machine), trace level on stderr (0 none, 1 per search, 2 per round)."""
+        self._check(self.lib.elfihip_gp_set_acq_options(self.h, int(host_threads), int(trace)))
+
     PHASES = ('gram', 'sweep', 'alpha', 'kstar', 'tri_first', 'tri_second', 'grad_finish', 'kinv_grad')
 
     def profile(self, enable=-1):
@@ -481,9 +486,16 @@ class HipGPRegression:
         cap = max(512, int(2 ** np.ceil(np.log2(max(n, 1)))))
         old = self._handle
         self._handle = GPHandle(self.input_dim, cap, ctx=_lib.default_context(self.device))
+        if self.acq_host_threads or self.acq_trace:
+            self._handle.set_acq_options(self.acq_host_threads, self.acq_trace)
         if old is not None:
             old.close()
         return True
+
+    # Options of the multi-start acquisition search handed to every device handle this model creates
+    # (GPHandle.set_acq_options): host threads (0: by the machine), trace level on stderr.
+    acq_host_threads = 0
+    acq_trace = 0
 
     # Points added per update() up to which the factorisation is extended by bordering (O(n^2) each)
     # instead of rebuilt (O(n^3)); the reference always rebuilds (gpy_regression.py:304-312), the

@@ -244,8 +244,13 @@ class HipLCBSC:
 
     def _value_and_gradient(self, X, t):
         """Criterion and gradient at the rows of X: ONE batched device call for the GP part + the user's cost."""
-        val, grad = self.model.lcb(X, self._beta(t), with_grad=True)
-        val, grad = val.reshape(-1), np.array(grad, dtype=float)
+        if getattr(self.model, '_handle', None) is None or self.model.n_evidence == 0:
+            # no evidence yet: the reference's GP predicts (0, 1) everywhere (gpy_regression.py:113-116)
+            X = np.atleast_2d(X)
+            val, grad = np.full(len(X), -np.sqrt(self._beta(t))), np.zeros((len(X), self.model.input_dim))
+        else:
+            val, grad = self.model.lcb(X, self._beta(t), with_grad=True)
+            val, grad = val.reshape(-1), np.array(grad, dtype=float)
         if self.additive_cost is not None:
             val = val + np.asarray(self.additive_cost.evaluate(X), dtype=float).reshape(-1)
             grad = grad + np.asarray(self.additive_cost.evaluate_gradient(X), dtype=float).reshape(grad.shape)
@@ -282,13 +287,15 @@ class HipLCBSC:
         if start_points is None:
             start_points = self._start_points()
         bounds = self.model.bounds
-        if getattr(self.model, '_handle', None) is None or self.model.n_evidence == 0:
+        no_evidence = getattr(self.model, '_handle', None) is None or self.model.n_evidence == 0
+        host_form = self.constraints is not None or self.additive_cost is not None
+        if no_evidence and not host_form:
             # no evidence yet: the reference's GP predicts (0, 1) everywhere, every start is a minimum
             self.last_opt = None
             return np.array(start_points[0], dtype=float), float(-np.sqrt(self._beta(t)))
         rank, world = _dist_rank_world() if self.shard_starts else (0, 1)
         mine = np.arange(rank, len(start_points), world)     # start s belongs to rank s % world
-        if len(mine) and (self.constraints is not None or self.additive_cost is not None):
+        if len(mine) and host_form:   # (also without evidence: the user's cost / constraints still shape the search)
             locs, vals, iters, n_eval = self._minimize_on_host(t, start_points[mine])
         elif len(mine):
             locs, vals, iters, n_eval = self.model._handle.lcb_minimize(start_points[mine], bounds, self._beta(t),

@@ -425,6 +425,10 @@ int elfihip_gp_lcb(elfihip_gp* gp, const double* Xs, int64_t S, double beta, dou
 int elfihip_gp_lcb_minimize(elfihip_gp* gp, const double* starts, int64_t S, const double* lower,
                             const double* upper, double beta, int maxiter, double* x_out, double* f_out,
                             int* iters_out, int64_t* n_eval_out);
+/* Options of that search (no environment switches): host_threads of the quasi-Newton algebra for searches of >= 64 starts
+ * (0: min(16, hardware threads, CPUs the cgroup grants)); trace: 1 = one line per search on stderr (rounds, evaluations,
+ * device / host milliseconds), 2 = + active points and device time of every round, 0 = nothing. */
+int elfihip_gp_set_acq_options(elfihip_gp* gp, int host_threads, int trace);
 
 /* ExpIntVar (elfi/methods/bo/acquisition.py:629-821) needs the GP's posterior covariance between its M
  * integration points and each candidate: cov(p_i, q) = k(p_i, q) - k(p_i, X) K^-1 k(X, q), which the

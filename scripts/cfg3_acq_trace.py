@@ -1,5 +1,5 @@
 """Developer tool: BASELINE configs[2] through the reference's loop with the acquisition trace on -- rounds, point
-evaluations, device and host time of every acquire() call (ELFIHIP_ACQ_TRACE=1 lines on stderr), summarised.
+evaluations, device and host time of every acquire() call (HipGPRegression.acq_trace = 1: lines on stderr), summarised.
 usage: python scripts/cfg3_acq_trace.py [n_evidence]"""
 import os
 import re
@@ -11,11 +11,13 @@ if os.environ.get("CFG3_CHILD") == "1":
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import bench
+    import elfi_amd
+    elfi_amd.HipGPRegression.acq_trace = 1
     r = bench.cfg3_end_to_end(n_evidence=int(sys.argv[1]))
     print("wall %.2f s" % r["wall_s"])
     sys.exit(0)
 n = sys.argv[1] if len(sys.argv) > 1 else "2048"
-env = dict(os.environ, CFG3_CHILD="1", ELFIHIP_ACQ_TRACE="1")
+env = dict(os.environ, CFG3_CHILD="1")
 p = subprocess.run([sys.executable, os.path.abspath(__file__), n], env=env, capture_output=True, text=True)
 rows = [tuple(float(v) for v in m) for m in re.findall(
     r"S=(\d+) n=(\d+) rounds=(\d+) evals=(\d+) device ([\d.]+) ms host ([\d.]+) ms", p.stderr)]

@@ -390,6 +390,26 @@ def test_dense_form_of_the_products_vs_streaming_form_and_oracle(hip_ctx, n, d, 
     gp.set_dense_threshold(0)
 
 
+def test_dense_form_many_points_in_rounds(hip_ctx):
+    """S far above one round of the dense predictor (rounds of at most 4096 points reuse one workspace, csrc/gp_dense.hip):
+    a posterior evaluated on a grid -- every point equals its own small call, ragged last round included."""
+    n, d, S = 1500, 3, 9001
+    X, y, bounds = _problem(n, d, seed=77)
+    gp, _, ref = _fit(X, y, bounds)
+    xs = np.random.RandomState(3).uniform(-2, 2, (S, d))
+    m, v, dm, dv = gp.predict_grad(xs)
+    assert m.shape[0] == S and np.all(np.isfinite(m)) and np.all(np.isfinite(dv))
+    for lo in (0, 4000, 4096 - 3, 8192 - 1, S - 70):
+        sl = slice(lo, lo + 70)
+        ms, vs, dms, dvs = gp.predict_grad(xs[sl])
+        _close(m[sl], ms, 1e-12, 'mu rounds')
+        assert np.max(np.abs(v[sl] - vs)) <= 1e-11 * (ref.var + ref.bias)
+        _close(dm[sl], dms, 1e-11, 'grad mu rounds')
+        _close(dv[sl], dvs, 1e-10, 'grad var rounds')
+    rmu, rvar = ref.predict(xs[-50:], noiseless=True)
+    _close(m[-50:], rmu, 1e-8, 'mu')
+
+
 @pytest.mark.parametrize('n,d,S', [(700, 5, 10), (2100, 2, 16), (4096, 10, 10), (1000, 20, 40)])
 def test_fused_lockstep_form_equals_the_six_launch_form(hip_ctx, n, d, S):
     """elfihip_gp_set_lockstep_form: the reduction of the first product's partials and the gradient sums of the second as
