@@ -168,3 +168,45 @@ def test_other_optimizers_reach_the_map_objective(hip_ctx, optimizer):
     with pytest.raises(ValueError):
         bad = HipGPRegression(names, bounds=dict(zip(names, bounds)), optimizer='nope')
         bad.update(X, y, optimize=True)
+
+
+@pytest.mark.timeout(1200)
+def test_whole_scg_search_at_n_2048_next_to_the_oracle(hip_ctx):
+    """a10 at scale: ONE whole MAP search of the hyper-parameters (SCG, gpy_regression.py:317-323) on the device next to
+    the oracle's SCG, at the size a configs[2] run searches at -- n = 2048, d = 2, evidence of the MA2 model as BOLFI
+    collects it (parameters from the example's priors, y = log distance of the simulated autocovariances to the observed
+    ones).  Every evaluation is a device rebuild + K^-1 gradient on one side, a LAPACK Cholesky + dense gradient on the
+    other: the same number of iterations and of evaluations, the same stopping reason, per-iteration objective values
+    within 5e-6 of the search's total decrease (SCG takes its curvature from a gradient difference over a step of 1e-7:
+    the 1e-9 agreement of the two gradients reaches the step lengths as 1e-2 x 1e-4 -- measured 1e-6), and end points that
+    agree as far as SCG's own stopping rule determines them."""
+    from elfi_amd import HipGPRegression
+    from elfi_amd import hyperopt as H
+    rs = np.random.RandomState(4)
+    n = 2048
+    u = rs.uniform(size=n)                                   # elfi/examples/ma2.py: CustomPrior1 (b = 2), CustomPrior2 (a = 1)
+    t1 = np.where(u < 0.5, np.sqrt(2. * u) * 2 - 2, -np.sqrt(2. * (1. - u)) * 2 + 2)
+    t2 = rs.uniform(-1.0, 1.0, n)                            # (inside the bounds; the triangle's corners do not matter here)
+    w = rs.randn(n, 102)
+    x = w[:, 2:] + t1[:, None] * w[:, 1:-1] + t2[:, None] * w[:, :-2]
+    S1, S2 = np.mean(x[:, 1:] * x[:, :-1], axis=1), np.mean(x[:, 2:] * x[:, :-2], axis=1)
+    y = np.log(np.sqrt((S1 - 0.55) ** 2 + (S2 - 0.18) ** 2))[:, None]
+    X = np.column_stack([t1, t2])
+    bounds = [(-2, 2), (-1, 1)]
+    m = HipGPRegression(['t1', 't2'], bounds={'t1': bounds[0], 't2': bounds[1]})
+    m.update(X, y)
+    pri = G.default_priors(bounds, y)
+    h0 = G.initial_hyper(y)
+    assert m._hyper == h0
+    m.optimize()
+    info = m._opt_info
+    href, iref = HO.optimize(X, y, h0, pri, max_iters=50)
+    fg, fc = np.array(info['objective']), np.array(iref['objective'])
+    assert len(fg) == len(fc), (len(fg), len(fc), info['status'], iref['status'])
+    assert info['n_fits'] == iref['n_fits']
+    scale = abs(fc[0] - fc[-1]) + 1.0
+    assert np.max(np.abs(fg - fc)) <= 5e-6 * scale, (np.max(np.abs(fg - fc)), scale)
+    assert info['status'] == iref['status']
+    for k in H.NAMES:
+        assert abs(m._hyper[k] - href[k]) <= 1e-4 * href[k], (k, m._hyper[k], href[k])
+    assert fg[-1] < fg[0] - 1.0
