@@ -58,6 +58,10 @@ for (n, m) in ((10**6, 32), (1250000, 64), (4 * 10**6, 2)):
     state = torch.zeros(1 + 2 * m, dtype=torch.float64, device=dev)
     ms = timed(lambda: ctx.call('elfihip_welford_update_dev', nxt().data_ptr(), n, m, m, state.data_ptr()))
     rows.append(('welford (2 passes)', n, m, ms, 2 * 8 * m * n))
+    st2 = torch.zeros(1 + 2 * m, dtype=torch.float64, device=dev)
+    ms = timed(lambda: ctx.call('elfihip_adaptive_push_dev', None, nxt().data_ptr(), n, m, m, y.data_ptr(), W.data_ptr(), K,
+                                outk.data_ptr(), st2.data_ptr(), 0))
+    rows.append(('adaptive pass: K=3 distances + column statistics in one read', n, m, ms, (8 * m + 8 * K) * n))
     XT = [x.t().contiguous() for x in Xs[:2]]   # column-major (m, n): column j at j*n
     ms = timed(lambda: ctx.call('elfihip_dist_cols_dev', 0, XT[c[0] % 2].data_ptr(), n, m, n, y.data_ptr(), None, 2.0,
                                 out.data_ptr()))
