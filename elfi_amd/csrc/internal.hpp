@@ -20,6 +20,8 @@ int dist_multiw_dev_impl(elfihip_ctx* ctx, const double* dX, int64_t n, int m, i
 int topk_dev_impl(elfihip_ctx* ctx, const double* dD, int64_t n, int64_t stride, int64_t k, double* dvals,
                   int64_t* didx, bool force_multi);
 
+int topk_resident_err_async(elfihip_ctx* ctx, unsigned int* host_err);   // see topk.hip
+
 // reject.hip: the sampler state; push of a device-resident batch (no device guard, no argument checks)
 elfihip_ctx* reject_ctx(elfihip_reject* h);
 int reject_push_rows_impl(elfihip_reject* h, int metric, const double* dX, int64_t n, int m, int64_t ldx,

@@ -496,11 +496,24 @@ int reject_push_rows_impl(elfihip_reject* h, int metric, const double* dX, int64
 // ---- one AdaptiveDistance batch: distances + column statistics + selection in one read (adaptive.hip) -------------
 // The j best rows of a batch's prefix sit at the head of the candidate list with batch-local row numbers: make the
 // numbers global, make the j-th distance the threshold of the pass over the rest, and let the list continue behind them.
-__global__ void reject_seed_kernel(double* thr, unsigned int* count, const double* cand_val, long long* cand_row, int j,
-                                   long long row_base) {
-  for (int e = threadIdx.x; e < j; e += blockDim.x) cand_row[e] += row_base;
+__global__ __launch_bounds__(256) void reject_seed_kernel(double* thr, unsigned int* count, const double* cand_val,
+                                                          long long* cand_row, int j, long long row_base) {
+  // (the selection hands the j smallest over in ROW order, not sorted: the threshold is their maximum)
+  __shared__ double red[256];
+  double m = -__builtin_huge_val();
+  for (int e = threadIdx.x; e < j; e += blockDim.x) {
+    cand_row[e] += row_base;
+    const double v = cand_val[e];
+    m = v > m ? v : m;
+  }
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int s_ = 128; s_ > 0; s_ >>= 1) {
+    if ((int)threadIdx.x < s_) red[threadIdx.x] = red[threadIdx.x + s_] > red[threadIdx.x] ? red[threadIdx.x + s_] : red[threadIdx.x];
+    __syncthreads();
+  }
   if (threadIdx.x == 0) {
-    *thr = cand_val[j - 1];
+    *thr = red[0];
     *count = (unsigned int)j;
   }
 }
@@ -583,7 +596,7 @@ int adaptive_push_impl(elfihip_ctx* ctx, elfihip_reject* h, const double* dX, in
     // A large first batch (an SMC round starts from an empty state: samplers.py:474-487).  Every row could enter, so
     // there is no threshold for the kernel to filter with, and a radix selection over all n distances costs as much
     // as the pass itself (10^7 x 3: 0.65 ms).  Instead: the j-th smallest distance T of a PREFIX of s rows (j a few
-    // standard deviations above the k s / n of the batch's k best that fall into the prefix of exchangeable rows) is
+    // standard deviations -- five -- above the k s / n of the batch's k best that fall into the prefix of exchangeable rows) is
     // with overwhelming probability above the batch's k-th smallest, and then the prefix's j best + the rows of the
     // rest below T -- about j n / s of them -- contain the batch's k best.  That is CHECKED (the list's length is read
     // back): if fewer than k rows qualified (the rows were not exchangeable: sorted input), or far too many, the
@@ -591,12 +604,16 @@ int adaptive_push_impl(elfihip_ctx* ctx, elfihip_reject* h, const double* dX, in
     ELFIHIP_TRY(reject_flush(h));
     const int64_t s = std::min<int64_t>(std::max<int64_t>(n / 32, 16384), n / 2);
     const double mu = (double)h->k * (double)s / (double)n;
-    int64_t j = (int64_t)std::ceil(mu + 6.0 * std::sqrt(mu) + 8.0);
+    int64_t j = (int64_t)std::ceil(mu + 5.0 * std::sqrt(mu) + 4.0);
     if (j > h->k) j = h->k;
     double* pre = dout;
     if (!pre) ELFIHIP_TRY(scratch_out(s, &pre));
     ELFIHIP_TRY(pass(0, s, nullptr, false, pre));
-    ELFIHIP_TRY(topk_dev_impl(ctx, pre + (K - 1), s, K, j, h->cand_val, reinterpret_cast<int64_t*>(h->cand_row), true));
+    // (the prefix's selection as ONE resident launch: its barrier time-out flag is read back with the list's length below,
+    // and a time-out takes the route of a failed check)
+    ELFIHIP_TRY(topk_dev_impl(ctx, pre + (K - 1), s, K, j, h->cand_val, reinterpret_cast<int64_t*>(h->cand_row), false));
+    unsigned int sel_err = 0;
+    ELFIHIP_TRY(topk_resident_err_async(ctx, &sel_err));
     hipLaunchKernelGGL(reject_seed_kernel, dim3(1), dim3(256), 0, st, h->thr, h->count, h->cand_val, h->cand_row, (int)j,
                        (long long)row_base);
     RejectFilter F;
@@ -610,7 +627,7 @@ int adaptive_push_impl(elfihip_ctx* ctx, elfihip_reject* h, const double* dX, in
     unsigned int c = 0;
     ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(&c, h->count, sizeof c, hipMemcpyDeviceToHost, st));
     ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(st));
-    if ((int64_t)c >= h->k && (int64_t)c <= std::max<int64_t>(REJ_PROV_MAX_CAND, 64 * j) && c <= h->cap) {
+    if (sel_err == 0 && (int64_t)c >= h->k && (int64_t)c <= std::max<int64_t>(REJ_PROV_MAX_CAND, 64 * j) && c <= h->cap) {
       ELFIHIP_TRY(merge_list(-1, 0));
     } else {
       // the prefix did not represent the batch: selection over all n distances (recomputed when the caller kept none)
