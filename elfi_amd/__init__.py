@@ -21,7 +21,7 @@ from .weighted import weighted_sample_quantile, weighted_var  # noqa: F401
 from .gp import GPHandle, HipGPRegression  # noqa: F401
 from .selection import RunningBest, merge_batch, smallest_k  # noqa: F401
 from .sampler import HipRejection, hip_rejection_class  # noqa: F401
-from .distance import adaptive_batch  # noqa: F401
+from .distance import adaptive_batch, randn_rows  # noqa: F401
 from .adaptive import hip_adaptive_distance_class  # noqa: F401
 from .smc import HipAdaptiveDistanceSMC, HipAdaptiveThresholdSMC, HipSMC, hip_smc_class  # noqa: F401
 from .summaries import autocov, gauss_distance, ma2_distance, ma2_draw_distance, ss_mean, ss_var  # noqa: F401

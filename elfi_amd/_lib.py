@@ -86,6 +86,11 @@ PROTOTYPES = {
     "elfihip_adaptive_push": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_void_p,
                                        C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.c_void_p, C.c_void_p,
                                        C.c_int64]),
+    "elfihip_kept_rows": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
+    "elfihip_adaptive_push_kept": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                            C.POINTER(C.c_int64), C.c_void_p, C.c_void_p, C.c_int64]),
+    "elfihip_randn_rows": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int64, C.c_int, C.c_void_p, C.c_void_p,
+                                    C.c_void_p]),
     "elfihip_kept_distances": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
     "elfihip_reject_push_kept": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64]),
     "elfihip_ma2_draw_distance": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int64, C.c_int, C.c_void_p, C.c_void_p,
@@ -305,6 +310,27 @@ def remember_kept(arr, ctx):
     except TypeError:
         pass
     return arr
+
+
+_ROWS = {}      # id(array a device-side simulator returned) -> (weak reference, context, epoch of its device copy)
+
+
+def remember_rows(arr, ctx):
+    for key in [k for k, (ref, _, _) in _ROWS.items() if ref() is None]:
+        del _ROWS[key]
+    while len(_ROWS) > 8:
+        del _ROWS[next(iter(_ROWS))]
+    ep = C.c_uint64()
+    ctx.call("elfihip_kept_rows", C.byref(ep), None, None)
+    _ROWS[id(arr)] = (weakref.ref(arr), ctx, ep.value)
+    return arr
+
+
+def rows_epoch_of(arr, ctx):
+    ent = _ROWS.get(id(arr))
+    if ent is None or ent[0]() is not arr or ent[1] is not ctx:
+        return None
+    return ent[2]
 
 
 def alias_kept(new, old):

@@ -569,13 +569,12 @@ int elfihip_adaptive_push_dev(elfihip_ctx* ctx, elfihip_reject* state, const dou
   return adaptive_push_impl(ctx, state, dX, n, m, ldx, dy, dW, K, dout, dwelford, row_base);
 }
 
-int elfihip_adaptive_push(elfihip_ctx* ctx, elfihip_reject* state, const double* X, int64_t n, int m, int64_t ldx,
-                          const double* y, const double* W, int K, double* out, int64_t* count, double* mean,
-                          double* M2, int64_t row_base) {
-  if (!ctx) return fail(nullptr, ELFIHIP_ERR_ARG, "ctx is NULL");
-  ELFIHIP_REQUIRE(ctx, n >= 0 && m >= 1 && ldx >= m, "bad shape n=%lld m=%d ldx=%lld", (long long)n, m, (long long)ldx);
+// host form; X == nullptr: the rows are the context's kept copy (ctx->rows, pitch m)
+static int adaptive_push_host(elfihip_ctx* ctx, elfihip_reject* state, const double* X, int64_t n, int m, int64_t ldx,
+                              const double* y, const double* W, int K, double* out, int64_t* count, double* mean,
+                              double* M2, int64_t row_base) {
   ELFIHIP_REQUIRE(ctx, K >= 1 && K <= 64, "K=%d outside [1,64]", K);
-  ELFIHIP_REQUIRE(ctx, y && W && (n == 0 || X), "NULL data pointer");
+  ELFIHIP_REQUIRE(ctx, y && W, "NULL data pointer");
   ELFIHIP_REQUIRE(ctx, (!count && !mean && !M2) || (count && mean && M2), "count / mean / M2 come together");
   ELFIHIP_REQUIRE(ctx, !state || reject_ctx(state) == ctx, "the sampler state belongs to another context");
   if (n == 0) return ELFIHIP_OK;
@@ -596,12 +595,19 @@ int elfihip_adaptive_push(elfihip_ctx* ctx, elfihip_reject* state, const double*
   ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(dy, y, (size_t)m * sizeof(double), hipMemcpyHostToDevice, st));
   ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(dW, W, (size_t)K * m * sizeof(double), hipMemcpyHostToDevice, st));
   if (count) ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(dstate, hst.data(), ns * sizeof(double), hipMemcpyHostToDevice, st));
-  // the batch itself: packed (n, m), pitch m rounded up to even so that the rows stay 16-byte aligned
-  const int64_t ldd = (m + 1) & ~1;
-  ELFIHIP_CHECK_HIP(ctx, ctx->in.reserve((size_t)n * ldd * sizeof(double)));
-  double* dX = ctx->in.as<double>();
-  ELFIHIP_CHECK_HIP(ctx, hipMemcpy2DAsync(dX, (size_t)ldd * sizeof(double), X, (size_t)ldx * sizeof(double),
-                                          (size_t)m * sizeof(double), (size_t)n, hipMemcpyHostToDevice, st));
+  double* dX;
+  int64_t ldd;
+  if (X) {
+    // the batch itself: packed (n, m), pitch m rounded up to even so that the rows stay 16-byte aligned
+    ldd = (m + 1) & ~1;
+    ELFIHIP_CHECK_HIP(ctx, ctx->in.reserve((size_t)n * ldd * sizeof(double)));
+    dX = ctx->in.as<double>();
+    ELFIHIP_CHECK_HIP(ctx, hipMemcpy2DAsync(dX, (size_t)ldd * sizeof(double), X, (size_t)ldx * sizeof(double),
+                                            (size_t)m * sizeof(double), (size_t)n, hipMemcpyHostToDevice, st));
+  } else {
+    dX = ctx->rows.as<double>();
+    ldd = m;
+  }
   double* dout = nullptr;
   if (out) {
     ELFIHIP_CHECK_HIP(ctx, ctx->out.reserve((size_t)n * K * sizeof(double)));
@@ -620,6 +626,26 @@ int elfihip_adaptive_push(elfihip_ctx* ctx, elfihip_reject* state, const double*
     memcpy(M2, &hst[1 + m], (size_t)m * sizeof(double));
   }
   return ELFIHIP_OK;
+}
+
+int elfihip_adaptive_push(elfihip_ctx* ctx, elfihip_reject* state, const double* X, int64_t n, int m, int64_t ldx,
+                          const double* y, const double* W, int K, double* out, int64_t* count, double* mean,
+                          double* M2, int64_t row_base) {
+  if (!ctx) return fail(nullptr, ELFIHIP_ERR_ARG, "ctx is NULL");
+  ELFIHIP_REQUIRE(ctx, n >= 0 && m >= 1 && ldx >= m, "bad shape n=%lld m=%d ldx=%lld", (long long)n, m, (long long)ldx);
+  ELFIHIP_REQUIRE(ctx, n == 0 || X, "NULL data pointer");
+  return adaptive_push_host(ctx, state, X, n, m, ldx, y, W, K, out, count, mean, M2, row_base);
+}
+
+int elfihip_adaptive_push_kept(elfihip_ctx* ctx, elfihip_reject* state, uint64_t rows_epoch, const double* y,
+                               const double* W, int K, double* out, int64_t* count, double* mean, double* M2,
+                               int64_t row_base) {
+  if (!ctx) return fail(nullptr, ELFIHIP_ERR_ARG, "ctx is NULL");
+  if (rows_epoch != ctx->rows_epoch || (ctx->rows_n > 0 && !ctx->rows.p))
+    return fail(ctx, ELFIHIP_ERR_STATE, "the kept rows are those of a later call (epoch %llu, asked for %llu)",
+                (unsigned long long)ctx->rows_epoch, (unsigned long long)rows_epoch);
+  return adaptive_push_host(ctx, state, nullptr, ctx->rows_n, ctx->rows_m, ctx->rows_m, y, W, K, out, count, mean, M2,
+                            row_base);
 }
 
 }  // extern "C"

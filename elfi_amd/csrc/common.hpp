@@ -74,6 +74,12 @@ struct elfihip_ctx {
   uint64_t keep_epoch = 0;
   int64_t keep_n = 0;
   int keep_cols = 0;
+  // ... and the rows the last device-side simulator call (elfihip_randn_rows) returned: (rows_n, rows_m) row-major with
+  // pitch rows_m, for the distance call that follows (elfihip_kept_rows / elfihip_adaptive_push_kept)
+  elfihip::DevBuf rows;
+  uint64_t rows_epoch = 0;
+  int64_t rows_n = 0;
+  int rows_m = 0;
 };
 
 namespace elfihip {

@@ -30,6 +30,14 @@ extern "C" {
 
 int elfihip_version(void) { return ELFIHIP_VERSION; }
 
+int elfihip_kept_rows(elfihip_ctx* ctx, uint64_t* epoch, int64_t* n, int* m) {
+  if (!ctx) return fail(nullptr, ELFIHIP_ERR_ARG, "ctx is NULL");
+  if (epoch) *epoch = ctx->rows_epoch;
+  if (n) *n = ctx->rows_n;
+  if (m) *m = ctx->rows_m;
+  return ELFIHIP_OK;
+}
+
 int elfihip_kept_distances(elfihip_ctx* ctx, uint64_t* epoch, int64_t* n, int* ncols) {
   if (!ctx) return fail(nullptr, ELFIHIP_ERR_ARG, "ctx is NULL");
   if (epoch) *epoch = ctx->keep_epoch;
@@ -99,6 +107,7 @@ int elfihip_ctx_destroy(elfihip_ctx* ctx) {
     ctx->scratch.release();
     ctx->stat.release();
     ctx->keep.release();
+    ctx->rows.release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->ev_a) (void)hipEventDestroy(ctx->ev_a);

@@ -52,6 +52,22 @@ __global__ __launch_bounds__(256) void randn_kernel(uint64_t seed, uint64_t stre
   }
 }
 
+// out[i][j] = loc[i] + scale[j] z_e, e = i m + j (m even: a pair of normals stays inside a row) -- the draws of randn_kernel
+// with the same seed / stream, shaped into the rows of a synthetic Gaussian simulator
+__global__ __launch_bounds__(256) void randn_rows_kernel(uint64_t seed, uint64_t stream, int64_t n, int m, const double* loc,
+                                                         const double* scale, double* out) {
+  const int64_t npair = n * (int64_t)m / 2;
+  const int h = m / 2;
+  for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < npair; p += (int64_t)gridDim.x * 256) {
+    double z0, z1;
+    normal_pair(seed, stream, (uint64_t)p, z0, z1);
+    const int64_t i = p / h;
+    const int j = 2 * (int)(p - i * h);
+    const double l = loc[i];
+    *reinterpret_cast<double2*>(out + 2 * p) = make_double2(z0 * scale[j] + l, z1 * scale[j + 1] + l);
+  }
+}
+
 // NumPy's pairwise sum of n <= 128 terms by eight lanes (summaries.hip: np_pairwise8); lane j of an aligned group of 8
 template <class F>
 __device__ __forceinline__ double pairwise8(F f, int n, int j) {
@@ -245,6 +261,33 @@ int elfihip_randn_dev(elfihip_ctx* ctx, uint64_t seed, uint64_t stream, int64_t 
   const int64_t grid = std::min<int64_t>((npair + 255) / 256, (int64_t)ctx->cu_count * 16);
   hipLaunchKernelGGL(randn_kernel, dim3((unsigned)grid), dim3(256), 0, ctx->stream, seed, stream, n, loc, scale, dout);
   return launch_status(ctx, "randn_kernel");
+}
+
+int elfihip_randn_rows(elfihip_ctx* ctx, uint64_t seed, uint64_t stream, int64_t n, int m, const double* loc,
+                       const double* scale, double* out) {
+  if (!ctx) return fail(nullptr, ELFIHIP_ERR_ARG, "ctx is NULL");
+  ELFIHIP_REQUIRE(ctx, n >= 0 && m >= 2 && (m & 1) == 0, "bad shape n=%lld m=%d (m even)", (long long)n, m);
+  ELFIHIP_REQUIRE(ctx, n == 0 || (loc && scale && out), "NULL data pointer");
+  ++ctx->rows_epoch;
+  ctx->rows_n = 0;
+  ctx->rows_m = m;
+  if (n == 0) return ELFIHIP_OK;
+  DeviceGuard g(ctx->device);
+  ELFIHIP_CHECK_HIP(ctx, ctx->rows.reserve((size_t)n * m * sizeof(double)));
+  ELFIHIP_CHECK_HIP(ctx, ctx->par.reserve(((size_t)n + m) * sizeof(double)));
+  double* dloc = ctx->par.as<double>();
+  double* dsc = dloc + n;
+  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(dloc, loc, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(dsc, scale, (size_t)m * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  const int64_t npair = n * (int64_t)m / 2;
+  const int64_t grid = std::min<int64_t>((npair + 255) / 256, (int64_t)ctx->cu_count * 16);
+  hipLaunchKernelGGL(randn_rows_kernel, dim3((unsigned)grid), dim3(256), 0, ctx->stream, seed, stream, n, m, dloc, dsc,
+                     ctx->rows.as<double>());
+  ELFIHIP_TRY(launch_status(ctx, "randn_rows_kernel"));
+  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(out, ctx->rows.p, (size_t)n * m * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->rows_n = n;   // the device copy stays for the distance call that follows (elfihip_adaptive_push_kept)
+  return ELFIHIP_OK;
 }
 
 int elfihip_gauss_distance_dev(elfihip_ctx* ctx, const double* dZ, int64_t ldz, uint64_t seed, uint64_t stream, int64_t n,

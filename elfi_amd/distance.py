@@ -74,6 +74,7 @@ def cdist_rows(X, y, metric='euclidean', p=2.0, w=None, V=None, VI=None, ctx=Non
     GPU replacement for scipy.spatial.distance.cdist(X, Y (1, m), metric, ...)[:, 0] as
     called by elfi/model/elfi_model.py:1037.
     """
+    X0 = X
     X = np.asarray(X)
     if X.ndim != 2:
         raise ValueError('XA must be a 2-dimensional array.')
@@ -95,8 +96,13 @@ def cdist_rows(X, y, metric='euclidean', p=2.0, w=None, V=None, VI=None, ctx=Non
         X = _as_f64(X)
     ldx = X.strides[0] // 8 if n > 1 else m
     y = _as_f64(y).reshape(-1)
-    out = np.empty(n, dtype=np.float64)
     ctx = ctx or _lib.default_context()
+    if metric == 'euclidean' and _lib.rows_epoch_of(X0, ctx) is not None:
+        # rows a device-side simulator just returned (randn_rows): the pass runs on the device copy, no upload
+        # (one weight row: sqrt(sum w (x - y)^2) in cdist's order, bit-identical to the row kernel)
+        d, _ = adaptive_batch(X0, y, (np.ones(m) if aux is None else aux).reshape(1, m), ctx=ctx)
+        return _lib.alias_kept(d.reshape(-1), d)
+    out = np.empty(n, dtype=np.float64)
     ctx.call("elfihip_dist_rows", mid, _lib.ptr(X), n, m, ldx, _lib.ptr(y), _lib.ptr(aux),
              C.c_double(p), _lib.ptr(out))
     return _lib.remember_kept(out, ctx)
@@ -174,6 +180,7 @@ def adaptive_batch(X, y, W, store=None, state=None, row_base=None, distances=Tru
     with `state` (a selection.RunningBest), what Rejection._merge_batch keeps of the batch
     (elfi/methods/inference/samplers.py:209-237; rows numbered row_base + row, default: the rows pushed so far).
     Returns (distances or None, new store or None)."""
+    X0 = X
     X = np.asarray(X)
     if X.ndim != 2:
         raise ValueError('XA must be a 2-dimensional array.')
@@ -196,14 +203,41 @@ def adaptive_batch(X, y, W, store=None, state=None, row_base=None, distances=Tru
         mean = np.array(np.broadcast_to(np.asarray(store[1], dtype=np.float64), (m,)))
         M2 = np.array(np.broadcast_to(np.asarray(store[2], dtype=np.float64), (m,)))
     ctx = ctx or (state.ctx if state is not None else _lib.default_context())
-    ctx.call("elfihip_adaptive_push", state.h if state is not None else None, _lib.ptr(X), n, m, ldx, _lib.ptr(y),
-             _lib.ptr(W), K, _lib.ptr(out), C.byref(cnt) if store is not None else None, _lib.ptr(mean), _lib.ptr(M2),
-             int(row_base if row_base is not None else (state.n_pushed if state is not None else 0)))
+    base = int(row_base if row_base is not None else (state.n_pushed if state is not None else 0))
+    # rows that a device-side simulator (elfi_amd.randn_rows) just returned are still on the device: no upload
+    epoch = _lib.rows_epoch_of(X0, ctx)
+    rc = _lib.ERR_STATE
+    if epoch is not None:
+        rc = ctx.lib.elfihip_adaptive_push_kept(ctx.handle, state.h if state is not None else None, epoch, _lib.ptr(y),
+                                               _lib.ptr(W), K, _lib.ptr(out), C.byref(cnt) if store is not None else None,
+                                               _lib.ptr(mean), _lib.ptr(M2), base)
+        if rc not in (_lib.OK, _lib.ERR_STATE):
+            _lib.check(ctx.handle, rc)
+    if rc != _lib.OK:
+        ctx.call("elfihip_adaptive_push", state.h if state is not None else None, _lib.ptr(X), n, m, ldx, _lib.ptr(y),
+                 _lib.ptr(W), K, _lib.ptr(out), C.byref(cnt) if store is not None else None, _lib.ptr(mean), _lib.ptr(M2),
+                 base)
     if state is not None:
         state.n_pushed += n
     if out is not None:
         _lib.remember_kept(out, ctx)
     return out, ((cnt.value, mean, M2) if store is not None else None)
+
+
+def randn_rows(loc, scale, seed=0, stream=0, ctx=None):
+    """The synthetic Gaussian simulator of BASELINE configs[1] / [3] on the device: (n, m) = loc[:, None] + scale[None, :] *
+    standard normals (Philox4x32-10 keyed by `seed`, counter stream `stream`; m even).  The rows come back as a NumPy array
+    AND stay on the device for the distance call that follows (adaptive_batch recognises the array)."""
+    loc = np.ascontiguousarray(np.asarray(loc, dtype=np.float64).reshape(-1))
+    scale = np.ascontiguousarray(np.asarray(scale, dtype=np.float64).reshape(-1))
+    n, m = loc.shape[0], scale.shape[0]
+    if m < 2 or m % 2:
+        raise ValueError('the number of columns must be even (got %d)' % m)
+    out = np.empty((n, m), dtype=np.float64)
+    ctx = ctx or _lib.default_context()
+    ctx.call("elfihip_randn_rows", C.c_uint64(int(seed)), C.c_uint64(int(stream)), n, m, _lib.ptr(loc), _lib.ptr(scale),
+             _lib.ptr(out))
+    return _lib.remember_rows(out, ctx)
 
 
 class HipDistance:

@@ -23,7 +23,7 @@ from functools import partial
 
 import numpy as np
 
-from .distance import HipDistance
+from .distance import HipDistance, randn_rows
 from .summaries import gauss_distance, ma2_draw_distance
 
 
@@ -98,3 +98,28 @@ def gauss_model(n_obs=50, true_params=None, seed_obs=None):
     elfi.Summary(second_column, m['gauss'], name='ss_var')
     elfi.Distance(HipDistance('euclidean'), m['ss_mean'], m['ss_var'], name='d')
     return m
+
+
+def gauss_wide_rows(mu, scale=None, batch_size=1, random_state=None):
+    """Simulator operation of the wide synthetic Gaussian model: (batch, m) rows mu[:, None] + scale * z, drawn on the device."""
+    mu = np.asarray(mu, dtype=np.float64).reshape(-1)
+    if mu.shape[0] == 1 and batch_size > 1:
+        mu = np.repeat(mu, batch_size)
+    return randn_rows(mu, scale, seed=_seed_of(random_state))
+
+
+def gauss_wide_model(m=64, adaptive=True):
+    """BASELINE configs[3]'s model: one location parameter mu ~ U(-10, 10), a synthetic Gaussian simulator with m summaries of
+    standard deviations 1 .. 20 drawn ON THE DEVICE, observed zeros; the discrepancy node is a HipAdaptiveDistance over the
+    simulator's (batch, m) output (adaptive=False: elfi.Distance(HipDistance('euclidean'))).  Nodes mu, sim, d."""
+    elfi = _elfi()
+    import scipy.stats as ss
+    from .adaptive import hip_adaptive_distance_class
+    mdl = elfi.new_model()
+    mu = elfi.Prior(ss.uniform, -10, 20, model=mdl, name='mu')
+    sim = elfi.Simulator(partial(gauss_wide_rows, scale=np.linspace(1.0, 20.0, m)), mu, observed=np.zeros((1, m)), name='sim')
+    if adaptive:
+        hip_adaptive_distance_class()(sim, name='d')
+    else:
+        elfi.Distance(HipDistance('euclidean'), sim, name='d')
+    return mdl

@@ -243,6 +243,14 @@ int elfihip_adaptive_push(elfihip_ctx* ctx, elfihip_reject* state, const double*
                           const double* y, const double* W, int K, double* out, int64_t* count, double* mean,
                           double* M2, int64_t row_base);
 
+/* ... on rows that are still on the device: elfihip_randn_rows (below) leaves a device copy of the rows it returned --
+ * elfihip_kept_rows names it -- and elfihip_adaptive_push_kept runs the pass on that copy (no upload of the batch);
+ * ELFIHIP_ERR_STATE when a later elfihip_randn_rows call has replaced it. */
+int elfihip_kept_rows(elfihip_ctx* ctx, uint64_t* epoch, int64_t* n, int* m);
+int elfihip_adaptive_push_kept(elfihip_ctx* ctx, elfihip_reject* state, uint64_t rows_epoch, const double* y,
+                               const double* W, int K, double* out, int64_t* count, double* mean, double* M2,
+                               int64_t row_base);
+
 /* ------------------------------------------------------------------ SMC proposal density
  * GMDistribution.pdf (elfi/methods/utils.py:142-183): density of a Gaussian mixture with shared
  * covariance at M points, out[r] = sum_i weights[i] * N(x_r; means[i], cov).  The caller passes the
@@ -313,6 +321,11 @@ int elfihip_gauss_distance_dev(elfihip_ctx* ctx, const double* dZ, int64_t ldz, 
  * outputs of BASELINE configs[1] / configs[3]); the raw Philox4x32-10 blocks (4 x uint32 per block, counter =
  * (block, stream), key = seed) for known-answer tests. */
 int elfihip_randn_dev(elfihip_ctx* ctx, uint64_t seed, uint64_t stream, int64_t n, double loc, double scale, double* dout);
+/* The synthetic Gaussian simulator of BASELINE configs[1] / [3] as ONE host-form node operation: out (n, m) row-major,
+ * out[i][j] = loc[i] + scale[j] z, z = the draws of elfihip_randn_dev(seed, stream) in row-major order (m even).  The rows
+ * also stay on the device for the distance call that follows (elfihip_kept_rows, elfihip_adaptive_push_kept). */
+int elfihip_randn_rows(elfihip_ctx* ctx, uint64_t seed, uint64_t stream, int64_t n, int m, const double* loc,
+                       const double* scale, double* out);
 int elfihip_random_bits_dev(elfihip_ctx* ctx, uint64_t seed, uint64_t stream, int64_t nblocks, uint32_t* dout);
 
 /* ------------------------------------------------------------------- GP surrogate

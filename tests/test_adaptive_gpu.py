@@ -242,3 +242,35 @@ def test_argument_errors(hip_ctx):
         elfi_amd.adaptive_batch(X, y, np.ones((3, 4)), state=rb)
     d, _ = elfi_amd.adaptive_batch(np.zeros((0, 4)), y, np.ones((1, 4)))
     assert d.shape == (0, 1)
+
+
+def test_device_simulator_rows_and_the_pass_on_the_kept_copy(hip_ctx):
+    """elfi_amd.randn_rows: the synthetic Gaussian simulator on the device -- the draws of elfihip_randn_dev shaped into
+    rows -- whose output stays on the device: adaptive_batch / cdist_rows on the returned array run on that copy (same
+    results as on an uploaded copy of the same numbers), a later simulator call replaces it (the earlier array is uploaded)."""
+    import torch
+    import elfi_amd
+    from elfi_amd import _lib
+    n, m = 20001, 64
+    rs = np.random.RandomState(0)
+    loc, scale = rs.uniform(-3, 3, n), np.linspace(1.0, 20.0, m)
+    X = elfi_amd.randn_rows(loc, scale, seed=11, stream=2)
+    z = torch.empty(n * m, dtype=torch.float64, device='cuda')
+    hip_ctx.call("elfihip_randn_dev", C.c_uint64(11), C.c_uint64(2), n * m, C.c_double(0.0), C.c_double(1.0), z.data_ptr())
+    hip_ctx.synchronize()
+    ref = z.cpu().numpy().reshape(n, m) * scale + loc[:, None]
+    np.testing.assert_allclose(X, ref, rtol=0, atol=4 * np.spacing(np.abs(ref).max()))
+    assert abs(np.mean((X - loc[:, None]) / scale)) < 5e-3 and abs(np.std((X - loc[:, None]) / scale) - 1) < 5e-3
+    y = rs.randn(1, m)
+    W = np.vstack([np.ones(m), rs.uniform(0.1, 2, m)])
+    assert _lib.rows_epoch_of(X, hip_ctx) is not None
+    d, st = elfi_amd.adaptive_batch(X, y, W, store=(0, 0.0, 0.0))             # on the kept copy
+    d2, st2 = elfi_amd.adaptive_batch(X.copy(), y, W, store=(0, 0.0, 0.0))    # uploaded
+    assert np.array_equal(d, d2) and np.array_equal(st[1], st2[1]) and np.array_equal(st[2], st2[2])
+    assert np.array_equal(d, _nested_ref(X, y, W))
+    assert np.array_equal(elfi_amd.cdist_rows(X, y), O.cdist_rows(X, y, 'euclidean'))
+    assert np.array_equal(elfi_amd.cdist_rows(X, y, w=W[1]), O.cdist_rows(X, y, 'euclidean', w=W[1]))
+    X2 = elfi_amd.randn_rows(loc[:500], scale, seed=12)
+    assert _lib.rows_epoch_of(X, hip_ctx) != _lib.rows_epoch_of(X2, hip_ctx)
+    assert np.array_equal(elfi_amd.adaptive_batch(X, y, W)[0], d)             # stale copy: the array is uploaded instead
+    assert np.array_equal(elfi_amd.adaptive_batch(X2, y, W)[0], _nested_ref(X2, y, W))
