@@ -86,6 +86,8 @@ PROTOTYPES = {
     "elfihip_adaptive_push": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_void_p,
                                        C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.c_void_p, C.c_void_p,
                                        C.c_int64]),
+    "elfihip_host_alloc": (C.c_int, [C.c_size_t, c_void_pp]),
+    "elfihip_host_free": (C.c_int, [C.c_void_p]),
     "elfihip_kept_rows": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
     "elfihip_adaptive_push_kept": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                             C.POINTER(C.c_int64), C.c_void_p, C.c_void_p, C.c_int64]),
@@ -311,6 +313,43 @@ def remember_kept(arr, ctx):
         pass
     return arr
 
+
+class _PinnedPool:
+    """Page-locked result buffers, recycled: pinning 512 MB costs ~0.1 s, so a buffer goes back to the pool when the last
+    NumPy view of it dies (the finalizer sits on the ctypes object every view's base chain ends in)."""
+
+    def __init__(self, keep=4):
+        self.free, self.keep = {}, keep        # nbytes -> [addresses]
+
+    def array(self, shape):
+        lib = load_library()
+        count = int(np.prod(shape))
+        nbytes = max(8, count * 8)
+        lst = self.free.get(nbytes)
+        if lst:
+            addr = lst.pop()
+        else:
+            p = C.c_void_p()
+            rc = lib.elfihip_host_alloc(nbytes, C.byref(p))
+            if rc != OK or not p.value:
+                return np.empty(shape, dtype=np.float64)       # (no pinned memory left: an ordinary array)
+            addr = p.value
+        buf = (C.c_double * max(1, count)).from_address(addr)
+        weakref.finalize(buf, self._release, addr, nbytes)
+        return np.frombuffer(buf, dtype=np.float64, count=count).reshape(shape)
+
+    def _release(self, addr, nbytes):
+        lst = self.free.setdefault(nbytes, [])
+        if len(lst) < self.keep:
+            lst.append(addr)
+        else:
+            try:
+                load_library().elfihip_host_free(C.c_void_p(addr))
+            except Exception:
+                pass
+
+
+pinned = _PinnedPool()
 
 _ROWS = {}      # id(array a device-side simulator returned) -> (weak reference, context, epoch of its device copy)
 

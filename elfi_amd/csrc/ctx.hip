@@ -30,6 +30,23 @@ extern "C" {
 
 int elfihip_version(void) { return ELFIHIP_VERSION; }
 
+int elfihip_host_alloc(size_t bytes, void** out) {
+  if (!out) return fail(nullptr, ELFIHIP_ERR_ARG, "out is NULL");
+  *out = nullptr;
+  if (bytes == 0) return ELFIHIP_OK;
+  hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
+  if (e != hipSuccess) {
+    *out = nullptr;
+    return fail(nullptr, ELFIHIP_ERR_NOMEM, "hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+  }
+  return ELFIHIP_OK;
+}
+
+int elfihip_host_free(void* p) {
+  if (p) (void)hipHostFree(p);
+  return ELFIHIP_OK;
+}
+
 int elfihip_kept_rows(elfihip_ctx* ctx, uint64_t* epoch, int64_t* n, int* m) {
   if (!ctx) return fail(nullptr, ELFIHIP_ERR_ARG, "ctx is NULL");
   if (epoch) *epoch = ctx->rows_epoch;

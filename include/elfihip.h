@@ -71,6 +71,10 @@ int elfihip_ctx_set_stream(elfihip_ctx* ctx, void* hip_stream);
 int elfihip_ctx_synchronize(elfihip_ctx* ctx);
 /* Device properties the roofline needs: CU count, clock (kHz), memory clock (kHz),
  * bus width (bits), total global memory (bytes).  Any pointer may be NULL. */
+/* Page-locked host memory for results that leave the device in bulk (the (n, m) rows of a device-side simulator: a
+ * pageable destination takes the copy at ~1 GB/s on first touch, a pinned one at PCIe speed).  Not tied to a context. */
+int elfihip_host_alloc(size_t bytes, void** out);
+int elfihip_host_free(void* p);
 int elfihip_device_info(elfihip_ctx* ctx, int* cu_count, int* clock_khz, int* mem_clock_khz,
                         int* mem_bus_bits, int64_t* total_mem, char* name, int name_len);
 
