@@ -249,3 +249,46 @@ def test_lean_truncnorm_quantile_is_scipys_bit_for_bit():
         assert np.array_equal(ref, x) or (np.isnan(ref).all() and np.isnan(x).all()), (q, a, b, ref, x)
         n_checked += 1
     assert n_checked > 5000
+
+
+def test_kept_registries_and_pinned_pool_plumbing():
+    """elfi_amd._lib: the registries that let a distance / simulator result be recognised by identity later (weak
+    references: an entry dies with its array, an id reused by another array does not match), views aliasing an entry,
+    and the page-locked pool's fall-back to ordinary arrays where pinning is not possible (no GPU here)."""
+    import gc
+    from elfi_amd import _lib
+
+    class FakeCtx:
+        def __init__(self):
+            self.epoch = 0
+
+        def kept_epoch(self):
+            return self.epoch
+
+        def call(self, name, ep, *_):
+            assert name == "elfihip_kept_rows"
+            ep._obj.value = self.epoch
+    ctx, other = FakeCtx(), FakeCtx()
+    a = np.zeros((5, 2))
+    ctx.epoch = 7
+    assert _lib.remember_kept(a, ctx) is a
+    assert _lib.kept_epoch_of(a, ctx) == 7 and _lib.kept_epoch_of(a, other) is None
+    assert _lib.kept_epoch_of(a.copy(), ctx) is None
+    v = a.reshape(-1)
+    assert _lib.alias_kept(v, a) is v and _lib.kept_epoch_of(v, ctx) == 7
+    b = np.ones(3)
+    assert _lib.alias_kept(b.reshape(-1), b) is not None and _lib.kept_epoch_of(b, ctx) is None      # nothing to alias
+    ident = id(a)
+    del a, v
+    gc.collect()
+    assert ident not in _lib._KEPT or _lib._KEPT[ident][0]() is None
+    for i in range(100):                        # the registry stays small
+        _lib.remember_kept(np.zeros(1), ctx)
+    assert len(_lib._KEPT) <= 33
+    r = np.zeros((4, 6))
+    ctx.epoch = 9
+    assert _lib.remember_rows(r, ctx) is r and _lib.rows_epoch_of(r, ctx) == 9 and _lib.rows_epoch_of(r, other) is None
+    p = _lib.pinned.array((10, 4))
+    assert p.shape == (10, 4) and p.dtype == np.float64 and p.flags['WRITEABLE']
+    p[:] = 3.0
+    assert float(p.sum()) == 120.0
