@@ -61,6 +61,7 @@ _TRUNCNORM_DIRECT = None   # None: not yet checked in this process; True / False
 
 _PPF_LEAN = None       # None: being checked against SciPy's _ppf call by call; True: trusted; False: not used
 _PPF_LEAN_CHECKS = 0
+_PPF_LEAN_CALLS = 0    # uses since it became trusted: every 256th is checked again
 
 
 def _logsumexp2(p, q):
@@ -92,18 +93,20 @@ def _truncnorm_direct(a, b, loc, scale, random_state):
     distribution's own _ppf, then * scale + loc) without rv_continuous.rvs' argument machinery in front of it
     (350 us per call on this box against 200; a BOLFI acquisition makes one call per parameter).  The quantile itself
     through the lean restatement above (15 us against 100) once that has agreed with SciPy's _ppf bit for bit on its
-    first 64 uses in this process."""
-    global _PPF_LEAN, _PPF_LEAN_CHECKS
+    first 64 uses in this process (and on every 256th use after that: a disagreement retires it for good)."""
+    global _PPF_LEAN, _PPF_LEAN_CHECKS, _PPF_LEAN_CALLS
     U = random_state.uniform(low=0, high=1, size=1)
     x = None
     if _PPF_LEAN is not False:
         a1, b1 = np.asarray(a, dtype=float).reshape(1), np.asarray(b, dtype=float).reshape(1)
         x = _truncnorm_ppf_lean(U, a1, b1)
-        if x is not None and _PPF_LEAN is None:
+        if x is not None and _PPF_LEAN:
+            _PPF_LEAN_CALLS += 1
+        if x is not None and (_PPF_LEAN is None or _PPF_LEAN_CALLS % 256 == 0):
             ref = ss.truncnorm._ppf(U, a, b)
             if np.shape(ref) != np.shape(x) or not np.array_equal(ref, x):
                 _PPF_LEAN = False
-            else:
+            elif _PPF_LEAN is None:
                 _PPF_LEAN_CHECKS += 1
                 if _PPF_LEAN_CHECKS >= 64:
                     _PPF_LEAN = True

@@ -1,0 +1,62 @@
+"""Developer tool: what ONE product per lock-step could buy (the stored-K^-1 form of the predictor).
+
+The value-only lock-step (lcb without gradient: kernel row + the first triangular product with its fused reduction +
+finish) is the launch chain a symmetric product on a stored K^-1 would have -- one pass over 8n^2/2 bytes between the
+kernel row and the epilogue -- so its time bounds that form from below; elfihip_gp_form_kinv is what every rebuild would
+pay for the matrix.   usage: python scripts/r04_lockstep_bound.py [n] [d] [S]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+import gp_oracle as G  # noqa: E402
+from elfi_amd.gp import GPHandle  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+d = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+S = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+X, y, bounds = G.synthetic_gp_problem(n, d)
+h = G.default_hyper(bounds, y)
+gp = GPHandle(d, n)
+gp.set_hyper(h['var'], h['ls'], h['bias'], h['noise'])
+gp.set_data(X, y)
+gp.factorize()
+rs = np.random.RandomState(2)
+xs = rs.uniform(-2, 2, (S, d))
+
+
+def timed(f, reps=300):
+    for _ in range(20):
+        f()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        f()
+    return (time.perf_counter() - t0) / reps * 1e6
+
+
+def phases(f):
+    gp.profile(1)
+    for _ in range(100):
+        f()
+    ph = gp.profile(0)
+    return {k: round(1e3 * v[0] / max(1, v[1]), 1) for k, v in ph.items() if v[1]}
+
+
+us = []
+for name, f in (("value + gradient (two products)", lambda: gp.lcb(xs, 3.0)),
+                ("value only (one product)", lambda: gp.lcb(xs, 3.0, with_grad=False))):
+    us.append(timed(f))
+    print("n=%d d=%d S=%d %s: %.1f us per call (host); device phases us: %s" % (n, d, S, name, us[-1], phases(f)))
+
+# the price of the matrix: K^-1 = W^T W after a rebuild (the gradient kernel's SYRK without the contractions)
+t_fact = timed(gp.factorize, 20) / 1e3
+def both():
+    gp.factorize()
+    gp.form_kinv()
+t_both = timed(both, 20) / 1e3
+print("n=%d rebuild %.3f ms, rebuild + K^-1 %.3f ms => K^-1 costs %.3f ms per rebuild = the saving of %.0f lock-steps (%.1f us each)"
+      % (n, t_fact, t_both, t_both - t_fact, 1e3 * (t_both - t_fact) / max(1e-9, us[0] - us[1]), us[0] - us[1]))
