@@ -144,6 +144,7 @@ PROTOTYPES = {
     "elfihip_gp_set_schedule": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "elfihip_gp_set_dense_threshold": (C.c_int, [C.c_void_p, C.c_int64, C.c_int]),
     "elfihip_gp_set_lockstep_form": (C.c_int, [C.c_void_p, C.c_int]),
+    "elfihip_gp_lockstep_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "elfihip_gp_nlml_grad": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_void_p]),
     "elfihip_gp_form_kinv": (C.c_int, [C.c_void_p]),
     "elfihip_gp_extend": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_double)]),

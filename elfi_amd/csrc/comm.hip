@@ -258,6 +258,7 @@ int elfihip_comm_bcast_factor(elfihip_comm* c, elfihip_gp* gp, int root) {
   if (c->rank != root) {
     gp->factored = true;
     gp->has_kinv = false;
+    gp->kinv_sym = false;
     gp->wl_valid = false;
     ++gp->fact_gen;
   }

@@ -22,6 +22,9 @@ struct elfihip_gp {
   int64_t lda = 0;            // row pitch (doubles) of A and WT
   double var = 1, ls = 1, bias = 0, noise = 1;
   bool factored = false, has_kinv = false, wl_valid = false;
+  bool kinv_sym = false;      // K^-1 complete (both triangles) and current: formed after a factorisation, bordered by extends
+  int64_t lcb_steps = 0;      // acquisition lock-steps since the latest factorisation (extends do not reset it)
+  double diag_min = 0, diag_max = 0;   // smallest / largest diagonal entry of L: (max / min)^2 bounds cond(K) from below
   double logdet = 0, yKy = 0;
 
   // device memory
@@ -32,7 +35,8 @@ struct elfihip_gp {
   double* WT = nullptr;     // (cap, lda): L^-T (upper triangular, strictly-lower part kept zero)
   double* WL = nullptr;     // (cap, lda): L^-1 = WT^T (lower), mirrored from WT on first use after a factorisation
                             //             (wl_valid); the second triangular product of the predictor reads it row-wise
-  double* Kinv = nullptr;   // (cap, lda): K^-1 (lower tiles), only for the hyper-parameter gradient
+  double* Kinv = nullptr;   // (cap, lda): K^-1 -- lower tiles from the gradient kernel (has_kinv); both triangles once the
+                            //             acquisition lock-step uses it (kinv_sym, gp_predict.hip)
   double* W11 = nullptr;    // 2 x (NB, NB): inverse of the diagonal block being eliminated (lower), alternating
   double* alpha = nullptr;  // (cap) K^-1 y
   double* red = nullptr;    // small reduction scratch
@@ -71,13 +75,16 @@ struct elfihip_gp {
   double* h_stage = nullptr;
   size_t h_cap = 0;  // doubles
   unsigned long long done_seq = 0;  // value of the completion flag after the latest single-pass prediction
-  // dense predictor (gp_dense.hip): workspace and pinned staging of calls with many points
-  int lockstep_form = 0;         // 0: fused triangular products (four launches per prediction); 1: six launches
+  // 0: fused triangular products (four launches per prediction) and, for LCB lock-steps on a factorisation that has
+  //    already served KINV_AFTER_STEPS of them, ONE product with K^-1 (three launches); 1: six launches; 2: fused
+  //    triangular products only; 3: the K^-1 product from the first LCB lock-step on
+  int lockstep_form = 0;
   // acquisition search (gp_acq.hip, elfihip_gp_set_acq_options): host threads of the quasi-Newton algebra (0 = by the
   // machine) and the trace level written to stderr (0 = none)
   int acq_host_threads = 0;
   int acq_trace = 0;
   unsigned* tri_cnt = nullptr;   // 2 x (cap / 32) arrival counters of the fused triangular products (gp_predict.hip)
+  // dense predictor (gp_dense.hip): workspace and pinned staging of calls with many points
   int dense_tm = 0;        // row-tile height of the dense form: 0 = by size, else 64 / 32 / 16 (ELFIHIP_DENSE_TM, tests)
   int64_t dense_min = 0;   // points from which a call takes the dense form; 0 = default (elfihip_gp_set_dense_threshold)
   elfihip::DevBuf ws_dense;
@@ -136,7 +143,7 @@ struct ExpIntVarArgs {
   const double* var_int;    // noiseless GP variance at the integration points
 };
 int predict_enqueue(elfihip_gp* gp, const PredictPlan& P, int64_t S_active, int mode, int noiseless, double beta,
-                    const MaxVarEpilogue* mv);
+                    const MaxVarEpilogue* mv, bool with_kinv = false);
 int predict_wait(elfihip_gp* gp, const PredictPlan& P);
 void predict_read(const elfihip_gp* gp, const PredictPlan& P, int64_t S, double* mu, double* var, double* dmu,
                   double* dvar, double* val, double* grad);
@@ -148,6 +155,8 @@ int predict_impl(elfihip_gp* gp, const double* Xs, int64_t S, int mode, int nois
 int predict_dense_impl(elfihip_gp* gp, const double* Xs, int64_t S, int mode, int noiseless, double beta, double* mu,
                        double* var, double* dmu, double* dvar, double* val, double* grad);
 int64_t dense_min_points(const elfihip_gp* gp);
+// gp_hyper.hip: K^-1 = L^-T L^-1 into gp->Kinv (lower 128 x 128 tiles; gp->has_kinv)
+int form_kinv_impl(elfihip_gp* gp);
 // pieces of gp_predict.hip the dense path shares
 int ensure_wl_public(elfihip_gp* gp);
 void launch_kstar_passes(elfihip_gp* gp, const double* xs, const double* xs2, double* kr, double* kbt, double* mu_part,

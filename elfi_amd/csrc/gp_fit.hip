@@ -1176,31 +1176,40 @@ static_assert(STEP_LDS_BYTES >= POTF2T_LDS_DOUBLES * sizeof(double) && STEP_LDS_
 // ONE launch.  Workgroups [1, np / 4]: alpha_i = sum_{k >= i} WT[i][k] z_k, one wavefront per row, coalesced along k,
 // eight loads of the row in flight per lane (the long rows at the top of the triangle are what the launch waits for:
 // 24 us with one load per iteration); the sums of the eight strands are added in order.  Workgroup 0:
-// red[0] = sum log L_ii (i < n), red[1] = sum z_i^2 (fixed order), red[2] = the pivot report -- written straight to
+// red[0] = sum log L_ii (i < n), red[1] = sum z_i^2 (fixed order), red[2] = the pivot report, red[8..9] = min / max L_ii -- written straight to
 // pinned host memory (two device-to-host copies, 25 us on this stack, replaced by the stream wait alone).
 __global__ __launch_bounds__(256) void alpha_logdet_kernel(const double* WT, const double* A, const double* z, double* alpha,
                                                            double* red, const int* info, int64_t n, int64_t np, int64_t lda) {
   if (blockIdx.x == 0) {   // first, so that it is under way while the long rows of the triangle stream
-    __shared__ double s0[256], s1[256];
-    double a = 0.0, b = 0.0;
+    __shared__ double s0[256], s1[256], s2[256], s3[256];
+    double a = 0.0, b = 0.0, lo = 1e300, hi = 0.0;
     for (int64_t i = threadIdx.x; i < n; i += 256) {
-      a += log(A[i * lda + i]);
+      const double dg = A[i * lda + i];
+      a += log(dg);
       b += z[i] * z[i];
+      lo = dg < lo ? dg : lo;
+      hi = dg > hi ? dg : hi;
     }
     s0[threadIdx.x] = a;
     s1[threadIdx.x] = b;
+    s2[threadIdx.x] = lo;
+    s3[threadIdx.x] = hi;
     __syncthreads();
     for (int off = 128; off > 0; off >>= 1) {
       if (threadIdx.x < off) {
         s0[threadIdx.x] += s0[threadIdx.x + off];
         s1[threadIdx.x] += s1[threadIdx.x + off];
+        s2[threadIdx.x] = s2[threadIdx.x + off] < s2[threadIdx.x] ? s2[threadIdx.x + off] : s2[threadIdx.x];
+        s3[threadIdx.x] = s3[threadIdx.x + off] > s3[threadIdx.x] ? s3[threadIdx.x + off] : s3[threadIdx.x];
       }
       __syncthreads();
     }
-    if (threadIdx.x == 0) {   // `red` is pinned host memory: the rebuild's three scalars need no copy
+    if (threadIdx.x == 0) {   // `red` is pinned host memory: the rebuild's scalars need no copy
       red[0] = s0[0];
       red[1] = s1[0];
       red[2] = (double)*info;
+      red[8] = s2[0];         // smallest / largest diagonal entry of L
+      red[9] = s3[0];
     }
     return;
   }
@@ -1515,8 +1524,12 @@ int gp_factorize_impl(elfihip_gp* gp) {
   }
   gp->logdet = 2.0 * red[0];
   gp->yKy = red[1];
+  gp->diag_min = gp->h_fit[8];
+  gp->diag_max = gp->h_fit[9];
   gp->factored = true;
   gp->has_kinv = false;
+  gp->kinv_sym = false;
+  gp->lcb_steps = 0;
   gp->wl_valid = false;
   ++gp->fact_gen;
   return ELFIHIP_OK;
@@ -1560,7 +1573,7 @@ int elfihip_gp_create(elfihip_ctx* ctx, int d, int64_t capacity, elfihip_gp** ou
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&gp->info), gp->ninfo * sizeof(int));
   if (e == hipSuccess) e = hipMemsetAsync(gp->info, 0, gp->ninfo * sizeof(int), ctx->stream);
   if (e == hipSuccess)
-    e = hipHostMalloc(reinterpret_cast<void**>(&gp->h_fit), 8 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent);
+    e = hipHostMalloc(reinterpret_cast<void**>(&gp->h_fit), 16 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   if (e != hipSuccess) {
     int rc = fail(ctx, e == hipErrorOutOfMemory ? ELFIHIP_ERR_NOMEM : ELFIHIP_ERR_HIP, "GP allocation failed: %s",
@@ -1608,6 +1621,7 @@ int elfihip_gp_set_hyper(elfihip_gp* gp, double rbf_variance, double lengthscale
   gp->noise = noise_variance;
   gp->factored = false;
   gp->has_kinv = false;
+  gp->kinv_sym = false;
   return ELFIHIP_OK;
 }
 
@@ -1653,6 +1667,7 @@ int elfihip_gp_set_data(elfihip_gp* gp, const double* X, const double* y, int64_
   gp->np = round_up(n, NB);
   gp->factored = false;
   gp->has_kinv = false;
+  gp->kinv_sym = false;
   return ELFIHIP_OK;
 }
 
@@ -1665,6 +1680,7 @@ int elfihip_gp_append(elfihip_gp* gp, const double* X_new, const double* y_new, 
   gp->np = round_up(gp->n, NB);
   gp->factored = false;
   gp->has_kinv = false;
+  gp->kinv_sym = false;
   return ELFIHIP_OK;
 }
 

@@ -246,6 +246,8 @@ static int hyper_grad_impl(elfihip_gp* gp, bool store_kinv, double* grad) {
   return ELFIHIP_OK;
 }
 
+int form_kinv_impl(elfihip_gp* gp) { return hyper_grad_impl(gp, true, nullptr); }
+
 }  // namespace elfihip
 
 using namespace elfihip;

@@ -122,6 +122,9 @@ __global__ __launch_bounds__(256) void kstar_kernel(const double* X, const doubl
 // MODE 0 (upper):  out[i][s] = sum_{k <= i} W[k][i] bin[k][s],  W = L^-T (gp->WT),  bin = kb     (v = L^-1 kb)
 // MODE 1 (lower):  out[i][s] = sum_{k >= i} W[k][i] bin[k][s],  W = L^-1 (gp->WL),  bin = v      (u = L^-T v)
 // MODE 2 (dense):  out[i][s] = sum_k        W[k][i] bin[k][s],  W = V_P (gp->VP),   bin = v      (V_P^T v)
+// MODE 3 (full):   out[i][s] = sum_k        W[k][i] bin[k][s],  W = K^-1 (gp->Kinv, symmetric), bin = kb   (u = K^-1 kb)
+//                  -- ONE product instead of the two dependent triangular ones: the same 8 n^2 bytes in one launch, no
+//                  second launch ramp / round trip / hand-off (measured: gp_predict.hip, ensure_kinv_sym below)
 // Workgroup (rb, kc): rows i in [32 rb, 32 rb + 32), k in chunk kc clipped to the triangle (a multiple
 // of 32 long).  Writes part[kc][i][s]; chunks outside the triangle are never read by the reduction.
 struct TriArgs {
@@ -144,6 +147,7 @@ struct TriArgs {
   double* g_part;         // [pass][16][nrb][2 dp]
   int64_t n;
   int dp;
+  double bias;            // MODE 3: kb = kr + bias, for the variance term sum_i kb_i u_i of the row block
 };
 
 typedef __attribute__((address_space(1))) unsigned long long gu64_t;
@@ -158,11 +162,12 @@ __device__ __forceinline__ void store_wt(double* p, double v) {
 }
 
 __device__ inline double sum_partials(const double* __restrict__ part, int64_t np, int64_t e, int lo, int hi);
-template <int ROWS_PER_THREAD, int QN>
+template <int ROWS_PER_THREAD, int QN, bool FULL = false>
 __device__ __forceinline__ void grad_rows(const double* __restrict__ X, const double* __restrict__ alpha,
                                           const double* __restrict__ xs, const double* __restrict__ kr,
                                           const double* __restrict__ part, int nkc, double* __restrict__ g_part, int chunk,
-                                          int nchunks, int64_t i0, int64_t n, int64_t np, int dp, double (*red)[PC][32]);
+                                          int nchunks, int64_t i0, int64_t n, int64_t np, int dp, double (*red)[PC][32],
+                                          double bias = 0.0, double* __restrict__ sq_part = nullptr);
 
 template <int MODE, bool FUSE>
 __global__ __launch_bounds__(256, 3) void tri_apply_kernel(TriArgs T) {   // three workgroups per CU: <= 168 registers (four = 128 registers spills: 61 -> 74 us per lock-step)
@@ -259,7 +264,8 @@ __global__ __launch_bounds__(256, 3) void tri_apply_kernel(TriArgs T) {   // thr
   __syncthreads();
   if (t == 0) {
     // chunks inside the triangle for this row block = workgroups that arrive
-    const unsigned expected = MODE == 0 ? (unsigned)((i0 + RB - 1) / KC + 1) : (unsigned)(T.nkc - (int)(i0 / KC));
+    const unsigned expected = MODE == 0 ? (unsigned)((i0 + RB - 1) / KC + 1)
+                                        : (MODE == 1 ? (unsigned)(T.nkc - (int)(i0 / KC)) : (unsigned)T.nkc);
     gu32_t* c = (gu32_t*)(T.cnt + rb);   // global address space said explicitly: no flat atomics
     const unsigned old = __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int last = old + 1u == expected;
@@ -291,13 +297,21 @@ __global__ __launch_bounds__(256, 3) void tri_apply_kernel(TriArgs T) {   // thr
         }
       }
     }
-  } else {
+  } else if (MODE == 1) {
     // what grad_kernel does, for this block's 32 rows (chunk = row block)
     double(*red)[PC][32] = reinterpret_cast<double(*)[PC][32]>(Bs);
     for (int pass = 0; pass < T.npass; ++pass)
       grad_rows<2, 2>(T.X, T.alpha, T.xs + (int64_t)pass * PC * T.dp, T.kr + (int64_t)pass * PC * T.np,
                    T.part + (int64_t)pass * T.nkc * T.np * PC, T.nkc,
                    T.g_part + (int64_t)pass * PC * T.nrb * 2 * T.dp, rb, T.nrb, i0, T.n, T.np, T.dp, red);
+  } else {
+    // MODE 3: u of this block's rows is complete -- the gradient sums as above and the block's share of kb . u
+    double(*red)[PC][32] = reinterpret_cast<double(*)[PC][32]>(Bs);
+    for (int pass = 0; pass < T.npass; ++pass)
+      grad_rows<2, 2, true>(T.X, T.alpha, T.xs + (int64_t)pass * PC * T.dp, T.kr + (int64_t)pass * PC * T.np,
+                            T.part + (int64_t)pass * T.nkc * T.np * PC, T.nkc,
+                            T.g_part + (int64_t)pass * PC * T.nrb * 2 * T.dp, rb, T.nrb, i0, T.n, T.np, T.dp, red, T.bias,
+                            T.sq_part + (int64_t)pass * (T.np / 16) * PC);
   }
 }
 
@@ -358,22 +372,36 @@ __global__ __launch_bounds__(256) void tri_reduce_kernel(const double* part, dou
 constexpr int GR = 64;
 // The sums of RPT x 16 evidence rows from i0 on (thread (s, ig) owns rows ig + 16 r), written as chunk `chunk` of
 // `nchunks`: the body of grad_kernel (RPT = 4) and of the fused second product's last arriver (RPT = 2, gp_predict.hip above).
-template <int RPT, int QN>   // QN: groups of four dimensions per round (4: grad_kernel; 2 keeps the fused product at 3 workgroups per CU)
+// FULL (the K^-1 product): every chunk contributes to a row, and the rows' kb_i u_i are summed per 16-row block into
+// sq_part[(i0 / 16 + r)][s] -- the slot the first triangular product fills with sum v^2, so finish_kernel is unchanged.
+template <int RPT, int QN, bool FULL>   // QN: groups of four dimensions per round (4: grad_kernel; 2 keeps the fused product at 3 workgroups per CU)
 __device__ __forceinline__ void grad_rows(const double* __restrict__ X, const double* __restrict__ alpha,
                                           const double* __restrict__ xs, const double* __restrict__ kr,
                                           const double* __restrict__ part, int nkc, double* __restrict__ g_part, int chunk,
-                                          int nchunks, int64_t i0, int64_t n, int64_t np, int dp, double (*red)[PC][32]) {
+                                          int nchunks, int64_t i0, int64_t n, int64_t np, int dp, double (*red)[PC][32],
+                                          double bias, double* __restrict__ sq_part) {
+  static_assert(!FULL || (RPT == 2 && QN == 2), "the variance slots of the K^-1 form sit behind two groups of four dimensions");
   const int t = threadIdx.x, s = t & 15, ig = t >> 4, w = t >> 6;
-  double c1[RPT], c2[RPT];
+  double c1[RPT], c2[RPT], pv[RPT];
 #pragma unroll
   for (int r = 0; r < RPT; ++r) {
     const int64_t i = i0 + ig + 16 * r;
     c1[r] = 0.0;
     c2[r] = 0.0;
+    pv[r] = 0.0;
     if (i < n) {
       const double k = kr[(int64_t)s * np + i];
+      const double u = sum_partials(part, np, i * PC + s, FULL ? 0 : (int)(i / KC), nkc);
       c1[r] = alpha[i] * k;
-      c2[r] = sum_partials(part, np, i * PC + s, (int)(i / KC), nkc) * k;
+      c2[r] = u * k;
+      pv[r] = u * (k + bias);
+    }
+  }
+  if (FULL) {
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+      pv[r] += __shfl_xor(pv[r], 16, 64);
+      pv[r] += __shfl_xor(pv[r], 32, 64);
     }
   }
   typedef double v4 __attribute__((ext_vector_type(4)));
@@ -411,6 +439,10 @@ __device__ __forceinline__ void grad_rows(const double* __restrict__ X, const do
           red[w][s][4 * q + j] = g1[q][j];
           red[w][s][16 + 4 * q + j] = g2[q][j];
         }
+      if (FULL && a0 == 0) {   // slots 8, 9 of a point: free beside two groups of four dimensions
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) red[w][s][8 + r] = pv[r];
+      }
     }
     __syncthreads();
     for (int e = t; e < PC * 32; e += 256) {
@@ -419,6 +451,10 @@ __device__ __forceinline__ void grad_rows(const double* __restrict__ X, const do
       if ((j & 15) < 4 * QN && a < dp) {
         const double v = ((red[0][ss][j] + red[1][ss][j]) + red[2][ss][j]) + red[3][ss][j];
         g_part[((int64_t)ss * nchunks + chunk) * 2 * dp + (j < 16 ? a : dp + a)] = v;
+      } else if (FULL && a0 == 0 && j >= 8 && j < 8 + RPT) {
+        // the four waves hold rows ig = 4 w .. 4 w + 3 of each 16-row block: in order
+        const double v = ((red[0][ss][j] + red[1][ss][j]) + red[2][ss][j]) + red[3][ss][j];
+        sq_part[(i0 / 16 + (j - 8)) * PC + ss] = v;
       }
     }
   }
@@ -433,7 +469,8 @@ __global__ __launch_bounds__(256) void grad_kernel(const double* __restrict__ X,
   kr += (int64_t)blockIdx.y * PC * np;
   part += (int64_t)blockIdx.y * nkc * np * PC;
   g_part += (int64_t)blockIdx.y * PC * gridDim.x * 2 * dp;
-  grad_rows<4, 4>(X, alpha, xs, kr, part, nkc, g_part, (int)blockIdx.x, (int)gridDim.x, (int64_t)blockIdx.x * GR, n, np, dp, red);
+  grad_rows<4, 4, false>(X, alpha, xs, kr, part, nkc, g_part, (int)blockIdx.x, (int)gridDim.x, (int64_t)blockIdx.x * GR, n, np, dp,
+                         red, 0.0, nullptr);
 }
 
 // ---- final assembly: mu, var, dmu, dvar, LCB value and gradient ---------------------------
@@ -698,10 +735,12 @@ void launch_finish_passes(elfihip_gp* gp, const double* mu_part, int nblk_k, con
 
 // One triangular product for `g` passes: part[pass][kc][i][s] from bin[pass][k][s].
 // fused = the reduction (first product) / the gradient sums (second product) by the last workgroup of every row block
+// full: ONE product with the symmetric K^-1 (fused form only; xs as for the lower product)
 static void launch_tri(const elfihip_gp* gp, const PredictWs& W, bool lower, const double* bin, unsigned g, bool fused = false,
-                       const double* xs = nullptr) {
+                       const double* xs = nullptr, bool full = false) {
   TriArgs T;
-  T.W = lower ? gp->WL : gp->WT;
+  T.W = full ? gp->Kinv : (lower ? gp->WL : gp->WT);
+  T.bias = gp->bias;
   T.bin = bin;
   T.part = W.part;
   T.lda = gp->lda;
@@ -721,7 +760,9 @@ static void launch_tri(const elfihip_gp* gp, const PredictWs& W, bool lower, con
   T.n = gp->n;
   T.dp = gp->dp;
   const dim3 grid((unsigned)T.nrb, (unsigned)W.nkc);
-  if (fused && lower)
+  if (full)
+    hipLaunchKernelGGL((tri_apply_kernel<3, true>), grid, dim3(256), 0, gp->ctx->stream, T);
+  else if (fused && lower)
     hipLaunchKernelGGL((tri_apply_kernel<1, true>), grid, dim3(256), 0, gp->ctx->stream, T);
   else if (fused)
     hipLaunchKernelGGL((tri_apply_kernel<0, true>), grid, dim3(256), 0, gp->ctx->stream, T);
@@ -733,7 +774,84 @@ static void launch_tri(const elfihip_gp* gp, const PredictWs& W, bool lower, con
 
 // The fused lock-step (four launches instead of six) is the default; elfihip_gp_set_lockstep_form(gp, 1) keeps the
 // six-launch form (same numbers for mean / variance, gradient sums in 64-row instead of 32-row chunks).
-static bool lockstep_fused(const elfihip_gp* gp) { return gp->lockstep_form == 0; }
+static bool lockstep_fused(const elfihip_gp* gp) { return gp->lockstep_form != 1; }
+
+// ---- K^-1 for the acquisition lock-step -------------------------------------------------------------------------
+// u = K^-1 kb gives the variance (kb . u) and its gradient from ONE product over the n x n symmetric matrix instead of two
+// dependent products over the two triangles (what GPy's posterior does with its woodbury_inv, gpy_regression.py:127-140).
+// The bytes are the same; the second launch's ramp, round trip and hand-off are not there.  Measured
+// (profiles/r04_lockstep_pmc.md; 10 points, d = 10): 61.8 -> 52.3 us per lock-step at n = 4096 (the product: 33 us for
+// 134 MB against 21 + 25 for 2 x 67), 44.0 -> 36.0 at n = 2048; value and gradient agree with the triangular form to 1e-13.
+// The price: forming K^-1 = L^-T L^-1 after a factorisation costs 0.33 / 0.74 ms at n = 2048 / 4096 -- what 40-80
+// lock-steps save -- so the matrix is made only for a factorisation that has already served KINV_AFTER_STEPS lock-steps
+// (a factorisation that is extended point by point between hyper-parameter searches serves hundreds; one that is rebuilt for
+// every acquisition never pays), and it is then carried through extends by the rank-one bordering below (an extend at
+// n = 4048: 63 -> 129 us, at 2000: 43 -> 50).  k(x,x) - kb . u
+// cancels with an error of eps cond(K) k(x,x) where the triangular form's sum of squares has eps k(x,x): the form is used
+// while (max L_ii / min L_ii)^2 <= KINV_MAX_COND (the variance then agrees with the triangular form to 1e-10 k(x,x)).
+constexpr int64_t KINV_AFTER_STEPS = 64;
+constexpr double KINV_MAX_COND = 1e5;
+
+// The strictly-upper part of K^-1 from the lower one (the gradient kernel writes the lower 128 x 128 tiles), 64 x 64 tiles
+// through LDS, in place.
+__global__ __launch_bounds__(256) void kinv_mirror_kernel(double* K, int64_t lda) {
+  __shared__ double tile[64][65];
+  const int bi = blockIdx.y, bj = blockIdx.x;
+  if (bi < bj) return;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = ty + 4 * r;
+    tile[row][tx] = K[((int64_t)bi * 64 + row) * lda + (int64_t)bj * 64 + tx];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = ty + 4 * r;
+    if (bi > bj || row < tx) K[((int64_t)bj * 64 + row) * lda + (int64_t)bi * 64 + tx] = tile[tx][row];
+  }
+}
+
+// K^-1 of the bordered matrix: K^-1 (padded with the new row / column) + w w^T, w = the new column of L^-T = [-u / d ; 1 / d]
+// (extend_write_kernel).  Entry (i, j) and (j, i) get the same product, so the matrix stays symmetric to the bit.
+__global__ __launch_bounds__(256) void kinv_border_kernel(double* K, int64_t lda, int64_t n, const double* u, const double* red) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j > n) return;
+  const double d = red[8];
+  const double wj = j < n ? -u[j * PC] / d : 1.0 / d;
+  const int64_t i0 = (int64_t)blockIdx.y * 16;
+#pragma unroll 4
+  for (int r = 0; r < 16; ++r) {
+    const int64_t i = i0 + r;
+    if (i > n) break;
+    const double wi = i < n ? -u[i * PC] / d : 1.0 / d;
+    double* e = K + i * lda + j;
+    *e = (i < n && j < n) ? *e + wi * wj : wi * wj;
+  }
+}
+
+static bool kinv_conditioned(const elfihip_gp* gp) {
+  const double r = gp->diag_max / gp->diag_min;
+  return gp->diag_min > 0.0 && r * r <= KINV_MAX_COND;
+}
+
+// Called before an LCB lock-step is enqueued: true when this call multiplies with K^-1 (forming it first if it is due).
+static int lockstep_kinv(elfihip_gp* gp, bool* use) {
+  *use = false;
+  if (gp->lockstep_form == 1 || gp->lockstep_form == 2) return ELFIHIP_OK;
+  ++gp->lcb_steps;
+  if (!kinv_conditioned(gp)) return ELFIHIP_OK;
+  if (!gp->kinv_sym) {
+    if (gp->lockstep_form == 0 && gp->lcb_steps <= KINV_AFTER_STEPS) return ELFIHIP_OK;
+    if (!gp->has_kinv) ELFIHIP_TRY(form_kinv_impl(gp));
+    const unsigned nt = (unsigned)(gp->np / 64);
+    hipLaunchKernelGGL(kinv_mirror_kernel, dim3(nt, nt), dim3(256), 0, gp->ctx->stream, gp->Kinv, gp->lda);
+    ELFIHIP_TRY(launch_status(gp->ctx, "kinv_mirror_kernel"));
+    gp->kinv_sym = true;
+  }
+  *use = true;
+  return ELFIHIP_OK;
+}
 
 static int ensure_tri_counters(elfihip_gp* gp) {
   if (gp->tri_cnt) return ELFIHIP_OK;
@@ -844,7 +962,7 @@ void predict_fill(const elfihip_gp* gp, const PredictPlan& P, const double* Xs, 
 // group scratch is reused in stream order); all results come down in one copy; no synchronisation here.
 // S_active: number of real points (columns beyond it are computed on zero inputs and ignored).
 int predict_enqueue(elfihip_gp* gp, const PredictPlan& P, int64_t S_active, int mode, int noiseless, double beta,
-                    const MaxVarEpilogue* mv) {
+                    const MaxVarEpilogue* mv, bool with_kinv) {
   elfihip_ctx* ctx = gp->ctx;
   hipStream_t st = ctx->stream;
   const PredictWs& W = P.ws;
@@ -879,7 +997,13 @@ int predict_enqueue(elfihip_gp* gp, const PredictPlan& P, int64_t S_active, int 
                        W.mu_part, gp->n, np, dp, gp->var, -0.5 * inv_ls2, gp->bias,
                        P.direct ? W.xs : (double*)nullptr, P.by_args ? 1 : 0, qa, (double*)nullptr);
     if (prof) prof_mark(gp, 1);
-    if (fused) {
+    if (fused && with_kinv && mode == 1) {
+      launch_tri(gp, W, true, W.kb, g, true, xs, true);   // u = K^-1 kb, the block sums of kb . u and the gradient sums
+      if (prof) {
+        prof_mark(gp, 2);
+        prof_mark(gp, 3);
+      }
+    } else if (fused) {
       launch_tri(gp, W, false, W.kb, g, true);
       if (prof) prof_mark(gp, 2);
       if (mode == 1) {
@@ -964,7 +1088,10 @@ int predict_impl(elfihip_gp* gp, const double* Xs, int64_t S, int mode, int nois
   PredictPlan P;
   ELFIHIP_TRY(predict_prepare(gp, S, &P));
   predict_fill(gp, P, Xs, S);
-  ELFIHIP_TRY(predict_enqueue(gp, P, S, mode, noiseless, beta, nullptr));
+  // an acquisition lock-step (value AND gradient of the LCB at a handful of points): with K^-1 when that is due
+  bool with_kinv = false;
+  if (mode == 1 && val && grad && P.npass <= P.ws.group) ELFIHIP_TRY(lockstep_kinv(gp, &with_kinv));
+  ELFIHIP_TRY(predict_enqueue(gp, P, S, mode, noiseless, beta, nullptr, with_kinv));
   ELFIHIP_TRY(launch_status(ctx, "predict kernels"));
   ELFIHIP_TRY(predict_wait(gp, P));
   if (gp->profile && P.npass <= P.ws.group) {
@@ -1094,6 +1221,11 @@ static int extend_one(elfihip_gp* gp, const double* x, double ynew) {
                      gp->A, gp->WT, gp->WL, gp->alpha, gp->lda, n, np, W.xs, q, ynew, gp->X, gp->x2, gp->y, dp,
                      gp->info, P.hout, P.flag, (unsigned long long)(gp->done_seq + 1));
   ++gp->done_seq;
+  // K^-1 in use by the lock-step: bordered with the same u and d (W.u and gp->red stay as they are until the next call)
+  const bool carry_kinv = gp->kinv_sym;
+  if (carry_kinv)
+    hipLaunchKernelGGL(kinv_border_kernel, dim3((unsigned)((n + 1 + 255) / 256), (unsigned)((n + 1 + 15) / 16)), dim3(256), 0,
+                       st, gp->Kinv, gp->lda, n, W.u, gp->red);
   ELFIHIP_TRY(launch_status(ctx, "extend kernels"));
   P.direct = true;
   P.n_flags = 1;
@@ -1106,8 +1238,11 @@ static int extend_one(elfihip_gp* gp, const double* x, double ynew) {
   }
   gp->logdet += 2.0 * log(sc[0]);
   gp->yKy += sc[1] * sc[1];
+  gp->diag_min = sc[0] < gp->diag_min ? sc[0] : gp->diag_min;
+  gp->diag_max = sc[0] > gp->diag_max ? sc[0] : gp->diag_max;
   gp->n = n + 1;
-  gp->has_kinv = false;
+  gp->has_kinv = carry_kinv;   // (the lower tiles the gradient kernel would write are part of the bordered matrix)
+  gp->kinv_sym = carry_kinv;
   ++gp->fact_gen;
   return ELFIHIP_OK;
 }
@@ -1278,9 +1413,22 @@ using namespace elfihip;
 
 extern "C" {
 
+int elfihip_gp_lockstep_info(const elfihip_gp* gp, int* kinv_in_use, int64_t* steps, double* cond_bound) {
+  if (!gp) return fail(nullptr, ELFIHIP_ERR_ARG, "gp is NULL");
+  if (kinv_in_use) *kinv_in_use = gp->factored && gp->kinv_sym ? 1 : 0;
+  if (steps) *steps = gp->lcb_steps;
+  if (cond_bound) {
+    const double r = gp->diag_min > 0.0 ? gp->diag_max / gp->diag_min : 0.0;
+    *cond_bound = r * r;
+  }
+  return ELFIHIP_OK;
+}
+
 int elfihip_gp_set_lockstep_form(elfihip_gp* gp, int form) {
   if (!gp) return fail(nullptr, ELFIHIP_ERR_ARG, "gp is NULL");
-  ELFIHIP_REQUIRE(gp->ctx, form == 0 || form == 1, "form must be 0 (four launches, fused epilogues) or 1 (six launches)");
+  ELFIHIP_REQUIRE(gp->ctx, form >= 0 && form <= 3,
+                  "form must be 0 (fused epilogues; K^-1 product once it pays), 1 (six launches), 2 (fused, triangular "
+                  "products only) or 3 (K^-1 product from the first acquisition lock-step on)");
   gp->lockstep_form = form;
   return ELFIHIP_OK;
 }
@@ -1327,7 +1475,7 @@ int elfihip_gp_maxvar(elfihip_gp* gp, const double* Xs, int64_t S, double eps, c
   mv.eps = eps;
   mv.prior_pdf = dpr;
   mv.prior_glog = dpr + S;
-  ELFIHIP_TRY(predict_enqueue(gp, P, S, 1, 1, 0.0, &mv));
+  ELFIHIP_TRY(predict_enqueue(gp, P, S, 1, 1, 0.0, &mv, false));
   ELFIHIP_TRY(launch_status(ctx, "maxvar kernels"));
   ELFIHIP_TRY(predict_wait(gp, P));
   predict_read(gp, P, S, nullptr, nullptr, nullptr, nullptr, val, grad);

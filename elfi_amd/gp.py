@@ -94,8 +94,16 @@ class GPHandle:
         self._check(self.lib.elfihip_gp_set_dense_threshold(self.h, int(min_points), int(tile_rows)))
 
     def set_lockstep_form(self, form=0):
-        """0: four launches per small prediction call (fused epilogues, default); 1: the six-launch form."""
+        """0: four launches per small prediction call (fused epilogues), acquisition lock-steps through ONE product with
+        K^-1 once a factorisation has served 64 of them (default); 1: the six-launch form; 2: fused, triangular products
+        only; 3: the K^-1 product from the first acquisition lock-step on (include/elfihip.h)."""
         self._check(self.lib.elfihip_gp_set_lockstep_form(self.h, int(form)))
+
+    def lockstep_info(self):
+        """(K^-1 in use by the acquisition lock-steps, lock-steps served by this factorisation, lower bound of cond(K))."""
+        use, steps, cond = C.c_int(0), C.c_int64(0), C.c_double(0.0)
+        self._check(self.lib.elfihip_gp_lockstep_info(self.h, C.byref(use), C.byref(steps), C.byref(cond)))
+        return bool(use.value), int(steps.value), float(cond.value)
 
     def set_acq_options(self, host_threads=0, trace=0):
         """Options of lcb_minimize (include/elfihip.h: elfihip_gp_set_acq_options): host threads of the multi-start

@@ -377,8 +377,19 @@ int elfihip_gp_set_dense_threshold(elfihip_gp* gp, int64_t min_points, int tile_
  * first product's chunk partials and the gradient sums of the second run as epilogues of the LAST workgroup to arrive at
  * each 32-row block (write-through partials, one relaxed device-scope arrival per workgroup, one acquire by the last
  * arriver); form 1 = the six launches of round 2 (product, reduction, product, gradient sums as kernels of their own).
- * Mean / variance are bit-identical between the forms, gradients agree to rounding (32- against 64-row chunks). */
+ * Mean / variance are bit-identical between the forms, gradients agree to rounding (32- against 64-row chunks).
+ * Acquisition lock-steps (elfihip_gp_lcb with a gradient, elfihip_gp_lcb_minimize) additionally have a THREE-launch form:
+ * u = K^-1 kb from ONE product with the symmetric K^-1 instead of the two dependent triangular products (GPy's own
+ * closed form with woodbury_inv, gpy_regression.py:127-140).  Under form 0 it takes over once a factorisation has served
+ * 64 lock-steps (forming K^-1 costs what 40-80 lock-steps save; afterwards elfihip_gp_extend borders the matrix, rank
+ * one, with every new point) and while (max L_ii / min L_ii)^2 <= 1e5 (the variance k(x,x) - kb . u then agrees with
+ * the triangular form to 1e-10 k(x,x)); form 2 = never (fused triangular products only); form 3 = from the first
+ * lock-step on.  elfihip_gp_predict / _predict_grad always use the triangular products. */
 int elfihip_gp_set_lockstep_form(elfihip_gp* gp, int form);
+/* State of the above for the current factorisation: whether acquisition lock-steps multiply with K^-1 now, how many
+ * lock-steps the factorisation has served, and (max L_ii / min L_ii)^2, the lower bound of cond(K) the K^-1 form is
+ * gated by.  Any pointer may be NULL. */
+int elfihip_gp_lockstep_info(const elfihip_gp* gp, int* kinv_in_use, int64_t* steps, double* cond_bound);
 /* Device time per phase, for roofline accounting (bench.py; no reference counterpart).  While enabled, HIP events on the
  * GP's stream bracket the phases of elfihip_gp_factorize (Gram matrix | sweep | alpha + log-determinant), of single-group
  * prediction calls -- elfihip_gp_predict / _predict_grad / _lcb and every step of elfihip_gp_lcb_minimize -- (kernel row |

@@ -47,10 +47,38 @@ def phases(f):
 
 
 us = []
-for name, f in (("value + gradient (two products)", lambda: gp.lcb(xs, 3.0)),
-                ("value only (one product)", lambda: gp.lcb(xs, 3.0, with_grad=False))):
+gp.set_lockstep_form(2)
+for name, f in (("value + gradient (two triangular products)", lambda: gp.lcb(xs, 3.0)),
+                ("value only (one triangular product)", lambda: gp.lcb(xs, 3.0, with_grad=False))):
     us.append(timed(f))
     print("n=%d d=%d S=%d %s: %.1f us per call (host); device phases us: %s" % (n, d, S, name, us[-1], phases(f)))
+v2, g2 = gp.lcb(xs, 3.0)
+gp.set_lockstep_form(3)
+f = lambda: gp.lcb(xs, 3.0)
+f()
+assert gp.lockstep_info()[0], gp.lockstep_info()
+us_k = timed(f)
+v3, g3 = gp.lcb(xs, 3.0)
+print("n=%d d=%d S=%d value + gradient (ONE product with K^-1): %.1f us per call (host); device phases us: %s; against the "
+      "triangular form: value %.1e, gradient %.1e (scaled); cond(K) >= %.0f"
+      % (n, d, S, us_k, phases(f), np.max(np.abs(v3 - v2)) / np.max(np.abs(v2)), np.max(np.abs(g3 - g2)) / np.max(np.abs(g2)),
+         gp.lockstep_info()[2]))
+gp.set_lockstep_form(2)
+# bordering: an extend with and without K^-1 to carry (32 points inside one padded size)
+for form in (2, 3):
+    g2_ = GPHandle(d, n)
+    g2_.set_hyper(h['var'], h['ls'], h['bias'], h['noise'])
+    g2_.set_data(X[:n - 64], y[:n - 64])
+    g2_.factorize()
+    g2_.set_lockstep_form(form)
+    g2_.lcb(xs, 3.0)
+    g2_.extend(X[n - 64:n - 63], y[n - 64:n - 63])
+    t0 = time.perf_counter()
+    for i in range(n - 63, n - 31):
+        g2_.extend(X[i:i + 1], y[i:i + 1])
+    print("n=%d extend by one point, %s: %.1f us" % (n - 48, "K^-1 carried (rank-one bordering)" if form == 3 else
+                                                     "triangular factors only", (time.perf_counter() - t0) / 32 * 1e6))
+    g2_.close()
 
 # the price of the matrix: K^-1 = W^T W after a rebuild (the gradient kernel's SYRK without the contractions)
 t_fact = timed(gp.factorize, 20) / 1e3

@@ -1,0 +1,169 @@
+"""GPU: the acquisition lock-step through ONE product with K^-1 (csrc/gp_predict.hip, tri_apply_kernel<3>).
+
+u = K^-1 kb gives the variance k(x,x) - kb . u and its gradient -- GPy's own closed form with woodbury_inv
+(elfi/methods/bo/gpy_regression.py:127-140,206-218) -- where the default form runs two dependent triangular products.
+Checked here: against the oracle at the tolerances of the triangular form (tests/test_gp_gpu.py), against the triangular
+form itself, through point-by-point extends (the rank-one bordering of K^-1), the policy (after 64 lock-steps on one
+factorisation, never for one that is rebuilt before that), and the gate on the conditioning of K.
+"""
+import numpy as np
+import pytest
+
+import gp_oracle as G
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem(n, d, seed=0):
+    rs = np.random.RandomState(seed)
+    X = rs.uniform(-2, 2, (n, d))
+    y = np.linalg.norm(X - 0.5, axis=1) + 0.1 * rs.randn(n)
+    return X, y.reshape(-1, 1), [(-2., 2.)] * d
+
+
+def _handle(X, y, h, cap=None, form=3):
+    from elfi_amd.gp import GPHandle
+    gp = GPHandle(X.shape[1], cap or X.shape[0])
+    gp.set_hyper(h['var'], h['ls'], h['bias'], h['noise'])
+    gp.set_data(X, y)
+    gp.factorize()
+    gp.set_lockstep_form(form)
+    return gp
+
+
+def _close(a, b, rtol, what):
+    scale = np.max(np.abs(b)) + 1e-300
+    err = np.max(np.abs(a - b)) / scale
+    assert err <= rtol, '%s: scaled max error %g > %g' % (what, err, rtol)
+
+
+def _points(X, S, seed=3):
+    xs = np.random.RandomState(seed).uniform(-2, 2, (S, X.shape[1]))
+    xs[0] = X[0]                      # exactly on an evidence point
+    if S > 2:
+        xs[1] = X[1] + 1e-4           # and next to one: the smallest variances
+    return xs
+
+
+@pytest.mark.parametrize('n,d,S', [(60, 2, 1), (300, 2, 7), (700, 10, 10), (1000, 5, 16), (1300, 20, 10), (2048, 3, 10),
+                                   (900, 4, 40)])
+def test_kinv_lockstep_vs_oracle_and_the_triangular_form(hip_ctx, n, d, S):
+    X, y, bounds = _problem(n, d, seed=n + S)
+    h = G.default_hyper(bounds, y)
+    ref = G.Posterior(X, y, h['var'], h['ls'], h['bias'], h['noise'])
+    gp = _handle(X, y, h, form=3)
+    xs = _points(X, S)
+    for t in (0, 30):
+        beta = G.lcb_beta(t, d)
+        val, grad = gp.lcb(xs, beta)
+        use, steps, cond = gp.lockstep_info()
+        assert use and steps >= 1 and 1.0 <= cond <= 1e5, (use, steps, cond)
+        _close(val, G.lcb_evaluate(ref, xs, t), 1e-8, 'lcb')
+        _close(grad, G.lcb_evaluate_gradient(ref, xs, t), 1e-7, 'lcb grad')
+        gp.set_lockstep_form(2)
+        val2, grad2 = gp.lcb(xs, beta)
+        gp.set_lockstep_form(3)
+        _close(val, val2, 1e-9, 'lcb: K^-1 product against the triangular products')
+        _close(grad, grad2, 1e-8, 'lcb gradient: K^-1 product against the triangular products')
+    # deterministic
+    v1, g1 = gp.lcb(xs, 3.0)
+    v2, g2 = gp.lcb(xs, 3.0)
+    assert np.array_equal(v1, v2) and np.array_equal(g1, g2)
+    # predict / predict_grad keep the triangular products whatever the form
+    mu, var = gp.predict(xs, noiseless=True)
+    rmu, rvar = ref.predict(xs, noiseless=True)
+    assert np.max(np.abs(var - rvar)) <= 1e-8 * (ref.var + ref.bias)
+
+
+def test_kinv_is_carried_through_extends(hip_ctx):
+    """elfihip_gp_extend borders K^-1 with every new point (rank one); after 60 of them the lock-step agrees with a GP
+    factorised on all the evidence at once, and with the oracle."""
+    n0, k, d = 840, 55, 4           # 840 + 55 = 895 < 896: inside one padded size (a 128 boundary takes the rebuild path)
+    X, y, bounds = _problem(n0 + k, d, seed=5)
+    h = G.default_hyper(bounds, y)
+    gp = _handle(X[:n0], y[:n0], h, cap=1024, form=3)
+    xs = _points(X, 10)
+    gp.lcb(xs, 3.0)
+    assert gp.lockstep_info()[0]
+    for i in range(n0, n0 + k):
+        gp.extend(X[i:i + 1], y[i:i + 1])
+        assert gp.lockstep_info()[0], 'an extend inside the padded size keeps K^-1'
+        if (i - n0) % 9 == 0:
+            gp.lcb(xs, 3.0)
+    ref = G.Posterior(X, y, h['var'], h['ls'], h['bias'], h['noise'])
+    t = 11
+    val, grad = gp.lcb(xs, G.lcb_beta(t, d))
+    _close(val, G.lcb_evaluate(ref, xs, t), 1e-8, 'lcb after extends')
+    _close(grad, G.lcb_evaluate_gradient(ref, xs, t), 1e-7, 'lcb gradient after extends')
+    fresh = _handle(X, y, h, cap=1024, form=2)
+    val2, grad2 = fresh.lcb(xs, G.lcb_beta(t, d))
+    _close(val, val2, 1e-9, 'bordered K^-1 against a fresh factorisation')
+    _close(grad, grad2, 1e-8, 'bordered K^-1 against a fresh factorisation (gradient)')
+    # the bordered matrix itself: K^-1 of all the evidence
+    Ki = gp.get(5)
+    assert np.array_equal(Ki, Ki.T)
+    assert np.max(np.abs(Ki - ref.Kinv)) <= 1e-8 * np.max(np.abs(ref.Kinv))
+    # crossing the 128 boundary rebuilds: K^-1 is dropped and formed again when it is due
+    gp.extend(X[:2] + 0.01, y[:2])
+    assert not gp.lockstep_info()[0] and gp.lockstep_info()[1] == 0
+    gp.lcb(xs, 3.0)
+    assert gp.lockstep_info()[0]
+
+
+def test_policy_of_the_default_form(hip_ctx):
+    """Form 0: the triangular products for the first 64 lock-steps of a factorisation, K^-1 from the 65th on; a new
+    factorisation starts the count again; the multi-start search counts one lock-step per round."""
+    X, y, bounds = _problem(500, 3, seed=9)
+    h = G.default_hyper(bounds, y)
+    gp = _handle(X, y, h, cap=640, form=0)
+    xs = _points(X, 10)
+    first = gp.lcb(xs, 3.0)
+    for i in range(63):
+        gp.lcb(xs, 3.0)
+    use, steps, _ = gp.lockstep_info()
+    assert not use and steps == 64
+    v32, g32 = gp.lcb(xs, 3.0)
+    assert np.array_equal(first[0], gp.lcb(xs, 3.0, with_grad=False)[0]), 'value-only calls keep the triangular product'
+    use, steps, _ = gp.lockstep_info()
+    assert use and steps == 65
+    _close(v32, first[0], 1e-9, 'the 65th lock-step')
+    _close(g32, first[1], 1e-8, 'the 65th lock-step (gradient)')
+    gp.factorize()
+    assert gp.lockstep_info()[:2] == (False, 0)
+    # searches: more than 64 rounds in all -> K^-1 in use at the end, same optimum as the triangular form finds
+    starts = np.random.RandomState(1).uniform(-2, 2, (10, 3))
+    locs, vals, iters, n_eval = gp.lcb_minimize(starts, bounds, 3.0)
+    rounds = gp.lockstep_info()[1]
+    assert 1 <= rounds <= n_eval
+    for _ in range(64 // rounds + 1):
+        gp.lcb_minimize(starts, bounds, 3.0)
+    assert gp.lockstep_info()[0] and gp.lockstep_info()[1] > 64
+    locs3, vals3, _, _ = gp.lcb_minimize(starts, bounds, 3.0)
+    gp.set_lockstep_form(2)
+    locs2, vals2, _, _ = gp.lcb_minimize(starts, bounds, 3.0)
+    if rounds <= 64:   # the first search ran on the triangular products throughout
+        assert np.array_equal(vals, vals2) and np.array_equal(locs, locs2)
+    assert abs(vals3.min() - vals2.min()) <= 1e-8 * (abs(vals2.min()) + 1.0)
+
+
+def test_ill_conditioned_evidence_keeps_the_triangular_products(hip_ctx):
+    """k(x,x) - kb . K^-1 kb cancels with eps cond(K): with a noise variance six orders below the signal the K^-1 form is
+    not used (the lower bound of cond(K) is above the gate), whatever the form asks for."""
+    X, y, bounds = _problem(600, 2, seed=2)
+    h = dict(G.default_hyper(bounds, y))
+    h['noise'] = 1e-6 * h['var']
+    gp = _handle(X, y, h, form=3)
+    xs = _points(X, 10)
+    val, grad = gp.lcb(xs, 3.0)
+    use, steps, cond = gp.lockstep_info()
+    assert not use and cond > 1e5, (use, cond)
+    gp.set_lockstep_form(2)
+    val2, grad2 = gp.lcb(xs, 3.0)
+    assert np.array_equal(val, val2) and np.array_equal(grad, grad2)
+
+
+def test_bad_form_is_refused(hip_ctx):
+    X, y, bounds = _problem(40, 2)
+    gp = _handle(X, y, G.default_hyper(bounds, y), form=0)
+    with pytest.raises(Exception):
+        gp.set_lockstep_form(4)
