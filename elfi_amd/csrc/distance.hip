@@ -702,6 +702,120 @@ __global__ __launch_bounds__(256, 2) void dist_rows_mahalanobis_reg_kernel(RowAr
   }
 }
 
+// ---- 50 <= m <= 64 (four 16-column tiles of VI): the waves SHARE VI instead of each holding all of it ----------------
+// The register form above at KC = 4 keeps 64 doubles of VI per lane beside the staging registers of the next tile: the
+// compiler spilled the row addresses, and every reload (`scratch_load; s_waitcnt vmcnt(0)`) waited for ALL loads in flight
+// -- the eight 16-byte loads of a tile went out one memory round trip after the other, and with the addresses repaired
+// the reload moved behind the prefetch and made the MFMA loop wait for it: 12 / 9.5 us per 64-row tile, waves waiting
+// 68 % of their cycles, matrix pipes busy 0.28 / 0.36 (profiles/r04_mahalanobis_pmc.md).  Here wave w owns column tile w
+// of VI (16 doubles per lane) and multiplies ALL 64 rows of the tile by it -- the same 64 MFMAs per wave and tile -- and
+// the four waves' shares of delta^T VI delta meet in LDS: under 128 registers, no scratch, four workgroups per CU.
+// Row loads: thread (row t >> 5, column pair t & 31), eight rows apart per step; a lane beyond the row's last pair / the
+// tile's last row re-reads the last valid one (no predicated loads; the commit drops it).  The tile holds delta = x - y
+// (subtracted at the commit: the operand reads are the MFMA operands themselves).
+// Sum over the 16 lanes of a DPP row (lanes 16 j .. 16 j + 15), left in every lane of the row: two quad permutes, the
+// half-row mirror and the row mirror -- register moves, where __shfl_xor goes through the LDS crossbar (ds_bpermute: two
+// per double and step, each a round trip of a hundred cycles; the sixteen row sums of a tile were a third of its time).
+template <int CTRL>
+__device__ __forceinline__ double dpp_move_f64(double x) {
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row16_sum(double q) {
+  q += dpp_move_f64<0xB1>(q);    // quad_perm [1, 0, 3, 2]
+  q += dpp_move_f64<0x4E>(q);    // quad_perm [2, 3, 0, 1]
+  q += dpp_move_f64<0x141>(q);   // row_half_mirror
+  q += dpp_move_f64<0x140>(q);   // row_mirror
+  return q;
+}
+
+// KC = column tiles of VI = 1, 2 or 4 (m <= 16, <= 32, 50 .. 64): wave w owns column tile w % KC and the KC row groups
+// from (w / KC) KC on -- 4 KC^2 MFMAs per wave and tile whatever KC.  LDS row pitch 16 KC + 2 doubles: lane (row l & 15,
+// k-offset l >> 4) of an operand read lands in 8-byte bank (pitch row + k-offset) mod 32, and with pitch = 2 (mod 32) (or 18)
+// each half-wave covers the 32 banks once (the odd pitch m | 1 of the other kernels puts row + k-offset there: four lanes
+// per bank).
+template <int KC>
+__global__ __launch_bounds__(256, KC == 4 ? 3 : 4) void dist_rows_mahalanobis_split_kernel(RowArgs A) {   // (KC = 4 at four per CU: 3 spills, 0.282 against 0.274 ms)
+  extern __shared__ __align__(16) double lds[];
+  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, m = A.m, h = m >> 1;
+  constexpr int P = 16 * KC + 2;     // LDS row pitch
+  constexpr int KS = 4 * KC;         // k-steps of four
+  constexpr int CPB = 8 * KC;        // column pairs of a padded row: thread (row t / CPB, pair t % CPB), 256 / CPB rows per step
+  constexpr int RPS = 256 / CPB, U = MAHA_ROWS / RPS;
+  double* tile = lds;                // MAHA_ROWS x P: delta = x - y, zero from column m on (written once, below)
+  double* red = tile + MAHA_ROWS * P;   // [column tile][row]: the waves' shares of a row's quadratic form
+  for (int e = tid; e < MAHA_ROWS * P; e += 256) tile[e] = 0.0;
+  const int jt = w % KC, g0 = (w / KC) * KC;
+  const int c = 16 * jt + (l & 15);          // this lane's column of VI
+  double b[KS];
+#pragma unroll
+  for (int s_ = 0; s_ < KS; ++s_) {
+    const int k = 4 * s_ + (l >> 4);
+    b[s_] = (k < m && c < m) ? A.aux[(size_t)k * m + c] : 0.0;
+  }
+  const int cp = tid % CPB, r0 = tid / CPB;
+  const int cpc = cp < h ? cp : h - 1;
+  const uint32_t col = 2u * (uint32_t)cpc;
+  const double y0 = A.y[2 * cpc], y1 = A.y[2 * cpc + 1];
+  const int64_t ntiles = (A.n + MAHA_ROWS - 1) / MAHA_ROWS;
+  double2 v[U];
+  // straight-line: no branch around the loads (with the loads of a tile on one of several paths the compiler's wait
+  // counters are merged at the join and the first MFMA of the loop waits for the prefetch it should overlap with)
+  auto fetch = [&](int64_t tt) {
+    const int64_t row0 = tt * MAHA_ROWS;
+    const int rows = (int)((A.n - row0) < MAHA_ROWS ? (A.n - row0) : MAHA_ROWS);
+    const char* __restrict__ Xt = reinterpret_cast<const char*>(A.X + row0 * A.ldx);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int r = r0 + RPS * u;
+      v[u] = *reinterpret_cast<const double2*>(Xt + ((uint32_t)(r < rows ? r : rows - 1) * (uint32_t)A.ldx + col) * 8u);
+    }
+  };
+  int64_t t = blockIdx.x;
+  if (t < ntiles) fetch(t);
+  for (; t < ntiles; t += gridDim.x) {
+    const int64_t row0 = t * MAHA_ROWS;
+    const int rows = (int)((A.n - row0) < MAHA_ROWS ? (A.n - row0) : MAHA_ROWS);
+    __syncthreads();   // tile free, red read (and, the first time, the zeros in place)
+    if (cp < h) {
+#pragma unroll
+      for (int u = 0; u < U; ++u)   // (rows beyond a short last tile get copies of its last row: finite, discarded)
+        *reinterpret_cast<double2*>(tile + (r0 + RPS * u) * P + 2 * cp) = make_double2(v[u].x - y0, v[u].y - y1);
+    }
+    const int64_t tn = t + gridDim.x;
+    fetch(tn < ntiles ? tn : t);   // (beyond the last tile: this one again, dropped)
+    __syncthreads();
+    // the wave's KC 16-row groups side by side: independent accumulator chains (one chain of dependent MFMAs leaves the
+    // matrix pipe idle between a result and the next issue whenever the SIMD's other waves are waiting too)
+    const double* xa = tile + (16 * g0 + (l & 15)) * P + (l >> 4);   // A operand of group g0 + g: row 16 (g0 + g) + (l & 15), k = 4 s + (l >> 4)
+    v4d acc[KC];
+#pragma unroll
+    for (int g = 0; g < KC; ++g) acc[g] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s_ = 0; s_ < KS; ++s_)
+#pragma unroll
+      for (int g = 0; g < KC; ++g)
+        acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[16 * g * P + 4 * s_], b[s_], acc[g], 0, 0, 0);
+    // fold with delta: accumulator element i of lane l is T[row 16 (g0 + g) + (l >> 4) + 4 i][column c] (delta is 0 from column m on)
+#pragma unroll
+    for (int g = 0; g < KC; ++g)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = 16 * (g0 + g) + (l >> 4) + 4 * i;
+        const double q = row16_sum(acc[g][i] * tile[r * P + c]);
+        if ((l & 15) == 0) red[jt * MAHA_ROWS + r] = q;
+      }
+    __syncthreads();
+    if (tid < rows) {
+      double q = red[tid];
+      if (KC == 2) q += red[MAHA_ROWS + tid];
+      if (KC == 4) q = ((q + red[MAHA_ROWS + tid]) + red[2 * MAHA_ROWS + tid]) + red[3 * MAHA_ROWS + tid];
+      A.out[row0 + tid] = sqrt(q);
+    }
+  }
+}
+
 // F / filtered: fused selection (reject.hip).  *filtered tells the caller whether the kernel that ran offered the
 // candidates itself; otherwise the caller filters dout in a separate pass.
 int dist_rows_dev_impl(elfihip_ctx* ctx, int metric, const double* dX, int64_t n, int m, int64_t ldx, const double* dy,
@@ -718,16 +832,25 @@ int dist_rows_dev_impl(elfihip_ctx* ctx, int metric, const double* dX, int64_t n
   const bool w = daux != nullptr;
   if (cm == ELFIHIP_MAHALANOBIS) {
     ELFIHIP_REQUIRE(ctx, m <= kMaxTileM, "mahalanobis supports m <= %d", kMaxTileM);
-    if (m >= 8 && m <= 64 && A.vec2) {   // even m, 16-byte aligned rows: VI in registers, pipelined row loads
+    if (m >= 8 && m <= 64 && A.vec2 && ldx < (1 << 22)) {   // even m, 16-byte aligned rows: VI in registers, pipelined row loads
       const int kc = (m + 15) / 16;
       const size_t lb = ((size_t)MAHA_ROWS * A.mp + 64 + 64) * sizeof(double);
       const int g = grid_for(ctx, (n + MAHA_ROWS - 1) / MAHA_ROWS, lb, 256);
-      switch (kc) {
-        case 1: hipLaunchKernelGGL((dist_rows_mahalanobis_reg_kernel<1>), dim3(g), dim3(256), lb, ctx->stream, A); break;
-        case 2: hipLaunchKernelGGL((dist_rows_mahalanobis_reg_kernel<2>), dim3(g), dim3(256), lb, ctx->stream, A); break;
-        case 3: hipLaunchKernelGGL((dist_rows_mahalanobis_reg_kernel<3>), dim3(g), dim3(256), lb, ctx->stream, A); break;
-        default: hipLaunchKernelGGL((dist_rows_mahalanobis_reg_kernel<4>), dim3(g), dim3(256), lb, ctx->stream, A); break;
+      if (kc != 3) {   // the waves share VI (kc = 3 would leave a wave without a column tile)
+        const int kt = kc == 4 ? 4 : kc;
+        const size_t lb4 = ((size_t)MAHA_ROWS * (16 * kt + 2) + (size_t)kt * MAHA_ROWS) * sizeof(double);
+        int g4 = grid_for(ctx, (n + MAHA_ROWS - 1) / MAHA_ROWS, lb4, 256);
+        const int per_cu = kt == 4 ? 3 : (kt == 2 ? 5 : 8);   // workgroups per CU by registers (measured: m = 32 0.128 ms with 3, 0.075 with 5)
+        if (g4 > per_cu * ctx->cu_count) g4 = per_cu * ctx->cu_count;
+        if (kt == 4)
+          hipLaunchKernelGGL((dist_rows_mahalanobis_split_kernel<4>), dim3(g4), dim3(256), lb4, ctx->stream, A);
+        else if (kt == 2)
+          hipLaunchKernelGGL((dist_rows_mahalanobis_split_kernel<2>), dim3(g4), dim3(256), lb4, ctx->stream, A);
+        else
+          hipLaunchKernelGGL((dist_rows_mahalanobis_split_kernel<1>), dim3(g4), dim3(256), lb4, ctx->stream, A);
+        return launch_status(ctx, "dist_rows_mahalanobis_split_kernel");
       }
+      hipLaunchKernelGGL((dist_rows_mahalanobis_reg_kernel<3>), dim3(g), dim3(256), lb, ctx->stream, A);
       return launch_status(ctx, "dist_rows_mahalanobis_reg_kernel");
     }
     if (m >= 8 && m <= 64) {   // narrower rows: the padding to the 16-wide tile costs more than the lane-per-row form

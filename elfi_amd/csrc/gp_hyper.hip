@@ -236,7 +236,10 @@ static int hyper_grad_impl(elfihip_gp* gp, bool store_kinv, double* grad) {
   ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(st));
   const double s[4] = {gp->h_fit[4], gp->h_fit[5], gp->h_fit[6], gp->h_fit[7]};
   prof_add(gp, ELFIHIP_PHASE_KINV_GRAD, 0, 1);
-  if (store_kinv) gp->has_kinv = true;
+  if (store_kinv) {
+    gp->has_kinv = true;
+    gp->kinv_sym = false;   // the lower tiles are new: the upper ones are mirrored again before a product reads them
+  }
   if (grad) {
     grad[0] = s[0] / gp->var;
     grad[1] = s[1] / (gp->ls * gp->ls * gp->ls);
