@@ -156,4 +156,31 @@ inline int launch_status(elfihip_ctx* ctx, const char* what) {
   return ELFIHIP_OK;
 }
 
+#if defined(__HIPCC__)
+// ---- sums across lanes by DPP (register moves) ------------------------------------------------------------------
+// __shfl_xor of a double is two ds_bpermute_b32 -- a round trip through the LDS crossbar of a hundred cycles, and the
+// steps of a butterfly depend on each other; inside 16 lanes the same partners are reachable by the data-parallel
+// primitives: quad permutes for xor 1 / xor 2, the half-row mirror (lane i <-> 7 - i of each 8) and the row mirror
+// (i <-> 15 - i of each 16).  After the two quad steps every lane of a quad holds the quad's sum, so the mirrored partner
+// holds the very bits the xor-4 / xor-8 partner holds: the sums are bit-identical to the butterfly's.
+template <int CTRL>
+__device__ __forceinline__ double dpp_move_f64(double x) {
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+// every lane of an aligned group of 8 / 16 lanes gets the group's sum: (((x0 + x1) + (x2 + x3)) + ((x4 + x5) + (x6 + x7))) ...
+__device__ __forceinline__ double lanes8_sum(double q) {
+  q += dpp_move_f64<0xB1>(q);    // quad_perm [1, 0, 3, 2]
+  q += dpp_move_f64<0x4E>(q);    // quad_perm [2, 3, 0, 1]
+  q += dpp_move_f64<0x141>(q);   // row_half_mirror
+  return q;
+}
+__device__ __forceinline__ double lanes16_sum(double q) {
+  q = lanes8_sum(q);
+  q += dpp_move_f64<0x140>(q);   // row_mirror
+  return q;
+}
+#endif
+
 }  // namespace elfihip

@@ -321,11 +321,7 @@ __global__ __launch_bounds__(256) void dist_rows_mahalanobis_mfma_kernel(RowArgs
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      double v = part[i];
-      v += __shfl_xor(v, 1, 64);
-      v += __shfl_xor(v, 2, 64);
-      v += __shfl_xor(v, 4, 64);
-      v += __shfl_xor(v, 8, 64);
+      const double v = lanes16_sum(part[i]);
       const int r = 16 * w + (l >> 4) + 4 * i;
       if ((l & 15) == 0 && r < rows) A.out[row0 + r] = sqrt(v);
     }
@@ -691,11 +687,7 @@ __global__ __launch_bounds__(256, 2) void dist_rows_mahalanobis_reg_kernel(RowAr
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      double q = part[i];
-      q += __shfl_xor(q, 1, 64);
-      q += __shfl_xor(q, 2, 64);
-      q += __shfl_xor(q, 4, 64);
-      q += __shfl_xor(q, 8, 64);
+      const double q = lanes16_sum(part[i]);
       const int r = 16 * w + (l >> 4) + 4 * i;
       if ((l & 15) == 0 && r < rows) A.out[row0 + r] = sqrt(q);
     }
@@ -713,23 +705,6 @@ __global__ __launch_bounds__(256, 2) void dist_rows_mahalanobis_reg_kernel(RowAr
 // Row loads: thread (row t >> 5, column pair t & 31), eight rows apart per step; a lane beyond the row's last pair / the
 // tile's last row re-reads the last valid one (no predicated loads; the commit drops it).  The tile holds delta = x - y
 // (subtracted at the commit: the operand reads are the MFMA operands themselves).
-// Sum over the 16 lanes of a DPP row (lanes 16 j .. 16 j + 15), left in every lane of the row: two quad permutes, the
-// half-row mirror and the row mirror -- register moves, where __shfl_xor goes through the LDS crossbar (ds_bpermute: two
-// per double and step, each a round trip of a hundred cycles; the sixteen row sums of a tile were a third of its time).
-template <int CTRL>
-__device__ __forceinline__ double dpp_move_f64(double x) {
-  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xF, 0xF, true);
-  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xF, 0xF, true);
-  return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double row16_sum(double q) {
-  q += dpp_move_f64<0xB1>(q);    // quad_perm [1, 0, 3, 2]
-  q += dpp_move_f64<0x4E>(q);    // quad_perm [2, 3, 0, 1]
-  q += dpp_move_f64<0x141>(q);   // row_half_mirror
-  q += dpp_move_f64<0x140>(q);   // row_mirror
-  return q;
-}
-
 // KC = column tiles of VI = 1, 2 or 4 (m <= 16, <= 32, 50 .. 64): wave w owns column tile w % KC and the KC row groups
 // from (w / KC) KC on -- 4 KC^2 MFMAs per wave and tile whatever KC.  LDS row pitch 16 KC + 2 doubles: lane (row l & 15,
 // k-offset l >> 4) of an operand read lands in 8-byte bank (pitch row + k-offset) mod 32, and with pitch = 2 (mod 32) (or 18)
@@ -803,7 +778,7 @@ __global__ __launch_bounds__(256, KC == 4 ? 3 : 4) void dist_rows_mahalanobis_sp
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int r = 16 * (g0 + g) + (l >> 4) + 4 * i;
-        const double q = row16_sum(acc[g][i] * tile[r * P + c]);
+        const double q = lanes16_sum(acc[g][i] * tile[r * P + c]);   // (DPP: common.hpp; __shfl_xor here was a third of a tile's time)
         if ((l & 15) == 0) red[jt * MAHA_ROWS + r] = q;
       }
     __syncthreads();

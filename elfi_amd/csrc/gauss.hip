@@ -79,9 +79,7 @@ __device__ __forceinline__ double pairwise8(F f, int n, int j) {
   const int nfull = n - (n % 8);
   double r = f(j);
   for (int i = 8 + j; i < nfull; i += 8) r += f(i);
-  r += __shfl_xor(r, 1, 64);
-  r += __shfl_xor(r, 2, 64);
-  r += __shfl_xor(r, 4, 64);
+  r = lanes8_sum(r);   // (DPP, bit-identical to the xor butterfly: common.hpp)
   for (int i = nfull; i < n; ++i) r += f(i);
   return r;
 }

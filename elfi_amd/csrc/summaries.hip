@@ -79,9 +79,7 @@ __device__ __forceinline__ double np_pairwise8(F f, int n, int j) {
 #pragma unroll
   for (int k = 1; k < 16; ++k)
     if (8 * k < nfull) r += e[k];  // uniform condition
-  r += __shfl_xor(r, 1, 64);
-  r += __shfl_xor(r, 2, 64);
-  r += __shfl_xor(r, 4, 64);
+  r = lanes8_sum(r);   // (DPP, bit-identical to the xor butterfly: common.hpp)
   for (int i = nfull; i < n; ++i) r += f(i);
   return r;
 }
