@@ -165,10 +165,37 @@ def run(n=4096, d=10, S=10, iters=50, warm=3):
                         "mode": "bordering update (elfihip_gp_extend): two passes over L^-T per new point, "
                                 "HBM-bound: %.0f MB per update" % (2 * 8.0 * n * n / 2 / 1e6)},
     }
+    out["lockstep_us"] = lockstep_leg(n, d, S)
     out["fit_large"] = fit_only(8192, 20)
     # the sizes a real run's hyper-parameter searches rebuild at (configs[2]: 512 ... 4096): chain-bound, not MFMA-bound
     out["fit_small"] = {str(m): fit_only(m, d) for m in (1024, 2048)}
     out["cfg5"] = cfg5_leg()
+    return out
+
+
+def lockstep_leg(n=4096, d=10, S=10, reps=300):
+    """One acquisition lock-step (value and gradient of the LCB at S points; host wall per elfihip_gp_lcb call, us): the
+    two triangular products (four launches -- what a GP that is refactorised for every acquisition runs) against ONE
+    product with K^-1 (three launches -- what a GP that is extended point by point switches to after 64 lock-steps)."""
+    from .gp import GPHandle
+    X, y, bounds = problem(n, d)
+    h = heuristic_hyper(bounds, y)
+    gp = GPHandle(d, n)
+    gp.set_hyper(h['var'], h['ls'], h['bias'], h['noise'])
+    gp.set_data(X, y)
+    gp.factorize()
+    xs = np.random.RandomState(2).uniform(-2, 2, (S, d))
+    out = {}
+    for name, form in (("triangular_products", 2), ("kinv_product", 3)):
+        gp.set_lockstep_form(form)
+        for _ in range(20):
+            gp.lcb(xs, 3.0)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            gp.lcb(xs, 3.0)
+        out[name] = (time.perf_counter() - t0) / reps * 1e6
+    out["kinv_in_use"], _, out["cond_bound"] = gp.lockstep_info()
+    gp.close()
     return out
 
 
