@@ -93,6 +93,9 @@ PROTOTYPES = {
                                             C.POINTER(C.c_int64), C.c_void_p, C.c_void_p, C.c_int64]),
     "elfihip_randn_rows": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int64, C.c_int, C.c_void_p, C.c_void_p,
                                     C.c_void_p]),
+    "elfihip_prior_draw": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "elfihip_prior_draw_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_int64, C.c_void_p, C.c_void_p,
+                                        C.c_void_p]),
     "elfihip_kept_distances": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
     "elfihip_reject_push_kept": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64]),
     "elfihip_ma2_draw_distance": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int64, C.c_int, C.c_void_p, C.c_void_p,

@@ -68,6 +68,57 @@ __global__ __launch_bounds__(256) void randn_rows_kernel(uint64_t seed, uint64_t
   }
 }
 
+// ---- prior draws (include/elfihip.h: elfihip_prior_draw) --------------------------------------------------------
+// U_e = 53-bit uniform in [0, 1): element e of stream (seed, stream) is the first (e even) or second (e odd) 53-bit word of
+// Philox counter e / 2 -- the words normal_pair() turns into a Box-Muller pair.  Every transform keeps the reference's
+// operation order (multiply and add round separately, as NumPy's do).
+__device__ __forceinline__ void uniform_pair(uint64_t seed, uint64_t stream, uint64_t p, double& u0, double& u1) {
+  uint32_t r[4];
+  philox4x32_10((uint32_t)p, (uint32_t)(p >> 32), (uint32_t)stream, (uint32_t)(stream >> 32), (uint32_t)seed,
+                (uint32_t)(seed >> 32), r);
+  const uint64_t a = ((uint64_t)r[0] << 21) | (r[1] >> 11), b = ((uint64_t)r[2] << 21) | (r[3] >> 11);
+  u0 = (double)a * 0x1.0p-53;
+  u1 = (double)b * 0x1.0p-53;
+}
+
+// (plain operators: this file is compiled with fp contract off, the __dmul_rn / __dadd_rn header wrappers are not -- their
+// products and sums were fused into FMAs after inlining)
+template <int KIND>
+__device__ __forceinline__ double prior_transform(double u, double a0, double a1, double c) {
+  if (KIND == 0) {   // ss.uniform.rvs(loc, scale): U * scale + loc
+    const double t = u * a1;
+    return t + a0;
+  }
+  if (KIND == 1) {   // ma2.py:116-117: np.where(u < 0.5, np.sqrt(2. * u) * b - b, -np.sqrt(2. * (1. - u)) * b + b)
+    const double b = a0;
+    if (u < 0.5) {
+      const double r = sqrt(2.0 * u), t = r * b;
+      return t - b;
+    }
+    const double w = 1.0 - u, r = -sqrt(2.0 * w), t = r * b;
+    return t + b;
+  }
+  // ma2.py:163-165: locs = np.maximum(-a - t1, -a + t1); scales = a - locs; ss.uniform.rvs(loc=locs, scale=scales)
+  const double a = a0, l0 = -a - c, l1 = -a + c;
+  const double loc = l0 > l1 ? l0 : l1;
+  const double sc = a - loc, t = u * sc;
+  return t + loc;
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void prior_draw_kernel(uint64_t seed, uint64_t stream, int64_t n, double a0, double a1,
+                                                         const double* cond, double* out) {
+  const int64_t npair = (n + 1) / 2;
+  for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < npair; p += (int64_t)gridDim.x * 256) {
+    double u0, u1;
+    uniform_pair(seed, stream, (uint64_t)p, u0, u1);
+    const bool two = 2 * p + 1 < n;
+    const double c0 = KIND == 2 ? cond[2 * p] : 0.0, c1 = (KIND == 2 && two) ? cond[2 * p + 1] : 0.0;
+    out[2 * p] = prior_transform<KIND>(u0, a0, a1, c0);
+    if (two) out[2 * p + 1] = prior_transform<KIND>(u1, a0, a1, c1);
+  }
+}
+
 // NumPy's pairwise sum of n <= 128 terms by eight lanes (summaries.hip: np_pairwise8); lane j of an aligned group of 8
 template <class F>
 __device__ __forceinline__ double pairwise8(F f, int n, int j) {
@@ -259,6 +310,45 @@ int elfihip_randn_dev(elfihip_ctx* ctx, uint64_t seed, uint64_t stream, int64_t 
   const int64_t grid = std::min<int64_t>((npair + 255) / 256, (int64_t)ctx->cu_count * 16);
   hipLaunchKernelGGL(randn_kernel, dim3((unsigned)grid), dim3(256), 0, ctx->stream, seed, stream, n, loc, scale, dout);
   return launch_status(ctx, "randn_kernel");
+}
+
+int elfihip_prior_draw_dev(elfihip_ctx* ctx, int kind, uint64_t seed, uint64_t stream, int64_t n, const double* a,
+                           const double* dcond, double* dout) {
+  if (!ctx) return fail(nullptr, ELFIHIP_ERR_ARG, "ctx is NULL");
+  ELFIHIP_REQUIRE(ctx, kind >= 0 && kind <= 2, "unknown prior kind %d", kind);
+  ELFIHIP_REQUIRE(ctx, n >= 0 && a && (n == 0 || dout), "bad arguments");
+  ELFIHIP_REQUIRE(ctx, kind != ELFIHIP_PRIOR_MA2_T2 || n == 0 || dcond, "the conditional prior needs t1");
+  if (n == 0) return ELFIHIP_OK;
+  DeviceGuard g(ctx->device);
+  const int64_t npair = (n + 1) / 2;
+  const unsigned grid = (unsigned)std::min<int64_t>((npair + 255) / 256, (int64_t)ctx->cu_count * 16);
+  const double a0 = a[0], a1 = kind == ELFIHIP_PRIOR_UNIFORM ? a[1] : 0.0;
+  if (kind == ELFIHIP_PRIOR_UNIFORM)
+    hipLaunchKernelGGL((prior_draw_kernel<0>), dim3(grid), dim3(256), 0, ctx->stream, seed, stream, n, a0, a1, dcond, dout);
+  else if (kind == ELFIHIP_PRIOR_MA2_T1)
+    hipLaunchKernelGGL((prior_draw_kernel<1>), dim3(grid), dim3(256), 0, ctx->stream, seed, stream, n, a0, a1, dcond, dout);
+  else
+    hipLaunchKernelGGL((prior_draw_kernel<2>), dim3(grid), dim3(256), 0, ctx->stream, seed, stream, n, a0, a1, dcond, dout);
+  return launch_status(ctx, "prior_draw_kernel");
+}
+
+int elfihip_prior_draw(elfihip_ctx* ctx, int kind, uint64_t seed, uint64_t stream, int64_t n, const double* a,
+                       const double* cond, double* out) {
+  if (!ctx) return fail(nullptr, ELFIHIP_ERR_ARG, "ctx is NULL");
+  ELFIHIP_REQUIRE(ctx, n >= 0 && a && (n == 0 || out), "bad arguments");
+  ELFIHIP_REQUIRE(ctx, kind != ELFIHIP_PRIOR_MA2_T2 || n == 0 || cond, "the conditional prior needs t1");
+  if (n == 0) return ELFIHIP_OK;
+  DeviceGuard g(ctx->device);
+  const size_t bytes = (size_t)n * sizeof(double);
+  ELFIHIP_CHECK_HIP(ctx, ctx->par.reserve(2 * bytes));
+  double* dcond = ctx->par.as<double>();
+  double* dout = dcond + n;
+  if (kind == ELFIHIP_PRIOR_MA2_T2)
+    ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(dcond, cond, bytes, hipMemcpyHostToDevice, ctx->stream));
+  ELFIHIP_TRY(elfihip_prior_draw_dev(ctx, kind, seed, stream, n, a, kind == ELFIHIP_PRIOR_MA2_T2 ? dcond : nullptr, dout));
+  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(out, dout, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ELFIHIP_OK;
 }
 
 int elfihip_randn_rows(elfihip_ctx* ctx, uint64_t seed, uint64_t stream, int64_t n, int m, const double* loc,

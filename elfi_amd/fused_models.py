@@ -59,9 +59,10 @@ def second_column(y):
     return np.asarray(y)[:, 1]
 
 
-def ma2_model(n_obs=100, true_params=None, seed_obs=None):
+def ma2_model(n_obs=100, true_params=None, seed_obs=None, device_priors=True):
     """elfi.examples.ma2.get_model(n_obs, true_params, seed_obs) with the simulation on the device; nodes t1, t2, MA2,
-    S1, S2, d."""
+    S1, S2, d.  device_priors: the two Prior nodes draw on the device as well (elfi_amd.priors: same distributions, the
+    library's generator; False keeps the reference's CustomPrior1 / CustomPrior2 and their SciPy draws)."""
     elfi = _elfi()
     from elfi.examples import ma2
     if true_params is None:
@@ -69,8 +70,9 @@ def ma2_model(n_obs=100, true_params=None, seed_obs=None):
     y = ma2.MA2(*true_params, n_obs=n_obs, random_state=np.random.RandomState(seed_obs))
     obs = np.array([[ma2.autocov(y)[0], ma2.autocov(y, 2)[0]]])
     m = elfi.ElfiModel()
-    elfi.Prior(ma2.CustomPrior1, 2, model=m, name='t1')
-    elfi.Prior(ma2.CustomPrior2, m['t1'], 1, name='t2')
+    from . import priors
+    elfi.Prior(priors.MA2Prior1 if device_priors else ma2.CustomPrior1, 2, model=m, name='t1')
+    elfi.Prior(priors.MA2Prior2 if device_priors else ma2.CustomPrior2, m['t1'], 1, name='t2')
     elfi.Simulator(partial(ma2_summaries, observed_summaries=tuple(obs[0]), n_obs=n_obs), m['t1'], m['t2'], observed=obs,
                    name='MA2')
     elfi.Summary(first_column, m['MA2'], name='S1')
@@ -79,9 +81,10 @@ def ma2_model(n_obs=100, true_params=None, seed_obs=None):
     return m
 
 
-def gauss_model(n_obs=50, true_params=None, seed_obs=None):
+def gauss_model(n_obs=50, true_params=None, seed_obs=None, device_priors=True):
     """elfi.examples.gauss.get_model(n_obs, true_params, seed_obs) (1-D mean and standard deviation) with the simulation
-    on the device; nodes mu, sigma, gauss, ss_mean, ss_var, d."""
+    on the device; nodes mu, sigma, gauss, ss_mean, ss_var, d.  device_priors: the uniform prior of mu draws on the device
+    (sigma's truncated normal stays SciPy's)."""
     elfi = _elfi()
     from elfi.examples import gauss
     if true_params is None:
@@ -90,7 +93,9 @@ def gauss_model(n_obs=50, true_params=None, seed_obs=None):
     obs = np.array([[gauss.ss_mean(y)[0], gauss.ss_var(y)[0]]])
     m = elfi.new_model()
     eps_prior = 5
-    mu = elfi.Prior('uniform', true_params[0] - eps_prior, 2 * eps_prior, model=m, name='mu')
+    from . import priors
+    mu = elfi.Prior(priors.uniform if device_priors else 'uniform', true_params[0] - eps_prior, 2 * eps_prior, model=m,
+                    name='mu')
     sigma = elfi.Prior('truncnorm', np.amax([.01, true_params[1] - eps_prior]), 2 * eps_prior, model=m, name='sigma')
     elfi.Simulator(partial(gauss_summaries, observed_summaries=tuple(obs[0]), n_obs=n_obs), mu, sigma, observed=obs,
                    name='gauss')
@@ -116,7 +121,8 @@ def gauss_wide_model(m=64, adaptive=True):
     import scipy.stats as ss
     from .adaptive import hip_adaptive_distance_class
     mdl = elfi.new_model()
-    mu = elfi.Prior(ss.uniform, -10, 20, model=mdl, name='mu')
+    from . import priors
+    mu = elfi.Prior(priors.uniform, -10, 20, model=mdl, name='mu')      # (ss.uniform with the draws on the device)
     sim = elfi.Simulator(partial(gauss_wide_rows, scale=np.linspace(1.0, 20.0, m)), mu, observed=np.zeros((1, m)), name='sim')
     if adaptive:
         hip_adaptive_distance_class()(sim, name='d')

@@ -331,6 +331,22 @@ int elfihip_randn_dev(elfihip_ctx* ctx, uint64_t seed, uint64_t stream, int64_t 
 int elfihip_randn_rows(elfihip_ctx* ctx, uint64_t seed, uint64_t stream, int64_t n, int m, const double* loc,
                        const double* scale, double* out);
 int elfihip_random_bits_dev(elfihip_ctx* ctx, uint64_t seed, uint64_t stream, int64_t nblocks, uint32_t* dout);
+/* Prior draws on the device.  Replaces the draws behind elfi.Prior nodes -- rvs_from_distribution
+ * (elfi/model/utils.py:6-35) -> scipy.stats rvs on the host, 64 % of the reference loop's time per batch of 10^6 once
+ * simulator and distance run on the GPU.  U_e = the 53-bit uniform in [0, 1) made of the first
+ * (e even) / second (e odd) pair of words of Philox counter e / 2 of stream (seed, stream) -- the generator of
+ * elfihip_randn_dev -- transformed in the reference's own operation order:
+ *   ELFIHIP_PRIOR_UNIFORM: out = U * a[1] + a[0]                  ss.uniform.rvs(loc = a[0], scale = a[1])
+ *   ELFIHIP_PRIOR_MA2_T1:  CustomPrior1.rvs(b = a[0])             elfi/examples/ma2.py:102-118
+ *   ELFIHIP_PRIOR_MA2_T2:  CustomPrior2.rvs(t1 = cond, a = a[0])  elfi/examples/ma2.py:147-166 (cond: n values)
+ * a: host scalars.  Host form: cond / out host pointers; _dev form: device pointers, no synchronisation. */
+#define ELFIHIP_PRIOR_UNIFORM 0
+#define ELFIHIP_PRIOR_MA2_T1 1
+#define ELFIHIP_PRIOR_MA2_T2 2
+int elfihip_prior_draw(elfihip_ctx* ctx, int kind, uint64_t seed, uint64_t stream, int64_t n, const double* a,
+                       const double* cond, double* out);
+int elfihip_prior_draw_dev(elfihip_ctx* ctx, int kind, uint64_t seed, uint64_t stream, int64_t n, const double* a,
+                           const double* dcond, double* dout);
 
 /* ------------------------------------------------------------------- GP surrogate
  * Replaces the GPy model behind elfi.methods.bo.gpy_regression.GPyRegression
