@@ -105,6 +105,8 @@ PROTOTYPES = {
     "elfihip_reject_export_dev": (C.c_int, [C.c_void_p, C.c_void_p]),
     "elfihip_reject_flush": (C.c_int, [C.c_void_p]),
     "elfihip_reject_result": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "elfihip_gm_rvs": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_void_p,
+                                C.c_void_p, C.c_void_p]),
     "elfihip_gm_pdf": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_void_p,
                                  C.c_void_p, C.c_double, C.c_void_p]),
     "elfihip_weighted_var": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),

@@ -60,6 +60,7 @@ struct elfihip_reject {
   double* acc_dev = nullptr;
   unsigned long long* acc_count = nullptr;   // device: rows accepted so far
   unsigned long long acc_seen = 0;           // ... as of the previous meta() read
+  elfihip::DevBuf mask_mem;                  // accept-and-select pushes: this batch's count + the masked ranking column
   // k > REJ_MAX_K: sorted host copy of the state, merged on the host after every push
   bool host_mode = false, host_dirty = false;
   std::vector<double> hval;
@@ -75,6 +76,7 @@ constexpr unsigned int REJ_CAP = 1u << 16;   // smallest candidate list
 constexpr int64_t REJ_MAX_K_HOST = 1 << 20;  // host-merge states
 constexpr double REJ_HEAVY = 8192.0;         // expected candidates from which a push takes the radix selection
 constexpr int REJ_ACC_COLS = 64;             // nested columns an acceptance condition can cover (= kMaxK of distance.hip)
+constexpr int64_t REJ_ACC_SELECT_MIN = 1 << 15;   // batch rows from which an acceptance push selects instead of listing
 // provisional threshold of a large first batch (adaptive_push_impl)
 constexpr int64_t REJ_PROV_MIN_ROWS = 1 << 20;
 constexpr unsigned int REJ_PROV_MAX_CAND = 1u << 16;
@@ -258,6 +260,31 @@ __global__ __launch_bounds__(256) void reject_filter_kernel(const double* d, int
   if (use_accept && (threadIdx.x & 63) == 0 && mine) atomicAdd(acc_count, mine);
 }
 
+// An acceptance threshold and no useful k-th distance yet (a new SMC round: samplers.py:474-487 builds a fresh Rejection
+// per round, and its thresholds accept a quarter to a half of the proposals): every accepted row would be a candidate --
+// 3 10^5 of a batch of 10^6, merged 1024 at a time by one workgroup (17-80 ms per push, measured through
+// HipAdaptiveDistanceSMC).  Instead the ranking column is MASKED (+inf where a row is not acceptable), the accepted rows
+// are counted, and the batch's min(k, accepted) best come from the radix selection.
+__global__ __launch_bounds__(256) void reject_mask_kernel(const double* d, int64_t n, int64_t stride, int ncols,
+                                                          const double* acc, double* masked,
+                                                          unsigned long long* batch_count, unsigned long long* acc_count) {
+  const double inf = __longlong_as_double(0x7ff0000000000000ll);
+  const int64_t nround = (n + (int64_t)gridDim.x * 256 - 1) / ((int64_t)gridDim.x * 256);
+  unsigned long long mine = 0;
+  for (int64_t r = 0; r < nround; ++r) {
+    const int64_t i = (r * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
+    bool ok = i < n;
+    if (ok)
+      for (int c = 0; c < ncols; ++c) ok = ok && d[i * stride - c] <= acc[ncols - 1 - c];
+    mine += __popcll(__ballot(ok));   // uniform: every lane of the wave holds the wave's count
+    if (i < n) masked[i] = ok ? d[i * stride] : inf;
+  }
+  if ((threadIdx.x & 63) == 0 && mine) {
+    atomicAdd(batch_count, mine);
+    atomicAdd(acc_count, mine);
+  }
+}
+
 __global__ void reject_init_kernel(double* best_val, long long* best_row, double* thr, unsigned int* count,
                                    unsigned int* status, unsigned long long* acc_count, int k) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -432,6 +459,29 @@ static int reject_push(elfihip_reject* h, int64_t n, const double* dsel, int64_t
   const double expect = full ? (double)n * (double)h->k / (double)std::max<int64_t>(h->rows_seen, 1) : 1e300;
   const bool select = !h->has_accept && (!full || expect > REJ_HEAVY);
   h->rows_seen += n;
+  if (h->has_accept && !h->host_mode && n >= REJ_ACC_SELECT_MIN && (!full || expect > REJ_HEAVY)) {
+    // acceptance condition, state still filling up (or very many rows would qualify): mask, count, select (above)
+    ELFIHIP_TRY(reject_flush(h));
+    bool dummy = false;
+    ELFIHIP_TRY(run(nullptr, &dummy));
+    ELFIHIP_CHECK_HIP(ctx, h->mask_mem.reserve(((size_t)n + 2) * sizeof(double)));
+    unsigned long long* bcount = h->mask_mem.as<unsigned long long>();
+    double* masked = h->mask_mem.as<double>() + 2;
+    ELFIHIP_CHECK_HIP(ctx, hipMemsetAsync(bcount, 0, sizeof(unsigned long long), st));
+    int g = (int)((n + 255) / 256);
+    if (g > ctx->cu_count * 8) g = ctx->cu_count * 8;
+    hipLaunchKernelGGL(reject_mask_kernel, dim3(g), dim3(256), 0, st, dsel, n, stride, ncols, h->acc_dev, masked, bcount,
+                       h->acc_count);
+    unsigned long long accepted = 0;
+    ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(&accepted, bcount, sizeof accepted, hipMemcpyDeviceToHost, st));
+    ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(st));
+    const int64_t kb = (int64_t)accepted < h->k ? (int64_t)accepted : h->k;
+    if (kb > 0) {
+      ELFIHIP_TRY(topk_dev_impl(ctx, masked, n, 1, kb, h->cand_val, reinterpret_cast<int64_t*>(h->cand_row), true));
+      hipLaunchKernelGGL(reject_merge_kernel, dim3(1), dim3(1024), REJ_MERGE_LDS, st, merge_args(h, (int)kb, row_base));
+    }
+    return launch_status(ctx, "acceptance push: mask, select, merge");
+  }
   if (select) {
     // every row could enter (state still filling up) or very many would: plain distance pass, radix selection of the
     // batch's k best (batch-local rows), merge.  What the list holds from earlier pushes is merged first -- the
@@ -573,8 +623,10 @@ int adaptive_push_impl(elfihip_ctx* ctx, elfihip_reject* h, const double* dX, in
                   h->acc_ncols, K);
   ELFIHIP_TRY(ensure_cap(h, n));
   const bool full = h->host_mode ? (int64_t)h->hval.size() >= h->k : h->filled >= h->k;
-  if (!fused) {
-    // distances first, then the state's own candidate pass over them
+  const bool acc_select = h->has_accept && !h->host_mode && n >= REJ_ACC_SELECT_MIN &&
+                          (!full || (double)n * (double)h->k / (double)std::max<int64_t>(h->rows_seen, 1) > REJ_HEAVY);
+  if (!fused || acc_select) {
+    // distances (and, fused, the statistics) first, then the state's own candidate pass over them
     double* o = dout;
     if (!o) ELFIHIP_TRY(scratch_out(n, &o));
     ELFIHIP_TRY(pass(0, n, nullptr, false, o));
@@ -698,6 +750,7 @@ int elfihip_reject_free(elfihip_reject* h) {
   (void)hipStreamSynchronize(h->ctx->stream);
   h->mem.release();
   h->cand_mem.release();
+  h->mask_mem.release();
   h->acc_mem.release();
   delete h;
   return ELFIHIP_OK;

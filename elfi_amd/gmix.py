@@ -7,7 +7,9 @@ optional `weights`.  The reference loops over the N components on the host and c
 scipy.stats.multivariate_normal.pdf for each; here all M x N component densities are evaluated in
 one kernel (csrc/gmix.hip).  The covariance is factored on the host exactly as SciPy does
 (symmetric eigendecomposition, pseudo-determinant), so the only numerical difference is the
-device exp().  Sampling (`rvs`) is host-side random-number work and stays with the reference.
+device exp().  `rvs` draws on the device as well (csrc/gmix.hip gm_rvs_kernel: the library's counter-based
+generator, so a different -- equally valid -- random realisation than the reference's MT19937 stream; the validity
+check against the prior runs on the host exactly as in the reference).
 """
 import ctypes as C
 
@@ -82,3 +84,46 @@ class GMDistribution:
     @classmethod
     def logpdf(cls, x, means, cov=1, weights=None, ctx=None):
         return np.log(cls.pdf(x, means=means, cov=cov, weights=weights, ctx=ctx))
+
+    @classmethod
+    def rvs(cls, means, cov=1, weights=None, size=1, prior_logpdf=None, random_state=None, ctx=None):
+        """elfi.methods.utils.GMDistribution.rvs (utils.py:199-262) with the draws on the device: `size` variates (one has
+        the shape of a mean; size=None: one variate without the enclosing array), redrawn until `prior_logpdf` is finite
+        for all of them.  The seed comes from `random_state` (one randint)."""
+        means, weights = _normalize_params(means, weights)
+        no_wrap = size is None
+        size = 1 if no_wrap else int(size)
+        d = 1 if means.ndim == 1 else means.shape[1]
+        if d > 64:
+            raise NotImplementedError('GMDistribution on the GPU supports up to 64 dimensions')
+        mu = np.ascontiguousarray(means.reshape(len(means), d), dtype=np.float64)
+        c = np.asarray(cov, dtype=np.float64)
+        c = c * np.eye(d) if c.ndim == 0 else (np.diag(c) if c.ndim == 1 else c)
+        if c.shape != (d, d):
+            raise ValueError("Array 'cov' must be square with the dimension of the means (%d)." % d)
+        s, u = np.linalg.eigh(c)
+        A = np.ascontiguousarray(u * np.sqrt(np.maximum(s, 0.0)))        # A A^T = cov (semi-definite allowed)
+        cumw = np.cumsum(weights)
+        cumw[np.nonzero(weights)[0][-1]:] = 1.0                           # (rounding: the last component with mass ends at 1)
+        rs = random_state or np.random
+        seed = int(rs.randint(0, 2 ** 31 - 1))
+        ctx = ctx or _lib.default_context()
+        output = np.empty((size,) + means.shape[1:])
+        n_accepted, trials = 0, 0
+        while n_accepted < size:
+            n_left = size - n_accepted
+            x = np.empty((n_left, d), dtype=np.float64)
+            ctx.call("elfihip_gm_rvs", C.c_uint64(seed), C.c_uint64(2 * trials), n_left, d, _lib.ptr(mu), mu.shape[0],
+                     _lib.ptr(cumw), _lib.ptr(A), _lib.ptr(x))
+            x = x.reshape((n_left,) + means.shape[1:])
+            if prior_logpdf is not None:
+                x = x[np.isfinite(prior_logpdf(x))]
+            output[n_accepted:n_accepted + len(x)] = x
+            n_accepted += len(x)
+            trials += 1
+            if trials == 100:
+                import logging
+                logging.getLogger(__name__).warning(
+                    "SMC: It appears to be difficult to find enough valid proposals with prior pdf > 0. ELFI will keep "
+                    "trying, but you may wish to kill the process and adjust the model priors.")
+        return output[0] if no_wrap else output

@@ -64,6 +64,18 @@ def hip_smc_class(base_name='SMC'):
                 seed=seed,
                 max_parallel_batches=self.max_parallel_batches)
 
+        # -- samplers.py:434-459: the proposals of a batch; device_proposals = True draws them on the device -------
+        # (a different random realisation than the reference's MT19937 stream, hence opt-in: with False a run equals the
+        # reference class's sample by sample on the same seed)
+        device_proposals = False
+
+        def prepare_new_batch(self, batch_index):
+            if not self.device_proposals or self.state['round'] == 0:
+                return super().prepare_new_batch(batch_index)
+            params = GMDistribution.rvs(*self._gm_params, size=self.batch_size, prior_logpdf=self._prior.logpdf,
+                                        random_state=self._round_random_state)
+            return mod.arr2d_to_batch(params, self.parameter_names)
+
         # -- samplers.py:505-534 ------------------------------------------------------------------------------
         def _compute_weights_means_and_cov(self, pop):
             params = np.column_stack(tuple([pop.outputs[p] for p in self.parameter_names]))

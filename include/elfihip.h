@@ -263,6 +263,13 @@ int elfihip_adaptive_push_kept(elfihip_ctx* ctx, elfihip_reject* state, uint64_t
  * transformed by U once and a pair costs d subtractions). */
 int elfihip_gm_pdf(elfihip_ctx* ctx, const double* x, int64_t M, int d, const double* means, int64_t N,
                    const double* weights, const double* U, double log_norm, double* out);
+/* n draws from the same mixture -- GMDistribution.rvs (elfi/methods/utils.py:199-262), the proposal of an SMC batch
+ * (samplers.py:434-459): draw i picks the component at the inverse of the cumulative weights `cumw` (N values, last 1) at
+ * the uniform of Philox counter i of stream (seed, stream) and adds A z_i, A (d, d) row-major with A A^T = cov, z_i the d
+ * standard normals of counters i ceil(d / 2) ... of stream (seed, stream + 1) (the generator of elfihip_randn_dev).  The
+ * validity check against the prior (prior_logpdf) stays with the caller.  Host pointers; out (n, d). */
+int elfihip_gm_rvs(elfihip_ctx* ctx, uint64_t seed, uint64_t stream, int64_t n, int d, const double* means, int64_t N,
+                   const double* cumw, const double* A, double* out);
 
 /* ------------------------------------------------------------------ SMC population statistics
  * weighted_var (elfi/methods/utils.py:108-139; caller samplers.py:521-534): unbiased weighted variance of every

@@ -137,6 +137,45 @@ def test_hip_smc_equals_elfi_smc(hip_ctx, elfi):
             np.testing.assert_allclose(pb.cov, pa.cov, rtol=1e-9)
 
 
+def test_device_proposals_and_device_priors_give_the_same_posterior(hip_ctx, elfi):
+    """device_proposals = True (the proposals of rounds 2.. from elfi_amd.GMDistribution.rvs) with the prior drawn by
+    elfi_amd.priors.uniform: another random realisation of the same sampler -- the population statistics agree with the
+    reference classes' within Monte-Carlo error, thresholds shrink round by round, every sample lies in the prior's
+    support."""
+    import elfi_amd
+    from elfi_amd import priors
+
+    def noisy(mu, batch_size=1, random_state=None):
+        mu = np.asarray(mu, dtype=float).reshape((-1, 1))
+        return mu + random_state.randn(len(mu), 1)
+
+    def build(device):
+        m = elfi.new_model()
+        mu = elfi.Prior(priors.uniform if device else ss.uniform, 0, 50, model=m, name='mu')
+        y = elfi.Simulator(noisy, mu, observed=np.array([[20.0]]), name='y')
+        d = elfi.Distance('euclidean', y, name='d')
+        return m, d
+
+    _, d_ref = build(False)
+    ref = elfi.SMC(d_ref, batch_size=5000, seed=3).sample(2000, thresholds=[5, 2, 1], bar=False)
+    _, d_dev = build(True)
+    smc = elfi_amd.HipSMC(d_dev, batch_size=5000, seed=3)
+    smc.device_proposals = True
+    got = smc.sample(2000, thresholds=[5, 2, 1], bar=False)
+    assert got.n_populations == 3 and got.threshold <= 1.0
+    mu_g, mu_r = got.samples['mu'], ref.samples['mu']
+    assert np.all((mu_g >= 0) & (mu_g <= 50))
+    se = np.sqrt(np.var(mu_r) / len(mu_r) * 4)        # (weights: a generous effective sample size)
+    assert abs(np.average(mu_g, weights=got.weights) - np.average(mu_r, weights=ref.weights)) < 6 * se + 0.05
+    assert 0.5 < np.std(mu_g) / np.std(mu_r) < 2.0
+    # with the option off the device class IS the reference class sample by sample (test_hip_smc_equals_elfi_smc)
+    assert hip_smc_default_is_off(elfi_amd)
+
+
+def hip_smc_default_is_off(elfi_amd):
+    return elfi_amd.smc.hip_smc_class('SMC').device_proposals is False
+
+
 def test_node_state_pickles_and_saves(hip_ctx, elfi, tmp_path):
     """A model with the device node saves and loads (elfi_model.py:401-438 pickles the node states, the node class by
     reference) and keeps computing."""
