@@ -1,5 +1,6 @@
 """Developer tool: the acquisition lock-step (S <= 16 points) -- microseconds per call on the host and the library's phase
-timers, fused form (kernel row inside the first product) against the six-launch form.
+timers, the four-launch form (fused epilogues, form 0) against the six-launch form (form 1).  The one-product form on
+K^-1 and its bound: scripts/r04_lockstep_bound.py.
 usage: python scripts/r04_lockstep.py [n] [d] [S]"""
 import os
 import sys
@@ -38,5 +39,5 @@ for form in (0, 1):
         gp.lcb(xs, 3.0)
     ph = gp.profile(0)
     print("n=%d d=%d S=%d form %d (%s): %.1f us per call (host); device phases us: %s"
-          % (n, d, S, form, "fused" if form == 0 else "six launches", us,
+          % (n, d, S, form, "four launches" if form == 0 else "six launches", us,
              {k: round(1e3 * v[0] / max(1, v[1]), 1) for k, v in ph.items() if v[1]}))

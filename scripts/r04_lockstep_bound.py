@@ -1,9 +1,11 @@
-"""Developer tool: what ONE product per lock-step could buy (the stored-K^-1 form of the predictor).
+"""Developer tool: ONE product per lock-step -- measured and bounded.
 
-The value-only lock-step (lcb without gradient: kernel row + the first triangular product with its fused reduction +
-finish) is the launch chain a symmetric product on a stored K^-1 would have -- one pass over 8n^2/2 bytes between the
-kernel row and the epilogue -- so its time bounds that form from below; elfihip_gp_form_kinv is what every rebuild would
-pay for the matrix.   usage: python scripts/r04_lockstep_bound.py [n] [d] [S]"""
+  * two triangular products (four launches, form 2) against the value-only lock-step (one triangular product: the launch
+    chain a symmetric product on ONE stored triangle of K^-1 would have, i.e. its bound) against the one-product form
+    that was built (form 3: the full K^-1, three launches), with the difference of the results;
+  * an extend (bordering) with and without K^-1 to carry;
+  * the price of forming K^-1 after a rebuild (elfihip_gp_form_kinv).
+usage: python scripts/r04_lockstep_bound.py [n] [d] [S]"""
 import os
 import sys
 import time
