@@ -292,3 +292,27 @@ def test_kept_registries_and_pinned_pool_plumbing():
     assert p.shape == (10, 4) and p.dtype == np.float64 and p.flags['WRITEABLE']
     p[:] = 3.0
     assert float(p.sum()) == 120.0
+
+
+def test_prior_and_proposal_argument_checks_need_no_gpu():
+    """elfi_amd.priors / GMDistribution.rvs validate their arguments before any device call (shape errors are ValueErrors,
+    as scipy's are), and the densities of the prior objects are the reference distributions' own."""
+    import scipy.stats as ss
+    from elfi_amd import priors
+    from elfi_amd.gmix import GMDistribution
+    with pytest.raises(ValueError):
+        priors.prior_draw(priors.UNIFORM, (1.0,), None, (4,), seed=1)          # loc AND scale
+    with pytest.raises(ValueError):
+        priors.prior_draw(priors.MA2_T1, (1.0, 2.0), None, (4,), seed=1)       # b only
+    assert priors._shape(None) == () and priors._shape(5) == (5,) and priors._shape((2, 3)) == (2, 3)
+    x = np.linspace(-1, 6, 9)
+    assert np.array_equal(priors.uniform.pdf(x, 1.0, 4.0), ss.uniform.pdf(x, 1.0, 4.0))
+    assert np.array_equal(priors.uniform.logpdf(x, 1.0, 4.0), ss.uniform.logpdf(x, 1.0, 4.0))
+    assert np.array_equal(priors.uniform.cdf(x, 1.0, 4.0), ss.uniform.cdf(x, 1.0, 4.0))
+    # array parameters take SciPy's own path (no device call)
+    v = priors.uniform.rvs(np.zeros(3), np.ones(3), size=3, random_state=np.random.RandomState(0))
+    assert np.array_equal(v, ss.uniform.rvs(np.zeros(3), np.ones(3), size=3, random_state=np.random.RandomState(0)))
+    with pytest.raises(ValueError):
+        GMDistribution.rvs(np.zeros((4, 3)), np.eye(2), None, size=5)          # covariance of the wrong dimension
+    with pytest.raises(NotImplementedError):
+        GMDistribution.rvs(np.zeros((4, 65)), 1.0, None, size=5)
