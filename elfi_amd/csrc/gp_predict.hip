@@ -842,7 +842,8 @@ static int lockstep_kinv(elfihip_gp* gp, bool* use) {
   ++gp->lcb_steps;
   if (!kinv_conditioned(gp)) return ELFIHIP_OK;
   if (!gp->kinv_sym) {
-    if (gp->lockstep_form == 0 && gp->lcb_steps <= KINV_AFTER_STEPS) return ELFIHIP_OK;
+    // (a K^-1 the caller formed already -- HipGPRegression after a hyper-parameter search -- is used at once)
+    if (gp->lockstep_form == 0 && gp->lcb_steps <= KINV_AFTER_STEPS && !gp->has_kinv) return ELFIHIP_OK;
     if (!gp->has_kinv) ELFIHIP_TRY(form_kinv_impl(gp));
     const unsigned nt = (unsigned)(gp->np / 64);
     hipLaunchKernelGGL(kinv_mirror_kernel, dim3(nt, nt), dim3(256), 0, gp->ctx->stream, gp->Kinv, gp->lda);

@@ -505,6 +505,10 @@ class HipGPRegression:
     acq_host_threads = 0
     acq_trace = 0
 
+    # After a hyper-parameter search the refit at the optimum also forms K^-1 (from 256 evidence points on), so that the
+    # acquisitions of the interval run their lock-steps through ONE product from the first one on (hyperopt.py).
+    kinv_after_optimize = True
+
     # Points added per update() up to which the factorisation is extended by bordering (O(n^2) each)
     # instead of rebuilt (O(n^3)); the reference always rebuilds (gpy_regression.py:304-312), the
     # results agree to rounding.  0 disables the incremental path.

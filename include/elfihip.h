@@ -404,8 +404,9 @@ int elfihip_gp_set_dense_threshold(elfihip_gp* gp, int64_t min_points, int tile_
  * Acquisition lock-steps (elfihip_gp_lcb with a gradient, elfihip_gp_lcb_minimize) additionally have a THREE-launch form:
  * u = K^-1 kb from ONE product with the symmetric K^-1 instead of the two dependent triangular products (GPy's own
  * closed form with woodbury_inv, gpy_regression.py:127-140).  Under form 0 it takes over once a factorisation has served
- * 64 lock-steps (forming K^-1 costs what 40-80 lock-steps save; afterwards elfihip_gp_extend borders the matrix, rank
- * one, with every new point) and while (max L_ii / min L_ii)^2 <= 1e5 (the variance k(x,x) - kb . u then agrees with
+ * 64 lock-steps -- or at once when the caller has formed K^-1 for this factorisation (elfihip_gp_form_kinv) -- (forming
+ * K^-1 costs what 40-80 lock-steps save; afterwards elfihip_gp_extend borders the matrix, rank one, with every new
+ * point) and while (max L_ii / min L_ii)^2 <= 1e5 (the variance k(x,x) - kb . u then agrees with
  * the triangular form to 1e-10 k(x,x)); form 2 = never (fused triangular products only); form 3 = from the first
  * lock-step on.  elfihip_gp_predict / _predict_grad always use the triangular products. */
 int elfihip_gp_set_lockstep_form(elfihip_gp* gp, int form);

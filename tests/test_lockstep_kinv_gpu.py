@@ -146,6 +146,39 @@ def test_policy_of_the_default_form(hip_ctx):
     assert abs(vals3.min() - vals2.min()) <= 1e-8 * (abs(vals2.min()) + 1.0)
 
 
+def test_a_formed_kinv_is_used_at_once_and_the_model_forms_it_after_a_search(hip_ctx):
+    """Form 0 waits 64 lock-steps unless K^-1 exists already (elfihip_gp_form_kinv); HipGPRegression.optimize() forms it
+    with the refit at the optimum, so the acquisitions that follow use the one-product lock-step from the first one on."""
+    from elfi_amd import HipGPRegression
+    X, y, bounds = _problem(400, 2, seed=4)
+    h = G.default_hyper(bounds, y)
+    gp = _handle(X, y, h, cap=512, form=0)
+    xs = _points(X, 10)
+    v0, g0 = gp.lcb(xs, 3.0)
+    assert gp.lockstep_info()[:2] == (False, 1)
+    gp.form_kinv()
+    v1, g1 = gp.lcb(xs, 3.0)
+    assert gp.lockstep_info()[:2] == (True, 2)
+    _close(v1, v0, 1e-9, 'lcb after form_kinv')
+    _close(g1, g0, 1e-8, 'lcb gradient after form_kinv')
+    names = ['a', 'b']
+    m = HipGPRegression(names, bounds=dict(zip(names, bounds)), max_opt_iters=5)
+    m.update(X[:300], y[:300], optimize=True)
+    m.lcb(xs, 3.0)
+    assert m._handle.lockstep_info()[0], 'K^-1 formed with the refit of the search'
+    m.update(X[300:310], y[300:310])                      # bordering: K^-1 carried
+    assert m._handle.lockstep_info()[0]
+    ref = G.Posterior(m.X, m.Y, **m._hyper)
+    val, grad = m.lcb(xs, G.lcb_beta(3, 2))
+    _close(val, G.lcb_evaluate(ref, xs, 3), 1e-8, 'lcb of the model')
+    _close(grad, G.lcb_evaluate_gradient(ref, xs, 3), 1e-7, 'lcb gradient of the model')
+    m2 = HipGPRegression(names, bounds=dict(zip(names, bounds)), max_opt_iters=5)
+    m2.kinv_after_optimize = False
+    m2.update(X[:300], y[:300], optimize=True)
+    m2.lcb(xs, 3.0)
+    assert not m2._handle.lockstep_info()[0]
+
+
 def test_ill_conditioned_evidence_keeps_the_triangular_products(hip_ctx):
     """k(x,x) - kb . K^-1 kb cancels with eps cond(K): with a noise variance six orders below the signal the K^-1 form is
     not used (the lower bound of cond(K) is above the gate), whatever the form asks for."""
