@@ -57,9 +57,9 @@ class uniform:
 
     @classmethod
     def rvs(cls, loc=0, scale=1, size=1, random_state=None):
-        if np.ndim(loc) or np.ndim(scale):   # array parameters: SciPy's own path
-            import scipy.stats as ss
-            return ss.uniform.rvs(loc=loc, scale=scale, size=size, random_state=random_state)
+        if np.ndim(loc) or np.ndim(scale):
+            raise ValueError('elfi_amd.priors.uniform draws with scalar loc / scale (a prior without parent nodes); give '
+                             'elfi.Prior scipy.stats.uniform itself for array parameters')
         return prior_draw(UNIFORM, (loc, scale), None, size, random_state)
 
     @classmethod

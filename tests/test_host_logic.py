@@ -309,9 +309,9 @@ def test_prior_and_proposal_argument_checks_need_no_gpu():
     assert np.array_equal(priors.uniform.pdf(x, 1.0, 4.0), ss.uniform.pdf(x, 1.0, 4.0))
     assert np.array_equal(priors.uniform.logpdf(x, 1.0, 4.0), ss.uniform.logpdf(x, 1.0, 4.0))
     assert np.array_equal(priors.uniform.cdf(x, 1.0, 4.0), ss.uniform.cdf(x, 1.0, 4.0))
-    # array parameters take SciPy's own path (no device call)
-    v = priors.uniform.rvs(np.zeros(3), np.ones(3), size=3, random_state=np.random.RandomState(0))
-    assert np.array_equal(v, ss.uniform.rvs(np.zeros(3), np.ones(3), size=3, random_state=np.random.RandomState(0)))
+    # array parameters are refused (no silent host path)
+    with pytest.raises(ValueError):
+        priors.uniform.rvs(np.zeros(3), np.ones(3), size=3, random_state=np.random.RandomState(0))
     with pytest.raises(ValueError):
         GMDistribution.rvs(np.zeros((4, 3)), np.eye(2), None, size=5)          # covariance of the wrong dimension
     with pytest.raises(NotImplementedError):
