@@ -188,13 +188,6 @@ __device__ __forceinline__ void chunk_stats(const double (&x)[CH], double& mean,
   }
 }
 
-// Two groups of the same count n: Chan's update without the division (f = 1/2).
-__device__ __forceinline__ void merge_equal(double n, double& ma, double& qa, double mb, double qb) {
-  const double delta = mb - ma;
-  qa = qa + qb + delta * delta * (n * 0.5);
-  ma = ma + delta * 0.5;
-}
-
 // NU > 0: m / 2 divides the workgroup size, so load u of a thread is the same element pair QS rows further down and a
 // tile is exactly NU loads per thread -- source and LDS offsets are one add per load, and the loads of a full tile carry
 // no predicate (one straight run of NU global_load_dwordx4).  A thread then holds NU rows of the SAME two columns of every
