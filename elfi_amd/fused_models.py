@@ -118,7 +118,6 @@ def gauss_wide_model(m=64, adaptive=True):
     standard deviations 1 .. 20 drawn ON THE DEVICE, observed zeros; the discrepancy node is a HipAdaptiveDistance over the
     simulator's (batch, m) output (adaptive=False: elfi.Distance(HipDistance('euclidean'))).  Nodes mu, sim, d."""
     elfi = _elfi()
-    import scipy.stats as ss
     from .adaptive import hip_adaptive_distance_class
     mdl = elfi.new_model()
     from . import priors

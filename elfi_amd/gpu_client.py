@@ -27,7 +27,6 @@ This module imports `elfi`; it is not imported by `elfi_amd` itself.
 import itertools
 import logging
 import multiprocessing
-import os
 
 import elfi.client
 

@@ -36,7 +36,8 @@ def _shape(size):
 
 def prior_draw(kind, params, cond=None, size=1, random_state=None, seed=None, stream=0, ctx=None):
     """n = prod(size) draws of the prior `kind` (UNIFORM: params (loc, scale); MA2_T1: (b,); MA2_T2: (a,), cond = t1,
-    broadcast to `size`).  The seed comes from `random_state` (one randint, as ELFI's batch seeding decides it) unless given."""
+    broadcast to `size`).  The seed comes from `random_state` (one randint, as ELFI's batch seeding decides it) unless
+    given."""
     shape = _shape(size)
     n = int(np.prod(shape)) if shape else 1
     a = np.ascontiguousarray(np.asarray(params, dtype=np.float64).reshape(-1))
@@ -110,7 +111,8 @@ class MA2Prior1(_MA2Backed):
 
 
 class MA2Prior2(_MA2Backed):
-    """elfi.examples.ma2.CustomPrior2 (ma2.py:138-190): t2 given t1, uniform on [max(-a - t1, t1 - a), a]; rvs on the device."""
+    """elfi.examples.ma2.CustomPrior2 (ma2.py:138-190): t2 given t1, uniform on [max(-a - t1, t1 - a), a]; rvs on the
+    device."""
     _ref = 'CustomPrior2'
 
     @classmethod
