@@ -316,3 +316,51 @@ def test_prior_and_proposal_argument_checks_need_no_gpu():
         GMDistribution.rvs(np.zeros((4, 3)), np.eye(2), None, size=5)          # covariance of the wrong dimension
     with pytest.raises(NotImplementedError):
         GMDistribution.rvs(np.zeros((4, 65)), 1.0, None, size=5)
+
+
+def test_model_prior_replay_plan_is_the_public_call_bit_for_bit():
+    """lcb_acquisition.prior_rvs: ModelPrior.rvs (elfi/model/extensions.py:156-174) replayed from a plan made once --
+    same draws and same generator state as the public call, call after call, for dependent priors (MA2), many
+    independent ones and a one-dimensional prior; objects that are not a ModelPrior take the public call."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle'))
+    import ref_shim
+    if not ref_shim.available():
+        pytest.skip('reference ELFI not available')
+    ref_shim.install()
+    import scipy.stats as ss
+    import elfi
+    from elfi.examples import ma2
+    from elfi.model.extensions import ModelPrior
+    from elfi_amd import lcb_acquisition as L
+
+    def same_stream(mp, n, reps=5):
+        a, b = np.random.RandomState(7), np.random.RandomState(7)
+        for _ in range(reps):
+            x, y = mp.rvs(n, random_state=a), L.prior_rvs(mp, n, b)
+            assert np.shape(x) == np.shape(y) and np.array_equal(x, y)
+            sa, sb = a.get_state(), b.get_state()
+            assert sa[0] == sb[0] and np.array_equal(sa[1], sb[1]) and sa[2:] == sb[2:]
+        return L._PRIOR_PLANS[mp][n]
+
+    mp = ModelPrior(ma2.get_model(seed_obs=1))
+    assert isinstance(same_stream(mp, 10), L._PriorPlan) and isinstance(same_stream(mp, 3), L._PriorPlan)
+    m2 = elfi.new_model()
+    for i in range(6):
+        elfi.Prior(ss.uniform, -2, 4, model=m2, name='p%d' % i)
+    assert isinstance(same_stream(ModelPrior(m2), 64), L._PriorPlan)
+    m3 = elfi.new_model()
+    elfi.Prior('norm', 1, 2, model=m3, name='a')
+    mp3 = ModelPrior(m3)
+    same_stream(mp3, 5)
+    assert L.prior_rvs(mp3, 5, np.random.RandomState(1)).shape == (5,)
+    # the start points of a search come through it, clipped to the bounds as the reference clips them
+    pts = L.draw_start_points([(-2, 2), (-1, 1)], 10, mp, np.random.RandomState(3))
+    ref = np.clip(mp.rvs(10, random_state=np.random.RandomState(3)), [-2, -1], [2, 1])
+    assert np.array_equal(pts, ref)
+
+    class Other:
+        def rvs(self, n, random_state=None):
+            return np.zeros((n, 2))
+    assert L.prior_rvs(Other(), 4, np.random.RandomState(0)).shape == (4, 2)
