@@ -65,7 +65,9 @@ class _SurfaceRule:
         """Surface and gradient at the rows of theta: (S, 1), (S, d) -- one device call."""
         theta = _as_points(self.model, theta)
         pdf = np.ravel(self.prior.pdf(theta))
-        return self.model.maxvar_surface(theta, self.eps, pdf, self.prior.gradient_logpdf(theta))
+        # (the log-gradient of ELFI's ModelPrior is numeric and costs one executor pass per ROW: all rows in one pass)
+        from .posterior import prior_logpdf_and_gradient
+        return self.model.maxvar_surface(theta, self.eps, pdf, prior_logpdf_and_gradient(self.prior, theta)[1])
 
     def evaluate(self, theta_new, t=None):
         return self.value_and_gradient(theta_new)[0]

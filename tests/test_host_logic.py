@@ -364,3 +364,38 @@ def test_model_prior_replay_plan_is_the_public_call_bit_for_bit():
         def rvs(self, n, random_state=None):
             return np.zeros((n, 2))
     assert L.prior_rvs(Other(), 4, np.random.RandomState(0)).shape == (4, 2)
+
+
+def test_batched_prior_gradient_is_the_references_row_by_row():
+    """posterior.prior_logpdf_and_gradient: ModelPrior.logpdf / gradient_logpdf (extensions.py:176-240, numgrad
+    utils.py:275-314) for all rows from ONE pass over their stencils -- equal to the reference's row loop value for
+    value, inside the support, outside it, on its edge; other prior objects keep their own methods."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle'))
+    import ref_shim
+    if not ref_shim.available():
+        pytest.skip('reference ELFI not available')
+    ref_shim.install()
+    import elfi
+    from elfi.examples import ma2
+    from elfi.model.extensions import ModelPrior
+    from elfi_amd import posterior as P
+    rs = np.random.RandomState(0)
+    mp = ModelPrior(ma2.get_model(seed_obs=1))
+    x = np.vstack([mp.rvs(9, random_state=rs), [[3.0, 0.0], [0.0, 2.0], [1.99999, 0.9], [-2.0, 0.0]]])
+    lp, g = P.prior_logpdf_and_gradient(mp, x)
+    assert np.array_equal(lp, mp.logpdf(x)) and np.array_equal(g, mp.gradient_logpdf(x))
+    m2 = elfi.new_model()
+    elfi.Prior('norm', 1, 2, model=m2, name='a')
+    elfi.Prior('gamma', 2.0, model=m2, name='b')
+    elfi.Prior('beta', 2.0, 3.0, model=m2, name='c')
+    mp2 = ModelPrior(m2)
+    x2 = np.column_stack([rs.randn(11) + 1, np.abs(rs.randn(11)) - 0.2, rs.uniform(-0.1, 1.1, 11)])
+    lp2, g2 = P.prior_logpdf_and_gradient(mp2, x2)
+    assert np.array_equal(lp2, mp2.logpdf(x2)) and np.array_equal(g2, mp2.gradient_logpdf(x2))
+    assert np.any(g2 != 0.0) and np.any(np.isneginf(lp2))
+    box = P._UniformBoxPrior([(-1, 1), (0, 2)])
+    xb = rs.uniform(-2, 3, (7, 2))
+    lb, gb = P.prior_logpdf_and_gradient(box, xb)
+    assert np.array_equal(lb, box.logpdf(xb)) and np.array_equal(gb, box.gradient_logpdf(xb))
