@@ -148,92 +148,7 @@ def truncnorm_draw(a, b, loc, scale, size, random_state):
         return public()
 
 
-class _PriorPlan:
-    """ModelPrior.rvs(size, random_state) (elfi/model/extensions.py:156-174) replayed without ELFI's per-call graph work.
-
-    The reference builds, for every call, a ComputationContext, a loaded copy of the compiled prior net (networkx copies),
-    its execution order (a topological sort) and runs the nodes through Executor._run -- 0.25-0.3 ms for the two priors
-    of the MA2 example, a tenth of a BOLFI run whose GP is on the GPU (one call per acquisition for the start points of
-    the search, bo/utils.py:72-88).  The net of a prior does not change between calls: the plan is made ONCE through the
-    reference's own load_data / get_execution_order, and a call then runs the same node operations in the same order on
-    the caller's random_state -- same draws, same generator state afterwards.  That is verified against the public call
-    the first time a plan is used (value and generator state); a prior whose plan does not reproduce it keeps the public
-    call."""
-
-    def __init__(self, prior, size):
-        import importlib
-        ext = importlib.import_module(type(prior).__module__)
-        executor = importlib.import_module('elfi.executor').Executor
-        context = ext.ComputationContext(size, seed='global')
-        net = prior.client.load_data(prior._rvs_net, context, batch_index=0)
-        net.nodes['_random_state'].update({'output': None})
-        del net.nodes['_random_state']['operation']
-        self.steps = []
-        for node in executor.get_execution_order(net):
-            attr = net.nodes[node]
-            if 'operation' not in attr:
-                continue
-            pos, kw = [], {}
-            for parent in net.predecessors(node):
-                param = net[parent][node]['param']
-                if isinstance(param, int):
-                    pos.append((param, parent))
-                else:
-                    kw[param] = parent
-            self.steps.append((node, attr['operation'], [p for _, p in sorted(pos, key=lambda t: t[0])], kw))
-        self.const = {k: a['output'] for k, a in net.nodes.items() if 'output' in a}
-        self.names, self.dim, self.size = list(prior.parameter_names), prior.dim, size
-
-    def run(self, random_state):
-        out = dict(self.const)
-        out['_random_state'] = random_state
-        for node, op, pos, kw in self.steps:
-            out[node] = op(*[out[p] for p in pos], **{k: out[p] for k, p in kw.items()})
-        rvs = np.column_stack([out[p] for p in self.names])
-        if self.dim == 1:
-            rvs = rvs.reshape(self.size)
-        return rvs
-
-
-_PRIOR_PLANS = None   # prior object -> {size: _PriorPlan (verified), False (public call only)}
-
-
-def prior_rvs(prior, n, random_state):
-    """prior.rvs(n, random_state=random_state) -- through a replay plan (above) for ELFI's ModelPrior and a RandomState;
-    anything else: the public call."""
-    global _PRIOR_PLANS
-    if not (hasattr(prior, '_rvs_net') and hasattr(prior, 'client') and hasattr(prior, 'parameter_names')
-            and hasattr(random_state, 'get_state') and isinstance(n, (int, np.integer)) and n >= 1):
-        return prior.rvs(n, random_state=random_state)
-    if _PRIOR_PLANS is None:
-        import weakref
-        _PRIOR_PLANS = weakref.WeakKeyDictionary()
-    try:
-        plans = _PRIOR_PLANS.setdefault(prior, {})
-    except TypeError:            # (not weakly referenceable)
-        return prior.rvs(n, random_state=random_state)
-    plan = plans.get(int(n))
-    if plan is False:
-        return prior.rvs(n, random_state=random_state)
-    if plan is not None:
-        return plan.run(random_state)
-    # first use at this size: the public call decides, the plan must reproduce it (values and generator state)
-    before = random_state.get_state()
-    ref = prior.rvs(n, random_state=random_state)
-    after = random_state.get_state()
-    plans[int(n)] = False
-    try:
-        cand = _PriorPlan(prior, int(n))
-        random_state.set_state(before)
-        got = cand.run(random_state)
-        now = random_state.get_state()
-        if (np.shape(got) == np.shape(ref) and np.array_equal(got, ref) and now[0] == after[0]
-                and np.array_equal(now[1], after[1]) and tuple(now[2:]) == tuple(after[2:])):
-            plans[int(n)] = cand
-    except Exception:
-        pass
-    random_state.set_state(after)
-    return ref
+from .elfi_plans import prior_rvs  # noqa: E402  (ModelPrior.rvs replayed from a plan made once: same draws, same generator state)
 
 
 def draw_start_points(bounds, n, prior=None, random_state=None):

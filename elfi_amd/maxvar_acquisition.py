@@ -64,9 +64,11 @@ class _SurfaceRule:
     def value_and_gradient(self, theta):
         """Surface and gradient at the rows of theta: (S, 1), (S, d) -- one device call."""
         theta = _as_points(self.model, theta)
-        pdf = np.ravel(self.prior.pdf(theta))
-        # (the log-gradient of ELFI's ModelPrior is numeric and costs one executor pass per ROW: all rows in one pass)
+        # (ELFI's ModelPrior: the density through a plan made once -- elfi_plans.py --, its numeric log-gradient, one
+        # executor pass per ROW in the reference, for all rows in one pass; value for value the public calls)
+        from .elfi_plans import prior_logpdf
         from .posterior import prior_logpdf_and_gradient
+        pdf = np.ravel(prior_logpdf(self.prior, theta, log=False))
         return self.model.maxvar_surface(theta, self.eps, pdf, prior_logpdf_and_gradient(self.prior, theta)[1])
 
     def evaluate(self, theta_new, t=None):

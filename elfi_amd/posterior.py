@@ -66,7 +66,8 @@ def prior_logpdf_and_gradient(prior, x):
         idx = np.arange(d)
         Xi[:, idx, idx] = Xi[:, idx, idx] + (i - 1) * h
         pts[:, 1 + i * d:1 + (i + 1) * d, :] = Xi
-    vals = np.asarray(prior.logpdf(pts.reshape(-1, d)), dtype=float).reshape(S, 3 * d + 1)
+    from .elfi_plans import prior_logpdf        # (the pass itself from a plan made once per batch size: elfi_plans.py)
+    vals = np.asarray(prior_logpdf(prior, pts.reshape(-1, d)), dtype=float).reshape(S, 3 * d + 1)
     logp = vals[:, 0].copy()
     f = vals[:, 1:].reshape(S, 3, d)
     with np.errstate(invalid='ignore'):

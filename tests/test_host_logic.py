@@ -342,14 +342,16 @@ def test_model_prior_replay_plan_is_the_public_call_bit_for_bit():
             assert np.shape(x) == np.shape(y) and np.array_equal(x, y)
             sa, sb = a.get_state(), b.get_state()
             assert sa[0] == sb[0] and np.array_equal(sa[1], sb[1]) and sa[2:] == sb[2:]
-        return L._PRIOR_PLANS[mp][n]
+        from elfi_amd import elfi_plans
+        return elfi_plans._PLANS[mp][('rvs', n)]
 
     mp = ModelPrior(ma2.get_model(seed_obs=1))
-    assert isinstance(same_stream(mp, 10), L._PriorPlan) and isinstance(same_stream(mp, 3), L._PriorPlan)
+    from elfi_amd.elfi_plans import NetPlan
+    assert isinstance(same_stream(mp, 10), NetPlan) and isinstance(same_stream(mp, 3), NetPlan)
     m2 = elfi.new_model()
     for i in range(6):
         elfi.Prior(ss.uniform, -2, 4, model=m2, name='p%d' % i)
-    assert isinstance(same_stream(ModelPrior(m2), 64), L._PriorPlan)
+    assert isinstance(same_stream(ModelPrior(m2), 64), NetPlan)
     m3 = elfi.new_model()
     elfi.Prior('norm', 1, 2, model=m3, name='a')
     mp3 = ModelPrior(m3)
@@ -395,6 +397,15 @@ def test_batched_prior_gradient_is_the_references_row_by_row():
     lp2, g2 = P.prior_logpdf_and_gradient(mp2, x2)
     assert np.array_equal(lp2, mp2.logpdf(x2)) and np.array_equal(g2, mp2.gradient_logpdf(x2))
     assert np.any(g2 != 0.0) and np.any(np.isneginf(lp2))
+    # the pass itself comes from a plan after the first (verified) use, for the density as for its logarithm
+    from elfi_amd import elfi_plans as E
+    for log in (True, False):
+        public = mp2.logpdf if log else mp2.pdf
+        for _ in range(3):
+            assert np.array_equal(E.prior_logpdf(mp2, x2, log), public(x2), equal_nan=True)
+        assert isinstance(E._PLANS[mp2][('logpdf' if log else 'pdf', len(x2))], E.NetPlan)
+    assert np.array_equal(E.prior_logpdf(mp2, x2[:4]), mp2.logpdf(x2[:4]))       # another batch size: another plan
+    assert np.array_equal(E.prior_logpdf(mp2, x2[0]), mp2.logpdf(x2[0]))         # not (n, dim): the public call
     box = P._UniformBoxPrior([(-1, 1), (0, 2)])
     xb = rs.uniform(-2, 3, (7, 2))
     lb, gb = P.prior_logpdf_and_gradient(box, xb)
