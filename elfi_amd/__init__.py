@@ -27,6 +27,7 @@ from .smc import HipAdaptiveDistanceSMC, HipAdaptiveThresholdSMC, HipSMC, hip_sm
 from .summaries import autocov, gauss_distance, ma2_distance, ma2_draw_distance, ss_mean, ss_var  # noqa: F401
 from .lcb_acquisition import HipLCBSC  # noqa: F401
 from .posterior import HipBolfiPosterior, sample_posterior  # noqa: F401
+from .bolfi import HipBOLFI, hip_bolfi_class  # noqa: F401
 from . import chains, fused_models, multistart, priors  # noqa: F401
 from .maxvar_acquisition import HipExpIntVar, HipMaxVar, HipRandMaxVar  # noqa: F401
 

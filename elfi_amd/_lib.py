@@ -131,6 +131,7 @@ PROTOTYPES = {
     "elfihip_comm_bcast_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int]),
     "elfihip_comm_bcast_factor": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "elfihip_topk_set_form": (C.c_int, [C.c_void_p, C.c_int]),
+    "elfihip_dist_set_form": (C.c_int, [C.c_void_p, C.c_int]),
     "elfihip_gauss_distance": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int64, C.c_int, C.c_void_p,
                                          C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_void_p]),
@@ -145,6 +146,7 @@ PROTOTYPES = {
     "elfihip_gp_set_data": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
     "elfihip_gp_append": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
     "elfihip_gp_factorize": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "elfihip_gp_jitchol": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "elfihip_gp_profile": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "elfihip_gp_set_schedule": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "elfihip_gp_set_dense_threshold": (C.c_int, [C.c_void_p, C.c_int64, C.c_int]),

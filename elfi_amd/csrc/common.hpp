@@ -61,6 +61,7 @@ struct elfihip_ctx {
   hipEvent_t ev_a = nullptr, ev_b = nullptr;
   hipEvent_t ev_u[4] = {nullptr, nullptr, nullptr, nullptr};  // look-ahead window columns of the next panel group
   int cu_count = 0;
+  int dist_form = 0;                  // 0: LDS-DMA row stream where the shape allows; 1: register-staged pipeline (elfihip_dist_set_form)
   int topk_form = 0;                  // 0: resident selection with the nine-launch form as fallback; 1: nine-launch form
   unsigned dense_lds_mask = 0;        // dense_tri_kernel<.,64/32/16>: dynamic-LDS limit raised (gp_dense.hip)
   bool step_lds_enabled = false;      // step_kernel's dynamic-LDS limit has been raised (gp_fit.hip)

@@ -149,6 +149,13 @@ int elfihip_ctx_set_stream(elfihip_ctx* ctx, void* hip_stream) {
   return ELFIHIP_OK;
 }
 
+int elfihip_dist_set_form(elfihip_ctx* ctx, int form) {
+  if (!ctx) return fail(nullptr, ELFIHIP_ERR_ARG, "ctx is NULL");
+  ELFIHIP_REQUIRE(ctx, form == 0 || form == 1, "form %d is neither 0 (LDS-DMA row stream) nor 1 (register-staged pipeline)", form);
+  ctx->dist_form = form;
+  return ELFIHIP_OK;
+}
+
 int elfihip_topk_set_form(elfihip_ctx* ctx, int form) {
   if (!ctx) return fail(nullptr, ELFIHIP_ERR_ARG, "ctx is NULL");
   ELFIHIP_REQUIRE(ctx, form == 0 || form == 1, "form %d is neither 0 (resident) nor 1 (nine launches)", form);

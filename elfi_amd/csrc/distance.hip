@@ -23,6 +23,10 @@
 #include "tile_stream.hpp"
 #include "internal.hpp"
 
+#include <mutex>
+#include <set>
+#include <utility>
+
 #pragma clang fp contract(off)
 
 namespace elfihip {
@@ -145,6 +149,148 @@ __global__ __launch_bounds__(256) void dist_rows_pipe_kernel(RowArgs A) {
       A.out[row0 + tid] = dist;
     }
     if (A.F.thr) reject_offer(A.F, tid < rows && dist < thr, dist, A.F.row_base + row0 + tid);
+  }
+}
+
+// ---- LDS-DMA form of the row stream (round 5; m = 16 / 32 / 64 with 16-byte aligned rows) -----------------------------------
+// The tile no longer passes through registers: `global_load_lds_dwordx4` writes 1 KiB per wave-instruction straight into
+// LDS, so a wave can keep a RING of D slots (16 KiB each) in flight at no register cost and without any workgroup barrier --
+// a wave only ever reads slots it issued itself, behind its own counted `s_waitcnt vmcnt` (MI355X_MICROARCH.md: nothing
+// else orders a ds_read behind an LDS-DMA).  The DMA image is lane-linear (base + lane * 16), i.e. rows at pitch m with no
+// padding; the bank conflicts of "lane r reads row r" are removed by an XOR swizzle of the 16-byte granules that is applied
+// to the SOURCE address when the slot is filled and again when the row is read (cdna_hip_programming.md rule 21).  Lane r
+// still sums row r left to right, so the results stay bit-identical to cdist.  Non-temporal loads: the rows are read once.
+// Measured on 10^6 x 32 (scripts/native/glds_probe.hip, profiles/r05_glds_probe.md): 41.8-42.1 us = 6.3 TB/s (40.7 on the
+// best box), against 46.5-47.2 us for the register-staged pipeline in the same binary.
+template <bool NT>
+__device__ __forceinline__ void dma16_to_lds(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;   // M0 carries the LDS destination of the DMA; the compiler owns M0, so save / restore in one statement
+  if constexpr (NT)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+  else
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
+}
+// granule swizzle: rows at pitch MM doubles; RP rows share one 256-byte bank sweep, the key changes every RP rows
+template <int MM>
+__device__ __forceinline__ int dma_swizzle_key(int row) {
+  constexpr int H = MM / 2;                      // 16-byte granules per row
+  constexpr int RP = H >= 16 ? 1 : 16 / H;
+  constexpr int MASK = (H >= 16 ? 16 : H) - 1;
+  return (row / RP) & MASK;
+}
+// ... with the source given as a wave-uniform base (SGPR pair) + a per-lane 32-bit byte offset: the offsets of a slot's pieces
+// are the same for every slot, so a slot costs five scalar instructions per piece and no vector arithmetic (with per-lane
+// 64-bit addresses -- a multiply by the row pitch and a clamp per piece -- address generation was a third of a wave's time
+// and the kernel, at two waves per CU, was bound by it: 47-53 us in the library against 41 us for the probe's constant pitch)
+template <bool NT>
+__device__ __forceinline__ void dma16_to_lds_off(const void* base, unsigned voff, unsigned lds_dst) {
+  unsigned keep;
+  if constexpr (NT)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_dst) : "memory");
+  else
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_dst) : "memory");
+}
+template <int MM, int ROWS>
+__device__ __forceinline__ void dma_issue_slot(const RowArgs& A, const unsigned (&off)[ROWS * (MM / 2) / 64], int64_t row0,
+                                               unsigned lds_slot, int lane) {
+  constexpr int H = MM / 2;
+  constexpr int PIECES = ROWS * H / 64;
+  if (row0 + ROWS <= A.n) {
+    const uint64_t p = (uint64_t)(A.X + row0 * A.ldx);   // wave-uniform: make the compiler keep it in SGPRs
+    const uint64_t b = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)p) |
+                       ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(p >> 32)) << 32);
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) dma16_to_lds_off<true>((const void*)b, off[i], lds_slot + (unsigned)i * 1024u);
+  } else {
+    // the ragged last slot: rows beyond n read row n - 1 (a valid address), their results are discarded
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) {
+      const int G = i * 64 + lane;
+      const int row = G / H, g = G % H;
+      int64_t gr = row0 + row;
+      if (gr >= A.n) gr = A.n - 1;
+      dma16_to_lds<true>(A.X + gr * A.ldx + 2 * (g ^ dma_swizzle_key<MM>(row)), lds_slot + (unsigned)i * 1024u);
+    }
+  }
+}
+
+template <int METRIC, bool W, int MM, int ROWS, int D>
+__global__ __launch_bounds__(64) void dist_rows_dma_kernel(RowArgs A) {
+  extern __shared__ __align__(16) double lds[];
+  constexpr int SLOT = ROWS * MM;                // doubles
+  constexpr int H = MM / 2;
+  constexpr int PIECES = ROWS * H / 64;
+  static_assert(ROWS <= 64 && (ROWS * H) % 64 == 0, "a slot is a whole number of 1 KiB DMA pieces, one row per lane");
+  const int lane = threadIdx.x;
+  double* ring = lds;
+  double* ys = lds + (size_t)D * SLOT;
+  double* as = ys + MM;
+  const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)ring);
+  if (lane < MM) {
+    ys[lane] = A.y[lane];
+    if constexpr (W) as[lane] = A.aux[lane];
+  }
+  const int64_t nslots = (A.n + ROWS - 1) / ROWS;
+  const int64_t stride = gridDim.x;
+  const double thr = A.F.thr ? *A.F.thr : 0.0;   // fused selection: the sampler state's current k-th best distance
+  unsigned off[PIECES];   // byte offset of this lane's granule of piece i from the slot's first row (the launcher checks
+#pragma unroll            // that 64 rows of pitch ldx stay below 2^31 bytes)
+  for (int i = 0; i < PIECES; ++i) {
+    const int G = i * 64 + lane;
+    const int row = G / H, g = G % H;
+    off[i] = (unsigned)(((int64_t)row * A.ldx + 2 * (g ^ dma_swizzle_key<MM>(row))) * 8);
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // nothing of the prologue is outstanding: the counted
+  int64_t t = blockIdx.x;                                        // waits below see the DMA pieces and the stores only
+#pragma unroll
+  for (int k = 0; k < D - 1; ++k) {
+    const int64_t tk = t + k * stride;
+    if (tk < nslots) dma_issue_slot<MM, ROWS>(A, off, tk * ROWS, lds_base + (unsigned)(k * SLOT * 8), lane);
+  }
+  int cur = 0;
+  for (; t < nslots; t += stride) {
+    // keep the ring full: the slot read in the previous trip is free (its reads were waited for at the trip's end)
+    const int64_t tn = t + (int64_t)(D - 1) * stride;
+    int nxt = cur + D - 1;
+    if (nxt >= D) nxt -= D;
+    if (tn < nslots) {
+      dma_issue_slot<MM, ROWS>(A, off, tn * ROWS, lds_base + (unsigned)(nxt * SLOT * 8), lane);
+      // loads return in order: once at most the D - 1 younger slots' pieces are outstanding, slot `cur` has landed (a
+      // store of an earlier trip still in flight only makes this wait longer, never shorter)
+      wait_vmcnt<PIECES * (D - 1)>();
+    } else {
+      wait_vmcnt<0>();
+    }
+    const int64_t row0 = t * ROWS;
+    double dist = 0.0;
+    const bool mine = (ROWS == 64 || lane < ROWS) && row0 + lane < A.n;
+    if (ROWS == 64 || lane < ROWS) {
+      const double* row = ring + (size_t)cur * SLOT + (size_t)lane * MM;
+      const int key = dma_swizzle_key<MM>(lane);
+      double s = Op<METRIC, W>::init();
+#pragma unroll
+      for (int c = 0; c < H; ++c) {
+        const double2 v = *reinterpret_cast<const double2*>(row + 2 * (c ^ key));
+        const double2 yv = *reinterpret_cast<const double2*>(ys + 2 * c);
+        double2 av = make_double2(1.0, 1.0);
+        if constexpr (W) av = *reinterpret_cast<const double2*>(as + 2 * c);
+        s = Op<METRIC, W>::step(s, v.x, yv.x, av.x, A.p);
+        s = Op<METRIC, W>::step(s, v.y, yv.y, av.y, A.p);
+      }
+      dist = Op<METRIC, W>::finish(s, A.inv_p);
+      if (mine) A.out[row0 + lane] = dist;
+    }
+    if (A.F.thr) reject_offer(A.F, mine && dist < thr, dist, A.F.row_base + row0 + lane);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slot's reads are done before it is refilled
+    cur = cur + 1 == D ? 0 : cur + 1;
   }
 }
 
@@ -500,6 +646,23 @@ static int set_lds(elfihip_ctx* ctx, KernelT k, size_t lds) {
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   return ELFIHIP_OK;
 }
+// The same, once per (device, kernel): hipFuncSetAttribute is a host call of several microseconds -- on the 40 us launches
+// of the LDS-DMA row stream it made the HOST the bottleneck (54.7 us per launch measured, 40.7 in the probe).
+template <class KernelT>
+static int set_lds_once(elfihip_ctx* ctx, KernelT k, size_t lds) {
+  static std::mutex mu;
+  static std::set<std::pair<int, const void*>> done;
+  const std::pair<int, const void*> key(ctx->device, reinterpret_cast<const void*>(k));
+  {
+    std::lock_guard<std::mutex> g(mu);
+    if (done.count(key)) return ELFIHIP_OK;
+  }
+  ELFIHIP_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  std::lock_guard<std::mutex> g(mu);
+  done.insert(key);
+  return ELFIHIP_OK;
+}
 
 // 16-byte loads per thread of the pipelined row kernels.  Rows that cost a few flops per element (everything but
 // general Minkowski and the K-weight sums) stream best in tiles of 32 to 64 rows (8 to 16 KiB per workgroup); the
@@ -523,6 +686,30 @@ static int launch_rows(elfihip_ctx* ctx, RowArgs A, bool* filtered) {
   const int T = pick_block(A.m, 2 * (size_t)A.m, &lds);
   const int64_t ntiles = (A.n + T - 1) / T;
   const int g = grid_for(ctx, ntiles, lds, T);
+  if (A.vec2 && ctx->dist_form == 0 && METRIC != ELFIHIP_MINKOWSKI && METRIC != ELFIHIP_SEUCLIDEAN &&
+      (A.m == 16 || A.m == 32 || A.m == 64) && A.ldx <= (1 << 21)) {
+    // LDS-DMA form: one-wave workgroups, each with a ring of two 16 KiB slots (64 rows of 32 summaries, 32 rows of 64; four
+    // 8 KiB slots of 64 rows at 16 summaries), four workgroups per CU.  Measured on 10^6 x 32 / 5 10^5 x 64, plain | weighted
+    // (scripts/native/glds_probe.hip, profiles/r05_glds_probe.md): ring of 2 x 4 per CU 41.9 | 42.0 and 40.7 | 41.1 us; ring
+    // of 4 x 2 per CU 41.8 | 42.6 and 40.0 | 51.2 (two waves per CU cannot hide the weighted 64-column row sums); 8 KiB
+    // slots 42.3-43.7; without `nt` 46-48; the register-staged pipeline 46.6-47.2.  Metrics with a division or pow() per
+    // element (seuclidean, general Minkowski) keep the register-staged form below: they want all lanes of more waves.
+    const int rows = A.m == 64 ? 32 : 64;
+    const int D = A.m == 16 ? 4 : 2;
+    const size_t ldsd = ((size_t)D * rows * A.m + 2 * (size_t)A.m) * sizeof(double);
+    int64_t gd = (int64_t)ctx->cu_count * 4;
+    const int64_t nslots = (A.n + rows - 1) / rows;
+    if (gd > nslots) gd = nslots;
+    if (gd < 1) gd = 1;
+    if (A.m == 16)
+      hipLaunchKernelGGL((dist_rows_dma_kernel<METRIC, W, 16, 64, 4>), dim3((unsigned)gd), dim3(64), ldsd, ctx->stream, A);
+    else if (A.m == 32)
+      hipLaunchKernelGGL((dist_rows_dma_kernel<METRIC, W, 32, 64, 2>), dim3((unsigned)gd), dim3(64), ldsd, ctx->stream, A);
+    else
+      hipLaunchKernelGGL((dist_rows_dma_kernel<METRIC, W, 64, 32, 2>), dim3((unsigned)gd), dim3(64), ldsd, ctx->stream, A);
+    if (filtered) *filtered = A.F.thr != nullptr;   // this form offers its candidates itself, too
+    return launch_status(ctx, "dist_rows_dma_kernel");
+  }
   if (A.vec2 && A.m <= 128) {
     // pipelined form: 128 threads, U register pairs each = one whole tile of R rows.  Small tiles win: 8 KiB in
     // flight per workgroup (32 rows of 32) with 8 workgroups per CU streams 10^6 x 32 in 47.5 us, the 32 KiB tile

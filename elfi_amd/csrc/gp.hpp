@@ -26,6 +26,12 @@ struct elfihip_gp {
   int64_t lcb_steps = 0;      // acquisition lock-steps since the latest factorisation (extends do not reset it)
   double diag_min = 0, diag_max = 0;   // smallest / largest diagonal entry of L: (max / min)^2 bounds cond(K) from below
   double logdet = 0, yKy = 0;
+  // GPy's jitchol ladder (gp_fit.hip: gp_factorize_impl): tries allowed after a failed plain Cholesky (0 = fail at once),
+  // the jitter the current factor carries on its diagonal (0: none was needed) and the retries the latest call made
+  int jitchol_maxtries = 5;
+  double jitter = 0.0;
+  int jitter_tries = 0;
+  bool wt_dirty = false;   // a failed attempt has run: the blocks of WT the sweep relies on being zero may hold NaN / Inf
 
   // device memory
   double* X = nullptr;      // (cap, dp) evidence inputs, zero padded

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs G) {
           v = (i == j) ? 1.0 : 0.0;
         } else {
           double r2 = (G.x2[i] + G.x2[j]) + (-2.0 * acc[a][c][r]);
-          r2 = r2 > 0.0 ? r2 : 0.0;
+          r2 = r2 < 0.0 ? 0.0 : r2;   // (a NaN stays a NaN: it must reach the pivot test, not turn into distance 0)
           if (i == j) r2 = 0.0;
           v = G.var * exp(r2 * G.neg_half_inv_ls2) + G.bias;
           if (i == j) v += G.diag_add;
@@ -516,7 +516,8 @@ __global__ __launch_bounds__(256) void trsm_gemm_kernel(PanelArgs P) {
 // 2o / 2o+1 holds k = 8o + 2q / + 1), so a 16-byte load feeds two MFMAs.  In place: the barrier separates the strip's
 // last read from its first overwrite.  (The LDS-staged 32-row form above: 8.3 us per launch at n = 4096.)
 template <int W>
-__device__ __forceinline__ void trsm16_wave(double* Pb, int64_t lda, const double* W11, int l) {
+__device__ __forceinline__ void trsm16_wave(double* Pb, int64_t lda, const double* W11, int l,
+                                            const unsigned* wait_cnt = nullptr, int* info = nullptr) {
   constexpr int T0 = W, T1 = 7 - W;              // the wave's column tiles
   constexpr int O0 = 2 * (T0 + 1), O1 = 2 * (T1 + 1);   // k octets they need
   const int q2 = 2 * (l >> 4);
@@ -541,6 +542,17 @@ __device__ __forceinline__ void trsm16_wave(double* Pb, int64_t lda, const doubl
     c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[o].y, b1[o].y, c1, 0, 0, 0);
   }
   __syncthreads();   // every wave holds its copy of the strip: it may be overwritten
+  if (wait_cnt) {
+    // panel_look_kernel: rows of row block k+1 -- the tile waves of the same launch read them RAW; write after they have
+    int spins = 0;
+    while (__hip_atomic_load(wait_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 4u * 36u) {
+      if (++spins >= (1 << 22)) {
+        if (threadIdx.x == 0) atomicCAS(info, 0, -1 /* STEP_INFO_TIMEOUT */);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
   double* po = Pb + (int64_t)(l >> 4) * lda + (l & 15);
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -770,6 +782,150 @@ __global__ __launch_bounds__(256) void lookahead_tile_kernel(PanelArgs P, int cb
   }
 }
 constexpr size_t LOOKAHEAD_TILE_LDS = 4 * 32 * 33 * sizeof(double);
+
+// --------------------------------------------------------------- panel solve AND diagonal tile in ONE launch (round 5)
+// Per step the fused sweep ran trsm16_kernel (6.4 us) -> lookahead_tile_kernel<1> (5.3 us) -> step_kernel: two launches on
+// the critical chain of every block column during which the matrix pipes idle (profiles/r04_fit_n4096_trace.md).  The tile
+// (k+1, k+1) -= P P^T only needs the 128 rows of the panel below the diagonal block, P = A21 W11^T -- and those rows can be
+// formed from the RAW block A21 by whoever needs them.  panel_look_kernel does both in one launch:
+//   workgroups [0, 36):  one 16 x 16 tile (i >= j) of the lower triangle of block (k+1, k+1) each (all the next diagonal
+//                        block reads: potf2_tiles_body fills the diagonal tiles symmetrically from their lower halves).
+//                        Four waves form the strips P_i and P_j (16 x 128 each, the SAME instruction sequence as
+//                        trsm16_wave, so the values are bit-identical to the panel the other workgroups store), pass them
+//                        through LDS into operand layout, and apply the K = 128 update split over the waves exactly as
+//                        lookahead_tile_kernel<1> splits it (k = 32 w ...; partials summed in wave order): the factor is
+//                        bit-identical to the three-launch form's.
+//   workgroups [36, ..): trsm16_wave on 16 rows of the panel each, as before, in place.
+// One dependency inside the launch, write-after-read only: the eight workgroups that overwrite rows of A21 (row block k+1)
+// hold their stores until all 144 tile waves have their raw strips in registers (one relaxed device-scope arrival per
+// wave after its loads have landed, one relaxed poll by the writers -- no data is handed over, so no fence).  The tile
+// workgroups come first in the grid: they are resident before any writer can wait for them.
+constexpr int LOOK_TILES = 36;
+constexpr int LOOK_PP = 130;   // pitch (doubles) of a strip in LDS: even (16-byte operand reads)
+constexpr size_t PANEL_LOOK_LDS = (2 * 16 * LOOK_PP + 4 * 16 * 17) * sizeof(double);
+
+template <int W>
+__device__ __forceinline__ void look_strips_wave(const double* Ai, const double* Aj, bool diag, int64_t lda,
+                                                 const double* W11, int l, double* Pi, double* Pj, unsigned* cnt) {
+  constexpr int T0 = W, T1 = 7 - W;
+  constexpr int O0 = 2 * (T0 + 1), O1 = 2 * (T1 + 1);
+  const int q2 = 2 * (l >> 4);
+  const double* pai = Ai + (int64_t)(l & 15) * lda + q2;
+  const double* paj = Aj + (int64_t)(l & 15) * lda + q2;
+  const double* pb0 = W11 + (int64_t)(16 * T0 + (l & 15)) * NB + q2;
+  const double* pb1 = W11 + (int64_t)(16 * T1 + (l & 15)) * NB + q2;
+  double2 ai[O1], aj[O1], b0[O0], b1[O1];
+#pragma unroll
+  for (int o = 0; o < O1; ++o) ai[o] = *reinterpret_cast<const double2*>(pai + 8 * o);
+#pragma unroll
+  for (int o = 0; o < O1; ++o) aj[o] = *reinterpret_cast<const double2*>(paj + 8 * o);   // (the same rows when diag)
+#pragma unroll
+  for (int o = 0; o < O0; ++o) b0[o] = *reinterpret_cast<const double2*>(pb0 + 8 * o);
+#pragma unroll
+  for (int o = 0; o < O1; ++o) b1[o] = *reinterpret_cast<const double2*>(pb1 + 8 * o);
+  // the raw strips are in registers: the rows may be overwritten now
+  __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);
+  if (l == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  v4d c0 = (v4d){0.0, 0.0, 0.0, 0.0}, c1 = c0;
+#pragma unroll
+  for (int o = 0; o < O1; ++o) {
+    if (o < O0) {
+      c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[o].x, b0[o].x, c0, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[o].y, b0[o].y, c0, 0, 0, 0);
+    }
+    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[o].x, b1[o].x, c1, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[o].y, b1[o].y, c1, 0, 0, 0);
+  }
+  double* po = Pi + (l >> 4) * LOOK_PP + (l & 15);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    po[4 * r * LOOK_PP + 16 * T0] = c0[r];
+    po[4 * r * LOOK_PP + 16 * T1] = c1[r];
+  }
+  if (!diag) {
+    c0 = (v4d){0.0, 0.0, 0.0, 0.0};
+    c1 = c0;
+#pragma unroll
+    for (int o = 0; o < O1; ++o) {
+      if (o < O0) {
+        c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(aj[o].x, b0[o].x, c0, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(aj[o].y, b0[o].y, c0, 0, 0, 0);
+      }
+      c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(aj[o].x, b1[o].x, c1, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(aj[o].y, b1[o].y, c1, 0, 0, 0);
+    }
+    double* pq = Pj + (l >> 4) * LOOK_PP + (l & 15);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      pq[4 * r * LOOK_PP + 16 * T0] = c0[r];
+      pq[4 * r * LOOK_PP + 16 * T1] = c1[r];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void panel_look_kernel(PanelArgs P, unsigned* cnt, int* info) {
+  extern __shared__ __align__(16) double lds[];
+  const int t = threadIdx.x, l = t & 63, w = t >> 6;
+  if (blockIdx.x >= LOOK_TILES) {
+    // ---- the panel solve, 16 rows per workgroup; row block k+1's pieces wait for the tile waves before they store
+    const int piece = blockIdx.x - LOOK_TILES;
+    double* Pb = panel_block(P, piece >> 3) + (int64_t)(piece & 7) * 16 * P.lda;
+    unsigned* wait = (piece >> 3) == 0 ? cnt : nullptr;
+    switch (w) {
+      case 0: trsm16_wave<0>(Pb, P.lda, P.W11, l, wait, info); break;
+      case 1: trsm16_wave<1>(Pb, P.lda, P.W11, l, wait, info); break;
+      case 2: trsm16_wave<2>(Pb, P.lda, P.W11, l, wait, info); break;
+      default: trsm16_wave<3>(Pb, P.lda, P.W11, l, wait, info); break;
+    }
+    return;
+  }
+  // ---- tile (i, j), i >= j, of block (k+1, k+1)
+  int i = 0, b = blockIdx.x;
+  while (b > i) {
+    b -= i + 1;
+    ++i;
+  }
+  const int j = b;
+  const bool diag = i == j;
+  const double* Ablk = P.A + ((int64_t)(P.k + 1) * NB) * P.lda + (int64_t)P.k * NB;   // raw A21 rows of row block k+1
+  double* C = P.A + ((int64_t)(P.k + 1) * NB + 16 * i) * P.lda + (int64_t)(P.k + 1) * NB + 16 * j;
+  double* Pi = lds;
+  double* Pj = diag ? lds : lds + 16 * LOOK_PP;
+  double* part = lds + 2 * 16 * LOOK_PP;
+  const double cv = C[(int64_t)(t >> 4) * P.lda + (t & 15)];   // old value of the tile entry this thread finishes
+  const double* Ai = Ablk + (int64_t)(16 * i) * P.lda;
+  const double* Aj = Ablk + (int64_t)(16 * j) * P.lda;
+  switch (w) {
+    case 0: look_strips_wave<0>(Ai, Aj, diag, P.lda, P.W11, l, Pi, Pj, cnt); break;
+    case 1: look_strips_wave<1>(Ai, Aj, diag, P.lda, P.W11, l, Pi, Pj, cnt); break;
+    case 2: look_strips_wave<2>(Ai, Aj, diag, P.lda, P.W11, l, Pi, Pj, cnt); break;
+    default: look_strips_wave<3>(Ai, Aj, diag, P.lda, P.W11, l, Pi, Pj, cnt); break;
+  }
+  __syncthreads();
+  // tile -= P_i P_j^T: wave w takes k in [32 w, 32 w + 32), k permuted as everywhere (lane group q of MFMA 2o / 2o+1
+  // holds k = 8o + 2q / + 1), partials summed in wave order -- lookahead_tile_kernel<1>'s arithmetic
+  {
+    const int kb = 32 * w + 2 * (l >> 4);
+    const double* pa = Pi + (l & 15) * LOOK_PP + kb;
+    const double* pb = Pj + (l & 15) * LOOK_PP + kb;
+    v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      const double2 a = *reinterpret_cast<const double2*>(pa + 8 * o);
+      const double2 bb = *reinterpret_cast<const double2*>(pb + 8 * o);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, bb.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, bb.y, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) part[w * 16 * 17 + ((l >> 4) + 4 * r) * 17 + (l & 15)] = acc[r];
+  }
+  __syncthreads();
+  {
+    const int o = (t >> 4) * 17 + (t & 15);
+    const double sum = ((part[o] + part[16 * 17 + o]) + part[2 * 16 * 17 + o]) + part[3 * 16 * 17 + o];
+    C[(int64_t)(t >> 4) * P.lda + (t & 15)] = cv - sum;
+  }
+}
 
 // out-of-line instance for the fused step kernel: inlined there, the block's 128 live registers would be allocated
 // next to the update tile's
@@ -1329,9 +1485,14 @@ static int sweep_fused(elfihip_gp* gp, int nb, hipStream_t st, bool chained) {
     P.W11 = W11buf[k & 1];
     const int nrows = (nb - 1 - k) + 1 + k;  // below + y block + L^-T rows above
     const int m = nb - 1 - k;
-    if (!chained || m == 0) hipLaunchKernelGGL(trsm16_kernel, dim3(8 * nrows), dim3(256), 0, st, P);
+    const bool merged = !chained && m > 0 && gp->schedule != 4;
+    if (merged)   // panel solve + tile (k+1, k+1) in one launch; word 3 of the step's counter block counts the tile waves
+      hipLaunchKernelGGL(panel_look_kernel, dim3(LOOK_TILES + 8 * nrows), dim3(256), PANEL_LOOK_LDS, st, P,
+                         reinterpret_cast<unsigned*>(gp->info) + 4 + 4 * k + 3, gp->info);
+    else if (!chained || m == 0)
+      hipLaunchKernelGGL(trsm16_kernel, dim3(8 * nrows), dim3(256), 0, st, P);
     if (m == 0) break;
-    if (!chained) hipLaunchKernelGGL(lookahead_tile_kernel<1>, dim3(16), dim3(256), LOOKAHEAD_TILE_LDS, st, P, k + 1);
+    if (!chained && !merged) hipLaunchKernelGGL(lookahead_tile_kernel<1>, dim3(16), dim3(256), LOOKAHEAD_TILE_LDS, st, P, k + 1);
     StepArgs S;
     S.P = P;
     S.W11 = W11buf[(k + 1) & 1];
@@ -1459,14 +1620,19 @@ static int sweep_streams(elfihip_gp* gp, int nb, hipStream_t st) {
   return launch_status(ctx, "cholesky sweep (streams)");
 }
 
-int gp_factorize_impl(elfihip_gp* gp);
-
-int gp_factorize_impl(elfihip_gp* gp) {
+// One attempt: Gram matrix with `diag_add` on the diagonal, sweep, alpha + log-determinant.  *info_out = 0 on success,
+// the 1-based index of the first non-positive pivot otherwise (the object is left unfactorised).
+static int gp_factorize_attempt(elfihip_gp* gp, double diag_add, int* info_out) {
   elfihip_ctx* ctx = gp->ctx;
-  ELFIHIP_REQUIRE(ctx, gp->n > 0, "GP has no evidence");
   hipStream_t st = ctx->stream;
   const int64_t np = gp->np;
   const int nb = (int)(np / NB);
+  if (gp->wt_dirty) {
+    // a sweep that met a non-positive (or NaN) pivot carries Inf / NaN through its products, also into the strictly lower
+    // blocks of WT that every later sweep relies on being zero (0 * NaN = NaN): clear the matrix before the next attempt
+    ELFIHIP_CHECK_HIP(ctx, hipMemsetAsync(gp->WT, 0, (size_t)gp->cap * gp->lda * sizeof(double), st));
+    gp->wt_dirty = false;
+  }
   prof_mark(gp, 0);
   {
     const int T = 256;
@@ -1484,7 +1650,7 @@ int gp_factorize_impl(elfihip_gp* gp) {
     G.var = gp->var;
     G.neg_half_inv_ls2 = -0.5 / (gp->ls * gp->ls);
     G.bias = gp->bias;
-    G.diag_add = gp->noise + GP_JITTER;
+    G.diag_add = diag_add;
     G.info = gp->info;
     G.ninfo = gp->ninfo;
     const int64_t nt = np / 64;
@@ -1496,7 +1662,7 @@ int gp_factorize_impl(elfihip_gp* gp) {
   // schedule of the sweep: gp->schedule 1 = streams, 2 = fused steps (panel solve | diagonal tile | step launch per block
   // column), 3 = fused steps chained inside ONE launch per block column (measured slower: DESIGN.md section 7), 0 = by
   // size (elfihip_gp_set_schedule)
-  const bool fused = gp->schedule == 2 || gp->schedule == 3 || (gp->schedule == 0 && nb < FUSED_BELOW_NB);
+  const bool fused = gp->schedule == 2 || gp->schedule == 3 || gp->schedule == 4 || (gp->schedule == 0 && nb < FUSED_BELOW_NB);
   if (fused)
     ELFIHIP_TRY(sweep_fused(gp, nb, st, gp->schedule == 3));
   else
@@ -1508,11 +1674,43 @@ int gp_factorize_impl(elfihip_gp* gp) {
   ELFIHIP_TRY(launch_status(ctx, "alpha/logdet"));
   prof_mark(gp, 3);
   ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(st));
-  const double red[2] = {gp->h_fit[0], gp->h_fit[1]};
-  const int info = (int)gp->h_fit[2];
+  *info_out = (int)gp->h_fit[2];
+  if (*info_out != 0) gp->wt_dirty = true;
   prof_add(gp, ELFIHIP_PHASE_GRAM, 0, 1);
   prof_add(gp, ELFIHIP_PHASE_SWEEP, 1, 2);
   prof_add(gp, ELFIHIP_PHASE_ALPHA, 2, 3);
+  return ELFIHIP_OK;
+}
+
+int gp_factorize_impl(elfihip_gp* gp);
+
+// The factorisation with GPy's `jitchol` semantics ([GPy-upstream] GPy/util/linalg.py: jitchol, reached from
+// ExactGaussianInference -> pdinv behind GPyRegression.update / optimize, elfi/methods/bo/gpy_regression.py:286-323):
+// a plain Cholesky first; if a pivot is not positive, retry with jitter = mean(diag Ky) * 1e-6 added to the diagonal,
+// the jitter growing tenfold per failed try, at most five tries; then "not positive definite, even with jitter"
+// (LinAlgError in the reference, ELFIHIP_ERR_NOT_PD here).  The factor, alpha, log-determinant and L^-T all belong to the
+// jittered matrix, as GPy's posterior does.  The diagonal of Ky is constant for this kernel (var + bias + noise + 1e-8),
+// so its mean is that value.
+int gp_factorize_impl(elfihip_gp* gp) {
+  elfihip_ctx* ctx = gp->ctx;
+  ELFIHIP_REQUIRE(ctx, gp->n > 0, "GP has no evidence");
+  const double diag0 = gp->noise + GP_JITTER;
+  int info = 0;
+  gp->jitter = 0.0;
+  gp->jitter_tries = 0;
+  ELFIHIP_TRY(gp_factorize_attempt(gp, diag0, &info));
+  if (info != 0 && info != STEP_INFO_TIMEOUT && gp->jitchol_maxtries > 0) {
+    double jitter = (gp->var + gp->bias + diag0) * 1e-6;
+    for (int t = 1; t <= gp->jitchol_maxtries && std::isfinite(jitter); ++t, jitter *= 10.0) {
+      gp->jitter_tries = t;
+      ELFIHIP_TRY(gp_factorize_attempt(gp, diag0 + jitter, &info));
+      if (info == 0 || info == STEP_INFO_TIMEOUT) {
+        if (info == 0) gp->jitter = jitter;
+        break;
+      }
+    }
+  }
+  const double red[2] = {gp->h_fit[0], gp->h_fit[1]};
   if (info == STEP_INFO_TIMEOUT) {
     gp->factored = false;
     return fail(ctx, ELFIHIP_ERR_HIP, "factorisation sweep: a hand-off inside a step launch timed out (the launch's "
@@ -1520,6 +1718,9 @@ int gp_factorize_impl(elfihip_gp* gp) {
   }
   if (info != 0) {
     gp->factored = false;
+    if (gp->jitter_tries > 0)
+      return fail(ctx, ELFIHIP_ERR_NOT_PD, "not positive definite, even with jitter (pivot %d <= 0 after %d tries)", info,
+                  gp->jitter_tries);
     return fail(ctx, ELFIHIP_ERR_NOT_PD, "covariance matrix is not positive definite (pivot %d <= 0)", info);
   }
   gp->logdet = 2.0 * red[0];
@@ -1693,6 +1894,15 @@ int elfihip_gp_factorize(elfihip_gp* gp, double* log_marginal) {
   return ELFIHIP_OK;
 }
 
+int elfihip_gp_jitchol(elfihip_gp* gp, int maxtries, double* jitter, int* tries) {
+  if (!gp) return fail(nullptr, ELFIHIP_ERR_ARG, "gp is NULL");
+  ELFIHIP_REQUIRE(gp->ctx, maxtries <= 16, "maxtries %d above 16", maxtries);
+  if (maxtries >= 0) gp->jitchol_maxtries = maxtries;
+  if (jitter) *jitter = gp->factored ? gp->jitter : 0.0;
+  if (tries) *tries = gp->jitter_tries;
+  return ELFIHIP_OK;
+}
+
 int elfihip_gp_profile(elfihip_gp* gp, int enable, double* phase_ms, int64_t* phase_calls) {
   if (!gp) return fail(nullptr, ELFIHIP_ERR_ARG, "gp is NULL");
   elfihip_ctx* ctx = gp->ctx;
@@ -1717,7 +1927,7 @@ int elfihip_gp_profile(elfihip_gp* gp, int enable, double* phase_ms, int64_t* ph
 
 int elfihip_gp_set_schedule(elfihip_gp* gp, int schedule, int panel_group) {
   if (!gp) return fail(nullptr, ELFIHIP_ERR_ARG, "gp is NULL");
-  ELFIHIP_REQUIRE(gp->ctx, schedule >= 0 && schedule <= 3, "schedule %d outside {0, 1, 2, 3}", schedule);
+  ELFIHIP_REQUIRE(gp->ctx, schedule >= 0 && schedule <= 4, "schedule %d outside {0, 1, 2, 3, 4}", schedule);
   ELFIHIP_REQUIRE(gp->ctx, panel_group == 0 || panel_group == 1 || panel_group == 2 || panel_group == 4,
                   "panel_group %d outside {0, 1, 2, 4}", panel_group);
   gp->schedule = schedule;

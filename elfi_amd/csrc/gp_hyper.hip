@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void kinv_grad_kernel(HyperArgs H) {
         const int64_t gj = j0 + col;
         if (gi < H.n && gj <= gi) {
           double r2 = (x2i + H.x2[gj]) + (-2.0 * dot[j]);
-          r2 = r2 > 0.0 ? r2 : 0.0;
+          r2 = r2 < 0.0 ? 0.0 : r2;
           if (gi == gj) r2 = 0.0;
           const double krbf = H.var * exp(r2 * H.neg_half_inv_ls2);
           const double D = 0.5 * ((first_chunk ? ai * H.alpha[gj] : 0.0) - acc.c[i][j][r]);

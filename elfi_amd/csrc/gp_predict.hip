@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void kstar_kernel(const double* X, const doubl
       double dot = 0.0;
       for (int c = 0; c < dp; ++c) dot += sx[c] * X[i * dp + c];
       double r2 = (sx[256] + x2[i]) + (-2.0 * dot);
-      r2 = r2 > 0.0 ? r2 : 0.0;
+      r2 = r2 < 0.0 ? 0.0 : r2;
       k = var * exp(r2 * neg_half_inv_ls2);
       contrib = (k + bias) * alpha[i];
     }
@@ -649,7 +649,7 @@ __global__ __launch_bounds__(256) void expintvar_kernel(const double* cov, const
     const double A = s2n + var_int[i];
     const double dl = c * c / den;
     double r = (A - dl) / (A + dl);
-    r = r > 0.0 ? r : 0.0;
+    r = r < 0.0 ? 0.0 : r;
     acc += w_int[i] * owens_t((eps - mean_int[i]) / sqrt(A), sqrt(r));
   }
   red[threadIdx.x] = acc;
@@ -697,7 +697,7 @@ __global__ __launch_bounds__(256) void kernel_matrix_kernel(const double* A, con
     dot += a * b;
   }
   double r2 = (a2 + b2) + (-2.0 * dot);
-  r2 = r2 > 0.0 ? r2 : 0.0;
+  r2 = r2 < 0.0 ? 0.0 : r2;
   if (same && i == j) r2 = 0.0;
   out[e] = var * exp(r2 * neg_half_inv_ls2) + bias;
 }
@@ -1508,8 +1508,12 @@ int elfihip_gp_extend(elfihip_gp* gp, const double* X_new, const double* y_new, 
   int64_t done = 0;
   // bordering works inside the current padded size; crossing a 128 boundary (or an unfactorised
   // GP) takes the ordinary path: append the rest and rebuild
-  while (done < k && gp->factored && gp->n > 0 && gp->n < gp->np) {
-    ELFIHIP_TRY(extend_one(gp, X_new + done * gp->d, y_new[done]));
+  // ... and so does a factor that carries jitchol jitter (GPy rebuilds on every update: the plain Cholesky gets its
+  // chance again) and a bordered pivot that is not positive (the rebuild below then walks the jitter ladder)
+  while (done < k && gp->factored && gp->n > 0 && gp->n < gp->np && gp->jitter == 0.0) {
+    const int rc = extend_one(gp, X_new + done * gp->d, y_new[done]);
+    if (rc == ELFIHIP_ERR_NOT_PD) break;
+    ELFIHIP_TRY(rc);
     ++done;
   }
   if (done < k) {

@@ -125,6 +125,13 @@ class GPHandle:
         self._check(self.lib.elfihip_gp_factorize(self.h, C.byref(lz)))
         return lz.value
 
+    def jitchol(self, maxtries=-1):
+        """(jitter on the current factor's diagonal, retries of the latest factorize()) -- GPy's jitchol ladder
+        (include/elfihip.h: elfihip_gp_jitchol); maxtries >= 0 sets the retries allowed (GPy: 5)."""
+        j, t = C.c_double(0.0), C.c_int(0)
+        self._check(self.lib.elfihip_gp_jitchol(self.h, int(maxtries), C.byref(j), C.byref(t)))
+        return float(j.value), int(t.value)
+
     def get(self, which):
         n, d = self.n, self.d
         shape = {0: (n, n), 1: (n, n), 2: (n, 1), 3: (n, d), 4: (n, 1), 5: (n, n)}[which]

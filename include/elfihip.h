@@ -99,6 +99,10 @@ int elfihip_dist_rows_dev(elfihip_ctx* ctx, int metric, const double* dX, int64_
                           int64_t ldx, const double* dy, const double* daux, double p,
                           double* dout);
 
+/* How the row-major distance calls stream their matrix (no reference counterpart; results are bit-identical either way):
+ * 0 (default) rows of 16 / 32 / 64 summaries with 16-byte aligned rows arrive in LDS by LDS-DMA (global_load_lds, rings
+ * of four 16 KiB slots per wave, non-temporal) -- every other shape, and 1 always, takes the register-staged pipeline. */
+int elfihip_dist_set_form(elfihip_ctx* ctx, int form);
 /* m separately stored summary columns of length n each (structure of arrays): the
  * form ELFI hands to distance_as_discrepancy BEFORE np.column_stack
  * (elfi/model/utils.py:39) -- lets the caller skip that host-side copy. */
@@ -374,8 +378,18 @@ int elfihip_gp_set_data(elfihip_gp* gp, const double* X, const double* y, int64_
 int elfihip_gp_append(elfihip_gp* gp, const double* X_new, const double* y_new, int64_t k);
 /* Gram matrix + Cholesky + L^-T + alpha (what GPy's ExactGaussianInference does when
  * gpy_regression.py:283-284 / :311-312 construct GPRegression).  log_marginal may be NULL.
- * ELFIHIP_ERR_NOT_PD if a pivot is not positive (GPy would raise LinAlgError). */
+ * A failed plain Cholesky is retried the way GPy's `jitchol` does it ([GPy-upstream] GPy/util/linalg.py, reached
+ * through ExactGaussianInference / pdinv from GPyRegression.update and .optimize, elfi/methods/bo/gpy_regression.py:286-323):
+ * jitter = mean(diag Ky) * 1e-6 on the diagonal, ten times more per failed try, at most `maxtries` (5) tries; L, alpha,
+ * log Z and L^-T then belong to the jittered matrix, as GPy's posterior object does.  ELFIHIP_ERR_NOT_PD only when the
+ * last try fails too ("not positive definite, even with jitter": LinAlgError in the reference, which
+ * GPyRegression.optimize catches and warns about, gpy_regression.py:320-323). */
 int elfihip_gp_factorize(elfihip_gp* gp, double* log_marginal);
+/* The ladder above: maxtries >= 0 sets the retries allowed (GPy: 5; 0 = fail at the first non-positive pivot),
+ * maxtries < 0 leaves it.  jitter receives what the CURRENT factor carries on its diagonal besides noise + 1e-8 (0 when
+ * the plain Cholesky went through), tries the retries the latest elfihip_gp_factorize made.  Pointers may be NULL.
+ * elfihip_gp_extend refuses to border a factor that carries jitter (it refactors instead, as GPy would). */
+int elfihip_gp_jitchol(elfihip_gp* gp, int maxtries, double* jitter, int* tries);
 /* How elfihip_gp_factorize schedules its sweep over the 128-wide block columns (no reference counterpart: GPy hands
  * the factorisation to LAPACK).  schedule 0 = chosen by size (default), 1 = two-stream look-ahead with panel groups,
  * 2 = fused steps on the caller's stream (panel solve, diagonal tile, then ONE launch with the next diagonal block

@@ -88,19 +88,25 @@ def initial_hyper(y, noise_var=None):
 
 
 def jitchol(A, maxtries=5):
-    """[GPy-upstream] util.linalg.jitchol."""
-    try:
-        return sl.cholesky(A, lower=True)
-    except sl.LinAlgError:
-        diagA = np.diag(A)
-        if np.any(diagA <= 0.):
-            raise np.linalg.LinAlgError("not pd: non-positive diagonal elements")
-        jitter = diagA.mean() * 1e-6
-        for _ in range(maxtries):
-            try:
-                return sl.cholesky(A + np.eye(A.shape[0]) * jitter, lower=True)
-            except sl.LinAlgError:
-                jitter *= 10
+    """[GPy-upstream] util.linalg.jitchol: LAPACK dpotrf first; on failure jitter = mean(diag) * 1e-6, times ten per
+    failed try, at most `maxtries` tries (GPy's loop catches every exception of the retry, so a matrix with NaN in it also
+    ends in "not positive definite, even with jitter")."""
+    A = np.ascontiguousarray(A)
+    L, info = sl.lapack.dpotrf(A, lower=1)
+    if info == 0:
+        return np.tril(L)
+    diagA = np.diag(A)
+    if np.any(diagA <= 0.):
+        raise np.linalg.LinAlgError("not pd: non-positive diagonal elements")
+    jitter = diagA.mean() * 1e-6
+    num_tries = 1
+    while num_tries <= maxtries and np.isfinite(jitter):
+        try:
+            return sl.cholesky(A + np.eye(A.shape[0]) * jitter, lower=True)
+        except Exception:
+            jitter *= 10
+        finally:
+            num_tries += 1
     raise np.linalg.LinAlgError("not positive definite, even with jitter.")
 
 

