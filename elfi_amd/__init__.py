@@ -12,7 +12,8 @@ Everything else (graph compilation, samplers, storage, plotting ...) stays refer
 ELFI.  The compute lives in libelfihip.so (C ABI: include/elfihip.h); this package is
 the thin host-side mirror of the reference interfaces.  See DESIGN.md / INTEGRATION.md.
 """
-from ._lib import LIB_PATH, Context, ElfiHipError, default_context, device_count, load_library  # noqa: F401
+from ._lib import (LIB_PATH, Context, ElfiHipError, default_context, device_count, load_library,  # noqa: F401
+                   set_device_handover)
 from .distance import (AdaptiveDistanceState, HipDiscrepancy, HipDistance, cdist_cols,  # noqa: F401
                        cdist_rows, nested_weighted_euclidean, welford_update)
 

@@ -294,6 +294,12 @@ class Context:
         self.call("elfihip_kept_distances", C.byref(ep), None, None)
         return ep.value
 
+    def kept_shape(self):
+        """(epoch, rows, columns) of the device copy the latest host-form distance call left."""
+        ep, n, k = C.c_uint64(), C.c_int64(), C.c_int()
+        self.call("elfihip_kept_distances", C.byref(ep), C.byref(n), C.byref(k))
+        return ep.value, n.value, k.value
+
     def timer_start(self):
         self.call("elfihip_timer_start")
 
@@ -308,15 +314,45 @@ class Context:
 # when the context still keeps that call's copy (include/elfihip.h: elfihip_kept_distances).
 _KEPT = {}
 
+# The hand-over is keyed by the IDENTITY of the host array, so it assumes that nobody writes into the array between the
+# call that returned it and the call that consumes it (ELFI's graph never does; a user operation might: `d[mask] = inf`,
+# `X *= s` on randn_rows output, an `out=` argument).  Guard: a fingerprint of 256 strided elements taken when the array is
+# handed out and compared before the device copy is used -- an array that was rewritten wholesale (scaling, `out=`) never
+# passes; a few scattered edits can (write to a copy instead, or switch the hand-over off with set_device_handover(False):
+# every consumer then uploads what the host array holds).
+_HANDOVER = [True]
+
+
+def set_device_handover(enabled=True):
+    """Switch the device-resident hand-over of distances / simulator rows between node operations on or off (default on).
+    Off: consumers always read the host arrays they are given.  Returns the previous setting."""
+    prev = _HANDOVER[0]
+    _HANDOVER[0] = bool(enabled)
+    if not enabled:
+        _KEPT.clear()
+        _ROWS.clear()
+    return prev
+
+
+def _fingerprint(arr):
+    try:
+        flat = arr.reshape(-1)
+        step = max(1, flat.shape[0] // 256)
+        return (arr.shape, arr.strides, flat[::step][:256].tobytes(), flat[-1:].tobytes())
+    except Exception:
+        return None
+
 
 def remember_kept(arr, ctx):
     if len(_KEPT) > 32:
-        for key in [k for k, (ref, _, _) in _KEPT.items() if ref() is None]:
+        for key in [k for k, ent in _KEPT.items() if ent[0]() is None]:
             del _KEPT[key]
         while len(_KEPT) > 32:
             del _KEPT[next(iter(_KEPT))]
+    if not _HANDOVER[0]:
+        return arr
     try:
-        _KEPT[id(arr)] = (weakref.ref(arr), ctx, ctx.kept_epoch())
+        _KEPT[id(arr)] = (weakref.ref(arr), ctx, ctx.kept_epoch(), _fingerprint(arr))
     except TypeError:
         pass
     return arr
@@ -363,19 +399,24 @@ _ROWS = {}      # id(array a device-side simulator returned) -> (weak reference,
 
 
 def remember_rows(arr, ctx):
-    for key in [k for k, (ref, _, _) in _ROWS.items() if ref() is None]:
+    for key in [k for k, ent in _ROWS.items() if ent[0]() is None]:
         del _ROWS[key]
     while len(_ROWS) > 8:
         del _ROWS[next(iter(_ROWS))]
+    if not _HANDOVER[0]:
+        return arr
     ep = C.c_uint64()
     ctx.call("elfihip_kept_rows", C.byref(ep), None, None)
-    _ROWS[id(arr)] = (weakref.ref(arr), ctx, ep.value)
+    _ROWS[id(arr)] = (weakref.ref(arr), ctx, ep.value, _fingerprint(arr))
     return arr
 
 
 def rows_epoch_of(arr, ctx):
     ent = _ROWS.get(id(arr))
     if ent is None or ent[0]() is not arr or ent[1] is not ctx:
+        return None
+    if ent[3] != _fingerprint(arr):      # written to since it was handed out: the device copy is not this array any more
+        del _ROWS[id(arr)]
         return None
     return ent[2]
 
@@ -385,7 +426,7 @@ def alias_kept(new, old):
     ent = _KEPT.get(id(old))
     if ent is not None and ent[0]() is old:
         try:
-            _KEPT[id(new)] = (weakref.ref(new), ent[1], ent[2])
+            _KEPT[id(new)] = (weakref.ref(new), ent[1], ent[2], _fingerprint(new))
         except TypeError:
             pass
     return new
@@ -395,6 +436,9 @@ def kept_epoch_of(arr, ctx):
     """Epoch of the device copy of `arr` on `ctx`, or None."""
     ent = _KEPT.get(id(arr))
     if ent is None or ent[0]() is not arr or ent[1] is not ctx:
+        return None
+    if ent[3] != _fingerprint(arr):      # written to since it was handed out: the device copy is not this array any more
+        del _KEPT[id(arr)]
         return None
     return ent[2]
 

@@ -570,7 +570,7 @@ static int adaptive_push_host(elfihip_ctx* ctx, elfihip_reject* state, const dou
   ELFIHIP_REQUIRE(ctx, y && W, "NULL data pointer");
   ELFIHIP_REQUIRE(ctx, (!count && !mean && !M2) || (count && mean && M2), "count / mean / M2 come together");
   ELFIHIP_REQUIRE(ctx, !state || reject_ctx(state) == ctx, "the sampler state belongs to another context");
-  if (n == 0) return ELFIHIP_OK;
+  if (n == 0) return out ? keep_distances(ctx, nullptr, 0, K) : ELFIHIP_OK;   // (an empty batch is still a distance call)
   DeviceGuard g(ctx->device);
   hipStream_t st = ctx->stream;
   const size_t ns = 1 + 2 * (size_t)m;

@@ -74,6 +74,7 @@ struct elfihip_ctx {
   elfihip::DevBuf keep;
   uint64_t keep_epoch = 0;
   int64_t keep_n = 0;
+  bool keep_valid = false;            // the copy the epoch names exists (false: the buffer could not be had)
   int keep_cols = 0;
   // ... and the rows the last device-side simulator call (elfihip_randn_rows) returned: (rows_n, rows_m) row-major with
   // pitch rows_m, for the distance call that follows (elfihip_kept_rows / elfihip_adaptive_push_kept)
@@ -139,14 +140,26 @@ struct DeviceGuard {
 int ctx_aux(elfihip_ctx* ctx);  // ctx.hip: lazily creates hi_stream / ev_a / ev_b
 
 // Host-form distance calls leave a device copy of what they return (n x cols doubles at dsrc, on the context's stream).
+// Every host-form distance call comes through here, also with n = 0 (an empty batch is a call: the epoch must move on, or
+// the previous call's rows would be folded in again under the new call's name).  keep_valid says whether the copy named by
+// the epoch really exists: when the buffer cannot be had, elfihip_reject_push_kept answers ELFIHIP_ERR_STATE and the
+// sampler uploads the host array instead (round 4 reported OK with zero rows: the batch was silently dropped).
 inline int keep_distances(elfihip_ctx* ctx, const double* dsrc, int64_t n, int cols) {
   ++ctx->keep_epoch;
   ctx->keep_n = 0;
   ctx->keep_cols = cols;
-  if (n <= 0) return ELFIHIP_OK;
-  if (ctx->keep.reserve((size_t)n * cols * sizeof(double)) != hipSuccess) return ELFIHIP_OK;   // (no copy kept: the sampler uploads)
+  ctx->keep_valid = false;
+  if (n <= 0) {
+    ctx->keep_valid = true;   // an empty batch: nothing to keep, nothing to fold in
+    return ELFIHIP_OK;
+  }
+  if (ctx->keep.reserve((size_t)n * cols * sizeof(double)) != hipSuccess) {
+    (void)hipGetLastError();
+    return ELFIHIP_OK;        // no copy kept (keep_valid stays false): the sampler uploads
+  }
   ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(ctx->keep.p, dsrc, (size_t)n * cols * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
   ctx->keep_n = n;
+  ctx->keep_valid = true;
   return ELFIHIP_OK;
 }
 

@@ -392,7 +392,7 @@ int elfihip_gauss_distance(elfihip_ctx* ctx, const double* Z, uint64_t seed, uin
   if (!ctx) return fail(nullptr, ELFIHIP_ERR_ARG, "ctx is NULL");
   ELFIHIP_REQUIRE(ctx, n >= 0 && n_obs >= 1, "bad shape n=%lld n_obs=%d", (long long)n, n_obs);
   ELFIHIP_REQUIRE(ctx, n == 0 || (mu && sigma && S1 && S2 && D), "NULL data pointer");
-  if (n == 0) return ELFIHIP_OK;
+  if (n == 0) return keep_distances(ctx, nullptr, 0, 1);   // an empty batch is still a call: the kept copy's name moves on
   DeviceGuard g(ctx->device);
   const size_t nz = Z ? (size_t)n * n_obs : 0, ny = Y ? (size_t)n * n_obs : 0;
   ELFIHIP_CHECK_HIP(ctx, ctx->in.reserve((nz + 2 * (size_t)n) * sizeof(double)));

@@ -517,7 +517,8 @@ __global__ __launch_bounds__(256) void trsm_gemm_kernel(PanelArgs P) {
 // last read from its first overwrite.  (The LDS-staged 32-row form above: 8.3 us per launch at n = 4096.)
 template <int W>
 __device__ __forceinline__ void trsm16_wave(double* Pb, int64_t lda, const double* W11, int l,
-                                            const unsigned* wait_cnt = nullptr, int* info = nullptr) {
+                                            const unsigned* wait_cnt = nullptr, int* info = nullptr,
+                                            unsigned wait_target = 28u * 8u + 8u * 4u) {
   constexpr int T0 = W, T1 = 7 - W;              // the wave's column tiles
   constexpr int O0 = 2 * (T0 + 1), O1 = 2 * (T1 + 1);   // k octets they need
   const int q2 = 2 * (l >> 4);
@@ -544,14 +545,18 @@ __device__ __forceinline__ void trsm16_wave(double* Pb, int64_t lda, const doubl
   __syncthreads();   // every wave holds its copy of the strip: it may be overwritten
   if (wait_cnt) {
     // panel_look_kernel: rows of row block k+1 -- the tile waves of the same launch read them RAW; write after they have
-    int spins = 0;
-    while (__hip_atomic_load(wait_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 4u * 36u) {
-      if (++spins >= (1 << 22)) {
-        if (threadIdx.x == 0) atomicCAS(info, 0, -1 /* STEP_INFO_TIMEOUT */);
-        break;
+    // (one polling lane per wave: 2048 lanes polling one address stood in the tile waves' way)
+    if (l == 0) {
+      int spins = 0;
+      while (__hip_atomic_load(wait_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < wait_target) {
+        if (++spins >= (1 << 22)) {
+          atomicCAS(info, 0, -1 /* STEP_INFO_TIMEOUT */);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
       }
-      __builtin_amdgcn_s_sleep(1);
     }
+    __builtin_amdgcn_wave_barrier();
   }
   double* po = Pb + (int64_t)(l >> 4) * lda + (l & 15);
 #pragma unroll
@@ -784,7 +789,13 @@ __global__ __launch_bounds__(256) void lookahead_tile_kernel(PanelArgs P, int cb
 constexpr size_t LOOKAHEAD_TILE_LDS = 4 * 32 * 33 * sizeof(double);
 
 // --------------------------------------------------------------- panel solve AND diagonal tile in ONE launch (round 5)
-// Per step the fused sweep ran trsm16_kernel (6.4 us) -> lookahead_tile_kernel<1> (5.3 us) -> step_kernel: two launches on
+// elfihip_gp_set_schedule(gp, 4, 0); kept for measurement, NOT the default: 11.5 us per launch at n = 4096 (10.7 at 1024)
+// against 6.5 + 5.4 us for the two launches it replaces -- a rebuild of 1.660 against 1.640 ms (profiles/r05_fit_trace.md).
+// A tile workgroup runs the panel solve's round trip (launch ramp, operand loads, 36 dependent MFMAs) and then the tile
+// update's (LDS exchange, 8 MFMAs, partial sums, read-modify-write) one after the other: the launch is as long as the two
+// it merges, less one kernel boundary, plus the write-after-read hand-off.  First form (four waves form both strips, 222
+// registers): 14.9 us.
+// Per step the fused sweep runs trsm16_kernel (6.4 us) -> lookahead_tile_kernel<1> (5.3 us) -> step_kernel: two launches on
 // the critical chain of every block column during which the matrix pipes idle (profiles/r04_fit_n4096_trace.md).  The tile
 // (k+1, k+1) -= P P^T only needs the 128 rows of the panel below the diagonal block, P = A21 W11^T -- and those rows can be
 // formed from the RAW block A21 by whoever needs them.  panel_look_kernel does both in one launch:
@@ -797,7 +808,7 @@ constexpr size_t LOOKAHEAD_TILE_LDS = 4 * 32 * 33 * sizeof(double);
 //                        bit-identical to the three-launch form's.
 //   workgroups [36, ..): trsm16_wave on 16 rows of the panel each, as before, in place.
 // One dependency inside the launch, write-after-read only: the eight workgroups that overwrite rows of A21 (row block k+1)
-// hold their stores until all 144 tile waves have their raw strips in registers (one relaxed device-scope arrival per
+// hold their stores until all 256 tile waves have their raw strips in registers (one relaxed device-scope arrival per
 // wave after its loads have landed, one relaxed poll by the writers -- no data is handed over, so no fence).  The tile
 // workgroups come first in the grid: they are resident before any writer can wait for them.
 constexpr int LOOK_TILES = 36;
@@ -805,73 +816,58 @@ constexpr int LOOK_PP = 130;   // pitch (doubles) of a strip in LDS: even (16-by
 constexpr size_t PANEL_LOOK_LDS = (2 * 16 * LOOK_PP + 4 * 16 * 17) * sizeof(double);
 
 template <int W>
-__device__ __forceinline__ void look_strips_wave(const double* Ai, const double* Aj, bool diag, int64_t lda,
-                                                 const double* W11, int l, double* Pi, double* Pj, unsigned* cnt) {
+__device__ __forceinline__ void look_strip_wave(const double* As, int64_t lda, const double* W11, int l, double* Ps,
+                                                unsigned* cnt) {
+  // one 16 x 128 strip of the panel, P = A W11^T: trsm16_wave's instruction sequence (same values), result into LDS
   constexpr int T0 = W, T1 = 7 - W;
   constexpr int O0 = 2 * (T0 + 1), O1 = 2 * (T1 + 1);
   const int q2 = 2 * (l >> 4);
-  const double* pai = Ai + (int64_t)(l & 15) * lda + q2;
-  const double* paj = Aj + (int64_t)(l & 15) * lda + q2;
+  const double* pa = As + (int64_t)(l & 15) * lda + q2;
   const double* pb0 = W11 + (int64_t)(16 * T0 + (l & 15)) * NB + q2;
   const double* pb1 = W11 + (int64_t)(16 * T1 + (l & 15)) * NB + q2;
-  double2 ai[O1], aj[O1], b0[O0], b1[O1];
+  double2 a[O1], b0[O0], b1[O1];
 #pragma unroll
-  for (int o = 0; o < O1; ++o) ai[o] = *reinterpret_cast<const double2*>(pai + 8 * o);
-#pragma unroll
-  for (int o = 0; o < O1; ++o) aj[o] = *reinterpret_cast<const double2*>(paj + 8 * o);   // (the same rows when diag)
+  for (int o = 0; o < O1; ++o) a[o] = *reinterpret_cast<const double2*>(pa + 8 * o);
 #pragma unroll
   for (int o = 0; o < O0; ++o) b0[o] = *reinterpret_cast<const double2*>(pb0 + 8 * o);
 #pragma unroll
   for (int o = 0; o < O1; ++o) b1[o] = *reinterpret_cast<const double2*>(pb1 + 8 * o);
-  // the raw strips are in registers: the rows may be overwritten now
+  // the raw strip is in registers: its rows may be overwritten now
   __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);
   if (l == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   v4d c0 = (v4d){0.0, 0.0, 0.0, 0.0}, c1 = c0;
 #pragma unroll
   for (int o = 0; o < O1; ++o) {
     if (o < O0) {
-      c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[o].x, b0[o].x, c0, 0, 0, 0);
-      c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[o].y, b0[o].y, c0, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[o].x, b0[o].x, c0, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[o].y, b0[o].y, c0, 0, 0, 0);
     }
-    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[o].x, b1[o].x, c1, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[o].y, b1[o].y, c1, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[o].x, b1[o].x, c1, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[o].y, b1[o].y, c1, 0, 0, 0);
   }
-  double* po = Pi + (l >> 4) * LOOK_PP + (l & 15);
+  double* po = Ps + (l >> 4) * LOOK_PP + (l & 15);
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     po[4 * r * LOOK_PP + 16 * T0] = c0[r];
     po[4 * r * LOOK_PP + 16 * T1] = c1[r];
   }
-  if (!diag) {
-    c0 = (v4d){0.0, 0.0, 0.0, 0.0};
-    c1 = c0;
-#pragma unroll
-    for (int o = 0; o < O1; ++o) {
-      if (o < O0) {
-        c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(aj[o].x, b0[o].x, c0, 0, 0, 0);
-        c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(aj[o].y, b0[o].y, c0, 0, 0, 0);
-      }
-      c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(aj[o].x, b1[o].x, c1, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(aj[o].y, b1[o].y, c1, 0, 0, 0);
-    }
-    double* pq = Pj + (l >> 4) * LOOK_PP + (l & 15);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      pq[4 * r * LOOK_PP + 16 * T0] = c0[r];
-      pq[4 * r * LOOK_PP + 16 * T1] = c1[r];
-    }
-  }
 }
 
-__global__ __launch_bounds__(256) void panel_look_kernel(PanelArgs P, unsigned* cnt, int* info) {
+// tile waves that arrive at the counter: eight per off-diagonal tile (four per strip), four per diagonal tile
+constexpr unsigned LOOK_ARRIVALS = 28u * 8u + 8u * 4u;
+
+__global__ __launch_bounds__(512) void panel_look_kernel(PanelArgs P, unsigned* cnt, int* info) {
   extern __shared__ __align__(16) double lds[];
-  const int t = threadIdx.x, l = t & 63, w = t >> 6;
+  const int t = threadIdx.x, l = t & 63, w = t >> 6, ww = w & 3, half = w >> 2;
   if (blockIdx.x >= LOOK_TILES) {
-    // ---- the panel solve, 16 rows per workgroup; row block k+1's pieces wait for the tile waves before they store
-    const int piece = blockIdx.x - LOOK_TILES;
-    double* Pb = panel_block(P, piece >> 3) + (int64_t)(piece & 7) * 16 * P.lda;
-    unsigned* wait = (piece >> 3) == 0 ? cnt : nullptr;
-    switch (w) {
+    // ---- the panel solve: two 16-row pieces per workgroup (waves 0-3 / 4-7); row block k+1's pieces wait for the tile
+    // waves before they store
+    const int piece = 2 * (blockIdx.x - LOOK_TILES) + half;
+    const int npieces = 8 * P.nb;
+    const int pc = piece < npieces ? piece : npieces - 1;   // (npieces is even: never taken; keeps the barrier count equal)
+    double* Pb = panel_block(P, pc >> 3) + (int64_t)(pc & 7) * 16 * P.lda;
+    unsigned* wait = (pc >> 3) == 0 ? cnt : nullptr;
+    switch (ww) {
       case 0: trsm16_wave<0>(Pb, P.lda, P.W11, l, wait, info); break;
       case 1: trsm16_wave<1>(Pb, P.lda, P.W11, l, wait, info); break;
       case 2: trsm16_wave<2>(Pb, P.lda, P.W11, l, wait, info); break;
@@ -879,7 +875,7 @@ __global__ __launch_bounds__(256) void panel_look_kernel(PanelArgs P, unsigned* 
     }
     return;
   }
-  // ---- tile (i, j), i >= j, of block (k+1, k+1)
+  // ---- tile (i, j), i >= j, of block (k+1, k+1): waves 0-3 form strip i, waves 4-7 strip j
   int i = 0, b = blockIdx.x;
   while (b > i) {
     b -= i + 1;
@@ -892,19 +888,22 @@ __global__ __launch_bounds__(256) void panel_look_kernel(PanelArgs P, unsigned* 
   double* Pi = lds;
   double* Pj = diag ? lds : lds + 16 * LOOK_PP;
   double* part = lds + 2 * 16 * LOOK_PP;
-  const double cv = C[(int64_t)(t >> 4) * P.lda + (t & 15)];   // old value of the tile entry this thread finishes
-  const double* Ai = Ablk + (int64_t)(16 * i) * P.lda;
-  const double* Aj = Ablk + (int64_t)(16 * j) * P.lda;
-  switch (w) {
-    case 0: look_strips_wave<0>(Ai, Aj, diag, P.lda, P.W11, l, Pi, Pj, cnt); break;
-    case 1: look_strips_wave<1>(Ai, Aj, diag, P.lda, P.W11, l, Pi, Pj, cnt); break;
-    case 2: look_strips_wave<2>(Ai, Aj, diag, P.lda, P.W11, l, Pi, Pj, cnt); break;
-    default: look_strips_wave<3>(Ai, Aj, diag, P.lda, P.W11, l, Pi, Pj, cnt); break;
+  double cv = 0.0;
+  if (t < 256) cv = C[(int64_t)(t >> 4) * P.lda + (t & 15)];   // old value of the tile entry this thread finishes
+  if (half == 0 || !diag) {
+    const double* As = Ablk + (int64_t)(16 * (half == 0 ? i : j)) * P.lda;
+    double* Ps = half == 0 ? Pi : Pj;
+    switch (ww) {
+      case 0: look_strip_wave<0>(As, P.lda, P.W11, l, Ps, cnt); break;
+      case 1: look_strip_wave<1>(As, P.lda, P.W11, l, Ps, cnt); break;
+      case 2: look_strip_wave<2>(As, P.lda, P.W11, l, Ps, cnt); break;
+      default: look_strip_wave<3>(As, P.lda, P.W11, l, Ps, cnt); break;
+    }
   }
   __syncthreads();
-  // tile -= P_i P_j^T: wave w takes k in [32 w, 32 w + 32), k permuted as everywhere (lane group q of MFMA 2o / 2o+1
+  // tile -= P_i P_j^T: wave w < 4 takes k in [32 w, 32 w + 32), k permuted as everywhere (lane group q of MFMA 2o / 2o+1
   // holds k = 8o + 2q / + 1), partials summed in wave order -- lookahead_tile_kernel<1>'s arithmetic
-  {
+  if (half == 0) {
     const int kb = 32 * w + 2 * (l >> 4);
     const double* pa = Pi + (l & 15) * LOOK_PP + kb;
     const double* pb = Pj + (l & 15) * LOOK_PP + kb;
@@ -920,7 +919,7 @@ __global__ __launch_bounds__(256) void panel_look_kernel(PanelArgs P, unsigned* 
     for (int r = 0; r < 4; ++r) part[w * 16 * 17 + ((l >> 4) + 4 * r) * 17 + (l & 15)] = acc[r];
   }
   __syncthreads();
-  {
+  if (t < 256) {
     const int o = (t >> 4) * 17 + (t & 15);
     const double sum = ((part[o] + part[16 * 17 + o]) + part[2 * 16 * 17 + o]) + part[3 * 16 * 17 + o];
     C[(int64_t)(t >> 4) * P.lda + (t & 15)] = cv - sum;
@@ -1485,9 +1484,9 @@ static int sweep_fused(elfihip_gp* gp, int nb, hipStream_t st, bool chained) {
     P.W11 = W11buf[k & 1];
     const int nrows = (nb - 1 - k) + 1 + k;  // below + y block + L^-T rows above
     const int m = nb - 1 - k;
-    const bool merged = !chained && m > 0 && gp->schedule != 4;
+    const bool merged = !chained && m > 0 && gp->schedule == 4;   // measured: no faster than the two launches (below)
     if (merged)   // panel solve + tile (k+1, k+1) in one launch; word 3 of the step's counter block counts the tile waves
-      hipLaunchKernelGGL(panel_look_kernel, dim3(LOOK_TILES + 8 * nrows), dim3(256), PANEL_LOOK_LDS, st, P,
+      hipLaunchKernelGGL(panel_look_kernel, dim3(LOOK_TILES + 4 * nrows), dim3(512), PANEL_LOOK_LDS, st, P,
                          reinterpret_cast<unsigned*>(gp->info) + 4 + 4 * k + 3, gp->info);
     else if (!chained || m == 0)
       hipLaunchKernelGGL(trsm16_kernel, dim3(8 * nrows), dim3(256), 0, st, P);

@@ -846,9 +846,9 @@ int elfihip_reject_push_dev(elfihip_reject* h, const double* dD, int64_t n, int6
 int elfihip_reject_push_kept(elfihip_reject* h, uint64_t epoch, int64_t row_base) {
   if (!h) return fail(nullptr, ELFIHIP_ERR_ARG, "state is NULL");
   elfihip_ctx* ctx = h->ctx;
-  if (epoch != ctx->keep_epoch || (ctx->keep_n > 0 && !ctx->keep.p))
-    return fail(ctx, ELFIHIP_ERR_STATE, "the kept distances are those of a later call (epoch %llu, asked for %llu)",
-                (unsigned long long)ctx->keep_epoch, (unsigned long long)epoch);
+  if (epoch != ctx->keep_epoch || !ctx->keep_valid || (ctx->keep_n > 0 && !ctx->keep.p))
+    return fail(ctx, ELFIHIP_ERR_STATE, "no kept distances under that name: a later call replaced them, or no copy could "
+                "be kept (epoch %llu, asked for %llu)", (unsigned long long)ctx->keep_epoch, (unsigned long long)epoch);
   const int64_t n = ctx->keep_n;
   const int K = ctx->keep_cols;
   ELFIHIP_REQUIRE(ctx, K >= 1 && K <= REJ_ACC_COLS, "ncols = %d outside [1, %d]", K, REJ_ACC_COLS);

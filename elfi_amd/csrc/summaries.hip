@@ -385,7 +385,7 @@ static int ma2_host(elfihip_ctx* ctx, const double* W, uint64_t seed, uint64_t s
                     const double* t2, double obs1, double obs2, double* S1, double* S2, double* D) {
   ELFIHIP_REQUIRE(ctx, n >= 0 && n_obs >= 3, "bad shape n=%lld n_obs=%d", (long long)n, n_obs);
   ELFIHIP_REQUIRE(ctx, n == 0 || (t1 && t2 && S1 && S2 && D), "NULL data pointer");
-  if (n == 0) return ELFIHIP_OK;
+  if (n == 0) return keep_distances(ctx, nullptr, 0, 1);   // an empty batch is still a call: the kept copy's name moves on
   DeviceGuard g(ctx->device);
   const int L = n_obs + 2;
   const size_t nw = W ? (size_t)n * L : 0;

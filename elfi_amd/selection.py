@@ -138,6 +138,8 @@ class RunningBest:
         `d` is the very array a distance call on this context just returned, the device copy that call left is folded
         in instead (no upload: include/elfihip.h, elfihip_reject_push_kept)."""
         epoch = _lib.kept_epoch_of(d, self.ctx)
+        if epoch is not None and self.ctx.kept_shape() != (epoch, len(d), 1 if np.ndim(d) == 1 else np.shape(d)[1]):
+            epoch = None        # the device copy is not (or no longer) this array's: upload it
         if epoch is not None:
             base = self.n_pushed if row_base is None else int(row_base)
             rc = self.lib.elfihip_reject_push_kept(self.h, epoch, base)

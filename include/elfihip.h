@@ -395,7 +395,8 @@ int elfihip_gp_jitchol(elfihip_gp* gp, int maxtries, double* jitter, int* tries)
  * 2 = fused steps on the caller's stream (panel solve, diagonal tile, then ONE launch with the next diagonal block
  * beside the trailing update: three launches per block column), 3 = the same chained by arrival counters inside ONE
  * launch per block column (kept for measurement: the in-launch hand-offs cost more than the two launches they replace;
- * needs all of the launch's workgroups resident, i.e. the device to itself);
+ * needs all of the launch's workgroups resident, i.e. the device to itself), 4 = fused steps with the panel solve and the
+ * diagonal tile in ONE launch (two launches per block column; bit-identical to 2, and no faster: kept for measurement);
  * panel_group 0 = by size, else 1 / 2 / 4 panels per pass over the trailing matrix (schedule 1).  Results agree to
  * rounding between schedules; each is deterministic. */
 int elfihip_gp_set_schedule(elfihip_gp* gp, int schedule, int panel_group);

@@ -21,12 +21,17 @@ for n, d in shapes:
     gp.set_data(X, y)
     flops = 2.0 * n * n * d + 2.0 * n ** 3 / 3.0
     ref = None
-    for name, sched, group in (("streams (auto group)", 1, 0), ("fused steps", 2, 0), ("fused steps, chained", 3, 0)):
+    for name, sched, group in (("streams (auto group)", 1, 0), ("fused steps (3 launches)", 2, 0),
+                               ("fused steps, 2 launches", 4, 0), ("fused steps, chained", 3, 0)):
         gp.set_schedule(sched, group)
         lz = gp.factorize()
         if ref is None:
             ref = lz
         assert abs(lz - ref) <= 1e-9 * abs(ref), (name, lz, ref)
+        if sched == 4:
+            assert lz == lz2, "the two-launch step must give the three-launch step's log Z bit for bit"
+        if sched == 2:
+            lz2 = lz
         reps = 10 if n <= 4096 else 4
         best = 1e9
         for _ in range(3):
@@ -34,5 +39,5 @@ for n, d in shapes:
             for _ in range(reps):
                 gp.factorize()
             best = min(best, (time.perf_counter() - t0) / reps)
-        print("%8d %4d | %-22s | %8.3f %8.1f" % (n, d, name, best * 1e3, flops / best / 1e12), flush=True)
+        print("%8d %4d | %-24s | %8.3f %8.1f" % (n, d, name, best * 1e3, flops / best / 1e12), flush=True)
     gp.close()

@@ -372,7 +372,8 @@ def _fit_with_schedule(X, y, h, schedule, group=0):
 @pytest.mark.parametrize('n,d,schedule,group', [
     (100, 2, 1, 0), (100, 2, 2, 0), (129, 3, 1, 0), (129, 3, 2, 0), (700, 5, 1, 2), (700, 5, 2, 0),
     (1500, 10, 1, 4), (1500, 10, 2, 0), (2500, 4, 1, 0), (2500, 4, 2, 0),
-    (100, 2, 3, 0), (129, 3, 3, 0), (700, 5, 3, 0), (2500, 4, 3, 0)])
+    (100, 2, 3, 0), (129, 3, 3, 0), (700, 5, 3, 0), (2500, 4, 3, 0),
+    (129, 3, 4, 0), (700, 5, 4, 0), (2500, 4, 4, 0)])   # 4: panel solve + diagonal tile in one launch (round 5)
 def test_both_sweep_schedules_vs_oracle(hip_ctx, n, d, schedule, group):
     X, y, bounds, h, post = _oracle_for(n, d)
     gp, logz = _fit_with_schedule(X, y, h, schedule, group)
@@ -380,6 +381,9 @@ def test_both_sweep_schedules_vs_oracle(hip_ctx, n, d, schedule, group):
     _close(gp.get(0), post.L, 1e-10, 'L')
     _close(gp.get(1), post.Linv.T, 1e-9, 'L^-T')
     _close(gp.get(2), post.alpha, 1e-8, 'alpha')
+    if schedule == 4:    # the merged launch repeats the three-launch step's arithmetic: the same factor, bit for bit
+        gp2, logz2 = _fit_with_schedule(X, y, h, 2, 0)
+        assert logz2 == logz and np.array_equal(gp2.get(0), gp.get(0)) and np.array_equal(gp2.get(1), gp.get(1))
 
 
 @pytest.mark.parametrize('n,d,schedule', [
