@@ -110,8 +110,8 @@ def run(n=4096, d=10, S=10, iters=50, warm=3):
     GPyRegression.update does), 'incremental' = bordering (elfihip_gp_extend), the product default
     between hyper-parameter changes.  The headline `value` is the refactor mode: it is the
     like-for-like of the reference's per-iteration work and the one with an MFMA roofline."""
-    from .gp import HipGPRegression
-    from .lcb_acquisition import HipLCBSC
+    from elfi_amd.gp import HipGPRegression
+    from elfi_amd.lcb_acquisition import HipLCBSC
     X, y, bounds = problem(n, d)
     names = ['t%d' % i for i in range(d)]
     n0 = n - (iters + warm)
@@ -120,19 +120,18 @@ def run(n=4096, d=10, S=10, iters=50, warm=3):
         gp = HipGPRegression(names, bounds=dict(zip(names, bounds)))
         gp.incremental_limit = 0 if mode == 'refactor' else 64
         gp.update(X[:n0], y[:n0])
-        gp._hyper = heuristic_hyper(bounds, y)
-        gp._refit()
+        gp.fix_hyperparameters(**heuristic_hyper(bounds, y))
         acq = HipLCBSC(gp, n_inits=S, exploration_rate=10, seed=2)
         res[mode] = _loop(gp, acq, X, y, n0, iters, warm)
         if mode == 'refactor':
             # a second, short pass with the library's phase timers on (events cost a little, so not in the timed loop)
-            gp._handle.profile(1)
+            gp.device_handle.profile(1)
             for i in range(6):
-                gp._refit()
+                gp.refit()
                 acq.acquire(1, t=n0 + i)
-            gp._handle.nlml_grad()
-            gp._handle.nlml_grad()
-            phases = _phase_rooflines(gp._handle.profile(0), gp.n_evidence, d)
+            gp.device_handle.nlml_grad()
+            gp.device_handle.nlml_grad()
+            phases = _phase_rooflines(gp.device_handle.profile(0), gp.n_evidence, d)
         del gp, acq
     fit, ac, E, steps = res['refactor']
     it_s = 1.0 / (fit + ac)
@@ -177,7 +176,7 @@ def lockstep_leg(n=4096, d=10, S=10, reps=300):
     """One acquisition lock-step (value and gradient of the LCB at S points; host wall per elfihip_gp_lcb call, us): the
     two triangular products (four launches -- what a GP that is refactorised for every acquisition runs) against ONE
     product with K^-1 (three launches -- what a GP that is extended point by point switches to after 64 lock-steps)."""
-    from .gp import GPHandle
+    from elfi_amd.gp import GPHandle
     X, y, bounds = problem(n, d)
     h = heuristic_hyper(bounds, y)
     gp = GPHandle(d, n)
@@ -204,17 +203,16 @@ def cfg5_leg(n=8192, d=20, S=256, refit_every=64, reps=3):
     deals them round-robin, 32 per rank, lcb_acquisition.py), the GP refit every 64 acquisitions.  Reported: one rebuild,
     one acquisition with all 256 starts (16 lock-step passes of 16 columns per evaluation round), and the amortised
     iteration (acquisition + rebuild / 64) -- between refits a new evidence point costs one bordering update."""
-    from .gp import HipGPRegression
-    from .lcb_acquisition import HipLCBSC
+    from elfi_amd.gp import HipGPRegression
+    from elfi_amd.lcb_acquisition import HipLCBSC
     X, y, bounds = problem(n, d)
     names = ['t%d' % i for i in range(d)]
     gp = HipGPRegression(names, bounds=dict(zip(names, bounds)))
     gp.update(X, y)
-    gp._hyper = heuristic_hyper(bounds, y)
-    gp._refit()
+    gp.fix_hyperparameters(**heuristic_hyper(bounds, y))
     t0 = time.perf_counter()
     for _ in range(reps):
-        gp._refit()
+        gp.refit()
     t_fit = (time.perf_counter() - t0) / reps
     acq = HipLCBSC(gp, n_inits=S, exploration_rate=10, seed=3)
     acq.acquire(1, t=n)
@@ -242,7 +240,7 @@ def cfg5_leg(n=8192, d=20, S=256, refit_every=64, reps=3):
 def fit_only(n, d, reps=3):
     """GP rebuild alone at a larger shape (configs[4]: n_evidence = 8192, d = 20), where the trailing
     update dominates the sweep: executed flops 2 n^2 d + 2 n^3 / 3 against the FP64-matrix peak."""
-    from .gp import GPHandle
+    from elfi_amd.gp import GPHandle
     X, y, bounds = problem(n, d)
     h = heuristic_hyper(bounds, y)
     gp = GPHandle(d, n)

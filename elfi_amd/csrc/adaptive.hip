@@ -415,6 +415,288 @@ __global__ __launch_bounds__(ADA_T, ADA_OCC) void adaptive_pass_kernel(AdaptArgs
   if (P.acc && (tid & 63) == 0 && nacc) atomicAdd(P.acc_count, nacc);
 }
 
+static bool ada_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ---- the same pass with the rows brought in by LDS-DMA (round 5; m = 16 / 32 / 64, K <= ADA_DMA_KMAX) ----------------------
+// NOT the default (elfihip_dist_set_form(ctx, 2) selects it; kept for measurement): 10^7 x 64, K = 3 takes 1.35 ms here
+// against 1.10 ms for adaptive_pass_kernel (profiles/r05_adaptive_dma.md).  The row stream itself is the faster one (the
+// distance-only kernel: 0.79 against 0.68 of 8 TB/s), but a one-wave workgroup does everything a slot needs one thing after
+// the other -- the K-column sweep of its rows 0.70 ms, the column statistics (read back from LDS, where the register-staged
+// kernel takes them from its staging registers for nothing) 0.37 ms, the distances' stores 0.28 ms (vmcnt counts stores and
+// DMA pieces together: the counted wait that frees the next slot also waits for the write acknowledgements) -- and four
+// waves per CU cannot hide 1.35 ms of it behind 0.85 ms of memory time.
+// The row stream of dist_rows_dma_kernel (distance.hip / tile_stream.hpp): one-wave workgroups, each with a ring of slots
+// filled by `global_load_lds_dwordx4 ... nt`, no workgroup barrier, four workgroups per CU.  What changes against
+// adaptive_pass_kernel, whose tile passes through registers:
+//   * lane r owns row r of a slot and forms ALL K nested distances in ONE sweep over the row: d = x - y and d^2 once per
+//     element, K independent left-to-right sums s_k = s_k + w_kj d^2 (each in cdist's order: bit-identical distances), the
+//     observed row and the weight rows as broadcast LDS reads;
+//   * the column statistics are read back from LDS: lane (g, c) owns column c of the rows g, g + G, ... of the slot
+//     (G = 64 / m row groups), takes the textbook two-pass sums of its CH = ROWS / G values in registers and folds them into
+//     its running triple with Chan's update; the G triples of a column meet in LDS at the end; one (1 + 2m) partial per
+//     workgroup for adaptive_finish_kernel, as before.  A column walk touches every word of a row once (the swizzle
+//     permutes 16-byte granules inside the row): conflict-free.
+constexpr int ADA_DMA_KMAX = 8;
+
+// One sweep over a row for KN weight vectors, eight 16-byte granules (16 elements) at a time: ALL LDS reads of a chunk --
+// the row's granules, the observed pairs, the KN weight pairs -- are issued before the first of them is waited for (a
+// scheduling barrier keeps the compiler from interleaving them with the arithmetic: left alone it read two or three operands,
+// waited, computed, and a slot of 32 x 64 cost 11 500 cycles of exposed LDS latency -- 1.46 ms per 10^7 x 64, K = 3).  A
+// one-wave workgroup has the SIMD's registers to itself, so the 8 (2 + KN) pairs of a chunk live in registers.
+template <int MM, int KN>
+__device__ __forceinline__ void dma_row_sums(const double* row, int key, const double* ys, const double* wk, double (&s)[KN]) {
+  constexpr int H = MM / 2;
+  constexpr int CG = 8;
+  static_assert(H % CG == 0, "whole chunks");
+#pragma unroll
+  for (int k = 0; k < KN; ++k) s[k] = 0.0;
+#pragma unroll
+  for (int c0 = 0; c0 < H; c0 += CG) {
+    double2 v[CG], yv[CG], wv[KN][CG];
+#pragma unroll
+    for (int i = 0; i < CG; ++i) v[i] = *reinterpret_cast<const double2*>(row + 2 * ((c0 + i) ^ key));
+#pragma unroll
+    for (int i = 0; i < CG; ++i) yv[i] = *reinterpret_cast<const double2*>(ys + 2 * (c0 + i));
+#pragma unroll
+    for (int k = 0; k < KN; ++k)
+#pragma unroll
+      for (int i = 0; i < CG; ++i) wv[k][i] = *reinterpret_cast<const double2*>(wk + k * MM + 2 * (c0 + i));
+    __builtin_amdgcn_sched_barrier(0);
+    double q[2 * CG];
+#pragma unroll
+    for (int i = 0; i < CG; ++i) {
+      const double d0 = v[i].x - yv[i].x, d1 = v[i].y - yv[i].y;
+      q[2 * i] = d0 * d0;
+      q[2 * i + 1] = d1 * d1;
+    }
+#pragma unroll
+    for (int i = 0; i < CG; ++i)
+#pragma unroll
+      for (int k = 0; k < KN; ++k) {
+        s[k] = s[k] + wv[k][i].x * q[2 * i];
+        s[k] = s[k] + wv[k][i].y * q[2 * i + 1];
+      }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// KNMAX sums at most per lane and sweep; kn of them in use
+template <int MM>
+__device__ __forceinline__ void dma_row_sweep(const double* row, int key, const double* ys, const double* wk, int kn,
+                                              double (&r)[4]) {
+  if (kn == 4) {
+    double s4[4];
+    dma_row_sums<MM, 4>(row, key, ys, wk, s4);
+    r[0] = sqrt(s4[0]), r[1] = sqrt(s4[1]), r[2] = sqrt(s4[2]), r[3] = sqrt(s4[3]);
+  } else if (kn == 3) {
+    double s3[3];
+    dma_row_sums<MM, 3>(row, key, ys, wk, s3);
+    r[0] = sqrt(s3[0]), r[1] = sqrt(s3[1]), r[2] = sqrt(s3[2]);
+  } else if (kn == 2) {
+    double s2[2];
+    dma_row_sums<MM, 2>(row, key, ys, wk, s2);
+    r[0] = sqrt(s2[0]), r[1] = sqrt(s2[1]);
+  } else if (kn == 1) {
+    double s1[1];
+    dma_row_sums<MM, 1>(row, key, ys, wk, s1);
+    r[0] = sqrt(s1[0]);
+  }
+}
+
+template <int MM, int ROWS, int D>
+__global__ __launch_bounds__(64) void adaptive_dma_kernel(AdaptArgs P) {
+  extern __shared__ __align__(16) double lds[];
+  constexpr int SLOT = ROWS * MM;                // doubles
+  constexpr int H = MM / 2;
+  constexpr int PIECES = ROWS * H / 64;
+  constexpr int G = 64 / MM;                     // row groups of the column statistics
+  constexpr int CH = ROWS / G;                   // rows per lane and slot there (a power of two)
+  constexpr int HALVES = 64 / ROWS;              // lanes per row in the distance sweep: 2 at 32-row slots (m = 64)
+  const RowArgs& A = P.A;
+  const int lane = threadIdx.x, K = A.K;
+  double* ring = lds;
+  double* ys = lds + (size_t)D * SLOT;           // (MM)
+  double* ws = ys + MM;                          // (K, MM)
+  double* accs = ws + (size_t)K * MM;            // (K)
+  double* ostage = accs + ((K + 1) & ~1);        // (ROWS, K): a slot's distances on their way to coalesced stores
+  const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)ring);
+  if (lane < MM) ys[lane] = A.y[lane];
+  for (int j = lane; j < K * MM; j += 64) ws[j] = A.aux[j];
+  if (P.acc)
+    for (int j = lane; j < K; j += 64) accs[j] = P.acc[j];
+  const int64_t nslots = (A.n + ROWS - 1) / ROWS;
+  const int64_t stride = gridDim.x;
+  const double inf = __longlong_as_double(0x7ff0000000000000ll);
+  const double thr = A.F.thr ? *A.F.thr : inf;
+  const bool stats = P.partial != nullptr;
+  unsigned off[PIECES];
+#pragma unroll
+  for (int i = 0; i < PIECES; ++i) {
+    const int Gi = i * 64 + lane;
+    const int row = Gi / H, g = Gi % H;
+    off[i] = (unsigned)(((int64_t)row * A.ldx + 2 * (g ^ dma_swizzle_key<MM>(row))) * 8);
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  int64_t t = blockIdx.x;
+#pragma unroll
+  for (int k = 0; k < D - 1; ++k) {
+    const int64_t tk = t + k * stride;
+    if (tk < nslots) dma_issue_slot<MM, ROWS>(A, off, tk * ROWS, lds_base + (unsigned)(k * SLOT * 8), lane);
+  }
+  // the distance sweep: lane = (half, row); with two lanes per row (32-row slots) the K columns are split between them --
+  // the first ceil(K / 2) to half 0, the rest (the LAST column among them) to half 1 -- so each sweeps the row once for its
+  // own columns and every sum keeps cdist's order
+  const int rrow = lane % ROWS, half = lane / ROWS;
+  const int ka = HALVES == 2 ? (K + 1) / 2 : K;          // columns per half: half 0 takes [0, ka), half 1 [ka, K) -- and, so
+  const int kbeg = half == 0 ? 0 : ka;                   // that both halves run the SAME sweep (lanes of one wave), half 1
+  const int kend = half == 0 ? ka : K;                   // repeats its last column when K is odd (clamped below, not stored)
+  // statistics: lane (sg, sc) = rows sg, sg + G, ... and column sc of every slot
+  const int sg = lane / MM, sc = lane % MM;
+  ColStat st = {0.0, 0.0, 0.0};
+  unsigned long long nacc = 0;
+  int cur = 0;
+  int64_t pend_row0 = 0;
+  int pend_rows = 0, pend_buf = 0, obuf = 0;
+  // (rows, K) doubles of a slot are contiguous in the output: 16-byte stores from the staging buffer
+  auto flush_out = [&](int64_t row0_, int rows_, int buf) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    const double* src = ostage + (size_t)buf * ROWS * K;
+    const int total = rows_ * K;                     // doubles
+    double* dst = A.out + row0_ * K;
+    if ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0) {
+      for (int e = 2 * lane; e < total; e += 128) {
+        if (e + 1 < total)
+          *reinterpret_cast<double2*>(dst + e) = *reinterpret_cast<const double2*>(src + e);
+        else
+          dst[e] = src[e];
+      }
+    } else {
+      for (int e = lane; e < total; e += 64) dst[e] = src[e];
+    }
+  };
+  for (; t < nslots; t += stride) {
+    const int64_t tn = t + (int64_t)(D - 1) * stride;
+    int nxt = cur + D - 1;
+    if (nxt >= D) nxt -= D;
+    if (tn < nslots) {
+      dma_issue_slot<MM, ROWS>(A, off, tn * ROWS, lds_base + (unsigned)(nxt * SLOT * 8), lane);
+      wait_vmcnt<PIECES * (D - 1)>();
+    } else {
+      wait_vmcnt<0>();
+    }
+    // the previous slot's distances leave now: their stores are the oldest operations in flight at the NEXT counted wait,
+    // a whole trip away (issued at the end of their own trip they sat between two DMA batches, and the wait that frees the
+    // next slot had to wait for their write acknowledgements as well: 0.25 ms of 1.2 per 10^7 x 64 rows)
+    if (A.out && pend_rows > 0) flush_out(pend_row0, pend_rows, pend_buf);
+    const int64_t row0 = t * ROWS;
+    const int rows = (int)((A.n - row0) < ROWS ? (A.n - row0) : ROWS);
+    const double* slot = ring + (size_t)cur * SLOT;
+    double* ost = ostage + (size_t)obuf * ROWS * K;
+    // ---- the K nested distances of this lane's row (its share of the columns), acceptance
+    bool ok = rrow < rows;
+    double dlast = 0.0;
+    {
+      const double* row = slot + (size_t)rrow * MM;
+      const int key = dma_swizzle_key<MM>(rrow);
+      for (int j0 = 0; j0 < ka; j0 += 4) {               // wave-uniform trip count and kn
+        const int kn = ka - j0 < 4 ? ka - j0 : 4;
+        int k0 = kbeg + j0;
+        if (k0 + kn > K) k0 = K - kn;                      // half 1, odd K: the sweep slides back over a column it has done
+        if (k0 < 0) k0 = 0;                                // (K = 1: half 1 repeats half 0's only column, nothing is kept)
+        double r[4];
+        dma_row_sweep<MM>(row, key, ys, ws + (size_t)k0 * MM, kn, r);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (k < kn && k0 + k >= kbeg && k0 + k < kend) {
+            if (A.out) ost[rrow * K + k0 + k] = r[k];
+            if (P.acc) ok = ok && r[k] <= accs[k0 + k];   // samplers.py:219-225 (a NaN distance is not accepted)
+            dlast = r[k];
+          }
+      }
+    }
+    if constexpr (HALVES == 2) {
+      // the row's verdict is the AND of its two lanes'; the last column lives in half 1 (half 0 when K = 1)
+      const int other = __shfl_xor((int)ok, 32, 64);
+      ok = ok && other != 0;
+      if (K == 1) {
+        ok = ok && half == 0;
+      } else {
+        ok = ok && half == 1;     // one lane per row counts and offers: the one that holds column K - 1
+      }
+    }
+    if (P.acc) nacc += (unsigned long long)__popcll(__ballot(ok));
+    if (A.F.thr) reject_offer(A.F, ok && dlast < thr, dlast, A.F.row_base + row0 + rrow);
+    pend_row0 = row0;
+    pend_rows = rows;
+    pend_buf = obuf;
+    obuf ^= 1;
+    // ---- column statistics of the slot
+    if (stats) {
+      const unsigned char* base = reinterpret_cast<const unsigned char*>(slot);
+      if (rows == ROWS) {
+        double x[CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+          const int r_ = sg + i * G;
+          x[i] = *reinterpret_cast<const double*>(base + (size_t)r_ * (MM * 8) + (((sc >> 1) ^ dma_swizzle_key<MM>(r_)) << 4) +
+                                                  ((sc & 1) << 3));
+        }
+        double mean, q;
+        chunk_stats<CH>(x, mean, q);
+        chan_merge(st, (double)CH, mean, q);
+      } else {
+        int cnt = 0;
+        double sum = 0.0;
+        for (int r_ = sg; r_ < rows; r_ += G) {
+          sum += *reinterpret_cast<const double*>(base + (size_t)r_ * (MM * 8) + (((sc >> 1) ^ dma_swizzle_key<MM>(r_)) << 4) +
+                                                  ((sc & 1) << 3));
+          ++cnt;
+        }
+        if (cnt > 0) {
+          const double mt = sum / (double)cnt;
+          double q = 0.0;
+          for (int r_ = sg; r_ < rows; r_ += G) {
+            const double e = *reinterpret_cast<const double*>(base + (size_t)r_ * (MM * 8) +
+                                                               (((sc >> 1) ^ dma_swizzle_key<MM>(r_)) << 4) + ((sc & 1) << 3)) - mt;
+            q += e * e;
+          }
+          chan_merge(st, (double)cnt, mt, q);
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slot's reads are done before it is refilled
+    cur = cur + 1 == D ? 0 : cur + 1;
+  }
+  if (A.out && pend_rows > 0) flush_out(pend_row0, pend_rows, pend_buf);
+  if (stats) {
+    // the G row groups of a column, merged in order; the ring is free (nothing is in flight after the last trip)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    double* red = ring;
+    double* e0 = red + 3 * ((size_t)sg * MM + sc);
+    e0[0] = st.n, e0[1] = st.mean, e0[2] = st.M2;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < MM) {
+      ColStat a = {0.0, 0.0, 0.0};
+      for (int g2 = 0; g2 < G; ++g2) {
+        const double* e = red + 3 * ((size_t)g2 * MM + lane);
+        chan_merge(a, e[0], e[1], e[2]);
+      }
+      double* o = P.partial + (size_t)blockIdx.x * (1 + 2 * MM);
+      if (lane == 0) o[0] = a.n;
+      o[1 + lane] = a.mean;
+      o[1 + MM + lane] = a.M2;
+    }
+  }
+  if (P.acc && lane == 0 && nacc) atomicAdd(P.acc_count, nacc);
+}
+
+bool adaptive_dma_supported(const elfihip_ctx* ctx, const double* dX, int m, int64_t ldx, int K) {
+  return ctx->dist_form == 2 && (m == 16 || m == 32 || m == 64) && K >= 1 && K <= ADA_DMA_KMAX && !(ldx & 1) &&
+         ldx <= (1 << 21) && ada_aligned16(dX);
+}
+
 // One workgroup per column: the `nparts` workgroup partials of the pass(es) -> the batch's (count, mean, M2) in `bst`
 // (1 + 2m).  Thread j merges partials j, j + 256, ... in that order, then the 256 triples are merged by a fixed tree.
 __global__ __launch_bounds__(256) void adaptive_finish_kernel(const double* partial, int nparts, int m, double* bst) {
@@ -459,8 +741,6 @@ __global__ void adaptive_fold_kernel(double* state, const double* bst, int m) {
     if (c == 0) state[0] = a.n;
   }
 }
-
-static bool ada_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 static size_t ada_lds_bytes(int m, int K, int R) {
   const int mp = m | 1;
@@ -510,6 +790,26 @@ int adaptive_pass_impl(elfihip_ctx* ctx, const double* dX, int64_t n, int m, int
   P.acc = dacc;
   P.acc_count = dacc_count;
   P.partial = partial;
+  if (adaptive_dma_supported(ctx, dX, m, ldx, K)) {
+    // LDS-DMA form: rings of two 16 KiB slots (four 8 KiB slots at m = 16) per one-wave workgroup, four workgroups per CU
+    const int rows = m == 64 ? 32 : 64;
+    const int D = m == 16 ? 4 : 2;
+    const size_t ldsd = ((size_t)D * rows * m + (size_t)(1 + K) * m + (size_t)((K + 1) & ~1) + 2 * (size_t)rows * K + 2) * sizeof(double);
+    int per_cu = (int)((160 * 1024) / ldsd);
+    if (per_cu > 4) per_cu = 4;
+    int64_t gd = (int64_t)ctx->cu_count * per_cu;
+    const int64_t nslots = (n + rows - 1) / rows;
+    if (gd > nslots) gd = nslots;
+    if (gd < 1) gd = 1;
+    if (m == 16)
+      hipLaunchKernelGGL((adaptive_dma_kernel<16, 64, 4>), dim3((unsigned)gd), dim3(64), ldsd, ctx->stream, P);
+    else if (m == 32)
+      hipLaunchKernelGGL((adaptive_dma_kernel<32, 64, 2>), dim3((unsigned)gd), dim3(64), ldsd, ctx->stream, P);
+    else
+      hipLaunchKernelGGL((adaptive_dma_kernel<64, 32, 2>), dim3((unsigned)gd), dim3(64), ldsd, ctx->stream, P);
+    if (nparts && partial) *nparts = (int)gd;
+    return launch_status(ctx, "adaptive_dma_kernel");
+  }
   const size_t lds = ada_lds_bytes(m, K, A.R);
   const int64_t ntiles = (n + A.R - 1) / A.R;
   int per_cu = (int)((160 * 1024) / lds);

@@ -151,7 +151,8 @@ int elfihip_ctx_set_stream(elfihip_ctx* ctx, void* hip_stream) {
 
 int elfihip_dist_set_form(elfihip_ctx* ctx, int form) {
   if (!ctx) return fail(nullptr, ELFIHIP_ERR_ARG, "ctx is NULL");
-  ELFIHIP_REQUIRE(ctx, form == 0 || form == 1, "form %d is neither 0 (LDS-DMA row stream) nor 1 (register-staged pipeline)", form);
+  ELFIHIP_REQUIRE(ctx, form >= 0 && form <= 2, "form %d outside {0: LDS-DMA row stream for the distance kernels, 1: register-staged "
+                  "pipelines, 2: LDS-DMA also for the fused adaptive pass}", form);
   ctx->dist_form = form;
   return ELFIHIP_OK;
 }

@@ -177,6 +177,73 @@ __device__ __forceinline__ void tile_commit(const RowArgs& A, double* tile, int 
 }
 
 
+#if defined(__HIPCC__)
+// ---- LDS-DMA streaming of row slots (round 5; used by distance.hip and adaptive.hip) ----------------------------------------
+// A slot is ROWS rows of MM doubles = ROWS * MM / 128 DMA pieces of 1 KiB (64 lanes x 16 bytes); its LDS image is
+// lane-linear with the 16-byte granules of a row XOR-swizzled on the SOURCE address and again on the read (see
+// dist_rows_dma_kernel in distance.hip for the design and the measurements).
+template <bool NT>
+__device__ __forceinline__ void dma16_to_lds(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;   // M0 carries the LDS destination of the DMA; the compiler owns M0, so save / restore in one statement
+  if constexpr (NT)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+  else
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
+}
+// granule swizzle: rows at pitch MM doubles; RP rows share one 256-byte bank sweep, the key changes every RP rows
+template <int MM>
+__device__ __forceinline__ int dma_swizzle_key(int row) {
+  constexpr int H = MM / 2;                      // 16-byte granules per row
+  constexpr int RP = H >= 16 ? 1 : 16 / H;
+  constexpr int MASK = (H >= 16 ? 16 : H) - 1;
+  return (row / RP) & MASK;
+}
+// ... with the source given as a wave-uniform base (SGPR pair) + a per-lane 32-bit byte offset: the offsets of a slot's pieces
+// are the same for every slot, so a slot costs five scalar instructions per piece and no vector arithmetic (with per-lane
+// 64-bit addresses -- a multiply by the row pitch and a clamp per piece -- address generation was a third of a wave's time
+// and the kernel, at two waves per CU, was bound by it: 47-53 us in the library against 41 us for the probe's constant pitch)
+template <bool NT>
+__device__ __forceinline__ void dma16_to_lds_off(const void* base, unsigned voff, unsigned lds_dst) {
+  unsigned keep;
+  if constexpr (NT)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_dst) : "memory");
+  else
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_dst) : "memory");
+}
+template <int MM, int ROWS>
+__device__ __forceinline__ void dma_issue_slot(const RowArgs& A, const unsigned (&off)[ROWS * (MM / 2) / 64], int64_t row0,
+                                               unsigned lds_slot, int lane) {
+  constexpr int H = MM / 2;
+  constexpr int PIECES = ROWS * H / 64;
+  if (row0 + ROWS <= A.n) {
+    const uint64_t p = (uint64_t)(A.X + row0 * A.ldx);   // wave-uniform: make the compiler keep it in SGPRs
+    const uint64_t b = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)p) |
+                       ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(p >> 32)) << 32);
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) dma16_to_lds_off<true>((const void*)b, off[i], lds_slot + (unsigned)i * 1024u);
+  } else {
+    // the ragged last slot: rows beyond n read row n - 1 (a valid address), their results are discarded
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) {
+      const int G = i * 64 + lane;
+      const int row = G / H, g = G % H;
+      int64_t gr = row0 + row;
+      if (gr >= A.n) gr = A.n - 1;
+      dma16_to_lds<true>(A.X + gr * A.ldx + 2 * (g ^ dma_swizzle_key<MM>(row)), lds_slot + (unsigned)i * 1024u);
+    }
+  }
+}
+
+#endif
+
 static inline bool tile_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 }  // namespace elfihip

@@ -550,6 +550,40 @@ class HipGPRegression:
         self._X = self._Xbuf[:n + k]
         self._Y = self._Ybuf[:n + k]
 
+    def fix_hyperparameters(self, var=None, ls=None, bias=None, noise=None, **hyper):
+        """Set hyper-parameters by hand (signal variance, lengthscale, bias variance, noise variance; unnamed ones keep
+        their values) and rebuild the GP with them -- what `m._gp.rbf.variance = v` etc. followed by a refit do on a
+        GPy model.  Until the next `optimize()` (an `update(..., optimize=True)` of the BOLFI loop) every update keeps
+        these values.  Returns the hyper-parameters in use."""
+        if self._gp is None:
+            raise RuntimeError('no evidence yet: hyper-parameters belong to a GP that exists (call update first)')
+        new = dict(self._hyper)
+        for k, v in dict(var=var, ls=ls, bias=bias, noise=noise, **hyper).items():
+            if v is None:
+                continue
+            if k not in new:
+                raise ValueError("unknown hyper-parameter %r (expected var, ls, bias, noise)" % (k,))
+            new[k] = float(v)
+        self._hyper = new
+        self._refit()
+        return dict(self._hyper)
+
+    @property
+    def device_handle(self):
+        """The GPHandle (C-ABI object: elfihip_gp) this model computes with -- phase timers, schedules, raw entry points."""
+        return self._handle
+
+    @property
+    def hyperparameters(self):
+        """dict(var, ls, bias, noise) in use (GPy: rbf.variance, rbf.lengthscale, bias.variance, Gaussian_noise.variance)."""
+        return None if self._gp is None else dict(self._hyper)
+
+    def refit(self):
+        """Rebuild the GP from all evidence with the current hyper-parameters (a full factorisation)."""
+        if self._gp is None:
+            raise RuntimeError('no evidence yet')
+        self._refit()
+
     def _refit(self):
         h = self._hyper
         self._handle.set_hyper(h['var'], h['ls'], h['bias'], h['noise'])

@@ -101,7 +101,9 @@ int elfihip_dist_rows_dev(elfihip_ctx* ctx, int metric, const double* dX, int64_
 
 /* How the row-major distance calls stream their matrix (no reference counterpart; results are bit-identical either way):
  * 0 (default) rows of 16 / 32 / 64 summaries with 16-byte aligned rows arrive in LDS by LDS-DMA (global_load_lds, rings
- * of four 16 KiB slots per wave, non-temporal) -- every other shape, and 1 always, takes the register-staged pipeline. */
+ * of two 16 KiB slots per wave, non-temporal) -- every other shape, and 1 always, takes the register-staged pipeline;
+ * 2 = as 0, and the fused adaptive-distance pass (elfihip_adaptive_push) streams the same way (measured slower than its
+ * register-staged form: kept for measurement). */
 int elfihip_dist_set_form(elfihip_ctx* ctx, int form);
 /* m separately stored summary columns of length n each (structure of arrays): the
  * form ELFI hands to distance_as_discrepancy BEFORE np.column_stack

@@ -86,5 +86,23 @@ class OracleGPRegression:
     def instance(self):
         return self._post
 
+    @property
+    def _gp(self):
+        """What the reference's ExpIntVar reaches for (acquisition.py:754,770): `model._gp.kern.K(X, X2)`, the PRIOR kernel
+        matrix [GPy-upstream: RBF + Bias]."""
+        post = self._post
+
+        class _Kern:
+            @staticmethod
+            def K(X, X2=None):
+                X = np.atleast_2d(np.asarray(X, float))
+                X2 = None if X2 is None else np.atleast_2d(np.asarray(X2, float))
+                return G.kern_K(X, X2, post.var, post.ls, post.bias)
+
+        class _Shim:
+            kern = _Kern
+
+        return _Shim
+
     def copy(self):
         return copy.deepcopy(self)

@@ -3,12 +3,13 @@ evaluation counts for the slowest call (developer tool)."""
 import sys, time
 sys.path.insert(0, '.'); sys.path.insert(0, 'oracle')
 import numpy as np
-from elfi_amd import bolfi_bench, HipGPRegression, HipLCBSC
+from elfi_amd import HipGPRegression, HipLCBSC
+from benchlib import bolfi_bench
 n, d, S = 4096, 10, 10
 X, y, bounds = bolfi_bench.problem(n, d)
 names = ['t%d' % i for i in range(d)]
 gp = HipGPRegression(names, bounds=dict(zip(names, bounds)))
-gp.update(X[:4090], y[:4090]); gp._hyper = bolfi_bench.heuristic_hyper(bounds, y); gp._refit()
+gp.update(X[:4090], y[:4090]); gp.fix_hyperparameters(**bolfi_bench.heuristic_hyper(bounds, y))
 acq = HipLCBSC(gp, n_inits=S, exploration_rate=10, seed=2)
 rows = []
 for t in range(4090, 4090 + 40):

@@ -1,5 +1,5 @@
 """Developer tool: the fused adaptive-distance pass alone (csrc/adaptive.hip), for rocprofv3 runs and timing sweeps.
-usage: python scripts/adaptive_once.py [n] [m] [K] [reps] [mode]     mode: fused | multiw | state"""
+usage: python scripts/adaptive_once.py [n] [m] [K] [reps] [mode]     mode: fused | nostats | noout | state | multiw | all"""
 import ctypes as C
 import os
 import sys
@@ -45,11 +45,16 @@ def one(i):
                  st.data_ptr(), 0)
 
 
-one(0)
-ctx.synchronize()
-ctx.timer_start()
-for i in range(reps):
-    one(i)
-ms = ctx.timer_stop() / reps
-by = (8.0 * m + 8.0 * K) * n
-print("%s n=%d m=%d K=%d: %.4f ms  %.0f GB/s  %.3f of 8 TB/s" % (mode, n, m, K, ms, by / ms / 1e6, by / ms / 1e6 / 8000))
+modes = ['fused', 'nostats', 'noout', 'state', 'multiw'] if mode == 'all' else [mode]
+for form in (2, 1):
+    ctx.call('elfihip_dist_set_form', form)
+    for mode in modes:
+        one(0)
+        ctx.synchronize()
+        ctx.timer_start()
+        for i in range(reps):
+            one(i)
+        ms = ctx.timer_stop() / reps
+        by = (8.0 * m + 8.0 * K) * n
+        print("form %d (%s) %s n=%d m=%d K=%d: %.4f ms  %.0f GB/s  %.3f of 8 TB/s" % (
+            form, 'LDS-DMA' if form == 2 else 'register stage', mode, n, m, K, ms, by / ms / 1e6, by / ms / 1e6 / 8000), flush=True)

@@ -6,7 +6,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
-from elfi_amd.bolfi_bench import problem, heuristic_hyper
+from benchlib.bolfi_bench import problem, heuristic_hyper
 from elfi_amd.gp import GPHandle
 
 n, d, S = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])

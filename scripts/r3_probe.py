@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'oracle'))
 import numpy as np
-from elfi_amd import bolfi_bench
+from benchlib import bolfi_bench
 from elfi_amd.gp import GPHandle
 
 what = sys.argv[1] if len(sys.argv) > 1 else 'all'

@@ -4,7 +4,7 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
-from elfi_amd.bolfi_bench import problem, heuristic_hyper
+from benchlib.bolfi_bench import problem, heuristic_hyper
 from elfi_amd.gp import GPHandle
 
 shapes = [(int(a.split(':')[0]), int(a.split(':')[1])) for a in sys.argv[1:]] or [(1024, 2), (2048, 10), (4096, 10), (8192, 20)]

@@ -7,7 +7,7 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
-from elfi_amd.bolfi_bench import problem, heuristic_hyper
+from benchlib.bolfi_bench import problem, heuristic_hyper
 from elfi_amd.gp import GPHandle
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096

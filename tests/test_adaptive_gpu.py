@@ -274,3 +274,35 @@ def test_device_simulator_rows_and_the_pass_on_the_kept_copy(hip_ctx):
     assert _lib.rows_epoch_of(X, hip_ctx) != _lib.rows_epoch_of(X2, hip_ctx)
     assert np.array_equal(elfi_amd.adaptive_batch(X, y, W)[0], d)             # stale copy: the array is uploaded instead
     assert np.array_equal(elfi_amd.adaptive_batch(X2, y, W)[0], _nested_ref(X2, y, W))
+
+
+@pytest.mark.parametrize('m,K', [(16, 1), (16, 8), (32, 3), (32, 7), (64, 1), (64, 3), (64, 8)])
+def test_lds_dma_form_of_the_pass(hip_ctx, m, K):
+    """The LDS-DMA form of the fused pass (csrc/adaptive.hip: adaptive_dma_kernel, elfihip_dist_set_form 2; 16 / 32 / 64
+    summaries and up to 8 weight vectors; measured slower, not the default) next to the register-staged form (1): the same nested distances
+    bit for bit (both equal to cdist), statistics inside the same a-priori bounds, the same selection -- on ragged sizes
+    around the slot (64 / 32 rows) and ring boundaries."""
+    import elfi_amd
+    rs = np.random.RandomState(100 * m + K)
+    y = rs.randn(1, m)
+    W = np.vstack([np.ones(m)] + [rs.uniform(0.01, 4, m) for _ in range(K - 1)])
+    try:
+        for n in (1, 31, 33, 64, 65, 129, 4099, 250007):
+            X = rs.randn(n, m) * rs.uniform(0.1, 100, m) + rs.uniform(-1000, 1000, m)
+            ref = _nested_ref(X, y, W)
+            out = {}
+            for form in (2, 1):
+                hip_ctx.call('elfihip_dist_set_form', form)
+                rb = elfi_amd.RunningBest(50)
+                d, store = elfi_amd.adaptive_batch(X, y, W, store=(0, 0.0, 0.0), state=rb)
+                assert np.array_equal(d, ref), (form, n)
+                if n > 1:
+                    _check_stats(store, X)
+                out[form] = (store, rb.result())
+            assert out[2][0][0] == out[1][0][0] == n
+            assert np.array_equal(out[2][1][0], out[1][1][0]) and np.array_equal(out[2][1][1], out[1][1][1])
+            if n > 1:     # two different summation trees of the same statistics: equal to rounding
+                np.testing.assert_allclose(out[2][0][1], out[1][0][1], rtol=1e-12, atol=1e-9)
+                np.testing.assert_allclose(out[2][0][2], out[1][0][2], rtol=1e-11)
+    finally:
+        hip_ctx.call('elfihip_dist_set_form', 0)

@@ -160,10 +160,10 @@ def test_hip_objects_pickle_without_device_state():
 
 
 def test_loop_timers_split_update_search_and_acquire():
-    """elfi_amd.loop_timing.instrument: wraps exactly the three calls the reference's BOLFI loop makes into the device
+    """benchlib.loop_timing.instrument: wraps exactly the three calls the reference's BOLFI loop makes into the device
     objects (bolfi.py:219,247: target_model.update(..., optimize) and acquisition_method.acquire) and takes itself out again."""
     import time
-    from elfi_amd.loop_timing import instrument
+    from benchlib.loop_timing import instrument
 
     class _GP:
         n_evidence = 0

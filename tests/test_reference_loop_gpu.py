@@ -169,7 +169,7 @@ def test_config2_bolfi_fit_4096_through_the_reference_loop(hip_ctx, elfi):
     """BASELINE.json configs[2] itself: elfi.BOLFI(log_d, batch_size=1, initial_evidence=512, update_interval=10,
     bounds, acq_noise_var=0.1, seed=1, target_model=HipGPRegression, acquisition_method=HipLCBSC).fit(4096) through the
     reference's loop (bolfi.py:201-254,289-292): 3584 acquisitions, a MAP search of the hyper-parameters every 10 of them."""
-    from elfi_amd.loop_timing import instrument
+    from benchlib.loop_timing import instrument
     n0, n1, interval = 512, 4096, 10
     hip = _bolfi(elfi, True, n0, interval)
     T = instrument(hip.target_model, hip.acquisition_method)
@@ -299,7 +299,7 @@ def test_config4_shape_bolfi_d20_through_the_reference_loop(hip_ctx, elfi):
     HipLCBSC(n_inits=256), update_interval=64 (bolfi.py:103-137,201-254), a shortened run that crosses four refits
     (initial_evidence=1792 -> fit(2048); the full 7936 -> 8192 runs in bench.py's cfg5_end_to_end leg, and here with
     ELFI_AMD_FULL_CFG5=1)."""
-    from elfi_amd.loop_timing import instrument
+    from benchlib.loop_timing import instrument
     full = os.environ.get('ELFI_AMD_FULL_CFG5') == '1'
     d, interval, n_inits = 20, 64, 256
     n0, n1 = (7936, 8192) if full else (1792, 2048)
