@@ -246,8 +246,17 @@ __global__ __launch_bounds__(ADA_T, ADA_OCC) void adaptive_pass_kernel(AdaptArgs
     if constexpr (POW2) {
       const double* __restrict__ src = A.X + row0 * A.ldx + soff;
       if (rows == R) {
+        if (A.nt) {
+          typedef double v2d_nt __attribute__((ext_vector_type(2)));
 #pragma unroll
-        for (int u = 0; u < U; ++u) v[u] = *reinterpret_cast<const double2*>(src + u * sstep);
+          for (int u = 0; u < U; ++u) {
+            const v2d_nt tv = __builtin_nontemporal_load(reinterpret_cast<const v2d_nt*>(src + u * sstep));
+            v[u] = make_double2(tv.x, tv.y);
+          }
+        } else {
+#pragma unroll
+          for (int u = 0; u < U; ++u) v[u] = *reinterpret_cast<const double2*>(src + u * sstep);
+        }
       } else {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -784,7 +793,7 @@ int adaptive_pass_impl(elfihip_ctx* ctx, const double* dX, int64_t n, int m, int
   A.K = K;
   A.vec2 = 1;
   A.R = ada_rows_per_tile(m);
-  A.nt = 0;
+  A.nt = ctx->dist_form != 1;   // the rows are read once
   A.div_h = make_fastdiv((uint32_t)(m / 2));
   A.F = F ? *F : RejectFilter{nullptr, nullptr, nullptr, nullptr, 0u, 0ll};
   P.acc = dacc;

@@ -471,7 +471,10 @@ struct ColArgs {
   double p, inv_p;
   int m;
   int vec2;
+  int nt;   // non-temporal loads of the columns (each element is read once)
 };
+
+typedef double v2d_cols __attribute__((ext_vector_type(2)));
 
 template <int METRIC, bool W>
 __global__ void dist_cols_kernel(ColArgs A) {
@@ -495,7 +498,15 @@ __global__ void dist_cols_kernel(ColArgs A) {
       for (; j + 8 <= m; j += 8) {
         double2 v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const double2*>(c + (int64_t)(j + u) * A.ldc);
+        for (int u = 0; u < 8; ++u) {
+          const double* src = c + (int64_t)(j + u) * A.ldc;
+          if (A.nt) {
+            const v2d_cols t = __builtin_nontemporal_load(reinterpret_cast<const v2d_cols*>(src));
+            v[u] = make_double2(t.x, t.y);
+          } else {
+            v[u] = *reinterpret_cast<const double2*>(src);
+          }
+        }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           s0 = Op<METRIC, W>::step(s0, v[u].x, ys[j + u], W ? as[j + u] : 1.0, A.p);
@@ -930,6 +941,7 @@ int dist_rows_dev_impl(elfihip_ctx* ctx, int metric, const double* dX, int64_t n
   ELFIHIP_TRY(canonical_metric(ctx, metric, p, daux, &cm));
   if (n == 0) return ELFIHIP_OK;
   RowArgs A = make_row_args(dX, n, m, ldx, dy, daux, p, dout);
+  A.nt = ctx->dist_form != 1;   // rows are read once: non-temporal loads (the register-staged forms: 16-byte nt loads)
   if (F) A.F = *F;
   const bool w = daux != nullptr;
   if (cm == ELFIHIP_MAHALANOBIS) {
@@ -1006,6 +1018,7 @@ static int dist_cols_dev_impl(elfihip_ctx* ctx, int metric, const double* dC, in
   A.inv_p = p != 0.0 ? 1.0 / p : 0.0;
   A.m = m;
   A.vec2 = (ldc % 2 == 0) && aligned16(dC) && aligned16(dout);
+  A.nt = ctx->dist_form != 1;
   const bool w = daux != nullptr;
 #define ELFIHIP_DISPATCH_COLS(M)                                                  \
   case M:                                                                         \
@@ -1032,6 +1045,7 @@ int dist_multiw_dev_impl(elfihip_ctx* ctx, const double* dX, int64_t n, int m, i
   ELFIHIP_REQUIRE(ctx, n == 0 || (dX && dy && dW && dout), "NULL data pointer");
   if (n == 0) return ELFIHIP_OK;
   RowArgs A = make_row_args(dX, n, m, ldx, dy, dW, 2.0, dout);
+  A.nt = ctx->dist_form != 1;
   A.K = K;
   if (F) A.F = *F;
   size_t lds;

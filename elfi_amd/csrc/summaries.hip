@@ -296,6 +296,7 @@ static int summary_dev_impl(elfihip_ctx* ctx, int kind, const double* dX, int64_
   if (n == 0) return ELFIHIP_OK;
   SumArgs S;
   S.R = summary_row_args(dX, n, L, ldx);
+  S.R.nt = ctx->dist_form != 1;
   S.lag = lag;
   S.t1 = S.t2 = nullptr;
   S.obs1 = S.obs2 = 0.0;
@@ -322,6 +323,7 @@ static int ma2_dev_impl(elfihip_ctx* ctx, const double* dW, int64_t n, int n_obs
   if (n == 0) return ELFIHIP_OK;
   SumArgs S;
   S.R = summary_row_args(draw ? nullptr : dW, n, n_obs + 2, ldw);
+  S.R.nt = ctx->dist_form != 1;
   S.seed = seed;
   S.stream = stream;
   S.lag = 0;

@@ -148,9 +148,11 @@ __device__ __forceinline__ void tile_fetch(const RowArgs& A, int64_t row0, int r
     v[u] = make_double2(0.0, 0.0);
     if (ok) {
       const double2* src = reinterpret_cast<const double2*>(X + (int64_t)q * A.ldx + 2 * jj);
-      if (A.nt) {  // streamed once: do not keep the lines in L2 / MALL
-        v[u].x = __builtin_nontemporal_load(&src->x);
-        v[u].y = __builtin_nontemporal_load(&src->y);
+      if (A.nt) {  // streamed once: do not keep the lines in L2 / MALL (ONE 16-byte load: the builtin on the scalar members
+                   // made two 8-byte loads of it, which is why round 2 measured no gain from it)
+        typedef double v2d_nt __attribute__((ext_vector_type(2)));
+        const v2d_nt t = __builtin_nontemporal_load(reinterpret_cast<const v2d_nt*>(src));
+        v[u] = make_double2(t.x, t.y);
       } else {
         v[u] = *src;
       }

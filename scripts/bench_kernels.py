@@ -14,6 +14,8 @@ ctx = elfi_amd.Context(0)
 stream = torch.cuda.Stream(dev)
 torch.cuda.set_stream(stream)
 ctx.set_stream(stream.cuda_stream)
+if len(sys.argv) > 1:
+    ctx.call('elfihip_dist_set_form', int(sys.argv[1]))   # 1: register-staged pipelines with default-policy loads
 
 
 def timed(fn, reps=30, warm=3):

@@ -34,3 +34,18 @@ for form in (0, 1, 0, 1):
         by = (8 * m + 8) * n
         print('form %d (%s) %s: %.2f us  %.0f GB/s  %.3f of 8 TB/s' % (form, 'LDS-DMA' if form == 0 else 'register pipeline',
               'weighted' if aux is not None else 'plain', ms * 1e3, by / ms / 1e6, by / ms / 1e6 / 8000), flush=True)
+# the same batch as m separate columns (what ELFI holds before column_stack: HipDiscrepancy's path)
+XT = [x.t().contiguous() for x in Xs]
+del Xs
+for form in (0, 1, 0, 1):
+    ctx.call('elfihip_dist_set_form', form)
+    for i in range(5):
+        ctx.call('elfihip_dist_cols_dev', 0, XT[i % NB].data_ptr(), n, m, n, y.data_ptr(), None, 2.0, out.data_ptr())
+    torch.cuda.synchronize()
+    ctx.timer_start()
+    for i in range(reps):
+        ctx.call('elfihip_dist_cols_dev', 0, XT[i % NB].data_ptr(), n, m, n, y.data_ptr(), None, 2.0, out.data_ptr())
+    ms = ctx.timer_stop() / reps
+    by = (8 * m + 8) * n
+    print('cols form %d (%s loads): %.2f us  %.0f GB/s  %.3f of 8 TB/s' % (form, 'non-temporal' if form == 0 else 'default',
+          ms * 1e3, by / ms / 1e6, by / ms / 1e6 / 8000), flush=True)
