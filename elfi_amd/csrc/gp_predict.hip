@@ -788,7 +788,7 @@ static bool lockstep_fused(const elfihip_gp* gp) { return gp->lockstep_form != 1
 // every acquisition never pays), and it is then carried through extends by the rank-one bordering below (an extend at
 // n = 4048: 63 -> 129 us, at 2000: 43 -> 50).  k(x,x) - kb . u
 // cancels with an error of eps cond(K) k(x,x) where the triangular form's sum of squares has eps k(x,x): the form is used
-// while (max L_ii / min L_ii)^2 <= KINV_MAX_COND (the variance then agrees with the triangular form to 1e-10 k(x,x)).
+// while the estimate of cond(K) below is <= KINV_MAX_COND (the variance then agrees with the triangular form to 1e-10 k(x,x)).
 constexpr int64_t KINV_AFTER_STEPS = 64;
 constexpr double KINV_MAX_COND = 1e5;
 
@@ -830,10 +830,18 @@ __global__ __launch_bounds__(256) void kinv_border_kernel(double* K, int64_t lda
   }
 }
 
-static bool kinv_conditioned(const elfihip_gp* gp) {
+// (max L_ii / min L_ii)^2 only bounds cond(K) from BELOW (lambda_max can be n times the largest diagonal entry): the gate
+// uses n times that ratio, capped by the bound the hyper-parameters give for free -- Ky = K_psd + s I with a constant
+// diagonal v + b + s, so lambda_min >= s and lambda_max <= trace = n (v + b + s)
+static double kinv_cond_estimate(const elfihip_gp* gp) {
+  if (!(gp->diag_min > 0.0)) return __builtin_huge_val();
   const double r = gp->diag_max / gp->diag_min;
-  return gp->diag_min > 0.0 && r * r <= KINV_MAX_COND;
+  const double s = gp->noise + GP_JITTER + gp->jitter;
+  const double upper = (double)gp->n * (gp->var + gp->bias + s) / s;
+  const double est = (double)gp->n * r * r;
+  return est < upper ? est : upper;
 }
+static bool kinv_conditioned(const elfihip_gp* gp) { return kinv_cond_estimate(gp) <= KINV_MAX_COND; }
 
 // Called before an LCB lock-step is enqueued: true when this call multiplies with K^-1 (forming it first if it is due).
 static int lockstep_kinv(elfihip_gp* gp, bool* use) {
@@ -1418,10 +1426,7 @@ int elfihip_gp_lockstep_info(const elfihip_gp* gp, int* kinv_in_use, int64_t* st
   if (!gp) return fail(nullptr, ELFIHIP_ERR_ARG, "gp is NULL");
   if (kinv_in_use) *kinv_in_use = gp->factored && gp->kinv_sym ? 1 : 0;
   if (steps) *steps = gp->lcb_steps;
-  if (cond_bound) {
-    const double r = gp->diag_min > 0.0 ? gp->diag_max / gp->diag_min : 0.0;
-    *cond_bound = r * r;
-  }
+  if (cond_bound) *cond_bound = kinv_cond_estimate(gp);
   return ELFIHIP_OK;
 }
 

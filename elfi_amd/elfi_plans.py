@@ -56,9 +56,21 @@ def _is_model_prior(prior):
             and hasattr(prior, 'parameter_names') and hasattr(prior, 'dim') and type(prior).__module__.startswith('elfi.'))
 
 
+_MAX_PLANS = 16   # per prior: posterior sampling asks for a handful of row counts; anything beyond is an unusual caller
+
+
+class _PlanCache(dict):
+    """key -> NetPlan | False, at most _MAX_PLANS entries (the oldest goes first: every plan holds a loaded net's constants)."""
+
+    def __setitem__(self, key, value):
+        if key not in self and len(self) >= _MAX_PLANS:
+            del self[next(iter(self))]
+        dict.__setitem__(self, key, value)
+
+
 def _plans_of(prior):
     try:
-        return _PLANS.setdefault(prior, {})
+        return _PLANS.setdefault(prior, _PlanCache())
     except TypeError:            # (not weakly referenceable)
         return None
 
@@ -125,6 +137,9 @@ def prior_logpdf(prior, x, log=True):
     plans[key] = False
     try:
         cand = NetPlan(prior, prior._logpdf_net if log else prior._pdf_net, len(x), 0, names)
+        # a density net that consumed randomness could not be replayed from a plan (the reference makes a fresh RandomState
+        # per call): without the generator in the plan's constants such a net fails here and keeps the public call
+        cand.const.pop('_random_state', None)
         got = run(cand)
         if np.shape(got) == np.shape(ref) and np.array_equal(got, ref, equal_nan=True):
             plans[key] = cand

@@ -24,6 +24,7 @@ from functools import partial
 import numpy as np
 
 from .distance import HipDistance, randn_rows
+from .priors import SIMULATOR_STREAM_BASE
 from .summaries import gauss_distance, ma2_draw_distance
 
 
@@ -41,13 +42,15 @@ def _seed_of(random_state):
 
 def ma2_summaries(t1, t2, observed_summaries=(0.0, 0.0), n_obs=100, batch_size=1, random_state=None):
     """Simulator operation: (batch, 2) = [autocov(x, 1), autocov(x, 2)] of MA2 series drawn and reduced on the device."""
-    S1, S2, _ = ma2_draw_distance(t1, t2, observed_summaries, n_obs=n_obs, seed=_seed_of(random_state))
+    S1, S2, _ = ma2_draw_distance(t1, t2, observed_summaries, n_obs=n_obs, seed=_seed_of(random_state),
+                                  stream=SIMULATOR_STREAM_BASE)
     return np.column_stack((S1, S2))
 
 
 def gauss_summaries(mu, sigma, observed_summaries=(0.0, 0.0), n_obs=50, batch_size=1, random_state=None):
     """Simulator operation: (batch, 2) = [mean(y), var(y)] of Gaussian samples drawn and reduced on the device."""
-    S1, S2, _ = gauss_distance(mu, sigma, observed_summaries, n_obs=n_obs, seed=_seed_of(random_state))
+    S1, S2, _ = gauss_distance(mu, sigma, observed_summaries, n_obs=n_obs, seed=_seed_of(random_state),
+                               stream=SIMULATOR_STREAM_BASE)
     return np.column_stack((S1, S2))
 
 
@@ -110,7 +113,7 @@ def gauss_wide_rows(mu, scale=None, batch_size=1, random_state=None):
     mu = np.asarray(mu, dtype=np.float64).reshape(-1)
     if mu.shape[0] == 1 and batch_size > 1:
         mu = np.repeat(mu, batch_size)
-    return randn_rows(mu, scale, seed=_seed_of(random_state))
+    return randn_rows(mu, scale, seed=_seed_of(random_state), stream=SIMULATOR_STREAM_BASE)
 
 
 def gauss_wide_model(m=64, adaptive=True):

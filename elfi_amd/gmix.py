@@ -16,6 +16,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
+from .priors import PROPOSAL_STREAM_BASE
 
 
 def _normalize_params(means, weights):
@@ -113,7 +114,7 @@ class GMDistribution:
         while n_accepted < size:
             n_left = size - n_accepted
             x = np.empty((n_left, d), dtype=np.float64)
-            ctx.call("elfihip_gm_rvs", C.c_uint64(seed), C.c_uint64(2 * trials), n_left, d, _lib.ptr(mu), mu.shape[0],
+            ctx.call("elfihip_gm_rvs", C.c_uint64(seed), C.c_uint64(PROPOSAL_STREAM_BASE + 2 * trials), n_left, d, _lib.ptr(mu), mu.shape[0],
                      _lib.ptr(cumw), _lib.ptr(A), _lib.ptr(x))
             x = x.reshape((n_left,) + means.shape[1:])
             if prior_logpdf is not None:

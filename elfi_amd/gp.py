@@ -100,7 +100,8 @@ class GPHandle:
         self._check(self.lib.elfihip_gp_set_lockstep_form(self.h, int(form)))
 
     def lockstep_info(self):
-        """(K^-1 in use by the acquisition lock-steps, lock-steps served by this factorisation, lower bound of cond(K))."""
+        """(K^-1 in use by the acquisition lock-steps, lock-steps served by this factorisation, the estimate of cond(K) the
+        K^-1 form is gated by: include/elfihip.h)."""
         use, steps, cond = C.c_int(0), C.c_int64(0), C.c_double(0.0)
         self._check(self.lib.elfihip_gp_lockstep_info(self.h, C.byref(use), C.byref(steps), C.byref(cond)))
         return bool(use.value), int(steps.value), float(cond.value)

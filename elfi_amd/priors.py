@@ -22,6 +22,14 @@ from . import _lib
 
 UNIFORM, MA2_T1, MA2_T2 = 0, 1, 2
 
+# Counter-stream namespaces of the consumers that key Philox with a 31-bit seed drawn from an ELFI RandomState: a prior
+# node, a fused simulator and an SMC proposal that happen to draw the SAME seed (one pair in ~2^31 / N^2 ...: likely over
+# the 10^4-10^5 node-batches of a long run) must not read the same counter words.  Callers that pass `stream` themselves
+# (tests, device-resident pipelines) keep full control.
+PRIOR_STREAM_BASE = 0x5052494F52000000      # "PRIOR"; + the prior kind
+SIMULATOR_STREAM_BASE = 0x53494D0000000000  # "SIM"
+PROPOSAL_STREAM_BASE = 0x474D525653000000   # "GMRVS"; + 2 x the redraw round
+
 
 def _seed_of(random_state):
     rs = random_state or np.random
@@ -34,7 +42,7 @@ def _shape(size):
     return tuple(int(v) for v in np.atleast_1d(size))
 
 
-def prior_draw(kind, params, cond=None, size=1, random_state=None, seed=None, stream=0, ctx=None):
+def prior_draw(kind, params, cond=None, size=1, random_state=None, seed=None, stream=None, ctx=None):
     """n = prod(size) draws of the prior `kind` (UNIFORM: params (loc, scale); MA2_T1: (b,); MA2_T2: (a,), cond = t1,
     broadcast to `size`).  The seed comes from `random_state` (one randint, as ELFI's batch seeding decides it) unless
     given."""
@@ -48,6 +56,8 @@ def prior_draw(kind, params, cond=None, size=1, random_state=None, seed=None, st
         c = np.ascontiguousarray(np.broadcast_to(np.asarray(cond, dtype=np.float64), shape or (1,)).reshape(-1))
     out = np.empty(n, dtype=np.float64)
     ctx = ctx or _lib.default_context()
+    if stream is None:
+        stream = PRIOR_STREAM_BASE + int(kind) if seed is None else 0
     ctx.call("elfihip_prior_draw", int(kind), C.c_uint64(_seed_of(random_state) if seed is None else int(seed)),
              C.c_uint64(int(stream)), n, _lib.ptr(a), _lib.ptr(c), _lib.ptr(out))
     return out.reshape(shape) if shape else out[0]
