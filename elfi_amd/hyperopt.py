@@ -246,7 +246,14 @@ def optimize_hyperparameters(model, max_iters=50):
         raise
     theta = logexp(phi)
     model._hyper = dict(zip(NAMES, (float(t) for t in theta)))
-    model._refit()
+    if obj._phi is not None and np.array_equal(obj._phi, np.asarray(phi, dtype=np.float64)):
+        # the search's last evaluation WAS the optimum (SCG stops right after a successful step): the device GP holds that
+        # very factorisation -- same hyper-parameters, bit for bit -- so the refit would only repeat it (one rebuild in
+        # seventeen of a configs[2] search)
+        model._log_marginal = obj._logz
+        model._fitted_hyper = dict(model._hyper)
+    else:
+        model._refit()
     # The factorisation made here serves every acquisition until the next search (update_interval of them, each a dozen or
     # more lock-steps, extended point by point in between): K^-1 for the one-product lock-step is formed now -- 2-4 % of
     # what the search just cost -- instead of after the first 64 lock-steps (include/elfihip.h: elfihip_gp_set_lockstep_form)
