@@ -23,10 +23,6 @@
 #include "tile_stream.hpp"
 #include "internal.hpp"
 
-#include <mutex>
-#include <set>
-#include <utility>
-
 #pragma clang fp contract(off)
 
 namespace elfihip {
@@ -597,24 +593,6 @@ static int set_lds(elfihip_ctx* ctx, KernelT k, size_t lds) {
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   return ELFIHIP_OK;
 }
-// The same, once per (device, kernel): hipFuncSetAttribute is a host call of several microseconds -- on the 40 us launches
-// of the LDS-DMA row stream it made the HOST the bottleneck (54.7 us per launch measured, 40.7 in the probe).
-template <class KernelT>
-static int set_lds_once(elfihip_ctx* ctx, KernelT k, size_t lds) {
-  static std::mutex mu;
-  static std::set<std::pair<int, const void*>> done;
-  const std::pair<int, const void*> key(ctx->device, reinterpret_cast<const void*>(k));
-  {
-    std::lock_guard<std::mutex> g(mu);
-    if (done.count(key)) return ELFIHIP_OK;
-  }
-  ELFIHIP_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  std::lock_guard<std::mutex> g(mu);
-  done.insert(key);
-  return ELFIHIP_OK;
-}
-
 // 16-byte loads per thread of the pipelined row kernels.  Rows that cost a few flops per element (everything but
 // general Minkowski and the K-weight sums) stream best in tiles of 32 to 64 rows (8 to 16 KiB per workgroup); the
 // heavier per-row work wants all 128 lanes of the workgroup on rows (tiles of 128 rows).
