@@ -61,6 +61,11 @@ struct elfihip_ctx {
   hipEvent_t ev_a = nullptr, ev_b = nullptr;
   hipEvent_t ev_u[4] = {nullptr, nullptr, nullptr, nullptr};  // look-ahead window columns of the next panel group
   int cu_count = 0;
+  // small read-backs (a counter, a threshold, a time-out flag): a one-workgroup kernel writes them into this page-locked,
+  // device-visible mailbox and the host reads it after the stream's synchronisation it needs anyway -- a 4-byte
+  // hipMemcpyAsync into a pageable stack variable is a staged blit of 30 us on the stream (profiles/r05_cfg4_trace.md:
+  // 4.5 of them per adaptive-distance round)
+  unsigned long long* mail = nullptr;
   int dist_form = 0;                  // 0: LDS-DMA row stream where the shape allows; 1: register-staged pipeline (elfihip_dist_set_form)
   int topk_form = 0;                  // 0: resident selection with the nine-launch form as fallback; 1: nine-launch form
   unsigned dense_lds_mask = 0;        // dense_tri_kernel<.,64/32/16>: dynamic-LDS limit raised (gp_dense.hip)
@@ -138,6 +143,16 @@ struct DeviceGuard {
 };
 
 int ctx_aux(elfihip_ctx* ctx);  // ctx.hip: lazily creates hi_stream / ev_a / ev_b
+
+// Up to four device words (4 or 8 bytes each) -> the context's mailbox, in stream order; ctx.hip.  mail_read() after the
+// caller's hipStreamSynchronize returns word i (zero-extended).
+struct MailSrc {
+  const void* p[4];
+  int bytes[4];
+  int n;
+};
+int mail_post(elfihip_ctx* ctx, const MailSrc& S);
+inline unsigned long long mail_read(const elfihip_ctx* ctx, int i) { return ctx->mail[i]; }
 
 // Host-form distance calls leave a device copy of what they return (n x cols doubles at dsrc, on the context's stream).
 // Every host-form distance call comes through here, also with n = 0 (an empty batch is a call: the epoch must move on, or

@@ -9,6 +9,23 @@ thread_local std::string g_err;
 // Streams of the GP factorisation's stream schedule: `hi` (high priority) carries the critical chain, `bulk` the
 // rest of the trailing update.  (A CU-mask partition of the two was tried and removed: on this stack a stream made with
 // hipExtStreamCreateWithCUMask still runs on all 256 CUs -- scripts/native/cumask_probe.hip prints the XCC / CU ids.)
+__global__ void mail_kernel(MailSrc S, unsigned long long* box) {
+  const int t = threadIdx.x;
+  if (t < S.n)
+    box[t] = S.bytes[t] == 8 ? *reinterpret_cast<const unsigned long long*>(S.p[t])
+                             : (unsigned long long)*reinterpret_cast<const unsigned int*>(S.p[t]);
+}
+
+int mail_post(elfihip_ctx* ctx, const MailSrc& S) {
+  if (!ctx->mail) {
+    void* p = nullptr;
+    ELFIHIP_CHECK_HIP(ctx, hipHostMalloc(&p, 64, hipHostMallocMapped | hipHostMallocCoherent));
+    ctx->mail = reinterpret_cast<unsigned long long*>(p);
+  }
+  hipLaunchKernelGGL(mail_kernel, dim3(1), dim3(64), 0, ctx->stream, S, ctx->mail);
+  return launch_status(ctx, "mail_kernel");
+}
+
 int ctx_aux(elfihip_ctx* ctx) {
   if (ctx->hi_stream) return ELFIHIP_OK;
   int lo = 0, hi = 0;
@@ -134,6 +151,7 @@ int elfihip_ctx_destroy(elfihip_ctx* ctx) {
     if (ctx->hi_stream) (void)hipStreamDestroy(ctx->hi_stream);
     if (ctx->bulk_stream) (void)hipStreamDestroy(ctx->bulk_stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    if (ctx->mail) (void)hipHostFree(ctx->mail);
   }
   delete ctx;
   return ELFIHIP_OK;

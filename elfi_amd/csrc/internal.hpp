@@ -20,7 +20,7 @@ int dist_multiw_dev_impl(elfihip_ctx* ctx, const double* dX, int64_t n, int m, i
 int topk_dev_impl(elfihip_ctx* ctx, const double* dD, int64_t n, int64_t stride, int64_t k, double* dvals,
                   int64_t* didx, bool force_multi);
 
-int topk_resident_err_async(elfihip_ctx* ctx, unsigned int* host_err);   // see topk.hip
+const void* topk_resident_err_dev(elfihip_ctx* ctx);   // see topk.hip: device address of the resident selection's time-out flag, or NULL
 
 // reject.hip: the sampler state; push of a device-resident batch (no device guard, no argument checks)
 elfihip_ctx* reject_ctx(elfihip_reject* h);

@@ -371,8 +371,9 @@ static int host_merge(elfihip_reject* h, unsigned int ncand, long long row_offse
   hipStream_t st = ctx->stream;
   unsigned int c = ncand;
   if (ncand == ~0u) {
-    ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(&c, h->count, sizeof c, hipMemcpyDeviceToHost, st));
+    ELFIHIP_TRY(mail_post(ctx, MailSrc{{h->count, nullptr, nullptr, nullptr}, {4, 0, 0, 0}, 1}));
     ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(st));
+    c = (unsigned int)mail_read(ctx, 0);
     ELFIHIP_CHECK_HIP(ctx, hipMemsetAsync(h->count, 0, sizeof c, st));
     if (c > h->cap) return fail(ctx, ELFIHIP_ERR_STATE, "internal: candidate list overflow (%u > %u)", c, h->cap);
   }
@@ -472,9 +473,9 @@ static int reject_push(elfihip_reject* h, int64_t n, const double* dsel, int64_t
     if (g > ctx->cu_count * 8) g = ctx->cu_count * 8;
     hipLaunchKernelGGL(reject_mask_kernel, dim3(g), dim3(256), 0, st, dsel, n, stride, ncols, h->acc_dev, masked, bcount,
                        h->acc_count);
-    unsigned long long accepted = 0;
-    ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(&accepted, bcount, sizeof accepted, hipMemcpyDeviceToHost, st));
+    ELFIHIP_TRY(mail_post(ctx, MailSrc{{bcount, nullptr, nullptr, nullptr}, {8, 0, 0, 0}, 1}));
     ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(st));
+    const unsigned long long accepted = mail_read(ctx, 0);
     const int64_t kb = (int64_t)accepted < h->k ? (int64_t)accepted : h->k;
     if (kb > 0) {
       ELFIHIP_TRY(topk_dev_impl(ctx, masked, n, 1, kb, h->cand_val, reinterpret_cast<int64_t*>(h->cand_row), true));
@@ -664,8 +665,7 @@ int adaptive_push_impl(elfihip_ctx* ctx, elfihip_reject* h, const double* dX, in
     // (the prefix's selection as ONE resident launch: its barrier time-out flag is read back with the list's length below,
     // and a time-out takes the route of a failed check)
     ELFIHIP_TRY(topk_dev_impl(ctx, pre + (K - 1), s, K, j, h->cand_val, reinterpret_cast<int64_t*>(h->cand_row), false));
-    unsigned int sel_err = 0;
-    ELFIHIP_TRY(topk_resident_err_async(ctx, &sel_err));
+    const void* sel_err_dev = topk_resident_err_dev(ctx);   // (NULL: the nine-launch form ran -- nothing to time out)
     hipLaunchKernelGGL(reject_seed_kernel, dim3(1), dim3(256), 0, st, h->thr, h->count, h->cand_val, h->cand_row, (int)j,
                        (long long)row_base);
     RejectFilter F;
@@ -676,9 +676,11 @@ int adaptive_push_impl(elfihip_ctx* ctx, elfihip_reject* h, const double* dX, in
     F.cap = h->cap;
     F.row_base = (long long)row_base + s;
     ELFIHIP_TRY(pass(s, n, &F, false, dout ? dout + s * K : nullptr));
-    unsigned int c = 0;
-    ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(&c, h->count, sizeof c, hipMemcpyDeviceToHost, st));
+    // the list's length and the selection's time-out flag in ONE read-back
+    ELFIHIP_TRY(mail_post(ctx, MailSrc{{h->count, sel_err_dev ? sel_err_dev : h->count, nullptr, nullptr}, {4, 4, 0, 0}, 2}));
     ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(st));
+    const unsigned int c = (unsigned int)mail_read(ctx, 0);
+    const unsigned int sel_err = sel_err_dev ? (unsigned int)mail_read(ctx, 1) : 0u;
     if (sel_err == 0 && (int64_t)c >= h->k && (int64_t)c <= std::max<int64_t>(REJ_PROV_MAX_CAND, 64 * j) && c <= h->cap) {
       ELFIHIP_TRY(merge_list(-1, 0));
     } else {
@@ -975,11 +977,11 @@ int elfihip_reject_meta(elfihip_reject* h, double* kth, int64_t* in_use, int64_t
   elfihip_ctx* ctx = h->ctx;
   DeviceGuard g(ctx->device);
   ELFIHIP_TRY(reject_flush(h));
-  double thr = 0.0;
-  unsigned long long acc = 0;
-  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(&thr, h->thr, sizeof thr, hipMemcpyDeviceToHost, ctx->stream));
-  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(&acc, h->acc_count, sizeof acc, hipMemcpyDeviceToHost, ctx->stream));
+  ELFIHIP_TRY(mail_post(ctx, MailSrc{{h->thr, h->acc_count, nullptr, nullptr}, {8, 8, 0, 0}, 2}));
   ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const unsigned long long thr_bits = mail_read(ctx, 0), acc = mail_read(ctx, 1);
+  double thr;
+  memcpy(&thr, &thr_bits, sizeof thr);
   if (kth) *kth = thr;                      // +inf while fewer than k rows have entered
   if (in_use) *in_use = h->host_mode ? (int64_t)h->hval.size() : -1;   // device states: ask elfihip_reject_result
   if (accepted_last) *accepted_last = (int64_t)(acc - h->acc_seen);

@@ -587,14 +587,12 @@ int topk_dev_impl(elfihip_ctx* ctx, const double* dD, int64_t n, int64_t stride,
   return launch_status(ctx, "top-k selection kernels");
 }
 
-// The resident form's barrier time-out flag of the LATEST selection on this context, copied to *host_err in stream order
-// (the caller synchronises before it reads it): non-zero = that selection's result is not valid, run the nine-launch form.
-int topk_resident_err_async(elfihip_ctx* ctx, unsigned int* host_err) {
-  *host_err = 0;
-  if (ctx->topk_form == 1 || !ctx->scratch.p) return ELFIHIP_OK;
-  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(host_err, reinterpret_cast<const char*>(ctx->scratch.p) + offsetof(SelWork, err),
-                                        sizeof *host_err, hipMemcpyDeviceToHost, ctx->stream));
-  return ELFIHIP_OK;
+// The resident form's barrier time-out flag of the LATEST selection on this context lives here on the device (NULL: the
+// nine-launch form is configured): non-zero = that selection's result is not valid.  Callers read it back together with
+// whatever else they need (mail_post), in stream order, and synchronise before they look.
+const void* topk_resident_err_dev(elfihip_ctx* ctx) {
+  if (ctx->topk_form == 1 || !ctx->scratch.p) return nullptr;
+  return reinterpret_cast<const char*>(ctx->scratch.p) + offsetof(SelWork, err);
 }
 
 }  // namespace elfihip
