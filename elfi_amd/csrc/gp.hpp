@@ -47,6 +47,7 @@ struct elfihip_gp {
   double* alpha = nullptr;  // (cap) K^-1 y
   double* red = nullptr;    // small reduction scratch
   int* info = nullptr;      // device: 1-based index of the first non-positive pivot, 0 if none; from word 4 on the
+  int ov_flags_off = 0;     // first word of the overlapped sweep's counters in `info`
   int ninfo = 0;            // arrival counters of the fused sweep's steps (four words each); ninfo words in all
   double* h_fit = nullptr;  // pinned, device-visible: sum log L_ii, z'z and the pivot report of the latest rebuild
   // integration points of ExpIntVar (elfihip_gp_set_integration_points): V_P = L^-1 K(X, P) stored k-major

@@ -197,6 +197,31 @@ typedef double v2d_t __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) v2d_t ldouble2;
 typedef __attribute__((address_space(1))) v2d_t gdouble2;
 
+// One 8-byte WRITE-THROUGH store (global_store_dwordx2 ... sc1): the value leaves this XCD's L2 with the store, so a
+// workgroup that publishes results to workgroups of the same (or a concurrently running) launch needs no release fence
+typedef __attribute__((address_space(1))) unsigned long long gu64_fit_t;
+__device__ __forceinline__ void store_wt_f64(double* p, double v) {
+  __hip_atomic_store((gu64_fit_t*)(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+// stores of the diagonal block / a panel piece: plain, or write-through for the overlapped sweep (sweep_overlap below)
+template <bool WT>
+__device__ __forceinline__ void pst(gdouble* p, double v) {
+  if (WT)
+    __hip_atomic_store((gu64_fit_t*)(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else
+    *p = v;
+}
+template <bool WT>
+__device__ __forceinline__ void pst2(gdouble2* p, v2d_t v) {
+  if (WT) {
+    pst<true>((gdouble*)p, v.x);
+    pst<true>((gdouble*)p + 1, v.y);
+  } else {
+    *p = v;
+  }
+}
+
 #ifdef ELFIHIP_POTF2_STAMP   // developer probe (scripts/native/potf2_probe.hip): cycle stamps per wave, panel and phase
 __device__ long long g_potf2_stamp[16 * 8 * 8];
 #define STAMP(p, slot) do { if ((threadIdx.x & 63) == 0) g_potf2_stamp[(R * 8 + (p)) * 8 + (slot)] = __builtin_readcyclecounter(); } while (0)
@@ -204,7 +229,7 @@ __device__ long long g_potf2_stamp[16 * 8 * 8];
 #define STAMP(p, slot) do { } while (0)
 #endif
 
-template <int NT>
+template <int NT, bool WT = false>
 __device__ __forceinline__ void potf2_tiles_body(double* Akk_, int64_t lda, double* Wkk_, int64_t ldw, double* W11_, int* info,
                                                  int kblock, double* sm) {
   static_assert(NT >= POTF2T_THREADS, "eleven wave slots");
@@ -323,9 +348,9 @@ __device__ __forceinline__ void potf2_tiles_body(double* Akk_, int64_t lda, doub
           const v2d_t v = *(ldouble2*)(LT + i * 18 + 2 * sj);
           gdouble* dst = Akk + (int64_t)(16 * p + i) * lda + 16 * p + 2 * sj;
           if (2 * sj + 1 <= i)
-            *(gdouble2*)dst = v;
+            pst2<WT>((gdouble2*)dst, v);
           else if (2 * sj <= i)
-            dst[0] = v.x;
+            pst<WT>(dst, v.x);
         }
         __builtin_amdgcn_wave_barrier();
       }
@@ -436,7 +461,7 @@ __device__ __forceinline__ void potf2_tiles_body(double* Akk_, int64_t lda, doub
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int gcol = 16 * p + 4 * r + lr, grow = 16 * R + lc;
-          if (gcol >= grow) W11[gcol * NB + grow] = y[r];
+          if (gcol >= grow) pst<WT>(W11 + gcol * NB + grow, y[r]);
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -448,13 +473,13 @@ __device__ __forceinline__ void potf2_tiles_body(double* Akk_, int64_t lda, doub
         const v2d_t v = *(ldouble2*)(ST + i * 18 + 2 * sj);
         const int grow = 16 * R + i, gcol = 16 * p + 2 * sj;
         if (R > p) {
-          *(gdouble2*)(Akk + (int64_t)grow * lda + gcol) = v;
+          pst2<WT>((gdouble2*)(Akk + (int64_t)grow * lda + gcol), v);
         } else {
           gdouble* dst = Wkk + (int64_t)grow * ldw + gcol;
           if (gcol >= grow)
-            *(gdouble2*)dst = v;
+            pst2<WT>((gdouble2*)dst, v);
           else if (gcol + 1 >= grow)
-            dst[1] = v.y;
+            pst<WT>(dst + 1, v.y);
         }
       }
       __builtin_amdgcn_wave_barrier();
@@ -515,7 +540,7 @@ __global__ __launch_bounds__(256) void trsm_gemm_kernel(PanelArgs P) {
 // tiles w and 7 - w (nine 16-deep k blocks each).  k is permuted as in lookahead_tile_kernel (lane group q of MFMA
 // 2o / 2o+1 holds k = 8o + 2q / + 1), so a 16-byte load feeds two MFMAs.  In place: the barrier separates the strip's
 // last read from its first overwrite.  (The LDS-staged 32-row form above: 8.3 us per launch at n = 4096.)
-template <int W>
+template <int W, bool WT = false>
 __device__ __forceinline__ void trsm16_wave(double* Pb, int64_t lda, const double* W11, int l,
                                             const unsigned* wait_cnt = nullptr, int* info = nullptr,
                                             unsigned wait_target = 28u * 8u + 8u * 4u) {
@@ -561,8 +586,13 @@ __device__ __forceinline__ void trsm16_wave(double* Pb, int64_t lda, const doubl
   double* po = Pb + (int64_t)(l >> 4) * lda + (l & 15);
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    po[(int64_t)(4 * r) * lda + 16 * T0] = c0[r];
-    po[(int64_t)(4 * r) * lda + 16 * T1] = c1[r];
+    if (WT) {
+      store_wt_f64(po + (int64_t)(4 * r) * lda + 16 * T0, c0[r]);
+      store_wt_f64(po + (int64_t)(4 * r) * lda + 16 * T1, c1[r]);
+    } else {
+      po[(int64_t)(4 * r) * lda + 16 * T0] = c0[r];
+      po[(int64_t)(4 * r) * lda + 16 * T1] = c1[r];
+    }
   }
 }
 
@@ -695,14 +725,11 @@ __global__ __launch_bounds__(256) void trailing_update_col_kernel(PanelArgs P, i
 // form above the workgroup pulls 64 KUN KiB instead of 160 KUN KiB through its CU and four times as many CUs take part.
 // Updates deeper than 256 (panel groups of four) keep two 32-deep pieces per wave in flight and refill a buffer as soon
 // as its piece has been multiplied: two to three round trips instead of 24-32 (28-36 -> about 20 us per launch).
-template <int KUN>
-__global__ __launch_bounds__(256) void lookahead_tile_kernel(PanelArgs P, int cblk) {
-  extern __shared__ __align__(16) double lds[];
+// lb: the workgroup's (row block, 32-row sub block, 32-column slice) = (lb >> 4, (lb >> 2) & 3, lb & 3);  WT: the tile
+// leaves through write-through stores (overlapped sweep: another launch reads it while this one is still running)
+template <int KUN, bool WT>
+__device__ __forceinline__ void lookahead_tile_body(const PanelArgs& P, int cblk, int lb, double* lds) {
   const int t = threadIdx.x, l = t & 63, w = t >> 6;
-  cblk += blockIdx.y;  // gridDim.y consecutive block columns in one launch
-  // workgroups go round-robin over the 8 XCDs: renumber so that the four column slices of one 32-row sub block (the
-  // same rows of A) run on the same XCD and share its L2 (gridDim.x is a multiple of 16)
-  const int lb = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
   const int rb = lb >> 4, sub = (lb >> 2) & 3, cs = lb & 3;
   const int mrows = P.nb - cblk;
   if (rb >= mrows + 1 + P.ku0 + P.kun) return;
@@ -783,8 +810,20 @@ __global__ __launch_bounds__(256) void lookahead_tile_kernel(PanelArgs P, int cb
     const int e = t + 256 * u;
     const int o = (e >> 5) * TP + (e & 31);
     const double s = ((lds[o] + lds[32 * TP + o]) + lds[2 * 32 * TP + o]) + lds[3 * 32 * TP + o];
-    C[(int64_t)(e >> 5) * P.lda + (e & 31)] = cv[u] - s;
+    if (WT)
+      store_wt_f64(C + (int64_t)(e >> 5) * P.lda + (e & 31), cv[u] - s);
+    else
+      C[(int64_t)(e >> 5) * P.lda + (e & 31)] = cv[u] - s;
   }
+}
+
+template <int KUN>
+__global__ __launch_bounds__(256) void lookahead_tile_kernel(PanelArgs P, int cblk) {
+  extern __shared__ __align__(16) double lds[];
+  // gridDim.y consecutive block columns in one launch.  Workgroups go round-robin over the 8 XCDs: renumber so that the
+  // four column slices of one 32-row sub block (the same rows of A) run on the same XCD and share its L2 (gridDim.x is
+  // a multiple of 16)
+  lookahead_tile_body<KUN, false>(P, cblk + blockIdx.y, (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3), lds);
 }
 constexpr size_t LOOKAHEAD_TILE_LDS = 4 * 32 * 33 * sizeof(double);
 
@@ -932,6 +971,12 @@ __device__ __noinline__ void potf2_tiles_call(double* Akk, int64_t lda, double* 
                                               int kblock, double* sm) {
   potf2_tiles_body<1024>(Akk, lda, Wkk, ldw, W11, info, kblock, sm);
 }
+// (the same with write-through stores, for sweep_diag_kernel: inlined into that kernel's loop over the block columns the
+// body spills 280 bytes per lane)
+__device__ __noinline__ void potf2_tiles_call_wt(double* Akk, int64_t lda, double* Wkk, int64_t ldw, double* W11, int* info,
+                                                 int kblock, double* sm) {
+  potf2_tiles_body<1024, true>(Akk, lda, Wkk, ldw, W11, info, kblock, sm);
+}
 
 // --------------------------------------------------------------- one step of the sweep as ONE launch
 // step_kernel(k): workgroup 0 factors diagonal block k+1 (potf2_tiles_body) WHILE the other workgroups update the
@@ -1007,25 +1052,28 @@ __device__ int g_step_stamp_k = 16;
 
 // ---- hand-offs inside the fused step launch (guide: write-through stores, every storing wave drains, ONE relaxed
 // device-scope arrival per workgroup, ONE agent-scope acquire by the consumer -- no release fence anywhere)
-typedef __attribute__((address_space(1))) unsigned long long gu64_fit_t;
-__device__ __forceinline__ void store_wt_f64(double* p, double v) {
-  __hip_atomic_store((gu64_fit_t*)(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
-                     __HIP_MEMORY_SCOPE_AGENT);
-}
 constexpr int STEP_SPIN_LIMIT = 1 << 22;   // polls (a few seconds): a hand-off that never comes is reported, not waited for
 constexpr int STEP_INFO_TIMEOUT = -1;      // pivot report of a launch whose workgroups were not all resident
 
-// every thread of the workgroup: wait until *c >= target, then acquire
+// The workgroup waits until *c >= target: ONE lane polls and the workgroup's FIRST WAVE ALONE takes the agent-scope acquire
+// before the barrier.  (Round 3's form -- every thread polls, every wave acquires -- queued 16 x 255 cache invalidations
+// per hand-off; buffer_inv is a cache operation, not a per-wave one, and a load issued behind a thousand of them took
+// 8-25 us: scripts/native/overlap_probe.hip, profiles/r05_overlap.md.)  Called by every thread of the workgroup.
 __device__ __forceinline__ void step_wait(const unsigned* c, unsigned target, int* info) {
-  int spins = 0;
-  while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-    if (++spins >= STEP_SPIN_LIMIT) {
-      if (threadIdx.x == 0) atomicCAS(info, 0, STEP_INFO_TIMEOUT);
-      break;
+  if (threadIdx.x < 64) {
+    if (threadIdx.x == 0) {
+      int spins = 0;
+      while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        if (++spins >= STEP_SPIN_LIMIT) {
+          atomicCAS(info, 0, STEP_INFO_TIMEOUT);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
     }
-    __builtin_amdgcn_s_sleep(2);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  __syncthreads();
 }
 // after the workgroup's write-through stores: drain, meet, one arrival (at one or two counters)
 __device__ __forceinline__ void step_arrive(unsigned* c, unsigned n, unsigned* c2 = nullptr) {
@@ -1147,55 +1195,18 @@ __device__ __forceinline__ void step_tile_pieces(const PanelArgs& P, int pair, d
   }
 }
 
-// CHAINED: panel solve and diagonal tile inside this launch (S.cnt != NULL); the two forms are separate kernels so that
-// the three-launch form's update loop compiles exactly as it did without the other's roles around it
-template <bool CHAINED>
-__device__ __forceinline__ void step_body(const StepArgs& S) {
-  extern __shared__ __align__(16) double sm[];
+// The update workgroup's walk through its units of one step (wgi: its index among the update workgroups).  CHAINED: the
+// panel is solved inside the same launch (step_chain_kernel).  WT: the tiles leave through write-through stores -- the
+// overlapped sweep (sweep_update_kernel), where workgroups of a running launch on other XCDs read them in the next step.
+template <bool CHAINED, bool WT>
+__device__ __forceinline__ void step_units(const StepArgs& S, double* sm, int wgi) {
   const PanelArgs& P = S.P;
   constexpr bool chained = CHAINED;
-  SSTAMP(0);
-  if (blockIdx.x == 0) {
-    const int kk = P.k + 1;
-    double* Akk = P.A + ((int64_t)kk * NB) * P.lda + (int64_t)kk * NB;
-    double* Wkk = P.WT + ((int64_t)kk * NB) * P.lda + (int64_t)kk * NB;
-    if (chained) step_wait(S.cnt + 2, 8u, S.info);   // tile (k+1, k+1) complete (eight workgroups, two pieces each)
-    SSTAMP(1);
-    if (S.W11) potf2_tiles_call(Akk, P.lda, Wkk, P.lda, S.W11, S.info, kk, sm);   // (NULL: the update alone, scripts/native/step_probe.hip)
-    SSTAMP(2);
-    return;
-  }
-  const int idx = blockIdx.x - 1;
-  if (chained) {
-    // ---- the panel solve, dealt over the update workgroups; the first eight take strip (k+1, k) and then the diagonal
-    // tile: the chain to the next diagonal block is solve -> hop -> tile -> hop -> block, beside everybody's updates
-    const int lead = S.nwg >= 16 ? 8 : 0;   // workgroups that keep out of the rest of the panel
-    if (idx < 8) {
-      step_solve_piece(P, idx, sm);
-      step_arrive(S.cnt + 1, 1u, S.cnt);
-      SSTAMP(1);
-    }
-    unsigned done = 0;
-    if (idx >= lead)
-      for (int e = 8 + (idx - lead); e < S.nmini; e += S.nwg - lead) {
-        step_solve_piece(P, e, sm);
-        ++done;
-      }
-    if (done) step_arrive(S.cnt, done);
-    if (idx >= 8) SSTAMP(1);
-    if (idx < 8) {
-      step_wait(S.cnt + 1, 8u, S.info);
-      SSTAMP(2);
-      step_tile_pieces(P, idx, sm);
-      step_arrive(S.cnt + 2, 1u);
-      SSTAMP(3);
-    }
-  }
   constexpr int RT = 1;                 // 16-row MFMA tiles per wave along the rows
   constexpr int ROWS = 64 * RT;         // rows of a unit
   constexpr int BUF = (ROWS + 128) * GLP2;  // doubles of one LDS stage: A rows, then B rows
-  const int4 head = *reinterpret_cast<const int4*>(S.heads + (blockIdx.x - 1));
-  int u = S.wg_off[blockIdx.x - 1];
+  const int4 head = *reinterpret_cast<const int4*>(S.heads + wgi);
+  int u = S.wg_off[wgi];
   if (head.w <= 0) return;
   const int uend = u + head.w;
   const int t = threadIdx.x, l = t & 63, w = t >> 6;
@@ -1303,7 +1314,10 @@ __device__ __forceinline__ void step_body(const StepArgs& S) {
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          cp[(int64_t)(i * 16 + 4 * r) * lda + j * 16] = cur.keep * cv[i][j][r] - acc[i][j][r];
+          if (WT)
+            store_wt_f64(cp + (int64_t)(i * 16 + 4 * r) * lda + j * 16, cur.keep * cv[i][j][r] - acc[i][j][r]);
+          else
+            cp[(int64_t)(i * 16 + 4 * r) * lda + j * 16] = cur.keep * cv[i][j][r] - acc[i][j][r];
     if (!more) {
       SSTAMP(6);
       break;
@@ -1321,11 +1335,248 @@ __device__ __forceinline__ void step_body(const StepArgs& S) {
   }
 }
 
+// CHAINED: panel solve and diagonal tile inside this launch (S.cnt != NULL); the two forms are separate kernels so that
+// the three-launch form's update loop compiles exactly as it did without the other's roles around it
+template <bool CHAINED>
+__device__ __forceinline__ void step_body(const StepArgs& S) {
+  extern __shared__ __align__(16) double sm[];
+  const PanelArgs& P = S.P;
+  constexpr bool chained = CHAINED;
+  SSTAMP(0);
+  if (blockIdx.x == 0) {
+    const int kk = P.k + 1;
+    double* Akk = P.A + ((int64_t)kk * NB) * P.lda + (int64_t)kk * NB;
+    double* Wkk = P.WT + ((int64_t)kk * NB) * P.lda + (int64_t)kk * NB;
+    if (chained) step_wait(S.cnt + 2, 8u, S.info);   // tile (k+1, k+1) complete (eight workgroups, two pieces each)
+    SSTAMP(1);
+    if (S.W11) potf2_tiles_call(Akk, P.lda, Wkk, P.lda, S.W11, S.info, kk, sm);   // (NULL: the update alone, scripts/native/step_probe.hip)
+    SSTAMP(2);
+    return;
+  }
+  const int idx = blockIdx.x - 1;
+  if (chained) {
+    // ---- the panel solve, dealt over the update workgroups; the first eight take strip (k+1, k) and then the diagonal
+    // tile: the chain to the next diagonal block is solve -> hop -> tile -> hop -> block, beside everybody's updates
+    const int lead = S.nwg >= 16 ? 8 : 0;   // workgroups that keep out of the rest of the panel
+    if (idx < 8) {
+      step_solve_piece(P, idx, sm);
+      step_arrive(S.cnt + 1, 1u, S.cnt);
+      SSTAMP(1);
+    }
+    unsigned done = 0;
+    if (idx >= lead)
+      for (int e = 8 + (idx - lead); e < S.nmini; e += S.nwg - lead) {
+        step_solve_piece(P, e, sm);
+        ++done;
+      }
+    if (done) step_arrive(S.cnt, done);
+    if (idx >= 8) SSTAMP(1);
+    if (idx < 8) {
+      step_wait(S.cnt + 1, 8u, S.info);
+      SSTAMP(2);
+      step_tile_pieces(P, idx, sm);
+      step_arrive(S.cnt + 2, 1u);
+      SSTAMP(3);
+    }
+  }
+  step_units<CHAINED, false>(S, sm, idx);
+}
+
 __global__ __launch_bounds__(1024) void step_kernel(StepArgs S) { step_body<false>(S); }
 __global__ __launch_bounds__(1024) void step_chain_kernel(StepArgs S) { step_body<true>(S); }
 
 constexpr size_t STEP_LDS_BYTES = 2 * (64 + 128) * GLP2 * sizeof(double);  // two stages of a unit (> the diagonal block's)
 static_assert(STEP_LDS_BYTES >= POTF2T_LDS_DOUBLES * sizeof(double) && STEP_LDS_BYTES <= 160 * 1024, "LDS budget");
+
+// --------------------------------------------------------------- the sweep OVERLAPPED: chain beside the update (round 5)
+// elfihip_gp_set_schedule(gp, 5, 0).  In the three-launch form the matrix pipes of 255 CUs idle while the chain's two
+// small launches run (panel solve 6.5 us + diagonal tile 5.3 us + boundaries, per block column), and every step launch
+// pays 7 us before its first unit multiplies.  Here the three roles of a step run CONCURRENTLY as three launches on three
+// streams, ordered by counters in device memory instead of kernel boundaries or stream events:
+//   sweep_update_kernel   ONE launch, persistent (stream `bulk`): the update workgroups (one per CU beside the diagonal
+//                         block's) walk the same unit table, step by step; step k starts when panel k has been solved
+//   sweep_diag_kernel     ONE launch, persistent, one workgroup (stream `hi`): diagonal block k+1 as soon as its tile is
+//                         complete.  Only the CU the update leaves free can hold it (registers), as in the step launch
+//   chain_ov_kernel       one launch per block column on the caller's stream, enqueued ahead: 8 nb workgroups solve one
+//                         16-row piece of panel k each (trsm16_wave), 16 more update tile (k+1, k+1)
+//                         (lookahead_tile_body<1>).  Its waves fit beside the update's (96 + 120 registers of a SIMD's
+//                         512) and run at raised priority; launched while block k is still being factored, it polls.
+// Hand-offs (per step, words of the counter block): potf2_done -> {solve pieces} -> panel_solved -> {update}, strip ->
+// {tile pieces} -> tile_done -> {diagonal block}, upd_done -> {next step's solve pieces}.  Payloads are written through
+// (sc1), the storing waves drain, ONE lane per workgroup arrives; a consumer polls with ONE lane and its FIRST WAVE ALONE
+// takes the agent-scope acquire before the workgroup's barrier: buffer_inv is a cache operation, not a per-wave one, and
+// a thousand of them queued per hand-off (every wave of every workgroup) are what made a load behind them take 8-25 us
+// (scripts/native/overlap_probe.hip: 56 -> 21 us per hop pair).  The arithmetic, instruction for instruction, is the
+// three-launch form's: the factor is bit-identical (tests/test_gp_gpu.py).
+constexpr int OV_WORDS = 8;          // counter words per step: potf2_done, panel_solved, strip, tile_done, upd_done
+constexpr int OV_POTF2 = 0, OV_PANEL = 1, OV_STRIP = 2, OV_TILE = 3, OV_UPD = 4;
+// behind the steps' blocks: words of the launch as a whole
+constexpr int OV_AUX_XRANK = 0;      // [16] update workgroups that have started, per XCD
+constexpr int OV_AUX_NEXT = 16;      // the next update workgroup's index into the unit table
+constexpr int OV_AUX_DIAG_XCC = 17;  // 1 + the XCD the diagonal block's workgroup runs on
+constexpr int OV_AUX_RESIDENT = 18;  // workgroups of the two persistent launches that have started (and stay)
+constexpr int OV_AUX_WORDS = 32;
+constexpr int OV_TILE_WGS = 16;
+constexpr int OV_SPIN_LIMIT = 1 << 20;
+
+// one lane polls *c >= target (false: gave up -- the abort word info[1] is raised and every later wait returns at once)
+__device__ __forceinline__ bool ov_poll(const unsigned* c, unsigned target, int* info, int who = 0) {
+  int spins = 0;
+  while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    ++spins;
+    if (spins >= OV_SPIN_LIMIT || ((spins & 31) == 0 && __hip_atomic_load(info + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+      // the first to give up says who it is, what it saw and what it waited for (info[2], info[3]: the error message)
+      if (atomicCAS(info + 1, 0, 1) == 0) {
+        info[2] = who;
+        info[3] = (int)((__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << 16) | (target & 0xffffu));
+      }
+      atomicCAS(info, 0, STEP_INFO_TIMEOUT);
+      return false;
+    }
+    __builtin_amdgcn_s_sleep(8);
+  }
+  return true;
+}
+// the workgroup waits for up to two counters; its first wave alone acquires
+__device__ __forceinline__ bool ov_wait(const unsigned* c0, unsigned t0, const unsigned* c1, unsigned t1, int* info, int* s_ok,
+                                        int who) {
+  if (threadIdx.x < 64) {
+    if (threadIdx.x == 0) {
+      bool ok = ov_poll(c0, t0, info, who);
+      if (ok && c1) ok = ov_poll(c1, t1, info, who + 1);
+      *s_ok = ok ? 1 : 0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+  return *s_ok != 0;
+}
+// after the workgroup's write-through stores: drain, meet, one arrival (at one or two counters)
+__device__ __forceinline__ void ov_arrive(unsigned* c, unsigned* c2 = nullptr) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (c2) __hip_atomic_fetch_add(c2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+struct OvArgs {
+  PanelArgs P;              // A, WT, lda, nb (k and W11 belong to the step)
+  double* W11;              // the two buffers of the diagonal block's inverse, NB * NB each
+  int* info;                // [0] pivot report, [1] abort
+  unsigned* flags;          // OV_WORDS per step
+  const SweepUnit* units;   // the schedule's tables for all steps
+  const int32_t* wg_off;
+  const SweepUnit* heads;
+  unsigned* aux;            // OV_AUX_WORDS
+  int nwg;                  // update workgroups
+};
+
+__device__ __forceinline__ unsigned ov_xcc_id() { return __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u; }   // XCC_ID[3:0]
+
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5))) void sweep_update_kernel(OvArgs O) {
+  extern __shared__ __align__(16) double sm[];
+  __shared__ int s_ok;
+  // One workgroup per CU (LDS), and the diagonal block's workgroup (sweep_diag_kernel, resident before this launch
+  // starts: the gate on this stream) holds a CU of its own.  cu_count workgroups are launched and the first nwg =
+  // cu_count - 4 to START take the indices into the unit table from a counter and stay; the others leave at once,
+  // whenever they get a CU (at the latest when the sweep is over).  The dispatcher deals workgroups to the XCDs in
+  // turn, 32 each, and does not start a launch at XCD 0: the XCD the diagonal block was sent to is one CU short for
+  // this launch, whichever it is (measured: XCD 7), and a launch of exactly cu_count - 1 workgroups that all have to be
+  // resident waits there for the other launch to END -- measured, as were two more workgroups that found no CU.
+  __shared__ int s_wgi;
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(O.aux + OV_AUX_XRANK + ov_xcc_id(), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int w = (int)__hip_atomic_fetch_add(O.aux + OV_AUX_NEXT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (w < O.nwg) __hip_atomic_fetch_add(O.aux + OV_AUX_RESIDENT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_wgi = w;
+  }
+  __syncthreads();
+  const int wgi = s_wgi;
+  if (wgi >= O.nwg) return;
+  StepArgs S;
+  S.P = O.P;
+  S.P.kun = 1;
+  S.W11 = nullptr;
+  S.info = O.info;
+  S.units = O.units;
+  S.cnt = nullptr;
+  S.nmini = 0;
+  S.nwg = O.nwg;
+  for (int k = 0; k + 1 < O.P.nb; ++k) {
+    S.heads = O.heads + (size_t)k * O.nwg;
+    const int4 head = *reinterpret_cast<const int4*>(S.heads + wgi);
+    if (head.w <= 0) continue;   // no units in this step: neither waits nor arrives (the host counts the active ones)
+    unsigned* fl = O.flags + (size_t)OV_WORDS * k;
+    if (!ov_wait(fl + OV_PANEL, 8u * (unsigned)O.P.nb, nullptr, 0u, O.info, &s_ok, 1000 + k)) return;
+    S.P.k = k;
+    S.P.ku0 = k;
+    S.wg_off = O.wg_off + (size_t)k * (O.nwg + 1);
+    step_units<false, true>(S, sm, wgi);
+    ov_arrive(fl + OV_UPD);
+  }
+}
+
+__global__ __launch_bounds__(1024) void sweep_diag_kernel(OvArgs O) {
+  extern __shared__ __align__(16) double sm[];
+  __shared__ int s_ok;
+  // the two wave slots the diagonal block never uses leave now: the workgroup's barriers count live waves only
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (wid >= 11 || wid == 7 || wid == 8) return;
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(O.aux + OV_AUX_DIAG_XCC, 1u + ov_xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(O.aux + OV_AUX_RESIDENT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  const PanelArgs& P = O.P;
+  for (int k = 0; k + 1 < P.nb; ++k) {
+    unsigned* fl = O.flags + (size_t)OV_WORDS * k;
+    if (!ov_wait(fl + OV_TILE, (unsigned)OV_TILE_WGS, nullptr, 0u, O.info, &s_ok, 2000 + k)) return;
+    const int kk = k + 1;
+    double* Akk = P.A + ((int64_t)kk * NB) * P.lda + (int64_t)kk * NB;
+    double* Wkk = P.WT + ((int64_t)kk * NB) * P.lda + (int64_t)kk * NB;
+    potf2_tiles_call_wt(Akk, P.lda, Wkk, P.lda, O.W11 + (size_t)(kk & 1) * NB * NB, O.info, kk, sm);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0)
+      __hip_atomic_store(fl + OV_WORDS + OV_POTF2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// P.k: the panel; fl: its counter words; upd_target: update workgroups with units in step k-1 (their arrivals at the
+// previous step's OV_UPD say that block column k has received everything); ntile: 16, or 0 behind the last panel
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void chain_ov_kernel(PanelArgs P, unsigned* fl, unsigned upd_target, int ntile, int* info) {
+  extern __shared__ __align__(16) double lds[];
+  __shared__ int s_ok;
+  __builtin_amdgcn_s_setprio(3);   // beside the update's waves (older, and never short of an MFMA to issue)
+  // the tile workgroups first in the grid, then the pieces of row block k+1 they wait for: when the launch has more
+  // workgroups than the chip has room beside the update (one per CU), the ones that start late are not on the chain
+  if ((int)blockIdx.x < ntile) {
+    if (!ov_wait(fl + OV_STRIP, 8u, nullptr, 0u, info, &s_ok, 5000 + P.k)) return;
+    lookahead_tile_body<1, true>(P, P.k + 1, blockIdx.x, lds);
+    ov_arrive(fl + OV_TILE);
+    return;
+  }
+  const int b = blockIdx.x - ntile;
+  if (P.k > 0 && !ov_wait(fl + OV_POTF2, 1u, fl - OV_WORDS + OV_UPD, upd_target, info, &s_ok, 3000 + 2 * P.k)) return;
+  double* Pb = panel_block(P, b >> 3) + (int64_t)(b & 7) * 16 * P.lda;   // (row block k+1 first: pieces 0-7)
+  const int l = threadIdx.x & 63;
+  switch (threadIdx.x >> 6) {
+    case 0: trsm16_wave<0, true>(Pb, P.lda, P.W11, l); break;
+    case 1: trsm16_wave<1, true>(Pb, P.lda, P.W11, l); break;
+    case 2: trsm16_wave<2, true>(Pb, P.lda, P.W11, l); break;
+    default: trsm16_wave<3, true>(Pb, P.lda, P.W11, l); break;
+  }
+  ov_arrive(fl + OV_PANEL, (ntile && b < 8) ? fl + OV_STRIP : nullptr);
+}
+
+// One wave that polls a word: (1) on the update's stream before its launch -- the diagonal block's workgroup must be
+// resident first, it needs an EMPTY CU; (2) on the caller's stream between the first chain launch and the others -- they
+// may start only when every workgroup of the two persistent launches is resident.  (A chain launch that polls occupies
+// registers: two of its workgroups on a CU leave no room for an update workgroup, which the chain launch is waiting for.)
+__global__ __launch_bounds__(64) void ov_gate_kernel(const unsigned* word, unsigned target, int* info, int who) {
+  if (threadIdx.x == 0) ov_poll(word, target, info, who);
+}
 
 // --------------------------------------------------------------- alpha, logdet, y^T K^-1 y
 // ONE launch.  Workgroups [1, np / 4]: alpha_i = sum_{k >= i} WT[i][k] z_k, one wavefront per row, coalesced along k,
@@ -1512,6 +1763,70 @@ static int sweep_fused(elfihip_gp* gp, int nb, hipStream_t st, bool chained) {
   return launch_status(ctx, "cholesky sweep (fused steps)");
 }
 
+// ---- the sweep, overlapped (kernels above): the persistent update and diagonal-block launches on the context's two
+// auxiliary streams, the chain launches on the caller's; two stream events per REBUILD (fork after the first diagonal
+// block, join before alpha), none per step.
+static int sweep_overlap(elfihip_gp* gp, int nb, hipStream_t st) {
+  elfihip_ctx* ctx = gp->ctx;
+  ELFIHIP_TRY(ctx_aux(ctx));
+  if (!ctx->ov_lds_enabled) {
+    ELFIHIP_TRY(enable_lds(ctx, sweep_update_kernel, STEP_LDS_BYTES));
+    ctx->ov_lds_enabled = true;
+  }
+  const int nwg = std::max(8, ctx->cu_count - 4);   // update workgroups that stay (sweep_update_kernel)
+  ELFIHIP_TRY(sweep_plan(gp, nb, nwg, false, st));
+  hipStream_t su = ctx->bulk_stream, sd = ctx->hi_stream;
+  PanelArgs P;
+  P.A = gp->A;
+  P.WT = gp->WT;
+  P.lda = gp->lda;
+  P.nb = nb;
+  P.kun = 1;
+  P.k = 0;
+  P.ku0 = 0;
+  P.W11 = gp->W11;
+  unsigned* flags = reinterpret_cast<unsigned*>(gp->info) + gp->ov_flags_off;
+  unsigned* aux = flags + (size_t)OV_WORDS * (gp->cap / NB + 1);
+  hipLaunchKernelGGL(potf2_tiles_kernel<1024>, dim3(1), dim3(1024), POTF2T_LDS_DOUBLES * sizeof(double), st, gp->A,
+                     gp->lda, gp->WT, gp->lda, gp->W11, gp->info, 0);
+  if (nb > 1) {
+    ELFIHIP_CHECK_HIP(ctx, hipEventRecord(ctx->ev_a, st));
+    ELFIHIP_CHECK_HIP(ctx, hipStreamWaitEvent(su, ctx->ev_a, 0));
+    ELFIHIP_CHECK_HIP(ctx, hipStreamWaitEvent(sd, ctx->ev_a, 0));
+    OvArgs O;
+    O.P = P;
+    O.W11 = gp->W11;
+    O.info = gp->info;
+    O.flags = flags;
+    O.units = reinterpret_cast<const SweepUnit*>(gp->sched_units);
+    O.wg_off = reinterpret_cast<const int32_t*>(gp->sched_wgoff);
+    O.heads = reinterpret_cast<const SweepUnit*>(gp->sched_heads);
+    O.nwg = nwg;
+    O.aux = aux;
+    hipLaunchKernelGGL(sweep_diag_kernel, dim3(1), dim3(1024), POTF2T_LDS_DOUBLES * sizeof(double), sd, O);
+    hipLaunchKernelGGL(ov_gate_kernel, dim3(1), dim3(64), 0, su, aux + OV_AUX_DIAG_XCC, 1u, gp->info, 9001);
+    hipLaunchKernelGGL(sweep_update_kernel, dim3(std::max(nwg, ctx->cu_count)), dim3(1024), STEP_LDS_BYTES, su, O);
+  }
+  for (int k = 0; k < nb; ++k) {
+    P.k = k;
+    P.ku0 = k;
+    P.W11 = gp->W11 + (size_t)(k & 1) * NB * NB;
+    const int ntile = k + 1 < nb ? OV_TILE_WGS : 0;
+    const unsigned upd_target = k > 0 ? (unsigned)gp->sched_step_nwg[k - 1] : 0u;
+    hipLaunchKernelGGL(chain_ov_kernel, dim3(8 * nb + ntile), dim3(256), LOOKAHEAD_TILE_LDS, st, P,
+                       flags + (size_t)OV_WORDS * k, upd_target, ntile, gp->info);
+    if (k == 0 && nb > 1)
+      hipLaunchKernelGGL(ov_gate_kernel, dim3(1), dim3(64), 0, st, aux + OV_AUX_RESIDENT, (unsigned)nwg + 1u, gp->info, 9000);
+  }
+  if (nb > 1) {
+    ELFIHIP_CHECK_HIP(ctx, hipEventRecord(ctx->ev_a, su));
+    ELFIHIP_CHECK_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_a, 0));
+    ELFIHIP_CHECK_HIP(ctx, hipEventRecord(ctx->ev_b, sd));
+    ELFIHIP_CHECK_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_b, 0));
+  }
+  return launch_status(ctx, "cholesky sweep (overlapped)");
+}
+
 // ---- the sweep, stream schedule: critical chain on a high-priority stream, passes over the trailing matrix on a
 // second one, panel groups (one pass with K = 128 G per G panels).  Ahead from about 40 block columns, where a
 // K = 128 pass over the trailing matrix is HBM-limited (8 flop per byte).
@@ -1662,7 +1977,9 @@ static int gp_factorize_attempt(elfihip_gp* gp, double diag_add, int* info_out) 
   // column), 3 = fused steps chained inside ONE launch per block column (measured slower: DESIGN.md section 7), 0 = by
   // size (elfihip_gp_set_schedule)
   const bool fused = gp->schedule == 2 || gp->schedule == 3 || gp->schedule == 4 || (gp->schedule == 0 && nb < FUSED_BELOW_NB);
-  if (fused)
+  if (gp->schedule == 5 && nb < FUSED_BELOW_NB)
+    ELFIHIP_TRY(sweep_overlap(gp, nb, st));
+  else if (fused)
     ELFIHIP_TRY(sweep_fused(gp, nb, st, gp->schedule == 3));
   else
     ELFIHIP_TRY(sweep_streams(gp, nb, st));
@@ -1712,8 +2029,11 @@ int gp_factorize_impl(elfihip_gp* gp) {
   const double red[2] = {gp->h_fit[0], gp->h_fit[1]};
   if (info == STEP_INFO_TIMEOUT) {
     gp->factored = false;
+    int w[4] = {0, 0, 0, 0};
+    (void)hipMemcpy(w, gp->info, sizeof(w), hipMemcpyDeviceToHost);
     return fail(ctx, ELFIHIP_ERR_HIP, "factorisation sweep: a hand-off inside a step launch timed out (the launch's "
-                "workgroups were not all resident: another kernel holds compute units of this device)");
+                "workgroups were not all resident: another kernel holds compute units of this device) [waiter %d saw %d of %d]",
+                w[2], (int)((unsigned)w[3] >> 16), w[3] & 0xffff);
   }
   if (info != 0) {
     gp->factored = false;
@@ -1769,7 +2089,9 @@ int elfihip_gp_create(elfihip_ctx* ctx, int d, int64_t capacity, elfihip_gp** ou
   alloc(&gp->W11, (2 * (size_t)NB * NB + 64) * sizeof(double));   // two: block k's is read while block k+1's is written
   alloc(&gp->alpha, (size_t)gp->cap * sizeof(double));
   alloc(&gp->red, 64 * sizeof(double));
-  gp->ninfo = 4 + 4 * (int)(gp->cap / NB);   // pivot report; four counter words per step of the fused sweep
+  // pivot report and abort word; four counter words per step of the fused sweep; OV_WORDS per step of the overlapped one
+  gp->ov_flags_off = 4 + 4 * (int)(gp->cap / NB);
+  gp->ninfo = gp->ov_flags_off + OV_WORDS * ((int)(gp->cap / NB) + 1) + OV_AUX_WORDS;
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&gp->info), gp->ninfo * sizeof(int));
   if (e == hipSuccess) e = hipMemsetAsync(gp->info, 0, gp->ninfo * sizeof(int), ctx->stream);
   if (e == hipSuccess)
@@ -1926,7 +2248,7 @@ int elfihip_gp_profile(elfihip_gp* gp, int enable, double* phase_ms, int64_t* ph
 
 int elfihip_gp_set_schedule(elfihip_gp* gp, int schedule, int panel_group) {
   if (!gp) return fail(nullptr, ELFIHIP_ERR_ARG, "gp is NULL");
-  ELFIHIP_REQUIRE(gp->ctx, schedule >= 0 && schedule <= 4, "schedule %d outside {0, 1, 2, 3, 4}", schedule);
+  ELFIHIP_REQUIRE(gp->ctx, schedule >= 0 && schedule <= 5, "schedule %d outside {0, ..., 5}", schedule);
   ELFIHIP_REQUIRE(gp->ctx, panel_group == 0 || panel_group == 1 || panel_group == 2 || panel_group == 4,
                   "panel_group %d outside {0, 1, 2, 4}", panel_group);
   gp->schedule = schedule;

@@ -398,7 +398,12 @@ int elfihip_gp_jitchol(elfihip_gp* gp, int maxtries, double* jitter, int* tries)
  * beside the trailing update: three launches per block column), 3 = the same chained by arrival counters inside ONE
  * launch per block column (kept for measurement: the in-launch hand-offs cost more than the two launches they replace;
  * needs all of the launch's workgroups resident, i.e. the device to itself), 4 = fused steps with the panel solve and the
- * diagonal tile in ONE launch (two launches per block column; bit-identical to 2, and no faster: kept for measurement);
+ * diagonal tile in ONE launch (two launches per block column; bit-identical to 2, and no faster: kept for measurement),
+ * 5 = the three roles of a step as three CONCURRENT launches on three streams -- a persistent update launch, a
+ * persistent one-workgroup launch for the diagonal blocks, one chain launch (panel solve + diagonal tile) per block
+ * column -- ordered by counters in device memory (bit-identical to 2; measured slower, the update of step k and the
+ * panel solve of step k+1 depend on each other in full and cannot overlap: kept for measurement; needs the device to
+ * itself like 3, and reports a hand-off that does not arrive within about a third of a second as ELFIHIP_ERR_HIP);
  * panel_group 0 = by size, else 1 / 2 / 4 panels per pass over the trailing matrix (schedule 1).  Results agree to
  * rounding between schedules; each is deterministic. */
 int elfihip_gp_set_schedule(elfihip_gp* gp, int schedule, int panel_group);

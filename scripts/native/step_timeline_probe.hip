@@ -20,6 +20,7 @@ int main(int argc, char** argv) {
   for (int i = 0; i < n; ++i) y[i] = std::sin(X[(size_t)i * d]) + 0.1 * U(rng);
   CKE(elfihip_gp_set_hyper(gp, 1.0, 1.5, 0.0, 0.1));
   CKE(elfihip_gp_set_data(gp, X.data(), y.data(), n));
+  CKE(elfihip_gp_set_schedule(gp, argc > 4 ? atoi(argv[4]) : 3, 0));   // 3: the chained step launch (the stamps' subject)
   (void)hipMemcpyToSymbol(HIP_SYMBOL(elfihip::g_step_stamp_k), &step, sizeof(int));
   double lml;
   for (int rep = 0; rep < 5; ++rep) CKE(elfihip_gp_factorize(gp, &lml));

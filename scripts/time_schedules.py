@@ -22,12 +22,17 @@ for n, d in shapes:
     flops = 2.0 * n * n * d + 2.0 * n ** 3 / 3.0
     ref = None
     for name, sched, group in (("streams (auto group)", 1, 0), ("fused steps (3 launches)", 2, 0),
-                               ("fused steps, 2 launches", 4, 0), ("fused steps, chained", 3, 0)):
+                               ("fused steps, 2 launches", 4, 0), ("fused steps, chained", 3, 0),
+                               ("overlapped (3 streams)", 5, 0)):
+        if os.environ.get('ONLY_SCHEDULES') and str(sched) not in os.environ['ONLY_SCHEDULES'].split(','):
+            continue
         gp.set_schedule(sched, group)
         lz = gp.factorize()
         if ref is None:
             ref = lz
         assert abs(lz - ref) <= 1e-9 * abs(ref), (name, lz, ref)
+        if sched == 5:
+            print("        overlapped: log Z %.12f against %.12f (three launches), equal bit for bit: %s" % (lz, lz2, lz == lz2), flush=True)
         if sched == 4:
             assert lz == lz2, "the two-launch step must give the three-launch step's log Z bit for bit"
         if sched == 2:
