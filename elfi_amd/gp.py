@@ -85,7 +85,8 @@ class GPHandle:
 
     def set_schedule(self, schedule=0, panel_group=0):
         """Sweep schedule of factorize(): 0 by size, 1 two-stream look-ahead, 2 fused steps, 3 fused steps chained inside
-        one launch per block column (include/elfihip.h)."""
+        one launch per block column, 4 panel solve + diagonal tile in one launch, 5 three concurrent launches
+        (include/elfihip.h; 3-5 are kept for measurement)."""
         self._check(self.lib.elfihip_gp_set_schedule(self.h, int(schedule), int(panel_group)))
 
     def set_dense_threshold(self, min_points=0, tile_rows=0):
