@@ -1,3 +1,5 @@
+"""Developer tool: three rebuilds with the overlapped sweep (elfihip_gp_set_schedule(gp, 5, 0)), for profiler runs.
+usage: python scripts/ov_once.py n d"""
 import sys, os
 sys.path.insert(0, '/root/repo')
 import numpy as np
