@@ -314,12 +314,12 @@ class Context:
 # when the context still keeps that call's copy (include/elfihip.h: elfihip_kept_distances).
 _KEPT = {}
 
-# The hand-over is keyed by the IDENTITY of the host array, so it assumes that nobody writes into the array between the
-# call that returned it and the call that consumes it (ELFI's graph never does; a user operation might: `d[mask] = inf`,
-# `X *= s` on randn_rows output, an `out=` argument).  Guard: a fingerprint of 256 strided elements taken when the array is
-# handed out and compared before the device copy is used -- an array that was rewritten wholesale (scaling, `out=`) never
-# passes; a few scattered edits can (write to a copy instead, or switch the hand-over off with set_device_handover(False):
-# every consumer then uploads what the host array holds).
+# The hand-over is keyed by the IDENTITY of the host array, so nobody may write into the array between the call that
+# returned it and the call that consumes it (ELFI's graph never does; a user operation might: `d[mask] = inf`, `X *= s` on
+# randn_rows output, an `out=` argument).  That is enforced, not assumed: an array that names a device copy is handed out
+# READ-ONLY (`flags.writeable = False`: an in-place edit raises ValueError -- edit a copy, which takes the upload path, or
+# switch the hand-over off with set_device_handover(False)), and a consumer that finds the array writeable again drops the
+# entry and reads the host array.
 _HANDOVER = [True]
 
 
@@ -334,13 +334,20 @@ def set_device_handover(enabled=True):
     return prev
 
 
-def _fingerprint(arr):
+def _freeze(arr):
+    """Mark `arr` read-only; False when the object cannot be (not an ndarray)."""
     try:
-        flat = arr.reshape(-1)
-        step = max(1, flat.shape[0] // 256)
-        return (arr.shape, arr.strides, flat[::step][:256].tobytes(), flat[-1:].tobytes())
-    except Exception:
-        return None
+        arr.flags.writeable = False
+        return True
+    except (AttributeError, ValueError):
+        return False
+
+
+def _frozen(arr):
+    try:
+        return not arr.flags.writeable
+    except AttributeError:
+        return False
 
 
 def remember_kept(arr, ctx):
@@ -352,7 +359,8 @@ def remember_kept(arr, ctx):
     if not _HANDOVER[0]:
         return arr
     try:
-        _KEPT[id(arr)] = (weakref.ref(arr), ctx, ctx.kept_epoch(), _fingerprint(arr))
+        if _freeze(arr):
+            _KEPT[id(arr)] = (weakref.ref(arr), ctx, ctx.kept_epoch())
     except TypeError:
         pass
     return arr
@@ -407,7 +415,8 @@ def remember_rows(arr, ctx):
         return arr
     ep = C.c_uint64()
     ctx.call("elfihip_kept_rows", C.byref(ep), None, None)
-    _ROWS[id(arr)] = (weakref.ref(arr), ctx, ep.value, _fingerprint(arr))
+    if _freeze(arr):
+        _ROWS[id(arr)] = (weakref.ref(arr), ctx, ep.value)
     return arr
 
 
@@ -415,7 +424,7 @@ def rows_epoch_of(arr, ctx):
     ent = _ROWS.get(id(arr))
     if ent is None or ent[0]() is not arr or ent[1] is not ctx:
         return None
-    if ent[3] != _fingerprint(arr):      # written to since it was handed out: the device copy is not this array any more
+    if not _frozen(arr):      # made writeable again since it was handed out: the device copy may not be this array any more
         del _ROWS[id(arr)]
         return None
     return ent[2]
@@ -426,7 +435,8 @@ def alias_kept(new, old):
     ent = _KEPT.get(id(old))
     if ent is not None and ent[0]() is old:
         try:
-            _KEPT[id(new)] = (weakref.ref(new), ent[1], ent[2], _fingerprint(new))
+            if _frozen(old) and _freeze(new):       # (a view of a read-only array is read-only already)
+                _KEPT[id(new)] = (weakref.ref(new), ent[1], ent[2])
         except TypeError:
             pass
     return new
@@ -437,7 +447,7 @@ def kept_epoch_of(arr, ctx):
     ent = _KEPT.get(id(arr))
     if ent is None or ent[0]() is not arr or ent[1] is not ctx:
         return None
-    if ent[3] != _fingerprint(arr):      # written to since it was handed out: the device copy is not this array any more
+    if not _frozen(arr):      # made writeable again since it was handed out: the device copy may not be this array any more
         del _KEPT[id(arr)]
         return None
     return ent[2]

@@ -44,7 +44,8 @@ def logexp(phi):
 def logexp_inv(theta):
     """paramz Logexp.finv."""
     theta = np.asarray(theta, dtype=np.float64)
-    return np.where(theta > _LIM_VAL, theta, np.log(np.expm1(theta)))
+    # (the branch above the limit never reads expm1: evaluate it on the clipped argument -- same values below 36, no overflow)
+    return np.where(theta > _LIM_VAL, theta, np.log(np.expm1(np.minimum(theta, _LIM_VAL))))
 
 
 def logexp_gradfactor(theta):
@@ -89,7 +90,8 @@ class MarginalObjective:
                 a, b = self.priors[name]
                 t = theta[i]
                 lp += gamma_lnpdf(t, a, b) + (np.log(np.expm1(t)) - t if t <= _LIM_VAL else 0.0)
-                dlp[i] = (a - 1.) / t - b + 1. / np.expm1(t)
+                with np.errstate(over='ignore'):        # expm1(t) = inf above 709.78 -> the term is exactly 0, as in paramz
+                    dlp[i] = (a - 1.) / t - b + 1. / np.expm1(t)
         return lp, dlp
 
     def f(self, phi):

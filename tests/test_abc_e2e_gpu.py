@@ -63,6 +63,22 @@ def test_kept_distances_hand_over(hip_ctx):
     e.push_distances(D.copy())
     assert c.kept_pushes == 1 and all(np.array_equal(p, q) for p, q in zip(c.result(), e.result()))
     assert c.meta()[2] == int(np.sum(D[:, 1] <= 2.5))
+    # the hand-over is exact (round 6; the round-5 fingerprint of 256 elements could miss a scattered edit): an array that
+    # names a device copy is read-only, the edited copy is uploaded, an array made writeable again is uploaded too
+    d4 = elfi_amd.cdist_rows(X, y)
+    with pytest.raises(ValueError):
+        d4[0] = 1.0
+    with pytest.raises(ValueError):
+        d4[np.isnan(d4)] = np.inf
+    d5 = d4.copy()
+    d5[12345] = 0.0
+    f, g = elfi_amd.RunningBest(10), elfi_amd.RunningBest(10)
+    f.push_distances(d5)
+    assert getattr(f, 'kept_pushes', 0) == 0 and f.result()[0][0] == 0.0 and f.result()[1][0] == 12345
+    d4.flags.writeable = True
+    d4[777] = 0.0                               # one element of 50 000: the stale device copy must not be used
+    g.push_distances(d4)
+    assert getattr(g, 'kept_pushes', 0) == 0 and g.result()[0][0] == 0.0 and g.result()[1][0] == 777
 
 
 def test_hip_rejection_takes_the_device_copy(hip_ctx, elfi):

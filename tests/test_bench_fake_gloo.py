@@ -22,9 +22,24 @@ def _run(gpus, extra=()):
            "--warmup", "2"] + list(extra)
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-3000:]
-    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, "exactly one JSON line from rank 0, got %d" % len(lines)
-    return json.loads(lines[0])
+    out = p.stdout.splitlines()
+    lines = [ln for ln in out if ln.startswith("{")]
+    assert len(lines) == 1 and out[-1] == lines[0], "exactly one JSON line from rank 0, the last of stdout: got %d" % len(lines)
+    # the driver keeps the last 8 KB of stdout: the line it parses must fit with room to spare (round 5's 20.6 KB line
+    # left BENCH_r05.json.parsed = null)
+    assert len(lines[0]) < 6144, len(lines[0])
+    compact = json.loads(lines[0])
+    assert json.loads(json.dumps(compact)) == compact
+    detail = [ln for ln in p.stderr.splitlines() if ln.startswith("bench detail: ")]
+    assert len(detail) == 1
+    r = json.loads(detail[0][len("bench detail: "):])
+    for k in REQUIRED:      # the compact line carries the contract's keys with the detail record's values
+        assert compact[k] == r[k] or k in ("config", "roofline"), k
+    assert compact["config"]["world_size_seen"] == gpus == r["env"]["world_size_seen"]
+    assert compact["config"]["samples_per_gpu"] == r["config"]["samples_per_gpu"]
+    assert "detail" not in compact["roofline"] and compact["roofline"]["frac"] == r["roofline"]["frac"]
+    assert all(not isinstance(v, (dict, list)) for v in compact["roofline"].values())
+    return r
 
 
 def test_two_ranks_run_the_whole_script():

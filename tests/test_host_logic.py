@@ -279,6 +279,26 @@ def test_kept_registries_and_pinned_pool_plumbing():
     assert _lib.alias_kept(v, a) is v and _lib.kept_epoch_of(v, ctx) == 7
     b = np.ones(3)
     assert _lib.alias_kept(b.reshape(-1), b) is not None and _lib.kept_epoch_of(b, ctx) is None      # nothing to alias
+    # the hand-over is exact: what names a device copy is read-only, a copy is an ordinary array that takes the upload
+    # path, and an array somebody made writeable again no longer names the device copy
+    with pytest.raises(ValueError):
+        a[0, 0] = 1.0
+    with pytest.raises(ValueError):
+        v[3] = 1.0
+    a2 = a.copy()
+    a2[0, 0] = 1.0
+    assert a2.flags.writeable and _lib.kept_epoch_of(a2, ctx) is None and b.flags.writeable
+    w = np.zeros(4)
+    _lib.remember_kept(w, ctx)
+    w.flags.writeable = True
+    w[np.array([2])] = np.inf              # the scattered edit the round-5 fingerprint could miss
+    assert _lib.kept_epoch_of(w, ctx) is None and id(w) not in _lib._KEPT
+    prev = _lib.set_device_handover(False)
+    try:
+        free = _lib.remember_kept(np.zeros(3), ctx)
+        assert free.flags.writeable and _lib.kept_epoch_of(free, ctx) is None
+    finally:
+        _lib.set_device_handover(prev)
     ident = id(a)
     del a, v
     gc.collect()
@@ -289,6 +309,10 @@ def test_kept_registries_and_pinned_pool_plumbing():
     r = np.zeros((4, 6))
     ctx.epoch = 9
     assert _lib.remember_rows(r, ctx) is r and _lib.rows_epoch_of(r, ctx) == 9 and _lib.rows_epoch_of(r, other) is None
+    with pytest.raises(ValueError):
+        r *= 2.0
+    r.flags.writeable = True
+    assert _lib.rows_epoch_of(r, ctx) is None
     p = _lib.pinned.array((10, 4))
     assert p.shape == (10, 4) and p.dtype == np.float64 and p.flags['WRITEABLE']
     p[:] = 3.0
