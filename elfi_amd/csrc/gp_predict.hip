@@ -169,20 +169,28 @@ __device__ __forceinline__ void grad_rows(const double* __restrict__ X, const do
                                           int nchunks, int64_t i0, int64_t n, int64_t np, int dp, double (*red)[PC][32],
                                           double bias = 0.0, double* __restrict__ sq_part = nullptr);
 
+#ifdef ELFIHIP_TRI_STAMP   // developer probe (scripts/tri_timeline.py): wall-clock stamps (100 MHz) per workgroup and phase
+__device__ unsigned long long g_tri_stamp[8192 * 8];
+#define PSTAMP(slot) do { const unsigned pidx_ = (MODE == 1 ? 4096u : 0u) + blockIdx.x + blockIdx.y * gridDim.x; \
+    if (threadIdx.x == 0 && pidx_ < 8192) g_tri_stamp[pidx_ * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define PSTAMP(slot) do { } while (0)
+#endif
+
 template <int MODE, bool FUSE>
-__global__ __launch_bounds__(256, 3) void tri_apply_kernel(TriArgs T) {   // three workgroups per CU: <= 168 registers (four = 128 registers spills: 61 -> 74 us per lock-step)
+__device__ __forceinline__ void tri_apply_body(const TriArgs& T, const int rb, const int kc, double* Bs, int* s_last_p) {
   // No LDS staging of the matrix: a lane's 16-byte load IS its MFMA operand.  Lane (kq = l >> 4, ip = l & 15)
   // of wave w loads W[k][i0 + 2 ip .. + 1] for k = k0 + 16 q + 4 w + kq, q = 0 .. len/16: one instruction covers
   // 4 rows x 256 contiguous bytes, and its two doubles feed two v_mfma_f64_16x16x4 (even rows i / odd rows i)
   // against B[k][s] from LDS.  All (up to 16) loads of a lane are issued before the first MFMA, so a workgroup
   // has its whole <= 64 KiB in flight at once; the four waves' partial tiles are added in fixed order at the end.
-  __shared__ __align__(16) double Bs[KC * PC];  // right-hand sides of this chunk [k][s]; later the wave partials
+  // (Bs: KC * PC doubles of LDS -- the right-hand sides of this chunk [k][s]; later the wave partials)
   // One workgroup serves ALL passes of the launch for its (row block, chunk): the matrix operands stay in registers
   // and only the right-hand sides change -- with a workgroup per pass every pass pulled its 64 KiB of the matrix
   // through L2 again (16 passes at n = 8192: 8.6 GB per evaluation round, L2-bound at 1.6 ms against 0.45 ms of
   // matrix-pipe time).
-  const int rb = blockIdx.x, kc = blockIdx.y;
   if (rb >= T.nrb) return;
+  PSTAMP(0);
   const int64_t i0 = (int64_t)rb * RB;
   int64_t k0 = (int64_t)kc * KC, k1 = k0 + KC;
   if (MODE == 1) {
@@ -227,6 +235,7 @@ __global__ __launch_bounds__(256, 3) void tri_apply_kernel(TriArgs T) {   // thr
 #pragma unroll
     for (int p = 0; p < 8; ++p) *reinterpret_cast<v2d*>(Bs + p * 512 + 2 * t) = breg[p];
     __syncthreads();
+    PSTAMP(2);
     if (pass + 1 < T.npass) load_b(pass + 1);   // in flight during this pass's products
     v4d acc0 = (v4d){0, 0, 0, 0}, acc1 = (v4d){0, 0, 0, 0};
 #pragma unroll
@@ -256,10 +265,11 @@ __global__ __launch_bounds__(256, 3) void tri_apply_kernel(TriArgs T) {   // thr
     }
   }
   if (!FUSE || MODE == 2) return;
+  int& s_last = *s_last_p;
+  PSTAMP(3);
   // ---- arrival at the row block (MI355X_MICROARCH.md, hand-off price list: write-through payload, every storing wave
   // drains, ONE lane arrives on the block's counter with a relaxed device-scope atomic; the last arriver takes ONE
   // agent-scope acquire -- its CU's L1 may hold the other workgroups' lines from an earlier launch -- then plain loads)
-  __shared__ int s_last;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (t == 0) {
@@ -276,6 +286,7 @@ __global__ __launch_bounds__(256, 3) void tri_apply_kernel(TriArgs T) {   // thr
     s_last = last;
   }
   __syncthreads();
+  PSTAMP(4);
   if (!s_last) return;
   if (MODE == 0) {
     // what tri_reduce_kernel does for these 32 rows (same order of summation, same per-16-row blocks of v^2)
@@ -312,6 +323,66 @@ __global__ __launch_bounds__(256, 3) void tri_apply_kernel(TriArgs T) {   // thr
                             T.part + (int64_t)pass * T.nkc * T.np * PC, T.nkc,
                             T.g_part + (int64_t)pass * PC * T.nrb * 2 * T.dp, rb, T.nrb, i0, T.n, T.np, T.dp, red, T.bias,
                             T.sq_part + (int64_t)pass * (T.np / 16) * PC);
+  }
+  PSTAMP(5);
+}
+
+constexpr int RB_PER_KC = KC / RB;
+
+// Tiles of a fused product as a ONE-dimensional grid, CHUNK by chunk (round 6).  The (row block, chunk) grid of rounds 2-5
+// launched 2048 workgroups at n = 4096 of which 960 lay outside the triangle and left at once, and ran the second product in
+// ASCENDING chunk order -- where every row block needs the LAST chunk, so all 128 last-arriver epilogues ran together after
+// the last tile.  Now only live tiles are launched and the second product runs its chunks in DESCENDING order: row blocks
+// 8 kc .. 8 kc + 7 are complete once chunk kc has run and their epilogues run under the next chunks' tiles.  Measured
+// (profiles/r06_lockstep_timeline.md): 62.4 -> 61.6 us per lock-step at n = 4096, 52.2 -> 50.6 with K^-1 -- the tail is still
+// ONE epilogue (5.5-6.4 us behind the last tile), which is a chain of dependent memory and barrier round trips, not work.
+// (Row block by row block instead -- measured -- is 15-40 % SLOWER: the tiles in flight then share their 256-byte column
+// offsets, i.e. their memory channels; chunk by chunk the 128 row blocks of a chunk cover whole 32 KiB rows.)
+// Same tiles, same partial slots, same order of summation as the two-dimensional grid.
+//   MODE 0 (k <= i): chunk kc holds the row blocks rb >= 8 kc, kc ascending (row blocks complete from the top anyway)
+//   MODE 1 (k >= i): chunk kc holds the row blocks rb < 8 (kc + 1), kc DESCENDING          MODE 3 (full): nrb tiles per chunk
+template <int MODE>
+__device__ __forceinline__ bool tri_tile_of(int b, int nrb, int nkc, int* rb, int* kc) {
+  if (MODE == 3) {
+    *kc = b / nrb;
+    *rb = b - *kc * nrb;
+    return *kc < nkc;
+  }
+  for (int c = 0; c < nkc; ++c) {
+    const int k = MODE == 0 ? c : nkc - 1 - c;
+    const int lim = RB_PER_KC * (k + 1);
+    const int cnt = MODE == 0 ? nrb - RB_PER_KC * k : (lim < nrb ? lim : nrb);
+    if (b < cnt) {
+      *kc = k;
+      *rb = MODE == 0 ? RB_PER_KC * k + b : b;
+      return true;
+    }
+    b -= cnt;
+  }
+  return false;
+}
+
+static int tri_tiles(int mode, int nrb, int nkc) {
+  if (mode == 3) return nrb * nkc;
+  int total = 0;
+  for (int rb = 0; rb < nrb; ++rb) total += mode == 0 ? rb / RB_PER_KC + 1 : nkc - rb / RB_PER_KC;
+  return total;
+}
+
+// Three workgroups per CU (<= 168 registers).  Four were measured twice: with 128 registers and spills (round 3: 61 -> 74 us per
+// lock-step) and, round 6, without spills (the right-hand sides DMA'd straight into LDS, 112 registers): 1024 tiles in flight
+// instead of 768 lengthen every tile's life from 7.1 to 10.8 us -- the products already pull 6.5 TB/s while their tiles are
+// in flight -- and the lock-step went from 61.6 to 67.5 us (profiles/r06_lockstep_timeline.md).
+template <int MODE, bool FUSE>
+__global__ __launch_bounds__(256, 3) void tri_apply_kernel(TriArgs T) {
+  __shared__ __align__(16) double Bs[KC * PC];
+  __shared__ int s_last;
+  if (FUSE && MODE != 2) {
+    int rb, kc;
+    if (!tri_tile_of<MODE>((int)blockIdx.x, T.nrb, T.nkc, &rb, &kc)) return;
+    tri_apply_body<MODE, FUSE>(T, rb, kc, Bs, &s_last);
+  } else {
+    tri_apply_body<MODE, FUSE>(T, (int)blockIdx.x, (int)blockIdx.y, Bs, &s_last);
   }
 }
 
@@ -736,8 +807,8 @@ void launch_finish_passes(elfihip_gp* gp, const double* mu_part, int nblk_k, con
 // One triangular product for `g` passes: part[pass][kc][i][s] from bin[pass][k][s].
 // fused = the reduction (first product) / the gradient sums (second product) by the last workgroup of every row block
 // full: ONE product with the symmetric K^-1 (fused form only; xs as for the lower product)
-static void launch_tri(const elfihip_gp* gp, const PredictWs& W, bool lower, const double* bin, unsigned g, bool fused = false,
-                       const double* xs = nullptr, bool full = false) {
+static TriArgs tri_args(const elfihip_gp* gp, const PredictWs& W, bool lower, const double* bin, unsigned g, const double* xs,
+                        bool full) {
   TriArgs T;
   T.W = full ? gp->Kinv : (lower ? gp->WL : gp->WT);
   T.bias = gp->bias;
@@ -759,13 +830,19 @@ static void launch_tri(const elfihip_gp* gp, const PredictWs& W, bool lower, con
   T.g_part = W.g_part;
   T.n = gp->n;
   T.dp = gp->dp;
+  return T;
+}
+
+static void launch_tri(const elfihip_gp* gp, const PredictWs& W, bool lower, const double* bin, unsigned g, bool fused = false,
+                       const double* xs = nullptr, bool full = false) {
+  const TriArgs T = tri_args(gp, W, lower, bin, g, xs, full);
   const dim3 grid((unsigned)T.nrb, (unsigned)W.nkc);
   if (full)
-    hipLaunchKernelGGL((tri_apply_kernel<3, true>), grid, dim3(256), 0, gp->ctx->stream, T);
+    hipLaunchKernelGGL((tri_apply_kernel<3, true>), dim3((unsigned)tri_tiles(3, T.nrb, T.nkc)), dim3(256), 0, gp->ctx->stream, T);
   else if (fused && lower)
-    hipLaunchKernelGGL((tri_apply_kernel<1, true>), grid, dim3(256), 0, gp->ctx->stream, T);
+    hipLaunchKernelGGL((tri_apply_kernel<1, true>), dim3((unsigned)tri_tiles(1, T.nrb, T.nkc)), dim3(256), 0, gp->ctx->stream, T);
   else if (fused)
-    hipLaunchKernelGGL((tri_apply_kernel<0, true>), grid, dim3(256), 0, gp->ctx->stream, T);
+    hipLaunchKernelGGL((tri_apply_kernel<0, true>), dim3((unsigned)tri_tiles(0, T.nrb, T.nkc)), dim3(256), 0, gp->ctx->stream, T);
   else if (lower)
     hipLaunchKernelGGL((tri_apply_kernel<1, false>), grid, dim3(256), 0, gp->ctx->stream, T);
   else
@@ -1421,6 +1498,16 @@ static int cross_cov_impl(elfihip_gp* gp, const double* Q, int64_t S, double* co
 using namespace elfihip;
 
 extern "C" {
+
+#ifdef ELFIHIP_TRI_STAMP
+int elfihip_debug_tri_stamps(unsigned long long* out, int clear) {
+  if (clear) {
+    static unsigned long long zero[8192 * 8];
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(elfihip::g_tri_stamp), zero, sizeof(zero));
+  }
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(elfihip::g_tri_stamp), sizeof(unsigned long long) * 8192 * 8);
+}
+#endif
 
 int elfihip_gp_lockstep_info(const elfihip_gp* gp, int* kinv_in_use, int64_t* steps, double* cond_bound) {
   if (!gp) return fail(nullptr, ELFIHIP_ERR_ARG, "gp is NULL");
