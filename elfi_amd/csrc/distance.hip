@@ -593,6 +593,151 @@ static int set_lds(elfihip_ctx* ctx, KernelT k, size_t lds) {
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   return ELFIHIP_OK;
 }
+// ---- narrow rows (round 6): m = 2 or 4 summaries, 16-byte aligned ----------------------------------------------------------
+// A row is one or two 16-byte granules: nothing to stage.  The tile kernels above put 128 rows (2 KiB at m = 2) through LDS
+// per pair of barriers with one lane in four idle and were launch- and barrier-bound at configs[0]'s own shape (4 10^6 x 2:
+// minkowski 0.23, mahalanobis 0.28, the K-weight form 0.26 of HBM -- profiles/r05_kernel_table.md).  Here lane r of a
+// 256-thread workgroup OWNS rows r, r + 256, ...: U rows (U 16- or 32-byte non-temporal loads) in flight per lane,
+// consecutive lanes on consecutive rows (a wave-instruction covers 1 KiB of contiguous rows), the row summed left to right in
+// registers exactly as the tile kernels sum it (bit-identical), one 8-byte store per row (512 contiguous bytes per wave).
+template <int M>
+__device__ __forceinline__ void narrow_load(const RowArgs& A, int64_t r, double (&x)[M]) {
+  typedef double v2d_nt __attribute__((ext_vector_type(2)));
+  const v2d_nt* src = reinterpret_cast<const v2d_nt*>(A.X + r * A.ldx);
+#pragma unroll
+  for (int h = 0; h < M / 2; ++h) {
+    const v2d_nt t = __builtin_nontemporal_load(src + h);
+    x[2 * h] = t.x;
+    x[2 * h + 1] = t.y;
+  }
+}
+
+template <int METRIC, bool W, int M, int U>
+__global__ __launch_bounds__(256) void dist_rows_narrow_kernel(RowArgs A) {
+  const int tid = threadIdx.x;
+  double yv[M], av[M];
+#pragma unroll
+  for (int j = 0; j < M; ++j) {
+    yv[j] = A.y[j];
+    av[j] = W ? A.aux[j] : 1.0;
+  }
+  const double thr = A.F.thr ? *A.F.thr : 0.0;   // fused selection: the sampler state's current k-th best distance
+  const int64_t per = 256 * U;
+  for (int64_t base = (int64_t)blockIdx.x * per; base < A.n; base += (int64_t)gridDim.x * per) {
+    double x[U][M];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t r = base + u * 256 + tid;
+      narrow_load<M>(A, r < A.n ? r : A.n - 1, x[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t r = base + u * 256 + tid;
+      double s = Op<METRIC, W>::init();
+#pragma unroll
+      for (int j = 0; j < M; ++j) s = Op<METRIC, W>::step(s, x[u][j], yv[j], av[j], A.p);
+      const double dist = Op<METRIC, W>::finish(s, A.inv_p);
+      if (r < A.n) A.out[r] = dist;
+      if (A.F.thr) reject_offer(A.F, r < A.n && dist < thr, dist, A.F.row_base + r);
+    }
+  }
+}
+
+// Mahalanobis on narrow rows: VI (M x M) in registers, the sums in dist_rows_mahalanobis_kernel's order (bit-identical to it).
+template <int M, int U>
+__global__ __launch_bounds__(256) void dist_rows_mahalanobis_narrow_kernel(RowArgs A) {
+  const int tid = threadIdx.x;
+  double yv[M], vi[M][M];
+#pragma unroll
+  for (int j = 0; j < M; ++j) {
+    yv[j] = A.y[j];
+#pragma unroll
+    for (int k = 0; k < M; ++k) vi[j][k] = A.aux[j * M + k];
+  }
+  const int64_t per = 256 * U;
+  for (int64_t base = (int64_t)blockIdx.x * per; base < A.n; base += (int64_t)gridDim.x * per) {
+    double x[U][M];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t r = base + u * 256 + tid;
+      narrow_load<M>(A, r < A.n ? r : A.n - 1, x[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t r = base + u * 256 + tid;
+      double d[M];
+#pragma unroll
+      for (int j = 0; j < M; ++j) d[j] = x[u][j] - yv[j];
+      double s = 0.0;
+#pragma unroll
+      for (int i = 0; i < M; ++i) {
+        double ti = 0.0;
+#pragma unroll
+        for (int k = 0; k < M; ++k) ti += d[k] * vi[i][k];
+        s += d[i] * ti;
+      }
+      if (r < A.n) A.out[r] = sqrt(s);
+    }
+  }
+}
+
+// K weighted euclidean distances per narrow row (AdaptiveDistance.nested_distance): the weights of up to 8 vectors in
+// registers, every sum left to right as dist_multiw_pipe_kernel forms it (bit-identical); the K results of a row are
+// adjacent in `out` (a wave writes 512 K contiguous bytes).
+template <int M, int U>
+__global__ __launch_bounds__(256) void dist_multiw_narrow_kernel(RowArgs A) {
+  constexpr int KMAX = 8;
+  const int tid = threadIdx.x, K = A.K;
+  double yv[M], wv[KMAX][M];
+#pragma unroll
+  for (int j = 0; j < M; ++j) yv[j] = A.y[j];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k)
+#pragma unroll
+    for (int j = 0; j < M; ++j) wv[k][j] = k < K ? A.aux[k * M + j] : 0.0;
+  const double thr = A.F.thr ? *A.F.thr : 0.0;   // fused selection, by the LAST nested distance (samplers.py:233)
+  const int64_t per = 256 * U;
+  for (int64_t base = (int64_t)blockIdx.x * per; base < A.n; base += (int64_t)gridDim.x * per) {
+    double x[U][M];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t r = base + u * 256 + tid;
+      narrow_load<M>(A, r < A.n ? r : A.n - 1, x[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t r = base + u * 256 + tid;
+      double d2[M];
+#pragma unroll
+      for (int j = 0; j < M; ++j) {
+        const double d = x[u][j] - yv[j];
+        d2[j] = d * d;
+      }
+      double dlast = 0.0;
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) {
+        if (k < K) {
+          double sk = 0.0;
+#pragma unroll
+          for (int j = 0; j < M; ++j) sk = sk + wv[k][j] * d2[j];
+          dlast = sqrt(sk);
+          if (r < A.n) A.out[r * K + k] = dlast;
+        }
+      }
+      if (A.F.thr) reject_offer(A.F, r < A.n && dlast < thr, dlast, A.F.row_base + r);
+    }
+  }
+}
+
+static inline bool narrow_rows(const elfihip_ctx* ctx, const RowArgs& A) {
+  return A.vec2 && (A.m == 2 || A.m == 4) && ctx->dist_form != 1;   // (form 1: the tile kernels of rounds 1-5, for comparison)
+}
+static inline unsigned narrow_grid(const elfihip_ctx* ctx, int64_t n, int U) {
+  int64_t g = (n + 256 * U - 1) / (256 * U), cap = (int64_t)ctx->cu_count * 8;
+  if (g > cap) g = cap;
+  return (unsigned)(g < 1 ? 1 : g);
+}
+
 // 16-byte loads per thread of the pipelined row kernels.  Rows that cost a few flops per element (everything but
 // general Minkowski and the K-weight sums) stream best in tiles of 32 to 64 rows (8 to 16 KiB per workgroup); the
 // heavier per-row work wants all 128 lanes of the workgroup on rows (tiles of 128 rows).
@@ -610,6 +755,15 @@ static int launch_rows(elfihip_ctx* ctx, RowArgs A, bool* filtered) {
     if (g > cap) g = cap;
     hipLaunchKernelGGL((dist_rows_wide_kernel<METRIC, W>), dim3((unsigned)g), dim3(256), 0, ctx->stream, A);
     return launch_status(ctx, "dist_rows_wide_kernel");
+  }
+  if (narrow_rows(ctx, A)) {
+    constexpr int U = 4;
+    if (A.m == 2)
+      hipLaunchKernelGGL((dist_rows_narrow_kernel<METRIC, W, 2, U>), dim3(narrow_grid(ctx, A.n, U)), dim3(256), 0, ctx->stream, A);
+    else
+      hipLaunchKernelGGL((dist_rows_narrow_kernel<METRIC, W, 4, U>), dim3(narrow_grid(ctx, A.n, U)), dim3(256), 0, ctx->stream, A);
+    if (filtered) *filtered = A.F.thr != nullptr;   // this form offers its candidates itself, too
+    return launch_status(ctx, "dist_rows_narrow_kernel");
   }
   size_t lds;
   const int T = pick_block(A.m, 2 * (size_t)A.m, &lds);
@@ -924,6 +1078,14 @@ int dist_rows_dev_impl(elfihip_ctx* ctx, int metric, const double* dX, int64_t n
   const bool w = daux != nullptr;
   if (cm == ELFIHIP_MAHALANOBIS) {
     ELFIHIP_REQUIRE(ctx, m <= kMaxTileM, "mahalanobis supports m <= %d", kMaxTileM);
+    if (narrow_rows(ctx, A)) {
+      constexpr int U = 4;
+      if (m == 2)
+        hipLaunchKernelGGL((dist_rows_mahalanobis_narrow_kernel<2, U>), dim3(narrow_grid(ctx, n, U)), dim3(256), 0, ctx->stream, A);
+      else
+        hipLaunchKernelGGL((dist_rows_mahalanobis_narrow_kernel<4, U>), dim3(narrow_grid(ctx, n, U)), dim3(256), 0, ctx->stream, A);
+      return launch_status(ctx, "dist_rows_mahalanobis_narrow_kernel");
+    }
     if (m >= 8 && m <= 64 && A.vec2 && ldx < (1 << 22)) {   // even m, 16-byte aligned rows: VI in registers, pipelined row loads
       const int kc = (m + 15) / 16;
       const size_t lb = ((size_t)MAHA_ROWS * A.mp + 64 + 64) * sizeof(double);
@@ -1026,6 +1188,15 @@ int dist_multiw_dev_impl(elfihip_ctx* ctx, const double* dX, int64_t n, int m, i
   A.nt = ctx->dist_form != 1;
   A.K = K;
   if (F) A.F = *F;
+  if (narrow_rows(ctx, A) && K <= 8) {
+    constexpr int U = 4;
+    if (m == 2)
+      hipLaunchKernelGGL((dist_multiw_narrow_kernel<2, U>), dim3(narrow_grid(ctx, n, U)), dim3(256), 0, ctx->stream, A);
+    else
+      hipLaunchKernelGGL((dist_multiw_narrow_kernel<4, U>), dim3(narrow_grid(ctx, n, U)), dim3(256), 0, ctx->stream, A);
+    if (filtered) *filtered = A.F.thr != nullptr;
+    return launch_status(ctx, "dist_multiw_narrow_kernel");
+  }
   size_t lds;
   int T = pick_block(m, (size_t)m + (size_t)K * m, &lds);
   ELFIHIP_REQUIRE(ctx, lds <= 160 * 1024, "m=%d with K=%d weight vectors does not fit LDS", m, K);

@@ -459,3 +459,64 @@ def test_lds_dma_row_stream_equals_the_register_pipeline_and_cdist(hip_ctx, m):
             assert np.array_equal(vals, allv[order]) and np.array_equal(rows, order), n
     finally:
         hip_ctx.call('elfihip_dist_set_form', 0)
+
+
+@pytest.mark.parametrize('m', [2, 4])
+def test_narrow_row_kernels_equal_the_tile_kernels_and_cdist(hip_ctx, m):
+    """Round 6: rows of 2 or 4 summaries (configs[0]'s own shape) are owned by lanes -- U 16-/32-byte loads per lane, no LDS
+    (csrc/distance.hip: dist_rows_narrow_kernel, dist_rows_mahalanobis_narrow_kernel, dist_multiw_narrow_kernel) -- against
+    SciPy's cdist and against the tile kernels they replace (form 1), bit for bit: every metric, weights, ragged and tiny n
+    on both sides of the 1024-row granule, a row pitch that is not the width, the K-weight form, and the sampler state fed
+    by the same pass."""
+    import elfi_amd
+    rs = np.random.RandomState(900 + m)
+    y, w = rs.randn(1, m), rs.uniform(0.1, 3, m)
+    w0 = w.copy()
+    w0[0] = 0.0
+    Z = rs.randn(40, m) @ rs.randn(m, m)
+    VI = np.linalg.inv(np.cov(Z.T).reshape(m, m) + 0.1 * np.eye(m))
+    VI = 0.5 * (VI + VI.T)
+    W = np.vstack([np.ones(m), rs.uniform(0.2, 2, (4, m))])
+    try:
+        for n in (1, 2, 255, 256, 257, 1023, 1024, 1025, 4099, 65536 + 17, 1000003):
+            X = rs.randn(n, m) * 1.5
+            big = np.zeros((n, m + 6))
+            big[:, 2:m + 2] = X                       # pitch m + 6 (even, rows stay 16-byte aligned), offset 2
+            cases = [('euclidean', {}), ('euclidean', dict(w=w)), ('sqeuclidean', dict(w=w)), ('cityblock', {}),
+                     ('cityblock', dict(w=w)), ('chebyshev', {}), ('chebyshev', dict(w=w0)), ('minkowski', dict(p=1.0)),
+                     ('minkowski', dict(p=np.inf)), ('minkowski', dict(p=3.0)), ('minkowski', dict(p=2.5, w=w)),
+                     ('seuclidean', dict(V=w)), ('mahalanobis', dict(VI=VI))]
+            for metric, kw in cases:
+                ref = O.cdist_rows(X, y, metric, **kw)
+                hip_ctx.call('elfihip_dist_set_form', 0)
+                nar = elfi_amd.cdist_rows(X, y, metric, **kw)
+                nar_pitched = elfi_amd.cdist_rows(big[:, 2:m + 2], y, metric, **kw)
+                hip_ctx.call('elfihip_dist_set_form', 1)
+                til = elfi_amd.cdist_rows(X, y, metric, **kw)
+                what = '%s %s n=%d m=%d' % (metric, sorted(kw), n, m)
+                assert np.array_equal(nar, til), 'narrow form differs from the tile kernel: ' + what
+                assert np.array_equal(nar_pitched, nar), 'pitched: ' + what
+                _check(nar, ref, _is_exact(metric, kw), what)
+            for K in (1, 3, 5):
+                hip_ctx.call('elfihip_dist_set_form', 0)
+                nar = elfi_amd.nested_weighted_euclidean(X, y, W[:K])
+                hip_ctx.call('elfihip_dist_set_form', 1)
+                til = elfi_amd.nested_weighted_euclidean(X, y, W[:K])
+                ref = np.column_stack([O.cdist_rows(X, y, 'euclidean', w=W[k]) for k in range(K)])
+                assert np.array_equal(nar, til) and np.array_equal(nar, ref), ('K-weight form', K, n, m)
+        # the sampler's running best-k through the same pass
+        hip_ctx.call('elfihip_dist_set_form', 0)
+        k = 300
+        rb = elfi_amd.RunningBest(k, metric='euclidean', w=w)
+        seen = []
+        for n in (100, 150, 4000, 250000, 9, 70001):
+            X = rs.randn(n, m)
+            d = rb.push(X, y)
+            assert np.array_equal(d, O.cdist_rows(X, y, 'euclidean', w=w))
+            seen.append(d)
+            vals, rows = rb.result()
+            allv = np.concatenate(seen)
+            order = np.lexsort((np.arange(len(allv)), allv))[:k]
+            assert np.array_equal(vals, allv[order]) and np.array_equal(rows, order), n
+    finally:
+        hip_ctx.call('elfihip_dist_set_form', 0)
