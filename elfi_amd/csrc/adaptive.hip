@@ -426,6 +426,165 @@ __global__ __launch_bounds__(ADA_T, ADA_OCC) void adaptive_pass_kernel(AdaptArgs
 
 static bool ada_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// ---- narrow rows (round 6): m = 2 or 4 summaries -------------------------------------------------------------------------------
+// A row is one or two 16-byte granules: lane r of a 256-thread workgroup OWNS rows r, r + 256, ... (U rows = U 16- or 32-byte
+// non-temporal loads in flight per lane, a wave-instruction covers 1 KiB of contiguous rows; no LDS tile, no barrier per tile).
+// Rounds 4-5 sent m = 2 through the separate K-weight and two-pass statistics kernels (three reads: 0.126 ms for 4 10^6 x 2,
+// K = 3 = 0.16 of HBM) because the tile kernel above streams such rows at a quarter of their rate.
+//   * distances: every sum left to right over the row's M elements with the weights in registers -- the expressions of
+//     dist_multiw_narrow_kernel (distance.hip): bit-identical to it and to cdist;
+//   * column statistics: the lane's U rows of an iteration -> two-pass (mean, M2) per column in registers (chunk_stats) ->
+//     Chan's update of the lane's running triples; at the end the 256 lanes' triples are merged by a fixed tree in LDS and
+//     one (1 + 2m) partial per workgroup leaves for adaptive_finish_kernel: no atomics, bit-reproducible for a launch shape;
+//   * selection: per-column acceptance and the sampler state's k-th distance on the distances while they are in registers.
+constexpr int ADA_NARROW_KMAX = 8;
+constexpr int ADA_NARROW_U = 4;
+
+template <int M, int U>
+__global__ __launch_bounds__(256) void adaptive_narrow_kernel(AdaptArgs P) {
+  __shared__ double rn[256], rm[256 * M], rq[256 * M];
+  __shared__ __align__(16) double stage_all[4 * 64 * ADA_NARROW_KMAX];   // per wave: the K results of 64 rows -> contiguous stores
+  const RowArgs& A = P.A;
+  const int tid = threadIdx.x, K = A.K;
+  double* stage = stage_all + (tid >> 6) * 64 * ADA_NARROW_KMAX;
+  const bool staged = A.out && (reinterpret_cast<uintptr_t>(A.out) & 15u) == 0;
+  double yv[M], wv[ADA_NARROW_KMAX][M], accs[ADA_NARROW_KMAX];
+#pragma unroll
+  for (int j = 0; j < M; ++j) yv[j] = A.y[j];
+#pragma unroll
+  for (int k = 0; k < ADA_NARROW_KMAX; ++k) {
+    accs[k] = (P.acc && k < K) ? P.acc[k] : 0.0;
+#pragma unroll
+    for (int j = 0; j < M; ++j) wv[k][j] = k < K ? A.aux[k * M + j] : 0.0;
+  }
+  const double inf = __longlong_as_double(0x7ff0000000000000ll);
+  const double thr = A.F.thr ? *A.F.thr : inf;
+  const bool stats = P.partial != nullptr;
+  ColStat st[M];
+#pragma unroll
+  for (int j = 0; j < M; ++j) st[j] = {0.0, 0.0, 0.0};
+  unsigned long long nacc = 0;
+  typedef double v2d_nt __attribute__((ext_vector_type(2)));
+  const int64_t per = 256 * U;
+  for (int64_t base = (int64_t)blockIdx.x * per; base < A.n; base += (int64_t)gridDim.x * per) {
+    double x[U][M];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t r = base + u * 256 + tid;
+      const v2d_nt* src = reinterpret_cast<const v2d_nt*>(A.X + (r < A.n ? r : A.n - 1) * A.ldx);
+#pragma unroll
+      for (int h = 0; h < M / 2; ++h) {
+        const v2d_nt t = __builtin_nontemporal_load(src + h);
+        x[u][2 * h] = t.x;
+        x[u][2 * h + 1] = t.y;
+      }
+    }
+    if (stats) {
+      if (base + per <= A.n) {   // every lane holds U rows (wave-uniform)
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+          double col[U], mean, q;
+#pragma unroll
+          for (int u = 0; u < U; ++u) col[u] = x[u][j];
+          chunk_stats<U>(col, mean, q);
+          chan_merge(st[j], (double)U, mean, q);
+        }
+      } else {
+        int cnt = 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) cnt += (base + u * 256 + tid < A.n) ? 1 : 0;
+        if (cnt > 0) {
+#pragma unroll
+          for (int j = 0; j < M; ++j) {
+            double sum = 0.0;
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+              if (base + u * 256 + tid < A.n) sum += x[u][j];
+            const double mean = sum / (double)cnt;
+            double q = 0.0;
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+              if (base + u * 256 + tid < A.n) {
+                const double e = x[u][j] - mean;
+                q += e * e;
+              }
+            chan_merge(st[j], (double)cnt, mean, q);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t r = base + u * 256 + tid;
+      const bool live = r < A.n;
+      double d2[M];
+#pragma unroll
+      for (int j = 0; j < M; ++j) {
+        const double d = x[u][j] - yv[j];
+        d2[j] = d * d;
+      }
+      double dlast = 0.0, dk[ADA_NARROW_KMAX];
+      bool ok = live;
+#pragma unroll
+      for (int k = 0; k < ADA_NARROW_KMAX; ++k) {
+        dk[k] = 0.0;
+        if (k < K) {
+          double sk = 0.0;
+#pragma unroll
+          for (int j = 0; j < M; ++j) sk = sk + wv[k][j] * d2[j];
+          dlast = sqrt(sk);
+          dk[k] = dlast;
+          if (A.out && !staged && live) A.out[r * K + k] = dlast;
+          if (P.acc) ok = ok && dlast <= accs[k];   // samplers.py:219-225 (a NaN distance is not accepted)
+        }
+      }
+      if (staged) {
+        const int64_t r0 = base + u * 256 + (tid & ~63);   // first row of this wave's 64
+        const int64_t left = A.n - r0;
+        if (left > 0) wave_store_rows<ADA_NARROW_KMAX>(stage, A.out + r0 * K, dk, K, tid & 63, left < 64 ? (int)left : 64);
+      }
+      if (P.acc) nacc += (unsigned long long)__popcll(__ballot(ok));   // wave-uniform
+      if (A.F.thr) reject_offer(A.F, ok && dlast < thr, dlast, A.F.row_base + r);
+    }
+  }
+  if (stats) {
+    // the 256 lanes' triples, column by column, by a fixed tree (the same merges in the same order at every launch)
+    rn[tid] = st[0].n;   // (the count is the same for every column of a lane)
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+      rm[j * 256 + tid] = st[j].mean;
+      rq[j * 256 + tid] = st[j].M2;
+    }
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      double nb = 0.0;
+      if (tid < s) nb = rn[tid + s];
+      if (tid < s) {
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+          ColStat a = {rn[tid], rm[j * 256 + tid], rq[j * 256 + tid]};
+          chan_merge(a, nb, rm[j * 256 + tid + s], rq[j * 256 + tid + s]);
+          rm[j * 256 + tid] = a.mean;
+          rq[j * 256 + tid] = a.M2;
+          if (j == M - 1) st[0].n = a.n;
+        }
+      }
+      __syncthreads();
+      if (tid < s) rn[tid] = st[0].n;
+      __syncthreads();
+    }
+    if (tid < M) {
+      double* o = P.partial + (size_t)blockIdx.x * (1 + 2 * M);
+      if (tid == 0) o[0] = rn[0];
+      o[1 + tid] = rm[tid * 256];
+      o[1 + M + tid] = rq[tid * 256];
+    }
+  }
+  if (P.acc && (tid & 63) == 0 && nacc) atomicAdd(P.acc_count, nacc);
+}
+
+
+
 // ---- the same pass with the rows brought in by LDS-DMA (round 5; m = 16 / 32 / 64, K <= ADA_DMA_KMAX) ----------------------
 // NOT the default (elfihip_dist_set_form(ctx, 2) selects it; kept for measurement): 10^7 x 64, K = 3 takes 1.35 ms here
 // against 1.10 ms for adaptive_pass_kernel (profiles/r05_adaptive_dma.md).  The row stream itself is the faster one (the
@@ -762,9 +921,14 @@ static int ada_rows_per_tile(int m) {
   return R > ADA_RMAX ? ADA_RMAX : R;
 }
 
+static bool adaptive_narrow(const double* dX, int m, int64_t ldx, int K) {
+  return (m == 2 || m == 4) && K >= 1 && K <= ADA_NARROW_KMAX && !(ldx & 1) && ada_aligned16(dX);
+}
+
 bool adaptive_pass_supported(const double* dX, int m, int64_t ldx, int K) {
-  // (m = 2 streams through the generic addressing at a quarter of the separate kernels' rate: 4 10^6 x 2, K = 3: 0.135 ms
-  // fused against 0.071 + 0.046)
+  if (adaptive_narrow(dX, m, ldx, K)) return true;   // lane-owned rows (adaptive_narrow_kernel)
+  // (m = 2 with more than eight weight vectors: the generic addressing streams such rows at a quarter of the separate
+  // kernels' rate -- they take those)
   if (m < 4 || m > ADA_T / 2 || (m & 1) || (ldx & 1) || !ada_aligned16(dX)) return false;
   return ada_lds_bytes(m, K, ada_rows_per_tile(m)) <= 64 * 1024;
 }
@@ -799,6 +963,17 @@ int adaptive_pass_impl(elfihip_ctx* ctx, const double* dX, int64_t n, int m, int
   P.acc = dacc;
   P.acc_count = dacc_count;
   P.partial = partial;
+  if (adaptive_narrow(dX, m, ldx, K)) {
+    constexpr int U = ADA_NARROW_U;
+    int64_t gn = (n + 256 * U - 1) / (256 * U);
+    if (gn > adaptive_max_parts(ctx)) gn = adaptive_max_parts(ctx);
+    if (m == 2)
+      hipLaunchKernelGGL((adaptive_narrow_kernel<2, U>), dim3((unsigned)gn), dim3(256), 0, ctx->stream, P);
+    else
+      hipLaunchKernelGGL((adaptive_narrow_kernel<4, U>), dim3((unsigned)gn), dim3(256), 0, ctx->stream, P);
+    if (nparts && partial) *nparts = (int)gn;
+    return launch_status(ctx, "adaptive_narrow_kernel");
+  }
   if (adaptive_dma_supported(ctx, dX, m, ldx, K)) {
     // LDS-DMA form: rings of two 16 KiB slots (four 8 KiB slots at m = 16) per one-wave workgroup, four workgroups per CU
     const int rows = m == 64 ? 32 : 64;

@@ -687,7 +687,10 @@ __global__ __launch_bounds__(256) void dist_rows_mahalanobis_narrow_kernel(RowAr
 template <int M, int U>
 __global__ __launch_bounds__(256) void dist_multiw_narrow_kernel(RowArgs A) {
   constexpr int KMAX = 8;
+  __shared__ __align__(16) double stage_all[4 * 64 * KMAX];   // per wave: the K results of 64 rows on their way to contiguous stores
   const int tid = threadIdx.x, K = A.K;
+  double* stage = stage_all + (tid >> 6) * 64 * KMAX;
+  const bool staged = (reinterpret_cast<uintptr_t>(A.out) & 15u) == 0;
   double yv[M], wv[KMAX][M];
 #pragma unroll
   for (int j = 0; j < M; ++j) yv[j] = A.y[j];
@@ -713,16 +716,23 @@ __global__ __launch_bounds__(256) void dist_multiw_narrow_kernel(RowArgs A) {
         const double d = x[u][j] - yv[j];
         d2[j] = d * d;
       }
-      double dlast = 0.0;
+      double dlast = 0.0, dk[KMAX];
 #pragma unroll
       for (int k = 0; k < KMAX; ++k) {
+        dk[k] = 0.0;
         if (k < K) {
           double sk = 0.0;
 #pragma unroll
           for (int j = 0; j < M; ++j) sk = sk + wv[k][j] * d2[j];
           dlast = sqrt(sk);
-          if (r < A.n) A.out[r * K + k] = dlast;
+          dk[k] = dlast;
+          if (!staged && r < A.n) A.out[r * K + k] = dlast;
         }
+      }
+      if (staged) {
+        const int64_t r0 = base + u * 256 + (tid & ~63);   // first row of this wave's 64
+        const int64_t left = A.n - r0;
+        if (left > 0) wave_store_rows<KMAX>(stage, A.out + r0 * K, dk, K, tid & 63, left < 64 ? (int)left : 64);
       }
       if (A.F.thr) reject_offer(A.F, r < A.n && dlast < thr, dlast, A.F.row_base + r);
     }

@@ -244,6 +244,30 @@ __device__ __forceinline__ void dma_issue_slot(const RowArgs& A, const unsigned 
   }
 }
 
+// The K results of each of a wave's 64 consecutive rows -> `dst` (= out + first row * K, 16-byte aligned) as ONE contiguous
+// block: the lanes deal their K values into the wave's LDS stage ([row][k], as the block lies in memory) and the wave writes
+// the block back out in 16-byte pieces, 1 KiB per store instruction.  (Lane r storing its own K doubles is K instructions of
+// 64 eight-byte pieces at stride 8 K: at K = 3 the narrow-row kernels wrote their 96 MB at 3 TB/s.)  nv: live rows of the
+// block (rows >= nv are not stored); stage: 64 * KMAX doubles owned by this wave.
+template <int KMAX>
+__device__ __forceinline__ void wave_store_rows(double* stage, double* dst, const double (&vals)[KMAX], int K, int lane, int nv) {
+  typedef double v2d_st __attribute__((ext_vector_type(2)));
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k)
+    if (k < K) stage[lane * K + k] = vals[k];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  const int total = nv * K, npieces = total >> 1;
+#pragma unroll
+  for (int i = 0; i < (KMAX + 1) / 2; ++i) {
+    const int p = lane + 64 * i;
+    if (p < npieces) *reinterpret_cast<v2d_st*>(dst + 2 * p) = *reinterpret_cast<const v2d_st*>(stage + 2 * p);
+  }
+  if ((total & 1) && lane == 0) dst[total - 1] = stage[total - 1];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();   // the stage is free again
+}
+
 #endif
 
 static inline bool tile_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
