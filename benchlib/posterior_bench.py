@@ -68,7 +68,7 @@ def _silently(fn, *a, **k):
         return fn(*a, **k)
 
 
-def sample_leg(cpu=True, cpu_iters=40):
+def sample_leg(cpu=True, cpu_iters=120):
     """`BOLFI.sample(1000)` on the documented run: 4 chains x 1000 NUTS iterations."""
     from elfi_amd import chains
     elfi = _elfi()
@@ -93,14 +93,15 @@ def sample_leg(cpu=True, cpu_iters=40):
         dt = time.perf_counter() - t0
         out["cpu_reference"] = {"kind": "reference loop (elfi.BOLFI.sample: one mcmc.nuts call per chain, bolfi.py:543-566) "
                                         "over the CPU oracle surrogate",
-                                "sample": "4 chains x %d NUTS iterations" % cpu_iters, "wall_s": dt, "cores": 1,
-                                "chain_iterations_per_s": 4 * cpu_iters / dt,
-                                "scaled_to_4x1000_s": dt * 1000 / cpu_iters}
+                                "sample": "4 chains x %d NUTS iterations (half of them warm-up, as in the timed run)" % cpu_iters,
+                                "wall_s": dt, "cores": 1, "chain_iterations_per_s": 4 * cpu_iters / dt,
+                                "scaled_to_4x1000_s": dt * 1000 / cpu_iters,
+                                "scaled_is": "an EXTRAPOLATION of the measured rate to 4 x 1000 iterations, not a measurement"}
         out["speedup_vs_cpu_reference"] = out["chain_iterations_per_s"] / out["cpu_reference"]["chain_iterations_per_s"]
     return out
 
 
-def sample_large_leg(n=4096, d=10, n_samples=300, n_chains=4):
+def sample_large_leg(n=4096, d=10, n_samples=300, n_chains=4, cpu=True):
     """The lock-step round at BASELINE's first-metric shape: every round is ONE batched value + gradient evaluation of all
     live chains on a 4096-point, 10-parameter surrogate."""
     import scipy.stats as ss
@@ -126,10 +127,81 @@ def sample_large_leg(n=4096, d=10, n_samples=300, n_chains=4):
     _silently(b.sample, n_samples, n_chains=n_chains, threshold=thr, n_evidence=n)
     wall = time.perf_counter() - t0
     rounds, points = chains.run_lockstep.n_rounds - r0, chains.run_lockstep.n_points - p0
-    return {"config": "synthetic surrogate, n = %d evidence points, d = %d: HipBOLFI.sample(%d), %d chains (NUTS)"
-                      % (n, d, n_samples, n_chains),
-            "wall_s": wall, "lockstep_rounds": rounds, "point_evaluations": points,
-            "us_per_round": 1e6 * wall / max(rounds, 1), "chain_iterations_per_s": n_chains * n_samples / wall}
+    out = {"config": "synthetic surrogate, n = %d evidence points, d = %d: HipBOLFI.sample(%d), %d chains (NUTS)"
+                     % (n, d, n_samples, n_chains),
+           "wall_s": wall, "lockstep_rounds": rounds, "point_evaluations": points,
+           "us_per_round": 1e6 * wall / max(rounds, 1), "chain_iterations_per_s": n_chains * n_samples / wall}
+    # the DEVICE share of a round (the row's number: the rest of a round is ELFI's ModelPrior -- numeric gradient of the prior
+    # -- and the NUTS Python, both outside the hot path): the library's event timers around the phases of every round of a
+    # shorter run
+    h = b.target_model._handle
+    r1 = chains.run_lockstep.n_rounds
+    h.profile(1)
+    _silently(b.sample, 60, n_chains=n_chains, threshold=thr, n_evidence=n)
+    ph = h.profile(0)
+    prof_rounds = chains.run_lockstep.n_rounds - r1
+    out["device_us_per_round"] = 1e3 * sum(ms for ms, _ in ph.values()) / max(prof_rounds, 1)
+    out["device_phases_us_per_round"] = {k: 1e3 * ms / max(prof_rounds, 1) for k, (ms, calls) in ph.items() if calls}
+    out["device_share_of_round"] = out["device_us_per_round"] / out["us_per_round"]
+    if cpu:
+        ref = out["cpu_reference"] = sample_large_cpu_reference(n, d, thr)
+        # per point evaluation: what a device round costs per live chain against one surrogate call of the reference
+        out["us_per_point_evaluation"] = 1e6 * wall / max(points, 1)
+        out["speedup_vs_cpu_reference_per_point_evaluation"] = 1e3 * ref["ms_per_surrogate_call"] / out["us_per_point_evaluation"]
+    return out
+
+
+class _Budget(Exception):
+    pass
+
+
+def sample_large_cpu_reference(n=4096, d=10, thr=None, cpu_iters=4, cpu_chains=2, budget_s=15.0):
+    """The reference's own loop (elfi.BOLFI.sample: one mcmc.nuts call per chain, bolfi.py:543-566, posteriors.py:88-189) over
+    the CPU oracle surrogate at sample_large_leg's shape, bounded: cpu_chains x cpu_iters NUTS iterations or budget_s seconds
+    of sampling, whichever ends first (a NUTS iteration of the reference costs hundreds of surrogate calls -- the tree and the
+    numeric gradient of ModelPrior -- at ~15 ms each at n = 4096).  The surrogate's point evaluations are counted: the number
+    comparable with a device lock-step round is the time per point evaluation."""
+    import scipy.stats as ss
+    from benchlib.bolfi_bench import heuristic_hyper, problem
+    from oracle_gp_model import OracleGPRegression
+    elfi = _elfi()
+    X, y, bounds = problem(n, d)
+    names = ['p%02d' % i for i in range(d)]
+    mdl = elfi.new_model()
+    pri = [elfi.Prior(ss.uniform, -2, 4, model=mdl, name=nm) for nm in names]
+    sim = elfi.Simulator(lambda *th, batch_size=1, random_state=None: np.column_stack([np.ravel(t) for t in th]), *pri,
+                         observed=np.zeros((1, d)), name='sim')
+    dist = elfi.Distance('euclidean', sim, name='d')
+    pre = {nm: X[:, i].copy() for i, nm in enumerate(names)}
+    pre['d'] = y[:, 0].copy()
+    if thr is None:
+        thr = float(np.min(y) + 0.3)
+    gp = OracleGPRegression(names, bounds={nm: (-2, 2) for nm in names})
+    gp.hyper = dict(heuristic_hyper(bounds, y))      # (set before the evidence arrives: ONE factorisation at n points)
+    calls = {"n": 0}
+    for meth in ("predict", "predictive_gradients"):
+        def counted(x, *a, _f=getattr(gp, meth), **k):
+            if calls["t0"] is not None and time.perf_counter() - calls["t0"] > budget_s:
+                raise _Budget()
+            calls["n"] += int(np.atleast_2d(x).shape[0])
+            return _f(x, *a, **k)
+        setattr(gp, meth, counted)
+    calls["t0"] = None
+    rb = elfi.BOLFI(dist, batch_size=1, initial_evidence=pre, bounds={nm: (-2, 2) for nm in names}, target_model=gp, seed=1)
+    calls["n"] = 0
+    t0 = calls["t0"] = time.perf_counter()
+    done = True
+    try:
+        _silently(rb.sample, cpu_iters, n_chains=cpu_chains, threshold=thr, n_evidence=n)
+    except _Budget:
+        done = False
+    dt = time.perf_counter() - t0
+    return {"kind": "reference loop (elfi.BOLFI.sample: one mcmc.nuts call per chain) over the CPU oracle surrogate (GPy not "
+                    "installable)", "cores": 1,
+            "sample": "%d chains x %d NUTS iterations at n = %d, d = %d%s"
+                      % (cpu_chains, cpu_iters, n, d, "" if done else ", stopped after %.0f s of sampling" % budget_s),
+            "wall_s": dt, "surrogate_calls": calls["n"], "ms_per_surrogate_call": 1e3 * dt / max(calls["n"], 1),
+            "chain_iterations_per_s": cpu_chains * cpu_iters / dt if done else None}
 
 
 def acquisition_family_leg(cpu=True):
@@ -157,15 +229,18 @@ def acquisition_family_leg(cpu=True):
         ref = {"kind": "reference classes (acquisition.py:304-470, 629-821) over the CPU oracle surrogate", "cores": 1}
         for key, cls in (("maxvar", MaxVar), ("expintvar", ExpIntVar)):
             acq = cls(model=rb.target_model, prior=prior2, quantile_eps=0.01, seed=3)
+            acq.acquire(1, t=0)                                   # the same warm-up call the device classes get
+            reps = 5 if key == "maxvar" else 2
             t0 = time.perf_counter()
-            acq.acquire(1, t=0)
-            ref[key + "_acquire_ms"] = 1e3 * (time.perf_counter() - t0)
-        ref["sample"] = "one acquire(1) call each"
+            for i in range(reps):
+                acq.acquire(1, t=i)
+            ref[key + "_acquire_ms"] = 1e3 * (time.perf_counter() - t0) / reps
+        ref["sample"] = "acquire(1) after one warm-up call, mean of 5 (MaxVar) / 2 (ExpIntVar) calls"
         out["cpu_reference"] = ref
     return out
 
 
 def run(cpu=True):
-    out = {"bolfi_sample": sample_leg(cpu=cpu), "bolfi_sample_n4096": sample_large_leg(),
+    out = {"bolfi_sample": sample_leg(cpu=cpu), "bolfi_sample_n4096": sample_large_leg(cpu=cpu),
            "acquisition_family": acquisition_family_leg(cpu=cpu)}
     return out
