@@ -193,7 +193,7 @@ def lockstep_leg(n=4096, d=10, S=10, reps=300):
         for _ in range(reps):
             gp.lcb(xs, 3.0)
         out[name] = (time.perf_counter() - t0) / reps * 1e6
-    out["kinv_in_use"], _, out["cond_bound"] = gp.lockstep_info()
+    out["kinv_in_use"], _, out["cond_estimate"] = gp.lockstep_info()
     gp.close()
     return out
 

@@ -23,6 +23,12 @@ struct elfihip_gp {
   double var = 1, ls = 1, bias = 0, noise = 1;
   bool factored = false, has_kinv = false, wl_valid = false;
   bool kinv_sym = false;      // K^-1 complete (both triangles) and current: formed after a factorisation, bordered by extends
+  // K^-1 lock-steps are VALIDATED once per K^-1 (formed after a full factorisation, then carried through extends by
+  // bordering): the first lock-step with it also runs through the triangular products and the two variances must agree
+  // (gp_predict.hip: predict_impl).  kinv_checked: this K^-1 passed; kinv_bad_full: the full factorisation (full_gen) whose
+  // K^-1 failed -- not formed or used again until the next full factorisation
+  bool kinv_checked = false;
+  long long full_gen = 0, kinv_bad_full = -1;
   int64_t lcb_steps = 0;      // acquisition lock-steps since the latest factorisation (extends do not reset it)
   double diag_min = 0, diag_max = 0;   // smallest / largest diagonal entry of L: (max / min)^2 bounds cond(K) from below
   double logdet = 0, yKy = 0;
@@ -31,6 +37,7 @@ struct elfihip_gp {
   int jitchol_maxtries = 5;
   double jitter = 0.0;
   int jitter_tries = 0;
+  int jit_start = 0;        // rung the NEXT factorisation starts at (set by elfihip_gp_extend on a jittered factor; consumed there)
   bool wt_dirty = false;   // a failed attempt has run: the blocks of WT the sweep relies on being zero may hold NaN / Inf
 
   // device memory

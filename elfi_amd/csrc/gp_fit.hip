@@ -1789,10 +1789,25 @@ static int sweep_overlap(elfihip_gp* gp, int nb, hipStream_t st) {
   unsigned* aux = flags + (size_t)OV_WORDS * (gp->cap / NB + 1);
   hipLaunchKernelGGL(potf2_tiles_kernel<1024>, dim3(1), dim3(1024), POTF2T_LDS_DOUBLES * sizeof(double), st, gp->A,
                      gp->lda, gp->WT, gp->lda, gp->W11, gp->info, 0);
+  // Once the persistent launches are on their streams, EVERY way out of this function joins them back into `st` -- on an
+  // error path (a failed event record / wait below) by waiting for the two streams on the host: the launches give up their
+  // spins by themselves (OV_SPIN_LIMIT), and the caller's next work on `st` (the memset of a retry, the next Gram matrix)
+  // must not race with them on A / WT.
+  struct Forked {
+    hipStream_t a, b;
+    bool armed = false;
+    ~Forked() {
+      if (armed) {
+        (void)hipStreamSynchronize(a);
+        (void)hipStreamSynchronize(b);
+      }
+    }
+  } forked{su, sd};
   if (nb > 1) {
     ELFIHIP_CHECK_HIP(ctx, hipEventRecord(ctx->ev_a, st));
     ELFIHIP_CHECK_HIP(ctx, hipStreamWaitEvent(su, ctx->ev_a, 0));
     ELFIHIP_CHECK_HIP(ctx, hipStreamWaitEvent(sd, ctx->ev_a, 0));
+    forked.armed = true;
     OvArgs O;
     O.P = P;
     O.W11 = gp->W11;
@@ -1823,6 +1838,7 @@ static int sweep_overlap(elfihip_gp* gp, int nb, hipStream_t st) {
     ELFIHIP_CHECK_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_a, 0));
     ELFIHIP_CHECK_HIP(ctx, hipEventRecord(ctx->ev_b, sd));
     ELFIHIP_CHECK_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_b, 0));
+    forked.armed = false;   // joined in stream order
   }
   return launch_status(ctx, "cholesky sweep (overlapped)");
 }
@@ -2014,10 +2030,19 @@ int gp_factorize_impl(elfihip_gp* gp) {
   int info = 0;
   gp->jitter = 0.0;
   gp->jitter_tries = 0;
-  ELFIHIP_TRY(gp_factorize_attempt(gp, diag0, &info));
-  if (info != 0 && info != STEP_INFO_TIMEOUT && gp->jitchol_maxtries > 0) {
+  // A rebuild that only APPENDS evidence to a factorisation that needed rung `first` (elfihip_gp_extend on a jittered factor:
+  // GPy rebuilds on every update) starts AT that rung: pivot k of a right-looking sweep is a function of the leading k x k
+  // block alone, so the plain attempt and the rungs below `first` would fail at the same pivot with the same arithmetic --
+  // and each of them costs a full sweep plus, after the failure, a memset of the whole L^-T matrix (512 MB at capacity
+  // 8192) per evidence point.  The result is the ladder's, (jitter, tries) included.
+  int first = gp->jit_start;
+  gp->jit_start = 0;
+  if (first > gp->jitchol_maxtries) first = 0;
+  if (first == 0) ELFIHIP_TRY(gp_factorize_attempt(gp, diag0, &info));
+  if ((first > 0 || (info != 0 && info != STEP_INFO_TIMEOUT)) && gp->jitchol_maxtries > 0) {
     double jitter = (gp->var + gp->bias + diag0) * 1e-6;
-    for (int t = 1; t <= gp->jitchol_maxtries && std::isfinite(jitter); ++t, jitter *= 10.0) {
+    for (int t = 1; t < first; ++t) jitter *= 10.0;
+    for (int t = first > 0 ? first : 1; t <= gp->jitchol_maxtries && std::isfinite(jitter); ++t, jitter *= 10.0) {
       gp->jitter_tries = t;
       ELFIHIP_TRY(gp_factorize_attempt(gp, diag0 + jitter, &info));
       if (info == 0 || info == STEP_INFO_TIMEOUT) {
@@ -2052,6 +2077,7 @@ int gp_factorize_impl(elfihip_gp* gp) {
   gp->lcb_steps = 0;
   gp->wl_valid = false;
   ++gp->fact_gen;
+  ++gp->full_gen;
   return ELFIHIP_OK;
 }
 

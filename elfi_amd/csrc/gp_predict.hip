@@ -23,6 +23,8 @@
 #include <chrono>
 #include <cstdlib>
 #include <type_traits>
+#include <vector>
+#include <cmath>
 
 #include "gp.hpp"
 #include "mfma_f64.hpp"
@@ -868,6 +870,7 @@ static bool lockstep_fused(const elfihip_gp* gp) { return gp->lockstep_form != 1
 // while the estimate of cond(K) below is <= KINV_MAX_COND (the variance then agrees with the triangular form to 1e-10 k(x,x)).
 constexpr int64_t KINV_AFTER_STEPS = 64;
 constexpr double KINV_MAX_COND = 1e5;
+constexpr double KINV_CHECK_TOL = 1e-9;   // of k(x,x): the first K^-1 lock-step of a factorisation against the triangular form
 
 // The strictly-upper part of K^-1 from the lower one (the gradient kernel writes the lower 128 x 128 tiles), 64 x 64 tiles
 // through LDS, in place.
@@ -909,7 +912,9 @@ __global__ __launch_bounds__(256) void kinv_border_kernel(double* K, int64_t lda
 
 // (max L_ii / min L_ii)^2 only bounds cond(K) from BELOW (lambda_max can be n times the largest diagonal entry): the gate
 // uses n times that ratio, capped by the bound the hyper-parameters give for free -- Ky = K_psd + s I with a constant
-// diagonal v + b + s, so lambda_min >= s and lambda_max <= trace = n (v + b + s)
+// diagonal v + b + s, so lambda_min >= s and lambda_max <= trace = n (v + b + s).  The result is an ESTIMATE, not a bound
+// (lambda_min can lie far below min L_ii^2): it only keeps hopeless matrices from being formed; what makes the K^-1 form
+// fail SAFE is the validation of its first lock-step against the triangular products (predict_impl, KINV_CHECK_TOL)
 static double kinv_cond_estimate(const elfihip_gp* gp) {
   if (!(gp->diag_min > 0.0)) return __builtin_huge_val();
   const double r = gp->diag_max / gp->diag_min;
@@ -926,6 +931,7 @@ static int lockstep_kinv(elfihip_gp* gp, bool* use) {
   if (gp->lockstep_form == 1 || gp->lockstep_form == 2) return ELFIHIP_OK;
   ++gp->lcb_steps;
   if (!kinv_conditioned(gp)) return ELFIHIP_OK;
+  if (gp->kinv_bad_full == gp->full_gen) return ELFIHIP_OK;   // this factorisation's K^-1 failed its validation
   if (!gp->kinv_sym) {
     // (a K^-1 the caller formed already -- HipGPRegression after a hyper-parameter search -- is used at once)
     if (gp->lockstep_form == 0 && gp->lcb_steps <= KINV_AFTER_STEPS && !gp->has_kinv) return ELFIHIP_OK;
@@ -934,6 +940,7 @@ static int lockstep_kinv(elfihip_gp* gp, bool* use) {
     hipLaunchKernelGGL(kinv_mirror_kernel, dim3(nt, nt), dim3(256), 0, gp->ctx->stream, gp->Kinv, gp->lda);
     ELFIHIP_TRY(launch_status(gp->ctx, "kinv_mirror_kernel"));
     gp->kinv_sym = true;
+    gp->kinv_checked = false;   // a new K^-1: its first lock-step is validated (predict_impl)
   }
   *use = true;
   return ELFIHIP_OK;
@@ -1177,6 +1184,35 @@ int predict_impl(elfihip_gp* gp, const double* Xs, int64_t S, int mode, int nois
   // an acquisition lock-step (value AND gradient of the LCB at a handful of points): with K^-1 when that is due
   bool with_kinv = false;
   if (mode == 1 && val && grad && P.npass <= P.ws.group) ELFIHIP_TRY(lockstep_kinv(gp, &with_kinv));
+  if (with_kinv && !gp->kinv_checked) {
+    // the first K^-1 lock-step of a factorisation: the same points through the triangular products as well.  k(x,x) - kb . u
+    // cancels with eps cond(K) k(x,x); the two variances have to agree to KINV_CHECK_TOL k(x,x) or this factorisation keeps
+    // the triangular form (two extra lock-steps per factorisation that uses K^-1)
+    std::vector<double> vt((size_t)S), vk((size_t)S);
+    for (int pass = 0; pass < 2; ++pass) {
+      ELFIHIP_TRY(predict_enqueue(gp, P, S, mode, noiseless, beta, nullptr, pass == 1));
+      ELFIHIP_TRY(launch_status(ctx, "predict kernels"));
+      ELFIHIP_TRY(predict_wait(gp, P));
+      predict_read(gp, P, S, nullptr, pass == 0 ? vt.data() : vk.data(), nullptr, nullptr, nullptr, nullptr);
+    }
+    double worst = 0.0;
+    bool finite = true;
+    for (int64_t s = 0; s < S; ++s) {
+      const double e = std::fabs(vk[(size_t)s] - vt[(size_t)s]);
+      finite = finite && std::isfinite(e);
+      if (e > worst) worst = e;
+    }
+    double tol = KINV_CHECK_TOL;
+    if (const char* e = std::getenv("ELFIHIP_KINV_CHECK_TOL")) tol = std::atof(e);   // (tests: 0 rejects every K^-1)
+    if (finite && worst <= tol * (gp->var + gp->bias) && tol > 0.0) {
+      gp->kinv_checked = true;
+    } else {
+      gp->kinv_bad_full = gp->full_gen;
+      gp->kinv_sym = false;     // (extends stop carrying it)
+      gp->has_kinv = false;
+      with_kinv = false;
+    }
+  }
   ELFIHIP_TRY(predict_enqueue(gp, P, S, mode, noiseless, beta, nullptr, with_kinv));
   ELFIHIP_TRY(launch_status(ctx, "predict kernels"));
   ELFIHIP_TRY(predict_wait(gp, P));
@@ -1509,11 +1545,11 @@ int elfihip_debug_tri_stamps(unsigned long long* out, int clear) {
 }
 #endif
 
-int elfihip_gp_lockstep_info(const elfihip_gp* gp, int* kinv_in_use, int64_t* steps, double* cond_bound) {
+int elfihip_gp_lockstep_info(const elfihip_gp* gp, int* kinv_in_use, int64_t* steps, double* cond_estimate) {
   if (!gp) return fail(nullptr, ELFIHIP_ERR_ARG, "gp is NULL");
   if (kinv_in_use) *kinv_in_use = gp->factored && gp->kinv_sym ? 1 : 0;
   if (steps) *steps = gp->lcb_steps;
-  if (cond_bound) *cond_bound = kinv_cond_estimate(gp);
+  if (cond_estimate) *cond_estimate = kinv_cond_estimate(gp);
   return ELFIHIP_OK;
 }
 
@@ -1609,7 +1645,10 @@ int elfihip_gp_extend(elfihip_gp* gp, const double* X_new, const double* y_new, 
     ++done;
   }
   if (done < k) {
+    // (same hyper-parameters, evidence only appended: the rebuild starts at the rung the current factor needed)
+    const int rung = (gp->factored && gp->jitter > 0.0) ? gp->jitter_tries : 0;
     ELFIHIP_TRY(elfihip_gp_append(gp, X_new + done * gp->d, y_new + done, k - done));
+    gp->jit_start = rung;
     ELFIHIP_TRY(elfihip_gp_factorize(gp, nullptr));
   }
   if (log_marginal)

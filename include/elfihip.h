@@ -433,10 +433,12 @@ int elfihip_gp_set_dense_threshold(elfihip_gp* gp, int64_t min_points, int tile_
  * lock-step on.  elfihip_gp_predict / _predict_grad always use the triangular products. */
 int elfihip_gp_set_lockstep_form(elfihip_gp* gp, int form);
 /* State of the above for the current factorisation: whether acquisition lock-steps multiply with K^-1 now, how many
- * lock-steps the factorisation has served, and the estimate of cond(K) the K^-1 form is gated by: min(n (max L_ii /
- * min L_ii)^2, n (var + bias + s) / s) with s = noise + 1e-8 + jitter -- the second a true upper bound.  Any pointer may
- * be NULL. */
-int elfihip_gp_lockstep_info(const elfihip_gp* gp, int* kinv_in_use, int64_t* steps, double* cond_bound);
+ * lock-steps the factorisation has served, and the ESTIMATE of cond(K) that keeps hopeless matrices from being formed:
+ * min(n (max L_ii / min L_ii)^2, n (var + bias + s) / s) with s = noise + 1e-8 + jitter (only the second is a true upper
+ * bound; the first can lie below cond(K)).  What makes the K^-1 form fail safe is not this number: the first lock-step with
+ * a newly formed K^-1 is also run through the triangular products and the two variances must agree to 1e-9 k(x,x), or the
+ * factorisation keeps the triangular form.  Any pointer may be NULL. */
+int elfihip_gp_lockstep_info(const elfihip_gp* gp, int* kinv_in_use, int64_t* steps, double* cond_estimate);
 /* Device time per phase, for roofline accounting (bench.py; no reference counterpart).  While enabled, HIP events on the
  * GP's stream bracket the phases of elfihip_gp_factorize (Gram matrix | sweep | alpha + log-determinant), of single-group
  * prediction calls -- elfihip_gp_predict / _predict_grad / _lcb and every step of elfihip_gp_lcb_minimize -- (kernel row |

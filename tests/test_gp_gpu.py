@@ -552,3 +552,32 @@ def test_fused_lockstep_form_equals_the_six_launch_form(hip_ctx, n, d, S):
         _close(g1, g0, 1e-11, 'lcb grad')
     rmu, rvar = ref.predict(xs, noiseless=True)
     _close(m1, rmu, 1e-8, 'mu')
+
+
+@pytest.mark.parametrize('n', [12, 126, 200])
+def test_extend_on_a_jittered_factor_restarts_at_the_known_rung(hip_ctx, n):
+    """elfihip_gp_extend on a factor that carries jitchol jitter rebuilds (GPy rebuilds on every update) -- from round 6 on
+    starting at the rung the current factor needed instead of repeating the plain attempt (a full sweep that must fail at
+    the same pivot, plus a memset of the whole L^-T matrix, per evidence point).  The outcome is the full ladder's: the same
+    (jitter, tries), log Z and factor, bit for bit, as a fresh factorisation of all the evidence; across a 128 boundary too."""
+    from elfi_amd.gp import GPHandle
+    X, y, h = _jitter_problem(n + 5)
+    a = GPHandle(2, n + 5)
+    a.set_hyper(h['var'], h['ls'], h['bias'], h['noise'])
+    a.set_data(X[:n], y[:n])
+    a.factorize()
+    assert a.jitchol()[1] == 1
+    for i in range(n, n + 5):
+        lz = a.extend(X[i:i + 1], y[i:i + 1])
+        b = GPHandle(2, n + 5)
+        b.set_hyper(h['var'], h['ls'], h['bias'], h['noise'])
+        b.set_data(X[:i + 1], y[:i + 1])
+        lzb = b.factorize()
+        assert a.jitchol() == b.jitchol() and a.jitchol()[1] == 1
+        assert lz == lzb, (i, lz, lzb)
+        assert np.array_equal(a.get(0), b.get(0)) and np.array_equal(a.get(2), b.get(2))
+        b.close()
+    # hyper-parameters that need no jitter: the next factorisation is a plain one again
+    a.set_hyper(1.0, 1.0, 0.0, 0.5)
+    a.factorize()
+    assert a.jitchol() == (0.0, 0)

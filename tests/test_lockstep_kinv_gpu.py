@@ -200,3 +200,34 @@ def test_bad_form_is_refused(hip_ctx):
     gp = _handle(X, y, G.default_hyper(bounds, y), form=0)
     with pytest.raises(Exception):
         gp.set_lockstep_form(4)
+
+
+def test_first_kinv_lockstep_is_validated_against_the_triangular_form(hip_ctx, monkeypatch):
+    """Round 6: the cond(K) estimate that gates the K^-1 form is not an upper bound, so the first lock-step with a
+    newly formed K^-1 also runs through the triangular products and the two variances must agree to 1e-9 k(x,x).  Passing:
+    the K^-1 form is in use and agrees.  Failing (tolerance forced to 0 through the test hook ELFIHIP_KINV_CHECK_TOL): the
+    call returns the triangular form's numbers bit for bit, K^-1 is dropped -- also across extends -- until the next full
+    factorisation, which gets a fresh validation."""
+    X, y, bounds = _problem(700, 2, seed=5)
+    h = G.default_hyper(bounds, y)
+    xs = _points(X, 10)
+    tri = _handle(X[:690], y[:690], h, form=2)
+    v_tri, g_tri = tri.lcb(xs, 3.0)
+    gp = _handle(X[:690], y[:690], h, form=3)
+    v, g = gp.lcb(xs, 3.0)
+    assert gp.lockstep_info()[0] == 1
+    assert np.max(np.abs(v - v_tri)) <= 1e-9 * np.max(np.abs(v_tri))
+    monkeypatch.setenv('ELFIHIP_KINV_CHECK_TOL', '0')
+    bad = _handle(X[:690], y[:690], h, form=3)
+    v2, g2 = bad.lcb(xs, 3.0)
+    assert bad.lockstep_info()[0] == 0
+    assert np.array_equal(v2, v_tri) and np.array_equal(g2, g_tri)
+    for i in range(690, 695):
+        bad.extend(X[i:i + 1], y[i:i + 1])
+        tri.extend(X[i:i + 1], y[i:i + 1])
+        a, b = bad.lcb(xs, 3.0), tri.lcb(xs, 3.0)
+        assert bad.lockstep_info()[0] == 0 and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    monkeypatch.delenv('ELFIHIP_KINV_CHECK_TOL')
+    bad.factorize()
+    v3, _ = bad.lcb(xs, 3.0)
+    assert bad.lockstep_info()[0] == 1
