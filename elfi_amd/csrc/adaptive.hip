@@ -867,7 +867,11 @@ bool adaptive_dma_supported(const elfihip_ctx* ctx, const double* dX, int m, int
 
 // One workgroup per column: the `nparts` workgroup partials of the pass(es) -> the batch's (count, mean, M2) in `bst`
 // (1 + 2m).  Thread j merges partials j, j + 256, ... in that order, then the 256 triples are merged by a fixed tree.
-__global__ __launch_bounds__(256) void adaptive_finish_kernel(const double* partial, int nparts, int m, double* bst) {
+// state != NULL: the fold into the running store (what adaptive_fold_kernel did as a launch of its own until round 6) by the
+// column's workgroup itself: every workgroup reads the OLD count before it arrives on `done`; the last of the m to arrive
+// -- every other one has read the count by then -- writes the new count and resets the counter.
+__global__ __launch_bounds__(256) void adaptive_finish_kernel(const double* partial, int nparts, int m, double* bst,
+                                                              double* state, unsigned* done) {
   __shared__ double rn[256], rm[256], rq[256];
   const int c = blockIdx.x, j = threadIdx.x, ns = 1 + 2 * m;
   ColStat a = {0.0, 0.0, 0.0};
@@ -892,21 +896,21 @@ __global__ __launch_bounds__(256) void adaptive_finish_kernel(const double* part
     if (c == 0) bst[0] = a.n;
     bst[1 + c] = a.mean;
     bst[1 + m + c] = a.M2;
-  }
-}
-
-// state (1 + 2m: count, mean, M2) <- state U batch: what AdaptiveDistance.add_data leaves after the batch
-// (elfi_model.py:1116-1124), in Chan's form.  One workgroup; every thread reads the old count before it is replaced.
-__global__ void adaptive_fold_kernel(double* state, const double* bst, int m) {
-  const double n_old = state[0];
-  __syncthreads();
-  for (int c = threadIdx.x; c < m; c += blockDim.x) {
-    ColStat a = {n_old, state[1 + c], state[1 + m + c]};
-    if (n_old == 0.0) a.mean = 0.0, a.M2 = 0.0;
-    chan_merge(a, bst[0], bst[1 + c], bst[1 + m + c]);
-    state[1 + c] = a.mean;
-    state[1 + m + c] = a.M2;
-    if (c == 0) state[0] = a.n;
+    if (state) {
+      // state (1 + 2m: count, mean, M2) <- state U batch: what AdaptiveDistance.add_data leaves after the batch
+      // (elfi_model.py:1116-1124), in Chan's form (the operations of adaptive_fold_kernel, in its order)
+      const double n_old = state[0];
+      ColStat f = {n_old, state[1 + c], state[1 + m + c]};
+      if (n_old == 0.0) f.mean = 0.0, f.M2 = 0.0;
+      chan_merge(f, a.n, a.mean, a.M2);
+      state[1 + c] = f.mean;
+      state[1 + m + c] = f.M2;
+      const unsigned old = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (old + 1u == (unsigned)m) {
+        state[0] = f.n;
+        __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
   }
 }
 
@@ -1022,9 +1026,13 @@ int adaptive_pass_impl(elfihip_ctx* ctx, const double* dX, int64_t n, int m, int
 // keep the batch's own statistics.
 int adaptive_stats_finish(elfihip_ctx* ctx, const double* partial, int nparts, int m, double* bst, double* dstate) {
   if (nparts <= 0) return ELFIHIP_OK;
-  hipLaunchKernelGGL(adaptive_finish_kernel, dim3((unsigned)m), dim3(256), 0, ctx->stream, partial, nparts, m, bst);
-  if (dstate) hipLaunchKernelGGL(adaptive_fold_kernel, dim3(1), dim3(128), 0, ctx->stream, dstate, bst, m);
-  return launch_status(ctx, "adaptive statistics kernels");
+  if (dstate && !ctx->fold_cnt) {
+    ELFIHIP_CHECK_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->fold_cnt), 64));
+    ELFIHIP_CHECK_HIP(ctx, hipMemsetAsync(ctx->fold_cnt, 0, 64, ctx->stream));
+  }
+  hipLaunchKernelGGL(adaptive_finish_kernel, dim3((unsigned)m), dim3(256), 0, ctx->stream, partial, nparts, m, bst, dstate,
+                     ctx->fold_cnt);
+  return launch_status(ctx, "adaptive statistics kernel");
 }
 
 }  // namespace elfihip

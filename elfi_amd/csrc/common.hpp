@@ -66,6 +66,7 @@ struct elfihip_ctx {
   // hipMemcpyAsync into a pageable stack variable is a staged blit of 30 us on the stream (profiles/r05_cfg4_trace.md:
   // 4.5 of them per adaptive-distance round)
   unsigned long long* mail = nullptr;
+  unsigned* fold_cnt = nullptr;       // arrival counter of adaptive_finish_kernel's fold (adaptive.hip), zero between launches
   int dist_form = 0;                  // 0: LDS-DMA row stream where the shape allows; 1: register-staged pipeline (elfihip_dist_set_form)
   int topk_form = 0;                  // 0: resident selection with the nine-launch form as fallback; 1: nine-launch form
   unsigned dense_lds_mask = 0;        // dense_tri_kernel<.,64/32/16>: dynamic-LDS limit raised (gp_dense.hip)

@@ -152,6 +152,7 @@ int elfihip_ctx_destroy(elfihip_ctx* ctx) {
     if (ctx->bulk_stream) (void)hipStreamDestroy(ctx->bulk_stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     if (ctx->mail) (void)hipHostFree(ctx->mail);
+    if (ctx->fold_cnt) (void)hipFree(ctx->fold_cnt);
   }
   delete ctx;
   return ELFIHIP_OK;
