@@ -55,6 +55,17 @@ struct QueryArgs {
   double x2[PC];
 };
 
+#ifdef ELFIHIP_TRI_STAMP   // developer probe (scripts/tri_timeline.py): wall-clock stamps (100 MHz) per workgroup and phase
+__device__ unsigned long long g_tri_stamp[8192 * 8];
+#define PSTAMP(slot) do { const unsigned pidx_ = (MODE == 1 ? 4096u : 0u) + blockIdx.x + blockIdx.y * gridDim.x; \
+    if (threadIdx.x == 0 && pidx_ < 8192) g_tri_stamp[pidx_ * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define KSTAMP(slot) do { const unsigned kidx_ = 7168u + blockIdx.x + 16u * blockIdx.y; \
+    if (threadIdx.x == 0 && blockIdx.z == 0 && kidx_ < 8192) g_tri_stamp[kidx_ * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define PSTAMP(slot) do { } while (0)
+#define KSTAMP(slot) do { } while (0)
+#endif
+
 // ---- kr[s][i], partial mu ----------------------------------------------------------
 __global__ __launch_bounds__(256) void kstar_kernel(const double* X, const double* x2, const double* alpha,
                                                     const double* xs, const double* xs2, double* kr, double* kb,
@@ -64,6 +75,7 @@ __global__ __launch_bounds__(256) void kstar_kernel(const double* X, const doubl
   __shared__ double red[256];
   __shared__ double sx[256 + 1];  // this workgroup's query point and its squared norm
   const int s = blockIdx.y;
+  KSTAMP(0);
   // several 16-point passes in one launch (blockIdx.z): per-pass slices of the query points and outputs
   xs += (int64_t)blockIdx.z * PC * dp;
   xs2 += (int64_t)blockIdx.z * PC;
@@ -95,6 +107,7 @@ __global__ __launch_bounds__(256) void kstar_kernel(const double* X, const doubl
     if (threadIdx.x == 0) sx[256] = xs2[s];
   }
   __syncthreads();
+  KSTAMP(1);
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   double contrib = 0.0;
   if (i < np) {
@@ -117,6 +130,7 @@ __global__ __launch_bounds__(256) void kstar_kernel(const double* X, const doubl
   for (int off = 32; off > 0; off >>= 1) contrib += __shfl_xor(contrib, off, 64);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = contrib;
   __syncthreads();
+  KSTAMP(2);
   if (threadIdx.x == 0) mu_part[s * gridDim.x + blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
 }
 
@@ -170,14 +184,6 @@ __device__ __forceinline__ void grad_rows(const double* __restrict__ X, const do
                                           const double* __restrict__ part, int nkc, double* __restrict__ g_part, int chunk,
                                           int nchunks, int64_t i0, int64_t n, int64_t np, int dp, double (*red)[PC][32],
                                           double bias = 0.0, double* __restrict__ sq_part = nullptr);
-
-#ifdef ELFIHIP_TRI_STAMP   // developer probe (scripts/tri_timeline.py): wall-clock stamps (100 MHz) per workgroup and phase
-__device__ unsigned long long g_tri_stamp[8192 * 8];
-#define PSTAMP(slot) do { const unsigned pidx_ = (MODE == 1 ? 4096u : 0u) + blockIdx.x + blockIdx.y * gridDim.x; \
-    if (threadIdx.x == 0 && pidx_ < 8192) g_tri_stamp[pidx_ * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define PSTAMP(slot) do { } while (0)
-#endif
 
 template <int MODE, bool FUSE>
 __device__ __forceinline__ void tri_apply_body(const TriArgs& T, const int rb, const int kc, double* Bs, int* s_last_p) {

@@ -39,9 +39,19 @@ for form in (2, 3):
     assert lib.elfihip_debug_tri_stamps(buf.ctypes.data, 0) == 0
     st = buf.reshape(8192, 8).astype(np.float64) / 100.0        # us
     live = st[:, 0] > 0
+    live[7168:] = False
     t0 = st[live, 0].min()
     print("form %d: %d live workgroups" % (form, live.sum()))
     groups = [("first product / K^-1 product", live & (np.arange(8192) < 4096)), ("second product", live & (np.arange(8192) >= 4096))]
+    ks = st[7168:7424]
+    kl = ks[:, 0] > 0
+    if kl.any():
+        print("  kernel rows (kstar_kernel), %d workgroups, us after the FIRST product's first stamp:" % kl.sum())
+        for j, nm in enumerate(["start", "query point in LDS", "rows done (before the last store)"]):
+            v = ks[kl, j] - t0
+            print("    %-34s min %6.2f  p50 %6.2f  max %6.2f" % (nm, v.min(), np.percentile(v, 50), v.max()))
+        print("    own duration start -> rows done: p50 %.2f, of which the query point %.2f" %
+              (np.percentile(ks[kl, 2] - ks[kl, 0], 50), np.percentile(ks[kl, 1] - ks[kl, 0], 50)))
     for gname, m in groups:
         print("  %s: %d workgroups" % (gname, m.sum()))
         for j, nm in enumerate(names):
