@@ -438,7 +438,7 @@ static bool ada_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p
 //     one (1 + 2m) partial per workgroup leaves for adaptive_finish_kernel: no atomics, bit-reproducible for a launch shape;
 //   * selection: per-column acceptance and the sampler state's k-th distance on the distances while they are in registers.
 constexpr int ADA_NARROW_KMAX = 8;
-constexpr int ADA_NARROW_U = 4;
+constexpr int ADA_NARROW_U = 8;
 
 template <int M, int U>
 __global__ __launch_bounds__(256) void adaptive_narrow_kernel(AdaptArgs P) {
@@ -970,7 +970,7 @@ int adaptive_pass_impl(elfihip_ctx* ctx, const double* dX, int64_t n, int m, int
   if (adaptive_narrow(dX, m, ldx, K)) {
     constexpr int U = ADA_NARROW_U;
     int64_t gn = (n + 256 * U - 1) / (256 * U);
-    if (gn > adaptive_max_parts(ctx)) gn = adaptive_max_parts(ctx);
+    if (gn > (int64_t)ctx->cu_count * 4) gn = (int64_t)ctx->cu_count * 4;   // (four workgroups per CU: fewer partials for the finish launch)
     if (m == 2)
       hipLaunchKernelGGL((adaptive_narrow_kernel<2, U>), dim3((unsigned)gn), dim3(256), 0, ctx->stream, P);
     else
