@@ -49,8 +49,11 @@ def test_two_ranks_run_the_whole_script():
     assert r["n_gpus"] == 2 and r["env"]["world_size_seen"] == 2 and r["env"]["backend"] == "gloo"
     assert r["steps"] == 5 and r["warmup"] == 2 and r["scaling"] == "weak" and r["higher_is_better"] is True
     assert r["data"].startswith("fake") and "NOT measurements" in r["config"]["dry_run"]
-    # the weak leg gathered the packed state every step (warm-up included), the nested strong leg after it
-    assert r["env"]["gathers_per_rank"] >= 7 + 5
+    # the weak leg gathered the packed state at the end of its (one, incomplete) exchange period of 8 steps; the nested strong
+    # leg -- a whole SMC round per step -- gathers in every step
+    assert r["config"]["exchange_every"] == 8 and r["env"]["gathers_per_rank"] >= 1 + 5
+    every = _run(2, ["--exchange-every", "1"])
+    assert every["config"]["exchange_every"] == 1 and every["env"]["gathers_per_rank"] >= 7 + 5
     assert r["value"] > 0 and abs(r["value"] - 2 * r["config"]["samples_per_gpu"] * 5 / (r["ms_per_step"] * 5e-3)) < 1e-6 * r["value"]
     c4 = r["cfg4_strong"]
     assert c4["scaling"] == "strong" and c4["n_gpus"] == 2 and c4["config"]["samples_per_gpu"] == 100000
