@@ -102,12 +102,23 @@ struct RejArgs {
   double* export_val;   // packed copy of the new state for the caller (may be NULL)
 };
 
-constexpr size_t REJ_MERGE_LDS = REJ_MAX_K * 16 + REJ_CHUNK * 16;
+constexpr size_t REJ_MERGE_LDS = REJ_MAX_K * 16 + 2 * REJ_CHUNK * 16;   // state, the chunk, the exchange buffer: 64 KiB
+
+// one compare-exchange of the bitonic network: this thread keeps the smaller (take_min) or the larger of its pair
+__device__ __forceinline__ void rej_cx(double& v, long long& r, double pv, long long pr, bool take_min) {
+  if (rej_less(pv, pr, v, r) == take_min) {
+    v = pv;
+    r = pr;
+  }
+}
 
 __global__ __launch_bounds__(1024) void reject_merge_kernel(RejArgs S) {
   // Merge by ranks, REJ_CHUNK candidates at a time.  (distance, row) is a strict total order (rows are unique), so an
   // element's place in the merged sequence is the number of elements before it:
-  //   1. the chunk is sorted in LDS (bitonic network over the next power of two, +inf / max-row padding);
+  //   1. the chunk is sorted, ONE pair per thread in registers (bitonic network over the next power of two, +inf /
+  //      max-row padding): partners less than 64 apart are lanes of the same wave and trade through lane shuffles, no
+  //      barrier; only the strides >= 64 -- 10 of the 55 steps of a 1024-chunk -- go through LDS, alternating between two
+  //      buffers so that a step costs one barrier;
   //   2. candidate i of the sorted chunk moves to  i + (state entries below it)      -- binary search in the state;
   //      state entry e           moves to  e + (chunk candidates below it)           -- binary search in the chunk;
   //   3. places >= k fall off.  Values travel in registers across the barrier, the scatter is in place.
@@ -115,12 +126,15 @@ __global__ __launch_bounds__(1024) void reject_merge_kernel(RejArgs S) {
   // of one state slot through a linked list (rounds 2-3) cost one dependent LDS round trip per candidate of the slot --
   // about one when a full state meets a few candidates, but the whole chunk when the state is still empty: every
   // candidate falls into slot 0, 1024 list steps each, 57 us per chunk (round 4: 171 us for the 2400 candidates of an SMC
-  // round's first batch).  Sorting the 1024-chunk alone is 55 compare-exchange steps whatever the state holds.
+  // round's first batch).  Rounds 4-5 sorted the chunk in LDS, two pairs per thread and a barrier per step (35 us for a
+  // merge of a few hundred candidates, 52 us for the two chunks of an SMC round's first batch).
   extern __shared__ __align__(16) unsigned char rej_sm[];
   double* bv = reinterpret_cast<double*>(rej_sm);
   long long* br = reinterpret_cast<long long*>(bv + REJ_MAX_K);
   double* cv = reinterpret_cast<double*>(br + REJ_MAX_K);
   long long* cr = reinterpret_cast<long long*>(cv + REJ_CHUNK);
+  double* xv_ = reinterpret_cast<double*>(cr + REJ_CHUNK);       // the second exchange buffer
+  long long* xr_ = reinterpret_cast<long long*>(xv_ + REJ_CHUNK);
   const int t = threadIdx.x, k = S.k;
   unsigned int c = S.ncand >= 0 ? (unsigned int)S.ncand : *S.count;
   if (c > S.cap) {
@@ -137,37 +151,48 @@ __global__ __launch_bounds__(1024) void reject_merge_kernel(RejArgs S) {
     const int nc = (int)min((unsigned int)REJ_CHUNK, c - c0);
     int P = 1;
     while (P < nc) P <<= 1;
-    __syncthreads();   // the state of the previous round is in place; the chunk buffers are free
-    if (t < P) {
-      double xv = inf;
-      long long xr = maxrow;
-      if (t < nc) {
-        xv = S.cand_val[c0 + t];
-        xr = S.cand_row[c0 + t] + S.row_offset;
-        if (!(xv == xv)) {   // a NaN never enters the state
-          xv = inf;
-          xr = maxrow;
-        }
+    double mv = inf;
+    long long mr = maxrow;
+    if (t < nc) {
+      mv = S.cand_val[c0 + t];
+      mr = S.cand_row[c0 + t] + S.row_offset;
+      if (!(mv == mv)) {   // a NaN never enters the state
+        mv = inf;
+        mr = maxrow;
       }
-      cv[t] = xv;
-      cr[t] = xr;
     }
+    int flip = 0;
     for (int size = 2; size <= P; size <<= 1) {
+      const bool asc = (t & size) == 0;
       for (int stride = size >> 1; stride > 0; stride >>= 1) {
-        __syncthreads();
-        if (t < (P >> 1)) {
-          const int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
-          const bool up = (lo & size) == 0;
-          const double av = cv[lo], bvv = cv[hi];
-          const long long ar = cr[lo], brr = cr[hi];
-          if (rej_less(bvv, brr, av, ar) == up) {
-            cv[lo] = bvv;
-            cr[lo] = brr;
-            cv[hi] = av;
-            cr[hi] = ar;
+        const bool take_min = ((t & stride) == 0) == asc;
+        double pv;
+        long long pr;
+        if (stride >= 64) {
+          double* ev = flip ? xv_ : cv;
+          long long* er = flip ? xr_ : cr;
+          flip ^= 1;
+          if (t < P) {
+            ev[t] = mv;
+            er[t] = mr;
           }
+          __syncthreads();   // (uniform: P is the same for every thread)
+          pv = mv, pr = mr;
+          if (t < P) {
+            pv = ev[t ^ stride];
+            pr = er[t ^ stride];
+          }
+        } else {
+          pv = __shfl_xor(mv, stride, 64);
+          pr = __shfl_xor(mr, stride, 64);
         }
+        rej_cx(mv, mr, pv, pr, take_min);
       }
+    }
+    __syncthreads();   // the state of the previous round is in place; every reader of the exchange buffers is done
+    if (t < P) {
+      cv[t] = mv;
+      cr[t] = mr;
     }
     __syncthreads();
     // places
@@ -763,7 +788,7 @@ int elfihip_reject_create(elfihip_ctx* ctx, int64_t k, elfihip_reject** out) {
   *out = nullptr;
   ELFIHIP_REQUIRE(ctx, k >= 1 && k <= REJ_MAX_K_HOST, "k = %lld outside [1, %lld]", (long long)k, (long long)REJ_MAX_K_HOST);
   DeviceGuard g(ctx->device);
-  // (the merge kernel keeps the state and a chunk of candidates in REJ_MERGE_LDS = 48 KiB of dynamic LDS: no attribute needed)
+  // (the merge kernel keeps the state and a chunk of candidates in REJ_MERGE_LDS = 64 KiB of dynamic LDS, the most a launch gets without an attribute)
   elfihip_reject* h = new elfihip_reject();
   h->ctx = ctx;
   h->k = k;
