@@ -68,7 +68,7 @@ struct elfihip_ctx {
   unsigned long long* mail = nullptr;
   unsigned* fold_cnt = nullptr;       // arrival counter of adaptive_finish_kernel's fold (adaptive.hip), zero between launches
   int dist_form = 0;                  // 0: LDS-DMA row stream where the shape allows; 1: register-staged pipeline (elfihip_dist_set_form)
-  int topk_form = 0;                  // 0: resident selection with the nine-launch form as fallback; 1: nine-launch form
+  int topk_form = 0;                  // 0: resident selection (keys in registers up to 2 10^6 rows) with the nine-launch form as fallback; 1: nine-launch form; 2: resident, keys re-read from memory in every phase
   unsigned dense_lds_mask = 0;        // dense_tri_kernel<.,64/32/16>: dynamic-LDS limit raised (gp_dense.hip)
   bool ov_lds_enabled = false;        // sweep_update_kernel's (gp_fit.hip)
   bool step_lds_enabled = false;      // step_kernel's dynamic-LDS limit has been raised (gp_fit.hip)

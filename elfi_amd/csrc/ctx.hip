@@ -178,7 +178,7 @@ int elfihip_dist_set_form(elfihip_ctx* ctx, int form) {
 
 int elfihip_topk_set_form(elfihip_ctx* ctx, int form) {
   if (!ctx) return fail(nullptr, ELFIHIP_ERR_ARG, "ctx is NULL");
-  ELFIHIP_REQUIRE(ctx, form == 0 || form == 1, "form %d is neither 0 (resident) nor 1 (nine launches)", form);
+  ELFIHIP_REQUIRE(ctx, form >= 0 && form <= 2, "form %d outside {0: resident, 1: nine launches, 2: resident without the register form}", form);
   ctx->topk_form = form;
   return ELFIHIP_OK;
 }

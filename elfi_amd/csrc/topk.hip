@@ -537,6 +537,303 @@ __global__ __launch_bounds__(SEL_NT) void sel_persistent_kernel(const double* d,
   }
 }
 
+// ---- the resident selection with the slice's keys kept ON THE CHIP (round 6) ----
+// sel_persistent_kernel reads its slice from memory in every phase -- up to four histogram passes, the collection of a small
+// class, the count, the write -- and its stable write walks the slice 1024 keys at a time with three workgroup barriers per
+// step: 10^6 keys, k = 1000 took 56 us, of which the arithmetic is a few.  For slices of at most SEL_RU x SEL_NT = 16 384
+// keys (n <= 2 x 10^6 on this chip: every selection the sampler makes except the fall-back over a whole 10^7-row batch) the
+// workgroup keeps the 64-bit keys of its slice in 128 KiB of LDS for the whole selection: ONE read of the distances, every
+// later phase from LDS, and -- wave w owning the CONTIGUOUS rows [1024 w, 1024 w + 1024) of the slice, lane l the rows
+// 64 u + l, each lane reading back only words it wrote itself (no barrier guards the slice) -- a stable write whose
+// positions are wave-ballot prefix counts: one barrier for the sixteen wave totals instead of forty-eight.  The values of
+// the k survivors are fetched again from the input (the keys are not invertible for -0.0 and NaN payloads).
+// Why LDS and not registers: the first form of this kernel held sixteen values per thread in registers, which needs every
+// loop over them unrolled -- 30 KB of code, and a kernel that runs each instruction once or twice pays for FETCHING it:
+// the first histogram pass took 12.5 us against 3.4 us for the second pass through the same (then cached) code
+// (wall-clock stamps, scripts/native/sel_probe.hip).  With the keys in LDS the loops stay rolled.
+// Same passes, same barriers between workgroups, same result (row order inside "< k-th", then "== k-th") as
+// sel_persistent_kernel.
+#ifdef ELFIHIP_SEL_STAMP   // developer probe (scripts/native/sel_probe.hip): wall-clock stamps (100 MHz) per workgroup and phase
+__device__ unsigned long long g_sel_stamp[512 * 32];
+#define SEL_STAMP() do { if (threadIdx.x == 0 && sel_si < 32) g_sel_stamp[blockIdx.x * 32 + sel_si] = __builtin_amdgcn_s_memrealtime(); ++sel_si; } while (0)
+#else
+#define SEL_STAMP() do { } while (0)
+#endif
+
+constexpr int SEL_RU = 16;
+constexpr size_t SEL_SLICE_LDS = (size_t)SEL_RU * SEL_NT * sizeof(unsigned long long);   // 128 KiB of dynamic LDS
+
+__global__ __launch_bounds__(SEL_NT) void sel_resident_lds_kernel(const double* d, int64_t n, int64_t stride, int64_t k,
+                                                                  SelWork* w, double* vals, int64_t* idx) {
+  extern __shared__ __align__(16) unsigned long long sel_keys[];   // [wave][u][lane]
+  __shared__ unsigned int h[SEL_BINS];
+  __shared__ unsigned int part[256];
+  __shared__ unsigned long long picked[4];
+  __shared__ unsigned long long cand[SEL_SMALL];
+  __shared__ unsigned int wl[SEL_NT / 64], we[SEL_NT / 64], base[2];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+#ifdef ELFIHIP_SEL_STAMP
+  int sel_si = 0;
+#endif
+  SEL_STAMP();   // 0: start
+  const unsigned int G = gridDim.x;
+  const int64_t lo = (int64_t)blockIdx.x * (SEL_RU * SEL_NT);
+  const int64_t hi = lo + SEL_RU * SEL_NT < n ? lo + SEL_RU * SEL_NT : n;
+  const int64_t first = lo + (int64_t)wv * (64 * SEL_RU) + lane;   // this lane's rows: first + 64 u, u < nv
+  const int64_t room = hi - first;
+  const int nv = room <= 0 ? 0 : (int)(room + 63 >> 6 < SEL_RU ? room + 63 >> 6 : SEL_RU);
+  const int nvw = __builtin_amdgcn_readfirstlane(nv);   // lane 0 owns the wave's lowest rows: its count bounds the wave's
+  unsigned long long* mine = sel_keys + wv * (64 * SEL_RU) + lane;   // key u at mine[64 u]
+  {
+    double v[SEL_RU];
+#pragma unroll
+    for (int u = 0; u < SEL_RU; ++u) v[u] = u < nv ? d[(first + 64 * u) * stride] : 0.0;   // all loads in flight together
+#pragma unroll
+    for (int u = 0; u < SEL_RU; ++u) mine[64 * u] = key_of(v[u]);
+  }
+  SEL_STAMP();   // 1: keys in LDS
+#ifdef ELFIHIP_SEL_STAMP
+  __syncthreads();
+  SEL_STAMP();   // 2 (stamped build only): every wave's keys are in LDS
+#endif
+  unsigned long long prefix = 0, rem = (unsigned long long)k, n_lt = 0;
+  unsigned int bar_no = 0;
+  for (int pass = 0; pass < SEL_PASSES; ++pass) {
+    for (int b = tid; b < SEL_BINS; b += SEL_NT) h[b] = 0;
+    __syncthreads();
+    const int shift = sel_shift(pass), width = sel_width(pass);
+    const unsigned int dmask = (1u << width) - 1u;
+    const unsigned long long himask = pass == 0 ? 0ull : (~0ull << (shift + width));
+    if (pass == 0) {
+      // The exponent bits: a workgroup's 16 384 keys share a handful of digits, and LDS atomics on a handful of words are
+      // serialised -- one atomic per key made this pass 8 us against 2 us for a pass whose digits spread (stamps:
+      // scripts/native/sel_probe.hip).  Every THREAD therefore counts up to four digits of its own sixteen keys in
+      // registers (compares and adds, nothing crosses lanes) and adds them once; a key with a fifth digit adds itself.
+      // (Measured against it, first + second pass: one atomic per wave, digit and 64 keys for up to four digits 16 + 2.8 us;
+      // four digits counted per WAVE in scalar registers 9.2 + 6.9 us -- the ballots cost more than they save.)
+      unsigned int pd0 = ~0u, pd1 = ~0u, pd2 = ~0u, pd3 = ~0u, pc0 = 0, pc1 = 0, pc2 = 0, pc3 = 0;
+      for (int u = 0; u < nv; ++u) {
+        const unsigned int digit = (unsigned int)(mine[64 * u] >> shift) & dmask;
+        if (digit == pd0)
+          ++pc0;
+        else if (digit == pd1)
+          ++pc1;
+        else if (digit == pd2)
+          ++pc2;
+        else if (digit == pd3)
+          ++pc3;
+        else if (pd0 == ~0u)
+          pd0 = digit, pc0 = 1;
+        else if (pd1 == ~0u)
+          pd1 = digit, pc1 = 1;
+        else if (pd2 == ~0u)
+          pd2 = digit, pc2 = 1;
+        else if (pd3 == ~0u)
+          pd3 = digit, pc3 = 1;
+        else
+          atomicAdd(&h[digit], 1u);
+      }
+      if (pc0) atomicAdd(&h[pd0], pc0);
+      if (pc1) atomicAdd(&h[pd1], pc1);
+      if (pc2) atomicAdd(&h[pd2], pc2);
+      if (pc3) atomicAdd(&h[pd3], pc3);
+    } else {
+#pragma unroll 2
+      for (int u = 0; u < nvw; ++u) {
+        const unsigned long long ku = mine[64 * u];
+        const bool in = u < nv && (ku & himask) == prefix;
+        const unsigned int digit = (unsigned int)(ku >> shift) & dmask;
+        const unsigned long long members = __ballot(in);
+        if (members == 0) continue;
+        const int lead = __ffsll((long long)members) - 1;
+        const unsigned int d0 = (unsigned int)__builtin_amdgcn_readlane((int)digit, lead);
+        if (__ballot(in && digit == d0) == members) {   // one atomic for the wave when every member shares the digit
+          if (lane == lead) atomicAdd(&h[d0], (unsigned int)__popcll(members));
+        } else if (in) {
+          atomicAdd(&h[digit], 1u);
+        }
+      }
+    }
+    __syncthreads();
+    SEL_STAMP();   // pass: workgroup histogram complete
+    for (int b = tid; b < SEL_BINS; b += SEL_NT)
+      if (h[b]) atomicAdd(&w->hist[pass][b], h[b]);
+    SEL_STAMP();   // pass: histogram flushed
+    sel_grid_barrier(w, G * ++bar_no);
+    SEL_STAMP();   // pass: barrier passed
+    // every workgroup picks the digit of this pass from the complete histogram (as sel_persistent_kernel)
+    constexpr int PER = SEL_BINS / 256;
+    unsigned int c[PER], sum = 0;
+    if (tid < 256) {
+#pragma unroll
+      for (int q = 0; q < PER; ++q) {
+        c[q] = __hip_atomic_load(&w->hist[pass][tid * PER + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sum += c[q];
+      }
+      part[tid] = sum;
+    }
+    __syncthreads();
+    if (tid < 64) {
+      unsigned int v0 = part[4 * tid], v1 = part[4 * tid + 1], v2 = part[4 * tid + 2], v3 = part[4 * tid + 3];
+      const unsigned int mine_s = v0 + v1 + v2 + v3;
+      unsigned int incl = mine_s;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const unsigned int o = __shfl_up(incl, off, 64);
+        if (tid >= off) incl += o;
+      }
+      unsigned int run = incl - mine_s;
+      part[4 * tid] = run;
+      run += v0;
+      part[4 * tid + 1] = run;
+      run += v1;
+      part[4 * tid + 2] = run;
+      run += v2;
+      part[4 * tid + 3] = run;
+    }
+    __syncthreads();
+    if (tid < 256) {
+      const unsigned long long below0 = part[tid];
+      if (rem > below0 && rem <= below0 + sum) {
+        unsigned long long below = below0;
+        int digit = tid * PER;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+          if (rem > below + c[q]) {
+            below += c[q];
+            digit = tid * PER + q + 1;
+          } else {
+            break;
+          }
+        }
+        picked[0] = prefix | ((unsigned long long)digit << shift);
+        picked[1] = rem - below;
+        picked[2] = n_lt + below;
+        picked[3] = c[digit - tid * PER];
+      }
+    }
+    __syncthreads();
+    prefix = picked[0];
+    rem = picked[1];
+    n_lt = picked[2];
+    const unsigned long long csize = picked[3];
+    __syncthreads();
+    SEL_STAMP();   // pass: digit picked
+    if (pass + 1 < SEL_PASSES && csize <= SEL_SMALL) {
+      const unsigned long long cmask = ~0ull << shift;
+      // the class's keys of this workgroup: places inside the workgroup from an LDS counter, ONE global reservation per
+      // workgroup (a global atomic per key put up to 1024 of them on one address)
+      unsigned int mine_n = 0;
+#pragma unroll 2
+      for (int u = 0; u < nv; ++u) mine_n += (mine[64 * u] & cmask) == prefix ? 1u : 0u;
+      if (tid < 2) base[tid] = 0;
+      __syncthreads();
+      unsigned int at = mine_n ? atomicAdd(&base[0], mine_n) : 0u;
+      __syncthreads();
+      if (tid == 0 && base[0]) base[1] = atomicAdd(&w->ncand, base[0]);
+      __syncthreads();
+      if (mine_n) {
+        at += base[1];
+        for (int u = 0; u < nv; ++u) {
+          const unsigned long long ku = mine[64 * u];
+          if ((ku & cmask) == prefix)   // write-through store: visible to the other XCDs without a fence
+            __hip_atomic_store(&w->cand[at++], ku, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      SEL_STAMP();   // small class: keys stored
+      sel_grid_barrier(w, G * ++bar_no);
+      SEL_STAMP();   // small class: barrier passed
+      const int m = (int)csize;
+      for (int j = tid; j < m; j += SEL_NT)
+        cand[j] = __hip_atomic_load(&w->cand[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      if (tid < m) {
+        const unsigned long long me = cand[tid];
+        unsigned int lt = 0, eq_before = 0;
+        for (int j = 0; j < m; ++j) {
+          const unsigned long long o = cand[j];
+          lt += o < me;
+          eq_before += (o == me) && j < tid;
+        }
+        if (lt + eq_before == (unsigned int)(rem - 1)) {
+          picked[0] = me;
+          picked[2] = n_lt + lt;
+        }
+      }
+      __syncthreads();
+      prefix = picked[0];
+      n_lt = picked[2];
+      __syncthreads();
+      SEL_STAMP();   // small class: ranked
+      break;
+    }
+  }
+  const unsigned long long kth = prefix;
+  // ---- this workgroup's counts: wave totals from ballots, then everybody's offsets
+  unsigned int wlt = 0, weq = 0;   // wave-uniform
+#pragma unroll 2
+  for (int u = 0; u < nvw; ++u) {
+    const unsigned long long ku = mine[64 * u];
+    wlt += (unsigned int)__popcll(__ballot(u < nv && ku < kth));
+    weq += (unsigned int)__popcll(__ballot(u < nv && ku == kth));
+  }
+  if (lane == 0) {
+    wl[wv] = wlt;
+    we[wv] = weq;
+  }
+  __syncthreads();
+  unsigned int pl = 0, pe = 0, tl = 0, te = 0;   // keys of the waves before this one; of the whole workgroup
+  for (int q = 0; q < SEL_NT / 64; ++q) {
+    if (q < wv) pl += wl[q], pe += we[q];
+    tl += wl[q];
+    te += we[q];
+  }
+  if (tid == 0) {
+    __hip_atomic_store(&w->counts[2 * blockIdx.x], tl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&w->counts[2 * blockIdx.x + 1], te, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  SEL_STAMP();   // counts stored
+  sel_grid_barrier(w, G * ++bar_no);
+  SEL_STAMP();   // counts: barrier passed
+  {
+    unsigned int o0 = 0, o1 = 0;
+    for (unsigned int b = tid; b < blockIdx.x; b += SEL_NT) {
+      o0 += __hip_atomic_load(&w->counts[2 * b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      o1 += __hip_atomic_load(&w->counts[2 * b + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (tid < 2) base[tid] = 0;
+    __syncthreads();
+    if (o0) atomicAdd(&base[0], o0);
+    if (o1) atomicAdd(&base[1], o1);
+    __syncthreads();
+  }
+  SEL_STAMP();   // offsets formed
+  // ---- stable write: slice order = wave order, then u, then lane
+  int64_t at_l = (int64_t)base[0] + pl, at_e = (int64_t)n_lt + (int64_t)base[1] + pe;
+  const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll 2
+  for (int u = 0; u < nvw; ++u) {
+    const int64_t i = first + 64 * u;
+    const unsigned long long ku = mine[64 * u];
+    const bool is_lt = u < nv && ku < kth, is_eq = u < nv && ku == kth;
+    const unsigned long long bl = __ballot(is_lt), be = __ballot(is_eq);
+    if (is_lt) {
+      const int64_t pos = at_l + __popcll(bl & below);
+      vals[pos] = d[i * stride];
+      idx[pos] = i;
+    } else if (is_eq) {
+      const int64_t pos = at_e + __popcll(be & below);
+      if (pos < k) {
+        vals[pos] = d[i * stride];
+        idx[pos] = i;
+      }
+    }
+    at_l += __popcll(bl);
+    at_e += __popcll(be);
+  }
+  SEL_STAMP();   // written
+}
+
 // force_multi: use the nine-launch form (the host entry point does when the resident form reports a timed-out barrier)
 int topk_dev_impl(elfihip_ctx* ctx, const double* dD, int64_t n, int64_t stride, int64_t k, double* dvals,
                   int64_t* didx, bool force_multi) {
@@ -550,8 +847,8 @@ int topk_dev_impl(elfihip_ctx* ctx, const double* dD, int64_t n, int64_t stride,
   if (!multi && !force_multi) {
     // 16 keys per thread and pass at least; at most one workgroup per two CUs, so that two selections running at the
     // same time (two contexts on one GPU) are still resident together
-    int grid = (int)std::min<int64_t>((n + 16 * SEL_NT - 1) / (16 * SEL_NT),
-                                      (int64_t)std::min(std::max(ctx->cu_count / 2, 1), SEL_MAX_GRID));
+    const int64_t max_grid = (int64_t)std::min(std::max(ctx->cu_count / 2, 1), SEL_MAX_GRID);
+    int grid = (int)std::min<int64_t>((n + 16 * SEL_NT - 1) / (16 * SEL_NT), max_grid);
     if (grid < 1) grid = 1;
     int64_t per = (n + grid - 1) / grid;
     per = (per + SEL_NT - 1) / SEL_NT * SEL_NT;
@@ -559,7 +856,18 @@ int topk_dev_impl(elfihip_ctx* ctx, const double* dD, int64_t n, int64_t stride,
     ELFIHIP_CHECK_HIP(ctx, ctx->scratch.reserve(sizeof(SelWork)));
     SelWork* w = ctx->scratch.as<SelWork>();
     ELFIHIP_CHECK_HIP(ctx, hipMemsetAsync(w, 0, sizeof(SelWork), st));
-    hipLaunchKernelGGL(sel_persistent_kernel, dim3(grid), dim3(SEL_NT), 0, st, dD, n, stride, per, k, w, dvals, didx);
+    const int64_t reg_grid = (n + SEL_RU * SEL_NT - 1) / (SEL_RU * SEL_NT);
+    if (reg_grid <= max_grid && ctx->topk_form != 2) {   // slices of 16 384 keys: the keys stay in LDS (form 2: the memory form, for the tests)
+      static bool lds_enabled[64] = {};
+      if (ctx->device < 0 || ctx->device >= 64 || !lds_enabled[ctx->device]) {
+        ELFIHIP_CHECK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(sel_resident_lds_kernel),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEL_SLICE_LDS));
+        if (ctx->device >= 0 && ctx->device < 64) lds_enabled[ctx->device] = true;
+      }
+      hipLaunchKernelGGL(sel_resident_lds_kernel, dim3((unsigned)reg_grid), dim3(SEL_NT), SEL_SLICE_LDS, st, dD, n, stride, k, w,
+                         dvals, didx);
+    } else
+      hipLaunchKernelGGL(sel_persistent_kernel, dim3(grid), dim3(SEL_NT), 0, st, dD, n, stride, per, k, w, dvals, didx);
     return launch_status(ctx, "top-k selection kernel");
   }
   int nblocks = (int)std::min<int64_t>((n + 4095) / 4096, (int64_t)ctx->cu_count * 8);

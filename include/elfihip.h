@@ -149,8 +149,10 @@ int elfihip_welford_merge_dev(elfihip_ctx* ctx, const double* dstates, int world
  * come back ascending by (distance, row); NaN last; k is clipped to n.  `stride` (in doubles) lets
  * the _dev form read one column of an (n, K) nested-distance matrix in place; the _dev form leaves
  * the k survivors unsorted (row order inside "< k-th" then "== k-th"). */
-/* Which implementation serves the selections of this context: 0 (default) the resident single-launch radix select,
- * falling back to the nine-launch form when its grid barrier times out; 1 the nine-launch form always. */
+/* Which implementation serves the selections of this context: 0 (default) the resident single-launch radix select
+ * (slices of 16 384 keys held in registers for n <= 2 x 10^6 on MI355X, re-read from memory per phase above that),
+ * falling back to the nine-launch form when its grid barrier times out; 1 the nine-launch form always; 2 the resident
+ * form without the register variant (measurement and tests). */
 int elfihip_topk_set_form(elfihip_ctx* ctx, int form);
 int elfihip_topk_smallest(elfihip_ctx* ctx, const double* D, int64_t n, int64_t stride, int64_t k, double* vals,
                           int64_t* idx);

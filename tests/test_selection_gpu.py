@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 def topk_form(hip_ctx):
     """Select the implementation for one test (elfihip_topk_set_form), restore the default afterwards."""
     def choose(form):
-        hip_ctx.call("elfihip_topk_set_form", 1 if form == 'nine-launch' else 0)
+        hip_ctx.call("elfihip_topk_set_form", {'resident': 0, 'nine-launch': 1, 'resident-memory': 2}[form])
     yield choose
     hip_ctx.call("elfihip_topk_set_form", 0)
 
@@ -20,9 +20,10 @@ def _ref(d, k):
     return d[order], order
 
 
-@pytest.mark.parametrize('form', ['resident', 'nine-launch'])
+@pytest.mark.parametrize('form', ['resident', 'nine-launch', 'resident-memory'])
 @pytest.mark.parametrize('n,k', [(1, 1), (10, 3), (1000, 1000), (1000, 5000), (4097, 100), (10**6, 1000),
-                                 (10**6, 1), (300000, 10000), (2 * 10**6 + 17, 64)])
+                                 (10**6, 1), (300000, 10000), (2 * 10**6 + 17, 64), (16384, 16384), (16385, 9000),
+                                 (70000, 63), (3 * 10**6, 1000)])
 def test_smallest_k_matches_numpy(hip_ctx, topk_form, form, n, k):
     import elfi_amd
     topk_form(form)
@@ -33,7 +34,7 @@ def test_smallest_k_matches_numpy(hip_ctx, topk_form, form, n, k):
     assert np.array_equal(vals, rv) and np.array_equal(idx, ri)
 
 
-@pytest.mark.parametrize('form', ['resident', 'nine-launch'])
+@pytest.mark.parametrize('form', ['resident', 'nine-launch', 'resident-memory'])
 def test_smallest_k_ties_negatives_nan_inf(hip_ctx, topk_form, form):
     import elfi_amd
     topk_form(form)
