@@ -680,7 +680,9 @@ int adaptive_push_impl(elfihip_ctx* ctx, elfihip_reject* h, const double* dX, in
     // back): if fewer than k rows qualified (the rows were not exchangeable: sorted input), or far too many, the
     // selection of all n distances runs instead.  Exact either way.
     ELFIHIP_TRY(reject_flush(h));
-    const int64_t s = std::min<int64_t>(std::max<int64_t>(n / 32, 16384), n / 2);
+    // (s = n / 16: j n / s = 1700 +- 160 candidates for k = 1000, i.e. two 1024-chunks of the merge; with n / 32 -- rounds 4-5 --
+    // they were 2050 +- 250, a third chunk every other round)
+    const int64_t s = std::min<int64_t>(std::max<int64_t>(n / 16, 16384), n / 2);
     const double mu = (double)h->k * (double)s / (double)n;
     int64_t j = (int64_t)std::ceil(mu + 5.0 * std::sqrt(mu) + 4.0);
     if (j > h->k) j = h->k;
