@@ -66,6 +66,7 @@ struct elfihip_ctx {
   // hipMemcpyAsync into a pageable stack variable is a staged blit of 30 us on the stream (profiles/r05_cfg4_trace.md:
   // 4.5 of them per adaptive-distance round)
   unsigned long long* mail = nullptr;
+  unsigned long long mail_ticket = 0;   // number of the latest mail_post (word 7 of the mailbox carries it: mail_wait)
   unsigned* fold_cnt = nullptr;       // arrival counter of adaptive_finish_kernel's fold (adaptive.hip), zero between launches
   int dist_form = 0;                  // 0: LDS-DMA row stream where the shape allows; 1: register-staged pipeline (elfihip_dist_set_form)
   int topk_form = 0;                  // 0: resident selection (keys in registers up to 2 10^6 rows) with the nine-launch form as fallback; 1: nine-launch form; 2: resident, keys re-read from memory in every phase
@@ -155,6 +156,12 @@ struct MailSrc {
 };
 int mail_post(elfihip_ctx* ctx, const MailSrc& S);
 inline unsigned long long mail_read(const elfihip_ctx* ctx, int i) { return ctx->mail[i]; }
+// Wait for the LATEST mail_post alone -- not for the kernels enqueued behind it: the mail kernel writes its ticket last
+// (system-scope release) and the host polls that word of the page-locked mailbox.  A caller that has more work for the
+// stream enqueues it first and then waits here, so that the device is busy while the host wakes up (a stream
+// synchronisation in the middle of a round left it idle for 20-30 us).  Falls back to hipStreamSynchronize when the ticket
+// does not arrive (a faulted stream reports its error there).
+int mail_wait(elfihip_ctx* ctx);
 
 // Host-form distance calls leave a device copy of what they return (n x cols doubles at dsrc, on the context's stream).
 // Every host-form distance call comes through here, also with n = 0 (an empty batch is a call: the epoch must move on, or

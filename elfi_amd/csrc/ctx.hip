@@ -1,6 +1,9 @@
 // Context lifecycle, error text, stream adoption and event timing for libelfihip.so.
 #include "common.hpp"
 
+#include <atomic>
+#include <chrono>
+
 #include <cstdlib>
 
 namespace elfihip {
@@ -9,11 +12,13 @@ thread_local std::string g_err;
 // Streams of the GP factorisation's stream schedule: `hi` (high priority) carries the critical chain, `bulk` the
 // rest of the trailing update.  (A CU-mask partition of the two was tried and removed: on this stack a stream made with
 // hipExtStreamCreateWithCUMask still runs on all 256 CUs -- scripts/native/cumask_probe.hip prints the XCC / CU ids.)
-__global__ void mail_kernel(MailSrc S, unsigned long long* box) {
+__global__ void mail_kernel(MailSrc S, unsigned long long* box, unsigned long long ticket) {
   const int t = threadIdx.x;
   if (t < S.n)
     box[t] = S.bytes[t] == 8 ? *reinterpret_cast<const unsigned long long*>(S.p[t])
                              : (unsigned long long)*reinterpret_cast<const unsigned int*>(S.p[t]);
+  __threadfence_system();   // (one wave: the words above are on their way to host memory before the ticket is)
+  if (t == 0) __hip_atomic_store(box + 7, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 int mail_post(elfihip_ctx* ctx, const MailSrc& S) {
@@ -21,9 +26,28 @@ int mail_post(elfihip_ctx* ctx, const MailSrc& S) {
     void* p = nullptr;
     ELFIHIP_CHECK_HIP(ctx, hipHostMalloc(&p, 64, hipHostMallocMapped | hipHostMallocCoherent));
     ctx->mail = reinterpret_cast<unsigned long long*>(p);
+    ctx->mail[7] = 0;
   }
-  hipLaunchKernelGGL(mail_kernel, dim3(1), dim3(64), 0, ctx->stream, S, ctx->mail);
+  hipLaunchKernelGGL(mail_kernel, dim3(1), dim3(64), 0, ctx->stream, S, ctx->mail, ++ctx->mail_ticket);
   return launch_status(ctx, "mail_kernel");
+}
+
+int mail_wait(elfihip_ctx* ctx) {
+  volatile unsigned long long* word = ctx->mail + 7;
+  const unsigned long long want = ctx->mail_ticket;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spins = 0; *word != want; ++spins) {
+    if ((spins & 1023u) == 1023u &&
+        std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 0.25) {
+      // not in a quarter of a second: let the stream say what happened (or finish: a long queue ahead of the mail kernel)
+      ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      if (*word != want) return fail(ctx, ELFIHIP_ERR_STATE, "internal: the mailbox ticket %llu never arrived", want);
+      break;
+    }
+    __builtin_ia32_pause();
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  return ELFIHIP_OK;
 }
 
 int ctx_aux(elfihip_ctx* ctx) {

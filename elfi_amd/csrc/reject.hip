@@ -705,13 +705,30 @@ int adaptive_push_impl(elfihip_ctx* ctx, elfihip_reject* h, const double* dX, in
     ELFIHIP_TRY(pass(s, n, &F, false, dout ? dout + s * K : nullptr));
     // the list's length and the selection's time-out flag in ONE read-back
     ELFIHIP_TRY(mail_post(ctx, MailSrc{{h->count, sel_err_dev ? sel_err_dev : h->count, nullptr, nullptr}, {4, 4, 0, 0}, 2}));
-    ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(st));
+    // An EMPTY state (every SMC round starts with one) is merged -- and the batch's statistics are finished -- BEFORE the
+    // verdict is known: the host waits for the mail kernel alone (mail_wait), the device works on while it wakes up, and a
+    // wrong merge is undone by emptying the state again.  (Rounds 4-5 synchronised the stream here: 20-30 us of idle device
+    // per round between the pass and the merge.)
+    const bool early = !h->host_mode && h->filled == 0;
+    bool stats_done = false;
+    if (early) {
+      ELFIHIP_TRY(merge_list(-1, 0));
+      ELFIHIP_TRY(finish_stats());
+      stats_done = true;
+      ELFIHIP_TRY(mail_wait(ctx));
+    } else {
+      ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(st));
+    }
     const unsigned int c = (unsigned int)mail_read(ctx, 0);
     const unsigned int sel_err = sel_err_dev ? (unsigned int)mail_read(ctx, 1) : 0u;
     if (sel_err == 0 && (int64_t)c >= h->k && (int64_t)c <= std::max<int64_t>(REJ_PROV_MAX_CAND, 64 * j) && c <= h->cap) {
-      ELFIHIP_TRY(merge_list(-1, 0));
+      if (!early) ELFIHIP_TRY(merge_list(-1, 0));
     } else {
       // the prefix did not represent the batch: selection over all n distances (recomputed when the caller kept none)
+      if (early)   // the state as reject_reset leaves it (the merge above may have kept too few rows, or flagged an overflow)
+        hipLaunchKernelGGL(reject_init_kernel, dim3((unsigned)((std::min<int64_t>(h->k, REJ_MAX_K) + 255) / 256)), dim3(256), 0, st,
+                           h->best_val, h->best_row, h->thr, h->count, h->status, h->acc_count,
+                           (int)std::min<int64_t>(h->k, REJ_MAX_K));
       hipLaunchKernelGGL(reject_unseed_kernel, dim3(1), dim3(1), 0, st, h->thr, h->count, h->best_val,
                          (int)std::min<int64_t>(h->k, REJ_MAX_K));
       if (h->host_mode) {
@@ -732,7 +749,7 @@ int adaptive_push_impl(elfihip_ctx* ctx, elfihip_reject* h, const double* dX, in
     h->filled = h->k;
     h->unmerged = 0;
     h->pending_rows = 0;
-    return finish_stats();
+    return stats_done ? ELFIHIP_OK : finish_stats();
   }
   if (select) {
     // (as reject_push: the state is still filling up, or very many rows would qualify) plain pass, radix selection of
