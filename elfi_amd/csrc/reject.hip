@@ -127,7 +127,9 @@ __global__ __launch_bounds__(1024) void reject_merge_kernel(RejArgs S) {
   // about one when a full state meets a few candidates, but the whole chunk when the state is still empty: every
   // candidate falls into slot 0, 1024 list steps each, 57 us per chunk (round 4: 171 us for the 2400 candidates of an SMC
   // round's first batch).  Rounds 4-5 sorted the chunk in LDS, two pairs per thread and a barrier per step (35 us for a
-  // merge of a few hundred candidates, 52 us for the two chunks of an SMC round's first batch).
+  // merge of a few hundred candidates, 52 us for the two chunks of an SMC round's first batch).  Round 6 also tried 2048
+  // candidates per chunk, two pairs per thread: 37 us for 1700 candidates against 34 us for the two 1024-chunks, and every
+  // small merge 1-4 us slower -- not kept.
   extern __shared__ __align__(16) unsigned char rej_sm[];
   double* bv = reinterpret_cast<double*>(rej_sm);
   long long* br = reinterpret_cast<long long*>(bv + REJ_MAX_K);

@@ -28,7 +28,7 @@ int main() {
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   const double inf = __builtin_inf();
   for (int full = 0; full < 2; ++full)
-    for (int c : {16, 100, 300, 1000, 1024, 2000, 3000, 4000, 8000}) {
+    for (int c : {16, 100, 300, 1000, 1024, 1025, 1700, 2000, 2048, 3000, 4000, 8000}) {
       float best = 1e9f;
       std::vector<double> got(k);
       for (int rep = 0; rep < 12; ++rep) {
