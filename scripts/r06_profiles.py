@@ -26,7 +26,8 @@ LDS stage) instead of passing 2 KiB tiles through LDS.  The 4 10^6 x 2 block, ro
 0.72, minkowski p=3 0.23 -> 0.61, mahalanobis 0.28 -> 0.69, K-weight 0.26 -> 0.62, adaptive pass 0.16 -> 0.40 (0.126 -> 0.050
 ms: one read instead of three; what is left is VALU time -- three correctly rounded square roots and two Chan updates with a
 division per four rows -- beside 160 MB of traffic), the two-pass welford entry point unchanged (0.33: four launches of ~12 us;
-the adaptive path no longer uses it at this width).  Boxes of the pool differ by +-3 %%: 10^6 x 32 euclidean %s us here,
+the adaptive path no longer uses it at this width).  The 1000 smallest of 10^6 distances: 56 -> 37 us (0.18 -> 0.27: the
+resident selection keeps a slice's keys in LDS, `profiles/r06_selection_timeline.md`).  Boxes of the pool differ by +-3 %%: 10^6 x 32 euclidean %s us here,
 41.4-43.2 over the round.
 
 ''' % e32 + kt)
