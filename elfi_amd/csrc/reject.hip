@@ -100,6 +100,7 @@ struct RejArgs {
   int ncand;
   long long row_offset;
   double* export_val;   // packed copy of the new state for the caller (may be NULL)
+  unsigned int ok_lo, ok_hi;   // ncand < 0: a list shorter than ok_lo or longer than ok_hi is left alone (the state too)
 };
 
 constexpr size_t REJ_MERGE_LDS = REJ_MAX_K * 16 + 2 * REJ_CHUNK * 16;   // state, the chunk, the exchange buffer: 64 KiB
@@ -139,6 +140,7 @@ __global__ __launch_bounds__(1024) void reject_merge_kernel(RejArgs S) {
   long long* xr_ = reinterpret_cast<long long*>(xv_ + REJ_CHUNK);
   const int t = threadIdx.x, k = S.k;
   unsigned int c = S.ncand >= 0 ? (unsigned int)S.ncand : *S.count;
+  if (S.ncand < 0 && (c < S.ok_lo || c > S.ok_hi)) return;   // (uniform) the caller's verdict on this list, taken here as well
   if (c > S.cap) {
     if (t == 0) atomicOr(S.status, 1u);   // the list is incomplete: the state can no longer be trusted (reported by result)
     c = S.cap;
@@ -342,6 +344,8 @@ static RejArgs merge_args(elfihip_reject* h, int ncand, long long row_offset) {
   S.ncand = ncand;
   S.row_offset = row_offset;
   S.export_val = reinterpret_cast<double*>(h->export_dst);
+  S.ok_lo = 0u;
+  S.ok_hi = ~0u;
   return S;
 }
 
@@ -713,8 +717,15 @@ int adaptive_push_impl(elfihip_ctx* ctx, elfihip_reject* h, const double* dX, in
     // per round between the pass and the merge.)
     const bool early = !h->host_mode && h->filled == 0;
     bool stats_done = false;
+    const int64_t c_hi = std::min<int64_t>(std::max<int64_t>(REJ_PROV_MAX_CAND, 64 * j), (int64_t)h->cap);
     if (early) {
-      ELFIHIP_TRY(merge_list(-1, 0));
+      // (the merge applies the verdict's bounds on the list's length itself: a list that fails them -- sorted input: a
+      // handful of candidates, or every row of the batch -- is not touched, nor is the state)
+      RejArgs A = merge_args(h, -1, 0);
+      A.ok_lo = (unsigned int)h->k;
+      A.ok_hi = (unsigned int)c_hi;
+      hipLaunchKernelGGL(reject_merge_kernel, dim3(1), dim3(1024), REJ_MERGE_LDS, st, A);
+      ELFIHIP_TRY(launch_status(ctx, "reject_merge_kernel"));
       ELFIHIP_TRY(finish_stats());
       stats_done = true;
       ELFIHIP_TRY(mail_wait(ctx));
@@ -723,11 +734,11 @@ int adaptive_push_impl(elfihip_ctx* ctx, elfihip_reject* h, const double* dX, in
     }
     const unsigned int c = (unsigned int)mail_read(ctx, 0);
     const unsigned int sel_err = sel_err_dev ? (unsigned int)mail_read(ctx, 1) : 0u;
-    if (sel_err == 0 && (int64_t)c >= h->k && (int64_t)c <= std::max<int64_t>(REJ_PROV_MAX_CAND, 64 * j) && c <= h->cap) {
+    if (sel_err == 0 && (int64_t)c >= h->k && (int64_t)c <= c_hi) {
       if (!early) ELFIHIP_TRY(merge_list(-1, 0));
     } else {
       // the prefix did not represent the batch: selection over all n distances (recomputed when the caller kept none)
-      if (early)   // the state as reject_reset leaves it (the merge above may have kept too few rows, or flagged an overflow)
+      if (early)   // the state as reject_reset leaves it (only a timed-out selection with a list of plausible length has been merged)
         hipLaunchKernelGGL(reject_init_kernel, dim3((unsigned)((std::min<int64_t>(h->k, REJ_MAX_K) + 255) / 256)), dim3(256), 0, st,
                            h->best_val, h->best_row, h->thr, h->count, h->status, h->acc_count,
                            (int)std::min<int64_t>(h->k, REJ_MAX_K));

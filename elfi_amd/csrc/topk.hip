@@ -151,6 +151,18 @@ __global__ __launch_bounds__(256) void sel_hist_kernel(const double* d, int64_t 
   if (threadIdx.x == 0) st->done = 0;
 }
 
+// the state of a selection before its first pass
+__global__ __launch_bounds__(256) void sel_init_kernel(SelState* st, unsigned long long k) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t < SEL_BINS) st->hist[t] = 0u;
+  if (t == 0) {
+    st->prefix = 0ull;
+    st->k_rem = k;
+    st->n_lt = 0ull;
+    st->done = 0u;
+  }
+}
+
 // counts[b] = {#keys < kth, #keys == kth} of block b's contiguous slice
 __global__ __launch_bounds__(256) void sel_count_kernel(const double* d, int64_t n, int64_t stride, int64_t per_block,
                                                         const SelState* st, unsigned int* counts) {
@@ -879,10 +891,9 @@ int topk_dev_impl(elfihip_ctx* ctx, const double* dD, int64_t n, int64_t stride,
   ELFIHIP_CHECK_HIP(ctx, ctx->scratch.reserve(bytes));
   SelState* ds = ctx->scratch.as<SelState>();
   unsigned int* counts = reinterpret_cast<unsigned int*>(ds + 1);
-  SelState init;
-  memset(&init, 0, sizeof init);
-  init.k_rem = (unsigned long long)k;
-  ELFIHIP_CHECK_HIP(ctx, hipMemcpyAsync(ds, &init, sizeof init, hipMemcpyHostToDevice, st));
+  // (a kernel, not a copy of a host struct: an asynchronous copy from this function's stack may be read after it returned
+  // when the stream is busy -- found by scripts/soak_round.py once the sampler stopped draining the stream before its fall-back)
+  hipLaunchKernelGGL(sel_init_kernel, dim3(SEL_BINS / 256), dim3(256), 0, st, ds, (unsigned long long)k);
   // one workgroup per CU at most: each pays a device-scope fence, and a launch of this size is latency-bound anyway
   // (10^6 keys: 0.16 ms with 8 workgroups per CU, 0.10 ms with one)
   const int hist_blocks = (int)std::min<int64_t>((n + 2047) / 2048, (int64_t)ctx->cu_count);

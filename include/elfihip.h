@@ -66,7 +66,10 @@ int elfihip_ctx_destroy(elfihip_ctx* ctx);
 /* Text of the last error on ctx (or the last context-less error if ctx == NULL). */
 const char* elfihip_last_error(const elfihip_ctx* ctx);
 /* Adopt an externally owned hipStream_t (e.g. torch's current stream); NULL restores
- * the context's own stream. */
+ * the context's own stream.  The own stream is NON-BLOCKING: it is not ordered against
+ * the null stream or any other stream, so a caller that fills device buffers elsewhere
+ * (the *_dev entry points) either adopts that stream here or synchronises it before the
+ * call; the *_dev entry points themselves are asynchronous on the context's stream. */
 int elfihip_ctx_set_stream(elfihip_ctx* ctx, void* hip_stream);
 int elfihip_ctx_synchronize(elfihip_ctx* ctx);
 /* Device properties the roofline needs: CU count, clock (kHz), memory clock (kHz),

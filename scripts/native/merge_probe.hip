@@ -37,7 +37,7 @@ int main() {
         CK(hipMemcpy(br, hsr.data(), k * 8, hipMemcpyHostToDevice));
         unsigned int cc = (unsigned int)c;
         CK(hipMemcpy(count, &cc, 4, hipMemcpyHostToDevice));
-        RejArgs S{bv, br, thr, cvv, crr, count, status, (unsigned int)cap, k, -1, 0, nullptr};
+        RejArgs S{bv, br, thr, cvv, crr, count, status, (unsigned int)cap, k, -1, 0, nullptr, 0u, ~0u};
         CK(hipDeviceSynchronize());
         CK(hipEventRecord(e0));
         hipLaunchKernelGGL(reject_merge_kernel, dim3(1), dim3(1024), REJ_MERGE_LDS, 0, S);

@@ -210,6 +210,7 @@ def test_large_first_batch_provisional_threshold(hip_ctx, order, k):
     for keep in (True, False):          # with and without a destination for the distances
         rb = elfi_amd.RunningBest(k)
         wel.zero_()
+        torch.cuda.synchronize()        # (torch's stream and the context's own stream are not ordered against each other)
         hip_ctx.call("elfihip_adaptive_push_dev", rb.h, X.data_ptr(), n, m, m, y.data_ptr(), W.data_ptr(), K,
                      out.data_ptr() if keep else None, wel.data_ptr(), 7 * n)
         vals, rows = rb.result()
@@ -224,6 +225,7 @@ def test_large_first_batch_provisional_threshold(hip_ctx, order, k):
     # a second batch against the now-full state
     X2 = torch.randn(300000, m, dtype=torch.float64, device='cuda', generator=g) * 0.9
     out2 = torch.empty(300000, K, dtype=torch.float64, device='cuda')
+    torch.cuda.synchronize()
     hip_ctx.call("elfihip_adaptive_push_dev", rb.h, X2.data_ptr(), 300000, m, m, y.data_ptr(), W.data_ptr(), K,
                  out2.data_ptr(), None, 9 * n)
     vals, rows = rb.result()
