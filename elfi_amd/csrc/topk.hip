@@ -442,8 +442,10 @@ __global__ __launch_bounds__(SEL_NT) void sel_persistent_kernel(const double* d,
         for (int u = 0; u < U; ++u) {
           const int64_t i = i0 + u * SEL_NT + tid;
           const unsigned long long kk = key_of(v[u]);
-          if (i < hi && (kk & cmask) == prefix)   // write-through store: visible to the other XCDs without a fence
-            __hip_atomic_store(&w->cand[atomicAdd(&w->ncand, 1u)], kk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (i < hi && (kk & cmask) == prefix) {   // write-through store: visible to the other XCDs without a fence
+            const unsigned int at = atomicAdd(&w->ncand, 1u);
+            if (at < (unsigned int)SEL_SMALL) __hip_atomic_store(&w->cand[at], kk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
         }
       }
       sel_grid_barrier(w, G * ++bar_no);
@@ -748,8 +750,9 @@ __global__ __launch_bounds__(SEL_NT) void sel_resident_lds_kernel(const double* 
         at += base[1];
         for (int u = 0; u < nv; ++u) {
           const unsigned long long ku = mine[64 * u];
-          if ((ku & cmask) == prefix)   // write-through store: visible to the other XCDs without a fence
-            __hip_atomic_store(&w->cand[at++], ku, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((ku & cmask) == prefix && at < (unsigned int)SEL_SMALL)   // write-through store: visible to the other XCDs without a
+            __hip_atomic_store(&w->cand[at++], ku, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // fence (the bound only
+                                                                                                    // matters if the input changes under the kernel)
         }
       }
       SEL_STAMP();   // small class: keys stored
