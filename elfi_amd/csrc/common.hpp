@@ -162,6 +162,14 @@ inline unsigned long long mail_read(const elfihip_ctx* ctx, int i) { return ctx-
 // synchronisation in the middle of a round left it idle for 20-30 us).  Falls back to hipStreamSynchronize when the ticket
 // does not arrive (a faulted stream reports its error there).
 int mail_wait(elfihip_ctx* ctx);
+// The same wait on any word of page-locked, device-visible memory that a kernel on the context's stream stores LAST, behind a
+// system-scope fence (the rebuild's scalars: gp_fit.hip / gp_hyper.hip).
+int host_wait_ticket(elfihip_ctx* ctx, const volatile unsigned long long* word, unsigned long long want);
+// device side of such a ticket: after the thread's own stores to the page-locked words
+__device__ __forceinline__ void post_ticket(double* slot, unsigned long long ticket) {
+  __threadfence_system();
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(slot), ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 // Host-form distance calls leave a device copy of what they return (n x cols doubles at dsrc, on the context's stream).
 // Every host-form distance call comes through here, also with n = 0 (an empty batch is a call: the epoch must move on, or

@@ -32,16 +32,14 @@ int mail_post(elfihip_ctx* ctx, const MailSrc& S) {
   return launch_status(ctx, "mail_kernel");
 }
 
-int mail_wait(elfihip_ctx* ctx) {
-  volatile unsigned long long* word = ctx->mail + 7;
-  const unsigned long long want = ctx->mail_ticket;
+int host_wait_ticket(elfihip_ctx* ctx, const volatile unsigned long long* word, unsigned long long want) {
   const auto t0 = std::chrono::steady_clock::now();
   for (unsigned spins = 0; *word != want; ++spins) {
     if ((spins & 1023u) == 1023u &&
         std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 0.25) {
-      // not in a quarter of a second: let the stream say what happened (or finish: a long queue ahead of the mail kernel)
+      // not in a quarter of a second: let the stream say what happened (or finish: a long queue ahead of the writer)
       ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-      if (*word != want) return fail(ctx, ELFIHIP_ERR_STATE, "internal: the mailbox ticket %llu never arrived", want);
+      if (*word != want) return fail(ctx, ELFIHIP_ERR_STATE, "internal: the ticket %llu never arrived", want);
       break;
     }
     __builtin_ia32_pause();
@@ -49,6 +47,8 @@ int mail_wait(elfihip_ctx* ctx) {
   std::atomic_thread_fence(std::memory_order_acquire);
   return ELFIHIP_OK;
 }
+
+int mail_wait(elfihip_ctx* ctx) { return host_wait_ticket(ctx, ctx->mail + 7, ctx->mail_ticket); }
 
 int ctx_aux(elfihip_ctx* ctx) {
   if (ctx->hi_stream) return ELFIHIP_OK;

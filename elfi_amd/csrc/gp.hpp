@@ -56,7 +56,9 @@ struct elfihip_gp {
   int* info = nullptr;      // device: 1-based index of the first non-positive pivot, 0 if none; from word 4 on the
   int ov_flags_off = 0;     // first word of the overlapped sweep's counters in `info`
   int ninfo = 0;            // arrival counters of the fused sweep's steps (four words each); ninfo words in all
-  double* h_fit = nullptr;  // pinned, device-visible: sum log L_ii, z'z and the pivot report of the latest rebuild
+  double* h_fit = nullptr;  // pinned, device-visible: sum log L_ii, z'z and the pivot report of the latest rebuild;
+                            // words 15 / 14: tickets of the latest rebuild / hyper-gradient (host_wait_ticket)
+  unsigned long long fit_ticket = 0, hyper_ticket = 0;
   // integration points of ExpIntVar (elfihip_gp_set_integration_points): V_P = L^-1 K(X, P) stored k-major
   double* VP = nullptr;     // (np, m_pad)
   double* Pint = nullptr;   // (m_pad, dp) the points, zero padded

@@ -1585,7 +1585,8 @@ __global__ __launch_bounds__(64) void ov_gate_kernel(const unsigned* word, unsig
 // red[0] = sum log L_ii (i < n), red[1] = sum z_i^2 (fixed order), red[2] = the pivot report, red[8..9] = min / max L_ii -- written straight to
 // pinned host memory (two device-to-host copies, 25 us on this stack, replaced by the stream wait alone).
 __global__ __launch_bounds__(256) void alpha_logdet_kernel(const double* WT, const double* A, const double* z, double* alpha,
-                                                           double* red, const int* info, int64_t n, int64_t np, int64_t lda) {
+                                                           double* red, const int* info, int64_t n, int64_t np, int64_t lda,
+                                                           unsigned long long ticket) {
   if (blockIdx.x == 0) {   // first, so that it is under way while the long rows of the triangle stream
     __shared__ double s0[256], s1[256], s2[256], s3[256];
     double a = 0.0, b = 0.0, lo = 1e300, hi = 0.0;
@@ -1616,6 +1617,7 @@ __global__ __launch_bounds__(256) void alpha_logdet_kernel(const double* WT, con
       red[2] = (double)*info;
       red[8] = s2[0];         // smallest / largest diagonal entry of L
       red[9] = s3[0];
+      post_ticket(red + 15, ticket);   // the host waits for THIS, not for the rows of alpha still streaming (gp_factorize_attempt)
     }
     return;
   }
@@ -2002,10 +2004,17 @@ static int gp_factorize_attempt(elfihip_gp* gp, double diag_add, int* info_out) 
   prof_mark(gp, 2);
   const double* z = gp->A + np * gp->lda;  // row np of A: z = L^-1 y
   hipLaunchKernelGGL(alpha_logdet_kernel, dim3((unsigned)(np / 4 + 1)), dim3(256), 0, st, gp->WT, gp->A, z, gp->alpha,
-                     gp->h_fit, gp->info, gp->n, np, gp->lda);
+                     gp->h_fit, gp->info, gp->n, np, gp->lda, ++gp->fit_ticket);
   ELFIHIP_TRY(launch_status(ctx, "alpha/logdet"));
   prof_mark(gp, 3);
-  ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(st));
+  // The rebuild's scalars (log-determinant, z'z, pivot report) are in page-locked memory as soon as the first workgroup of
+  // alpha_logdet_kernel has stored them and its ticket: the host polls the ticket instead of draining the stream, so that what
+  // the caller enqueues next (kernel rows of an acquisition, the gradient of a MAP search) reaches the device while the rows of
+  // alpha are still being formed.  (A profiled rebuild reads event times: it drains the stream.)
+  if (gp->profile)
+    ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(st));
+  else
+    ELFIHIP_TRY(host_wait_ticket(ctx, reinterpret_cast<const volatile unsigned long long*>(gp->h_fit + 15), gp->fit_ticket));
   *info_out = (int)gp->h_fit[2];
   if (*info_out != 0) gp->wt_dirty = true;
   prof_add(gp, ELFIHIP_PHASE_GRAM, 0, 1);
@@ -2122,6 +2131,7 @@ int elfihip_gp_create(elfihip_ctx* ctx, int d, int64_t capacity, elfihip_gp** ou
   if (e == hipSuccess) e = hipMemsetAsync(gp->info, 0, gp->ninfo * sizeof(int), ctx->stream);
   if (e == hipSuccess)
     e = hipHostMalloc(reinterpret_cast<void**>(&gp->h_fit), 16 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent);
+  if (e == hipSuccess) memset(gp->h_fit, 0, 16 * sizeof(double));   // (the ticket words start at 0: the first ticket is 1)
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   if (e != hipSuccess) {
     int rc = fail(ctx, e == hipErrorOutOfMemory ? ELFIHIP_ERR_NOMEM : ELFIHIP_ERR_HIP, "GP allocation failed: %s",

@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void kinv_grad_kernel(HyperArgs H) {
 }
 
 // red[2..5] = sum over tiles of part[t][0..3], fixed order.
-__global__ __launch_bounds__(256) void hyper_reduce_kernel(const double* part, int64_t ntiles, double* red) {
+__global__ __launch_bounds__(256) void hyper_reduce_kernel(const double* part, int64_t ntiles, double* red, unsigned long long ticket) {
   __shared__ double s[256][4];
   double a[4] = {0, 0, 0, 0};
   for (int64_t t = threadIdx.x; t < ntiles; t += 256)
@@ -156,6 +156,7 @@ __global__ __launch_bounds__(256) void hyper_reduce_kernel(const double* part, i
     __syncthreads();
   }
   if (threadIdx.x < 4) red[2 + threadIdx.x] = s[0][threadIdx.x];
+  if (threadIdx.x == 0) post_ticket(red + 12, ticket);   // (red = h_fit + 2: word 14; lanes 0-3 are one wave: their stores precede the fence)
 }
 
 static int hyper_grad_impl(elfihip_gp* gp, bool store_kinv, double* grad) {
@@ -230,10 +231,13 @@ static int hyper_grad_impl(elfihip_gp* gp, bool store_kinv, double* grad) {
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   prof_mark(gp, 0);
   hipLaunchKernelGGL(kinv_grad_kernel, dim3((unsigned)nitems), dim3(256), lds, st, H);
-  hipLaunchKernelGGL(hyper_reduce_kernel, dim3(1), dim3(256), 0, st, H.part, nitems, gp->h_fit + 2);   // pinned: no copy
+  hipLaunchKernelGGL(hyper_reduce_kernel, dim3(1), dim3(256), 0, st, H.part, nitems, gp->h_fit + 2, ++gp->hyper_ticket);   // pinned: no copy
   prof_mark(gp, 1);
   ELFIHIP_TRY(launch_status(ctx, "kinv_grad_kernel"));
-  ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(st));
+  if (gp->profile)   // (event times are read below)
+    ELFIHIP_CHECK_HIP(ctx, hipStreamSynchronize(st));
+  else
+    ELFIHIP_TRY(host_wait_ticket(ctx, reinterpret_cast<const volatile unsigned long long*>(gp->h_fit + 14), gp->hyper_ticket));
   const double s[4] = {gp->h_fit[4], gp->h_fit[5], gp->h_fit[6], gp->h_fit[7]};
   prof_add(gp, ELFIHIP_PHASE_KINV_GRAD, 0, 1);
   if (store_kinv) {
